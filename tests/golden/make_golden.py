@@ -1,0 +1,336 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the COMPILED REFERENCE.
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+Inputs are produced by this repo's own seeded generator (krakenuniq_amd/synth.py);
+expected outputs come from the reference binaries in oracle/_ref/ (classify,
+classifyExact, db_sort, count_unique, and oracle/ref_kat.cpp linked against the
+reference's objects) plus the reference's scripts/read_merger.pl.  Only data
+(inputs + expected outputs) is committed -- no reference source.
+
+Fixtures:
+  f1/   tiny DB (k=31, nt=7) + taxDB + 1000 x 150 bp reads.fq + reference outputs
+        out.tsv/report.tsv (-t 1), report_exact.tsv (classifyExact),
+        out_u1000.tsv/report_u1000.tsv (-u 1000: sketches stay sparse),
+        out_chunk.tsv/report_chunk.tsv (-x 70K -t 2), out_quick.tsv (-q -m 2),
+        out_c.tsv (-c), database.kdb.counts
+  f2/   edge FASTA (short / N / empty / lower-case / multi-line) + outputs
+  f4/   paired FASTQs -> read_merger.pl -> merged.fa + outputs
+  f7/   legacy KRAKIDX (type 1) index variant of f1 + outputs
+  kat.json  per-function known-answer vectors from ref_kat
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from krakenuniq_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+MERGER = "/root/reference/scripts/read_merger.pl"
+K, NT = 31, 7
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr.decode(errors="replace"))
+        raise SystemExit(f"command failed: {cmd}")
+    return r
+
+
+def classify(db, args, reads, binary="classify"):
+    cmd = [os.path.join(REF, binary), "-d", f"{db}/database.kdb", "-i", f"{db}/database.idx",
+           "-a", f"{db}/taxDB"] + args + reads
+    return run(cmd)
+
+
+def make_f1():
+    d = os.path.join(HERE, "f1")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    rng = np.random.default_rng(7)
+    tax = synth.small_taxonomy()
+    g4 = synth.procedural_genome(7, 4, 3000)
+    g5 = synth.mutate(g4, 0.03, rng)            # sibling species: shared k-mers -> LCA = genus 2
+    g6 = synth.procedural_genome(7, 6, 3000)
+    gp = np.concatenate([g6[2000:2300], synth.procedural_genome(7, 99, 300)])  # plasmid shares 300 bp with S6
+    genomes = {4: g4, 5: g5, 6: g6, 1000000001: gp}
+    kmers, vals = synth.lca_database(genomes, tax, K)
+    # a few DB k-mers whose taxid is absent from taxDB and a zero-valued entry (found, but taxon 0)
+    extra = synth.canonical(synth.kmers_forward(synth.procedural_genome(7, 1234, 200), K), K)
+    extra = np.setdiff1d(np.unique(extra), kmers)
+    kmers = np.concatenate([kmers, extra])
+    vals = np.concatenate([vals, np.where(np.arange(len(extra)) % 2 == 0, 777, 0).astype(np.uint32)])
+    genomes_for_reads = dict(genomes)
+    genomes_for_reads[777] = synth.procedural_genome(7, 1234, 200)
+    perm = rng.permutation(len(kmers))
+    synth.write_jdb(os.path.join(d, "database.jdb"), kmers[perm], vals[perm], K)
+    run([os.path.join(REF, "db_sort"), "-n", str(NT), "-d", f"{d}/database.jdb", "-o", f"{d}/database.kdb",
+         "-i", f"{d}/database.idx"])
+    os.remove(os.path.join(d, "database.jdb"))
+    tax.write(os.path.join(d, "taxDB"))
+    # our own writer must reproduce the reference's db_sort byte for byte
+    sk, sv, off = synth.sort_db(kmers, vals, K, NT)
+    synth.write_db(os.path.join(d, "_mine"), sk, sv, off, K, NT)
+    for fn in ("database.kdb", "database.idx"):
+        a = open(os.path.join(d, fn), "rb").read()
+        b = open(os.path.join(d, "_mine", fn), "rb").read()
+        assert a == b, f"synth.write_db differs from reference db_sort for {fn}"
+    shutil.rmtree(os.path.join(d, "_mine"))
+
+    reads, src = synth.sample_reads(genomes_for_reads, 1000, 150, rng, frac_random=0.25)
+    ids = [f"r{i}_t{t}" for i, t in enumerate(src)]
+    synth.write_fastq(os.path.join(d, "reads.fq"), reads, ids)
+
+    rd = [f"{d}/reads.fq"]
+    classify(d, ["-o", f"{d}/out.tsv", "-r", f"{d}/report.tsv"], rd)          # writes .counts too
+    classify(d, ["-o", f"{d}/out_exact.tsv", "-r", f"{d}/report_exact.tsv"], rd, "classifyExact")
+    classify(d, ["-u", "1000", "-o", f"{d}/out_u1000.tsv", "-r", f"{d}/report_u1000.tsv"], rd)
+    classify(d, ["-x", "70K", "-t", "2", "-o", f"{d}/out_chunk.tsv", "-r", f"{d}/report_chunk.tsv"], rd)
+    classify(d, ["-q", "-m", "2", "-o", f"{d}/out_quick.tsv"], rd)
+    classify(d, ["-c", "-o", f"{d}/out_c.tsv"], rd)
+    classify(d, ["-s", "-o", f"{d}/out_s.tsv"], rd)
+    assert open(f"{d}/out.tsv", "rb").read() == open(f"{d}/out_exact.tsv", "rb").read()
+    os.remove(f"{d}/out_exact.tsv")
+    return d, genomes_for_reads
+
+
+def make_f2(f1):
+    d = os.path.join(HERE, "f2")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    ids, seqs = synth.read_seqfile(os.path.join(f1, "reads.fq"))
+    hit = next(s for i, s in zip(ids, seqs) if i.endswith("_t4") and b"N" not in s)
+    recs = [
+        ("short", hit[:8]),
+        ("exactk", hit[:31]),
+        ("kminus1", hit[:30]),
+        ("withN", hit[:40] + b"N" + hit[41:79]),
+        ("empty", b""),
+        ("lower", hit.lower()),
+        ("mixed", hit[:75] + hit[75:].lower()),
+        ("iupac", hit[:60] + b"R" + hit[61:100] + b"y" + hit[101:]),
+        ("allN", b"N" * 64),
+        ("long", hit + hit[::-1] + hit),
+    ]
+    with open(os.path.join(d, "edge.fa"), "wb") as f:
+        for rid, s in recs:
+            f.write(b">" + rid.encode() + b" some description\n")
+            if rid == "long":  # multi-line record
+                for i in range(0, len(s), 60):
+                    f.write(s[i:i + 60] + b"\n")
+            else:
+                f.write(s + b"\n")
+    classify(f1, ["-o", f"{d}/out.tsv", "-r", f"{d}/report.tsv"], [f"{d}/edge.fa"])
+    return d
+
+
+def make_f4(f1, genomes):
+    d = os.path.join(HERE, "f4")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    rng = np.random.default_rng(11)
+    r1, s1 = synth.sample_reads(genomes, 200, 150, rng, frac_random=0.25, n_rate=0.003)
+    r2 = []
+    for a, t in zip(r1, s1):
+        if t == 0:
+            r2.append(synth.codes_to_ascii(rng.integers(0, 4, 150, dtype=np.uint8)))
+        else:
+            g = genomes[t]
+            s = int(rng.integers(0, max(1, len(g) - 150 + 1)))
+            r2.append(synth.codes_to_ascii(synth.revcomp_codes(g[s:s + 150])))
+    synth.write_fastq(os.path.join(d, "r_1.fq"), r1, [f"p{i}_t{t}/1" for i, t in enumerate(s1)])
+    synth.write_fastq(os.path.join(d, "r_2.fq"), r2, [f"p{i}_t{t}/2" for i, t in enumerate(s1)])
+    merged = run(["perl", MERGER, "--check-names", f"{d}/r_1.fq", f"{d}/r_2.fq"]).stdout
+    open(os.path.join(d, "merged.fa"), "wb").write(merged)
+    classify(f1, ["-o", f"{d}/out.tsv", "-r", f"{d}/report.tsv"], [f"{d}/merged.fa"])
+    return d
+
+
+def make_f7(f1):
+    """Same pairs under a legacy type-1 (unscrambled KRAKIDX) index."""
+    d = os.path.join(HERE, "f7")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    kmers, vals, _, k, nt, _ = synth.read_db(f1)
+    bk = synth.bin_key(kmers, k, nt, idx_type=1)
+    order = np.lexsort((kmers, bk))
+    counts = np.bincount(bk.astype(np.int64), minlength=4 ** nt)
+    off = np.zeros(4 ** nt + 1, dtype=np.uint64)
+    np.cumsum(counts, out=off[1:])
+    synth.write_db(d, kmers[order], vals[order], off, k, nt)
+    raw = bytearray(open(f"{d}/database.idx", "rb").read())
+    raw[:7] = b"KRAKIDX"
+    open(f"{d}/database.idx", "wb").write(bytes(raw))
+    shutil.copy(f"{f1}/taxDB", f"{d}/taxDB")
+    classify(d, ["-o", f"{d}/out.tsv", "-r", f"{d}/report.tsv"], [f"{f1}/reads.fq"])
+    assert open(f"{d}/out.tsv", "rb").read() == open(f"{f1}/out.tsv", "rb").read()
+    os.remove(f"{d}/database.kdb.counts")
+    return d
+
+
+class Kat:
+    def __init__(self):
+        self.p = subprocess.Popen([os.path.join(REF, "ref_kat")], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, text=True, bufsize=1)
+
+    def cmd(self, line, nlines=1):
+        self.p.stdin.write(line + "\n")
+        self.p.stdin.flush()
+        return [self.p.stdout.readline().rstrip("\n") for _ in range(nlines)]
+
+    def scan(self, seq):
+        self.p.stdin.write(f"SCAN {seq}\n")
+        self.p.stdin.flush()
+        n = int(self.p.stdout.readline())
+        return [self.p.stdout.readline().split() for _ in range(n)]
+
+
+def make_kat(f1):
+    rng = np.random.default_rng(3)
+    kat = {"k": K}
+    h = Kat()
+    h.cmd(f"K {K}")
+    h.cmd("IDX 2 7")
+    # scanner / canonical
+    seqs = ["ACGTTGCAAGGCTTAACCGGTTAGCATCGATCGGATATCGCGNACGTACGTTAGC"]
+    for L in (31, 32, 60, 150):
+        s = bytearray(synth.codes_to_ascii(rng.integers(0, 4, L, dtype=np.uint8)))
+        if L > 40:
+            s[int(rng.integers(0, L))] = ord("N")
+            s[int(rng.integers(0, L))] = ord("c")
+            s[int(rng.integers(0, L))] = ord("t")
+        seqs.append(s.decode())
+    kat["scan"] = [{"seq": s, "kmers": h.scan(s)} for s in seqs]
+    # canonical / revcomp for n in {7, 13, 15, 31}
+    vals = [int(x) for x in rng.integers(0, 2 ** 62, 64, dtype=np.uint64)]
+    kat["canon"] = []
+    for n in (7, 12, 13, 15, 31):
+        for v in vals[:16]:
+            v &= (1 << (2 * n)) - 1
+            kat["canon"].append({"x": f"{v:016x}", "n": n, "rc": h.cmd(f"RC {v:016x} {n}")[0],
+                                 "canon": h.cmd(f"CANON {v:016x} {n}")[0]})
+    # bin keys of canonical k-mers
+    kat["binkey"] = []
+    for v in vals:
+        c = int(synth.canonical(np.array([v], dtype=np.uint64), K)[0])
+        row = {"kmer": f"{c:016x}"}
+        for nt in (7, 10, 12, 13, 15):
+            row[f"nt{nt}"] = int(h.cmd(f"BINKEY {c:016x} {nt}")[0])
+        kat["binkey"].append(row)
+    h.cmd("IDX 1 7")
+    kat["binkey_type1_nt7"] = [{"kmer": r["kmer"], "bin": int(h.cmd(f"BINKEY1 {r['kmer']}")[0])}
+                               for r in kat["binkey"][:16]]
+    h.cmd("IDX 2 7")
+    # hash
+    hv = [0, 1, 42, 0x0123456789ABCDEF, 0xFFFFFFFFFFFFFFFF] + vals[:27]
+    kat["hash"] = [{"x": f"{v:016x}", "h": h.cmd(f"HASH {v:016x}")[0]} for v in hv]
+    # kmer_query on the f1 database: all DB k-mers are hits; random ones are misses
+    h.cmd(f"OPEN {f1}/database.kdb {f1}/database.idx")
+    kmers, dbvals, _, _, _, _ = synth.read_db(f1)
+    pick = rng.choice(len(kmers), 200, replace=False)
+    q = [int(kmers[i]) for i in pick] + [int(synth.canonical(np.array([v], dtype=np.uint64), K)[0]) for v in vals]
+    kat["query"] = [{"kmer": f"{v:016x}", "val": int(h.cmd(f"QUERY {v:016x}")[0])} for v in q]
+    # lca / resolve_tree on a random tree (ids sparse, incl. >= 1e9, an orphan, a self-parent)
+    ids = sorted(set(int(x) for x in rng.integers(2, 5000, 60)))
+    parent = {1: 1}
+    for i, t in enumerate(ids):
+        parent[t] = 1 if i < 4 else ids[int(rng.integers(0, i))]
+    parent[1000000005] = ids[10]
+    parent[1000000006] = 1000000005
+    parent[7001] = 9999      # orphan: parent id has no entry
+    parent[7002] = 7002      # self-parent (not root)
+    pm = {t: (0 if (p == t or p not in parent) else p) for t, p in parent.items()}  # Parent_map semantics
+    h.cmd("PARENT " + " ".join(f"{a}:{b}" for a, b in pm.items()))
+    allids = list(pm.keys())
+    kat["tree"] = {"parent_map": {str(a): b for a, b in pm.items()}, "lca": [], "resolve": []}
+    for _ in range(200):
+        a, b = (allids[int(rng.integers(0, len(allids)))] for _ in range(2))
+        if rng.random() < 0.1:
+            a = 0
+        kat["tree"]["lca"].append([a, b, int(h.cmd(f"LCA {a} {b}")[0])])
+    fixed = [{4: 3, 5: 3}, {}, {ids[5]: 2, ids[6]: 2, ids[0]: 1}, {7001: 3}, {7002: 1, ids[3]: 1}, {8888: 2},
+             {8888: 2, ids[2]: 2}]
+    for i in range(200):
+        if i < len(fixed):
+            hits = fixed[i]
+        else:
+            n = int(rng.integers(1, 7))
+            hits = {allids[int(rng.integers(0, len(allids)))]: int(rng.integers(1, 4)) for _ in range(n)}
+        res = int(h.cmd("RESOLVE " + " ".join(f"{a}:{b}" for a, b in hits.items()))[0])
+        kat["tree"]["resolve"].append({"hits": {str(a): b for a, b in hits.items()}, "call": res})
+    # HLL
+    kat["hll"] = []
+    sid = 0
+    mult = "9E3779B97F4A7C15"
+    for n in (1, 10, 100, 1000, 1023, 1024, 1025, 1026, 2000, 10000, 100000, 1000000):
+        for sparse in (1, 0):
+            for use_n in (0, 1):
+                h.cmd(f"HNEW {sid} 12 {sparse}")
+                h.cmd(f"HUSEN {sid} {use_n}")
+                h.cmd(f"HSEQ {sid} {n} {mult} 0")
+                ertl, heule, flaj, nobs, sp, lsz = h.cmd(f"HCARD {sid}")[0].split()
+                kat["hll"].append({"n": n, "sparse_start": sparse, "use_n": use_n, "ertl": int(ertl),
+                                   "n_observed": int(nobs), "is_sparse": int(sp), "list_size": int(lsz)})
+                sid += 1
+    # duplicates do not grow the sparse set but the 1025th *insert call* is what switches
+    h.cmd(f"HNEW {sid} 12 1"); h.cmd(f"HUSEN {sid} 0")
+    h.cmd(f"HSEQ {sid} 1024 {mult} 0"); a = h.cmd(f"HCARD {sid}")[0]
+    h.cmd(f"HSEQ {sid} 1 {mult} 5"); b = h.cmd(f"HCARD {sid}")[0]
+    kat["hll_dup_switch"] = {"after_1024": a, "after_dup_insert": b}
+    sid += 1
+    # state dumps + merges (sparse+sparse beyond 1024 stays sparse; dense+sparse; sparse+dense; dense+dense)
+    kat["hll_merge"] = []
+    for (na, sa, nb, sb) in ((600, 1, 600, 1), (3000, 1, 600, 1), (600, 1, 3000, 1), (3000, 1, 5000, 1),
+                             (0, 1, 700, 1), (700, 1, 0, 1), (50, 0, 50, 1)):
+        A, B = sid, sid + 1
+        sid += 2
+        h.cmd(f"HNEW {A} 12 {sa}"); h.cmd(f"HNEW {B} 12 {sb}")
+        h.cmd(f"HUSEN {A} 1"); h.cmd(f"HUSEN {B} 1")
+        if na: h.cmd(f"HSEQ {A} {na} {mult} 0")
+        if nb: h.cmd(f"HSEQ {B} {nb} {mult} {na // 2}")
+        h.cmd(f"HMERGE {A} {B}")
+        card = h.cmd(f"HCARD {A}")[0].split()
+        dump = h.cmd(f"HDUMP {A}")[0].split()
+        kat["hll_merge"].append({"na": na, "sa": sa, "nb": nb, "sb": sb, "start_b": na // 2, "ertl": int(card[0]),
+                                 "n_observed": int(card[3]), "is_sparse": int(card[4]), "kind": dump[0],
+                                 "state": [int(x) for x in dump[1:]]})
+    # small dumps of sparse lists / registers for exact state parity
+    kat["hll_state"] = []
+    for n, sparse in ((300, 1), (1025, 1), (5000, 0)):
+        h.cmd(f"HNEW {sid} 12 {sparse}")
+        h.cmd(f"HSEQ {sid} {n} {mult} 0")
+        dump = h.cmd(f"HDUMP {sid}")[0].split()
+        kat["hll_state"].append({"n": n, "sparse_start": sparse, "kind": dump[0], "state": [int(x) for x in dump[1:]]})
+        sid += 1
+    h.p.stdin.close()
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, separators=(",", ":"))
+
+
+def main():
+    if not os.path.exists(os.path.join(REF, "classify")):
+        raise SystemExit("build the reference first: make -C oracle ref")
+    f1, genomes = make_f1()
+    make_f2(f1)
+    make_f4(f1, genomes)
+    make_f7(f1)
+    make_kat(f1)
+    # count_unique known answer (HLL p=12 on the reads' k-mers)
+    r = run([os.path.join(REF, "count_unique"), "-k", "31", "-p", "12"], stdin=open(f"{HERE}/f2/edge.fa", "rb"))
+    open(os.path.join(HERE, "count_unique_edge.txt"), "wb").write(r.stdout)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
