@@ -1,0 +1,234 @@
+/* krakenuniq_amd.h -- C ABI of the MI355X-native KrakenUniq classify hot path.
+ *
+ * The reference (fbreitwieser/krakenuniq v1.0.4) has no library API: the
+ * boundary is the `classify` executable (src/classify.cpp) that
+ * scripts/krakenuniq:248 spawns.  This header is the thin C layer between that
+ * executable's host code (this repo's krakenuniq_amd/csrc/classify_main.cpp,
+ * flag-compatible with src/classify.cpp:1074) and the HIP kernels.  Every entry
+ * point names the reference code it replaces (file:line under the reference's
+ * src/).  Conventions: extern "C", opaque handles, plain pointers + sizes, int
+ * status (0 = KU_OK, negative = KU_E*), no exceptions / exit() inside the
+ * library, calls on one ku_ctx are serialised by the caller.  There is NO CPU
+ * fallback: every compute entry point fails with KU_EHIP when no gfx950 device
+ * is usable.
+ */
+#ifndef KRAKENUNIQ_AMD_H
+#define KRAKENUNIQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KU_ABI_VERSION 1
+
+/* status codes (the CLI maps them to the reference's sysexits, classify.cpp:1085-1131) */
+#define KU_OK 0
+#define KU_EINVAL (-1)   /* bad argument / flag           -> EX_USAGE   64 */
+#define KU_EDATA (-2)    /* malformed kdb/idx/taxDB       -> EX_DATAERR 65 */
+#define KU_ENOINPUT (-3) /* cannot open a file            -> EX_NOINPUT 66 */
+#define KU_ENOMEM (-4)   /* host or device allocation     -> EX_OSERR   71 */
+#define KU_EHIP (-5)     /* HIP runtime / no usable GPU   -> EX_SOFTWARE 70 */
+#define KU_ESTATE (-6)   /* call order violated           -> EX_SOFTWARE 70 */
+#define KU_EUNSUP (-7)   /* valid in the reference, not built here */
+
+/* Per-k-mer code for an ambiguous k-mer (classify.cpp:920-923 "ambig_list=1"). */
+#define KU_AMBIG 0xFFFFFFFFu
+/* HLL precision: the reference always runs p = 12 (hyperloglogplus.hpp:87; -p is a no-op). */
+#define KU_HLL_P 12
+#define KU_HLL_M 4096
+
+const char *ku_strerror(int status);
+/* thread-local detail for the last failing call on this thread ("" if none) */
+const char *ku_last_error(void);
+int ku_abi_version(void);
+/* number of usable gfx950 devices (0 when none; never fails) */
+int ku_device_count(void);
+
+/* ------------------------------------------------------------------ database
+ * Host view of database.kdb + database.idx.
+ * Replaces KrakenDB::KrakenDB / KrakenDBIndex::KrakenDBIndex + QuickFile mmap
+ * (krakendb.cpp:60-78,534-544; quickfile.cpp:44-78). */
+typedef struct ku_db ku_db;
+typedef struct ku_db_info {
+  uint32_t k;          /* key_bits / 2                       (krakendb.cpp:75) */
+  uint32_t nt;         /* minimizer length                   (krakendb.cpp:543) */
+  uint32_t idx_type;   /* 1 = KRAKIDX, 2 = KRAKIX2 scrambled (krakendb.cpp:536-541) */
+  uint32_t key_len;    /* bytes per key on disk              (krakendb.cpp:76) */
+  uint64_t key_ct;     /* pairs                              (krakendb.cpp:72) */
+  uint64_t n_bins;     /* 4^nt */
+} ku_db_info;
+
+int ku_db_open(const char *kdb_path, const char *idx_path, ku_db **out);
+/* Wrap caller-owned host memory laid out as on disk (pairs: key_ct * (key_len+4)
+ * bytes; offsets: 4^nt + 1 pair indices). */
+int ku_db_wrap(const void *pairs, uint64_t key_ct, uint32_t k, const uint64_t *offsets, uint32_t nt,
+               uint32_t idx_type, ku_db **out);
+void ku_db_close(ku_db *db);
+int ku_db_get_info(const ku_db *db, ku_db_info *out);
+/* Split the bin space into n_shards contiguous minimizer ranges of balanced
+ * bytes (8 per bin + pair_size per pair) -- the multi-GPU analogue of
+ * KrakenDB::prepare_chunking / upper_bound (krakendb.cpp:430-522).
+ * bin_bounds[n_shards + 1], bin_bounds[0] = 0, bin_bounds[n_shards] = 4^nt. */
+int ku_db_shard_plan(const ku_db *db, uint32_t n_shards, uint64_t *bin_bounds);
+/* Chunk plan for a byte budget, exactly as prepare_chunking computes it
+ * (krakendb.cpp:463-522): returns the number of chunks and fills up to
+ * cap + 1 bounds.  Chunks with zero pairs are skipped like the reference, so the
+ * last bound may be < 4^nt: the bins behind it hold no pairs (a caller that
+ * shards by these bounds extends the last chunk to 4^nt). */
+int ku_db_chunk_plan(const ku_db *db, uint64_t max_bytes, uint64_t *bin_bounds, uint32_t cap,
+                     uint32_t *n_chunks);
+
+/* ------------------------------------------------------------------ taxonomy
+ * Host taxonomy: taxDB text -> entries + Parent_map
+ * (taxdb.hpp:563-605 readTaxonomyIndex_, :411-433 createPointers, :383-398 getParentMap). */
+typedef struct ku_tax ku_tax;
+int ku_tax_open(const char *taxdb_path, ku_tax **out);
+/* ids/parents as in the taxDB file (self-parent or unknown parent = no parent) */
+int ku_tax_from_arrays(const uint32_t *ids, const uint32_t *parents, uint64_t n, ku_tax **out);
+void ku_tax_close(ku_tax *tax);
+uint64_t ku_tax_size(const ku_tax *tax);
+/* Parent_map value, 0 = none/root; returns KU_AMBIG when the taxid has no entry */
+uint32_t ku_tax_parent(const ku_tax *tax, uint32_t taxid);
+
+/* ------------------------------------------------------------------ device context
+ * One per GPU.  Holds the resident DB shard (12-byte pairs + offsets slice), the
+ * dense taxonomy tables, and the run's per-taxon state (HLL registers, n_kmers,
+ * n_reads) -- the device twin of the global `taxon_counts` map (classify.cpp:78). */
+typedef struct ku_ctx ku_ctx;
+int ku_ctx_create(int device, ku_ctx **out);
+void ku_ctx_destroy(ku_ctx *ctx);
+
+/* Upload the shard [bin_lo, bin_hi) of a host DB.  Device twin of
+ * QuickFile::load_file (-M, quickfile.cpp:80-117) / KrakenDB::load_chunk (-x,
+ * krakendb.cpp:411-425). */
+int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi);
+/* Adopt a shard that is already in HBM (bench / on-device DB construction):
+ * d_pairs = n_pairs 12-byte (8-byte LE key, 4-byte LE taxid) records of the
+ * bins [bin_lo, bin_hi); d_offsets = bin_hi - bin_lo + 1 uint64 *global* pair
+ * indices whose first entry is the global index of d_pairs[0].  The buffers
+ * stay owned by the caller and must outlive the context; values are remapped
+ * in place by ku_ctx_set_taxonomy. */
+int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, const uint64_t *d_offsets, uint32_t k,
+                    uint32_t nt, uint32_t idx_type, uint64_t bin_lo, uint64_t bin_hi);
+/* Distinct non-zero taxids stored in the resident shard, ascending (what
+ * KrakenDB::count_taxons enumerates, krakendb.cpp:90-113).  Call with out = NULL
+ * to get *n. */
+int ku_ctx_db_values(ku_ctx *ctx, uint32_t *out, uint64_t *n);
+/* Install the taxonomy and freeze the slot table.  all_values = ascending
+ * distinct taxids over ALL shards of the database (NULL = this shard only; in
+ * the sharded multi-GPU run the caller all-gathers ku_ctx_db_values first so
+ * every rank numbers slots identically).  Remaps the resident values to slot
+ * ids and allocates/zeroes the per-taxon state. */
+int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_t *all_values, uint64_t n_values);
+/* Per-taxid pair counts of the resident shard = database.kdb.counts content
+ * (KrakenDB::count_taxons, krakendb.cpp:90-113; classify.cpp:275-283), ascending
+ * taxid, includes value 0 if present.  out arrays sized via n (NULL to query). */
+int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *counts, uint64_t *n);
+/* zero HLL registers / n_kmers / n_reads (start of a run) */
+int ku_ctx_reset_counts(ku_ctx *ctx);
+
+/* ------------------------------------------------------------------ classification */
+#define KU_F_QUICK 0x1u        /* -q : stop at min_hits hits (classify.cpp:943-944,962-963) */
+#define KU_F_NO_COUNTS 0x2u    /* do not touch HLL / n_kmers / n_reads (pure lookup) */
+#define KU_F_KEEP_SLOTS 0x4u   /* leave taxa[] as internal slot ids (multi-GPU reduce stage) */
+
+typedef struct ku_opts {
+  uint32_t flags;
+  uint32_t min_hits;     /* -m, used with KU_F_QUICK (classify.cpp:101) */
+  uint32_t max_read_len; /* upper bound of seq_len[] in the batch; 0 = let the library find it */
+  uint32_t reserved;
+} ku_opts;
+
+/* Read batch layout (host or device): `seqs` is a byte buffer of n_bytes in which
+ * read i occupies seqs[seq_off[i] .. seq_off[i]+seq_len[i]) and is followed by
+ * at least one byte that is not one of ACGTacgt (raw FASTA/FASTQ text with its
+ * line terminators qualifies).  Any byte outside ACGTacgt makes the k-mers that
+ * cover it ambiguous (krakenutil.cpp:252-274); '\n'/'\r' *inside* a read are
+ * not skipped (the reference's readers never leave them there).
+ * Per-k-mer output `taxa` is parallel to `seqs`: taxa[seq_off[i] + j] is the
+ * taxid (0 = miss, KU_AMBIG = ambiguous) of the k-mer starting at base j of read
+ * i, j < seq_len[i]-k+1; other entries are unspecified.  `calls[i]` is the
+ * read's taxid (0 = unclassified); `hits[i]` (optional, may be NULL) is the
+ * quick-mode hit counter printed as "Q:n". */
+
+/* Whole hot path for one batch on host buffers (H2D + kernels + D2H, blocking):
+ * classify_sequence for every read (classify.cpp:897-968) + the merge into the
+ * global per-taxon counts (classify.cpp:541-544). */
+int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                      const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                      uint32_t *taxa, uint32_t *hits);
+
+/* Same on device-resident buffers, asynchronous on `stream` (a hipStream_t
+ * passed as void*; NULL = the context's own stream). */
+int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
+                             const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
+                             uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream);
+
+/* The two stages separately (sharded multi-GPU run: lookup on every rank, RCCL
+ * max-reduce of d_taxa, resolve on the reads each rank owns):
+ *  stage 1 = KmerScanner + canonical_representation + bin_key + kmer_query for
+ *            every k-mer whose bin this context owns + ReadCounts::add_kmer
+ *            (krakenutil.cpp:237-282, krakendb.cpp:200-321, classify.cpp:918-939;
+ *            ownership test = is_minimizer_in_chunk, krakendb.cpp:524-526);
+ *            writes slot ids (0 where not owned / miss, KU_AMBIG where ambiguous).
+ *  stage 2 = hit_counts + resolve_tree + incrementReadCount (classify.cpp:941-968,
+ *            krakenutil.cpp:149-200) and slot -> taxid translation of d_taxa. */
+int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const ku_opts *opts,
+                     uint32_t *d_taxa, void *stream);
+int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
+                      uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls, uint32_t *d_taxa,
+                      uint32_t *d_hits, void *stream);
+int ku_ctx_synchronize(ku_ctx *ctx);
+
+/* ------------------------------------------------------------------ per-taxon state
+ * Export of the run's `taxon_counts` (classify.cpp:78): one row per slot
+ * (slot 0 = taxid 0 = "no hit") with its k-mer count and dense p=12 registers,
+ * plus read counts per called taxid. */
+typedef struct ku_counts_dims {
+  uint64_t n_slots;  /* rows of slot_taxid / n_kmers / registers (includes slot 0) */
+  uint64_t n_nodes;  /* rows of node_taxid / n_reads */
+} ku_counts_dims;
+int ku_counts_dims_get(ku_ctx *ctx, ku_counts_dims *out);
+/* Any output pointer may be NULL.  registers: n_slots * 4096 bytes. */
+int ku_counts_export(ku_ctx *ctx, uint32_t *slot_taxid, uint64_t *n_kmers, uint8_t *registers,
+                     uint32_t *node_taxid, uint64_t *n_reads);
+/* Device pointers of the live state for in-place RCCL reduction at the end of a
+ * sharded run (max on registers, sum on the counters). */
+int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_register_bytes,
+                          uint64_t **d_n_kmers, uint64_t *n_slots, uint64_t **d_n_reads, uint64_t *n_nodes);
+
+/* ------------------------------------------------------------------ host-side helpers
+ * (double arithmetic / text; the reference does these on the host too) */
+/* Ertl improved estimator on dense registers, clipped to n_observed
+ * (HyperLogLogPlusMinus::ertlCardinality, hyperloglogplus.cpp:722-753). */
+uint64_t ku_hll_cardinality(const uint8_t *registers, uint32_t p, uint64_t n_observed);
+/* hitlist_string (classify.cpp:826-861): RLE of one read's codes; returns bytes
+ * written (buf must hold 24 * n + 8 bytes). */
+size_t ku_hitlist_string(const uint32_t *taxa, size_t n, char *buf);
+/* Kraken output lines for a batch (classify.cpp:980-1010).  ids: NUL-separated
+ * read ids (header up to first whitespace, seqreader.cpp:57-58).  flags:
+ * KU_P_ONLY_CLASSIFIED (-c), KU_P_SEQUENCE (-s), KU_P_QUICK.  Returns a
+ * malloc'ed buffer in *out (free with ku_free) and its length. */
+#define KU_P_ONLY_CLASSIFIED 0x1u
+#define KU_P_SEQUENCE 0x2u
+#define KU_P_QUICK 0x4u
+int ku_format_kraken(const char *seqs, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
+                     const char *ids, uint32_t k, const uint32_t *calls, const uint32_t *taxa,
+                     const uint32_t *hits, uint32_t flags, char **out, size_t *out_len);
+/* Report with the reference's default columns
+ * "%  reads  taxReads  kmers  dup  cov  taxID  rank  taxName"
+ * (TaxReport, taxdb.hpp:928-1123; classify.cpp:288-325).  counts_path =
+ * database.kdb.counts (NULL -> cov = NA).  Rows for sibling taxa with equal
+ * (reads, kmers) are ordered by ascending taxid (unspecified in the reference). */
+int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_taxid, const uint64_t *n_kmers,
+              const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads,
+              uint64_t n_nodes, char **out, size_t *out_len);
+void ku_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRAKENUNIQ_AMD_H */

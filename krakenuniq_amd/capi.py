@@ -1,0 +1,325 @@
+"""ctypes binding of libkrakenuniq_amd.so (the C ABI in include/krakenuniq_amd.h).
+
+Thin plumbing only: every method maps 1:1 onto a ku_* entry point and raises
+KuError on a non-zero status.  There is no Python/CPU classification fallback:
+if the shared library (HIP kernels included) is missing, importing fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkrakenuniq_amd.so")
+
+KU_AMBIG = 0xFFFFFFFF
+KU_HLL_M = 4096
+KU_F_QUICK, KU_F_NO_COUNTS, KU_F_KEEP_SLOTS = 1, 2, 4
+KU_P_ONLY_CLASSIFIED, KU_P_SEQUENCE, KU_P_QUICK = 1, 2, 4
+
+u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+
+class KuError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        detail = lib().ku_last_error().decode()
+        super().__init__(f"{where}: {lib().ku_strerror(status).decode()} ({status}): {detail}")
+
+
+class DbInfo(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("nt", C.c_uint32), ("idx_type", C.c_uint32), ("key_len", C.c_uint32),
+                ("key_ct", C.c_uint64), ("n_bins", C.c_uint64)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("min_hits", C.c_uint32), ("max_read_len", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class CountsDims(C.Structure):
+    _fields_ = [("n_slots", C.c_uint64), ("n_nodes", C.c_uint64)]
+
+
+# name -> (restype, argtypes); mirrors include/krakenuniq_amd.h one to one
+SIGNATURES = {
+    "ku_strerror": (C.c_char_p, [C.c_int]),
+    "ku_last_error": (C.c_char_p, []),
+    "ku_abi_version": (C.c_int, []),
+    "ku_device_count": (C.c_int, []),
+    "ku_db_open": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ku_db_wrap": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                             C.POINTER(C.c_void_p)]),
+    "ku_db_close": (None, [C.c_void_p]),
+    "ku_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(DbInfo)]),
+    "ku_db_shard_plan": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
+    "ku_db_chunk_plan": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_uint32, u32p]),
+    "ku_tax_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ku_tax_from_arrays": (C.c_int, [u32p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ku_tax_close": (None, [C.c_void_p]),
+    "ku_tax_size": (C.c_uint64, [C.c_void_p]),
+    "ku_tax_parent": (C.c_uint32, [C.c_void_p, C.c_uint32]),
+    "ku_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ku_ctx_destroy": (None, [C.c_void_p]),
+    "ku_ctx_load_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "ku_ctx_adopt_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, C.c_uint64, C.c_uint64]),
+    "ku_ctx_db_values": (C.c_int, [C.c_void_p, u32p, u64p]),
+    "ku_ctx_set_taxonomy": (C.c_int, [C.c_void_p, C.c_void_p, u32p, C.c_uint64]),
+    "ku_ctx_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
+    "ku_ctx_reset_counts": (C.c_int, [C.c_void_p]),
+    "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
+                                    u32p, u32p, u32p]),
+    "ku_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                           C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ku_lookup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Opts), C.c_void_p, C.c_void_p]),
+    "ku_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Opts),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ku_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "ku_counts_dims_get": (C.c_int, [C.c_void_p, C.POINTER(CountsDims)]),
+    "ku_counts_export": (C.c_int, [C.c_void_p, u32p, u64p, u8p, u32p, u64p]),
+    "ku_counts_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p), u64p,
+                                        C.POINTER(C.c_void_p), u64p]),
+    "ku_hll_cardinality": (C.c_uint64, [u8p, C.c_uint32, C.c_uint64]),
+    "ku_hitlist_string": (C.c_size_t, [u32p, C.c_size_t, C.c_char_p]),
+    "ku_format_kraken": (C.c_int, [C.c_void_p, u64p, u32p, C.c_uint64, C.c_char_p, C.c_uint32, u32p, u32p, u32p,
+                                   C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_report": (C.c_int, [C.c_void_p, C.c_char_p, u32p, u64p, u8p, C.c_uint64, u32p, u64p, C.c_uint64,
+                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_free": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C krakenuniq_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the ABI symbol is not exported
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(status, where):
+    if status != 0:
+        raise KuError(status, where)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Db:
+    """Host view of database.kdb/.idx (ku_db)."""
+
+    def __init__(self, kdb=None, idx=None, pairs=None, key_ct=None, k=None, offsets=None, nt=None, idx_type=2):
+        self.h = C.c_void_p()
+        if kdb is not None:
+            _chk(lib().ku_db_open(kdb.encode(), idx.encode(), C.byref(self.h)), "ku_db_open")
+        else:
+            self._keep = (pairs, offsets)
+            _chk(lib().ku_db_wrap(pairs.ctypes.data, key_ct, k, offsets.ctypes.data, nt, idx_type, C.byref(self.h)),
+                 "ku_db_wrap")
+        self.info = DbInfo()
+        _chk(lib().ku_db_get_info(self.h, C.byref(self.info)), "ku_db_get_info")
+
+    def close(self):
+        if self.h:
+            lib().ku_db_close(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def shard_plan(self, n):
+        b = np.zeros(n + 1, dtype=np.uint64)
+        _chk(lib().ku_db_shard_plan(self.h, n, _p(b, u64p)), "ku_db_shard_plan")
+        return b
+
+    def chunk_plan(self, max_bytes, cap=4096):
+        b = np.zeros(cap + 1, dtype=np.uint64)
+        n = C.c_uint32()
+        _chk(lib().ku_db_chunk_plan(self.h, max_bytes, _p(b, u64p), cap, C.byref(n)), "ku_db_chunk_plan")
+        return b[:n.value + 1]
+
+
+class Tax:
+    """Host taxonomy (ku_tax)."""
+
+    def __init__(self, path=None, ids=None, parents=None):
+        self.h = C.c_void_p()
+        if path is not None:
+            _chk(lib().ku_tax_open(path.encode(), C.byref(self.h)), "ku_tax_open")
+        else:
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            parents = np.ascontiguousarray(parents, dtype=np.uint32)
+            _chk(lib().ku_tax_from_arrays(_p(ids, u32p), _p(parents, u32p), len(ids), C.byref(self.h)),
+                 "ku_tax_from_arrays")
+
+    def close(self):
+        if self.h:
+            lib().ku_tax_close(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def parent(self, taxid):
+        return lib().ku_tax_parent(self.h, taxid)
+
+    def __len__(self):
+        return lib().ku_tax_size(self.h)
+
+
+class Ctx:
+    """Per-GPU context (ku_ctx)."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().ku_ctx_create(device, C.byref(self.h)), "ku_ctx_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ku_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def load_db(self, db: Db, bin_lo=0, bin_hi=None):
+        if bin_hi is None:
+            bin_hi = db.info.n_bins
+        _chk(lib().ku_ctx_load_db(self.h, db.h, bin_lo, bin_hi), "ku_ctx_load_db")
+
+    def adopt_db(self, d_pairs_ptr, n_pairs, d_offsets_ptr, k, nt, idx_type=2, bin_lo=0, bin_hi=None, keep=None):
+        if bin_hi is None:
+            bin_hi = 4 ** nt
+        self._keep.append(keep)
+        _chk(lib().ku_ctx_adopt_db(self.h, d_pairs_ptr, n_pairs, d_offsets_ptr, k, nt, idx_type, bin_lo, bin_hi),
+             "ku_ctx_adopt_db")
+
+    def db_values(self):
+        n = C.c_uint64()
+        _chk(lib().ku_ctx_db_values(self.h, None, C.byref(n)), "ku_ctx_db_values")
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        n2 = C.c_uint64(len(out))
+        _chk(lib().ku_ctx_db_values(self.h, _p(out, u32p), C.byref(n2)), "ku_ctx_db_values")
+        return out[:n2.value]
+
+    def set_taxonomy(self, tax: Tax, all_values=None):
+        if all_values is None:
+            _chk(lib().ku_ctx_set_taxonomy(self.h, tax.h, None, 0), "ku_ctx_set_taxonomy")
+        else:
+            v = np.ascontiguousarray(all_values, dtype=np.uint32)
+            _chk(lib().ku_ctx_set_taxonomy(self.h, tax.h, _p(v, u32p), len(v)), "ku_ctx_set_taxonomy")
+
+    def count_taxons(self):
+        n = C.c_uint64()
+        _chk(lib().ku_ctx_count_taxons(self.h, None, None, C.byref(n)), "ku_ctx_count_taxons")
+        t = np.zeros(max(n.value, 1), dtype=np.uint32)
+        c = np.zeros(max(n.value, 1), dtype=np.uint64)
+        n2 = C.c_uint64(len(t))
+        _chk(lib().ku_ctx_count_taxons(self.h, _p(t, u32p), _p(c, u64p), C.byref(n2)), "ku_ctx_count_taxons")
+        return t[:n2.value], c[:n2.value]
+
+    def reset_counts(self):
+        _chk(lib().ku_ctx_reset_counts(self.h), "ku_ctx_reset_counts")
+
+    def classify_batch(self, buf, off, lens, flags=0, min_hits=1, want_taxa=True):
+        """Host-buffer entry point.  buf: bytes/np.uint8 with a non-ACGT byte after every read."""
+        arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        calls = np.zeros(max(n, 1), dtype=np.uint32)
+        hits = np.zeros(max(n, 1), dtype=np.uint32)
+        taxa = np.zeros(max(len(arr), 1), dtype=np.uint32) if want_taxa else None
+        o = Opts(flags, min_hits, 0, 0)
+        _chk(lib().ku_classify_batch(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n, C.byref(o),
+                                     _p(calls, u32p), _p(taxa, u32p), _p(hits, u32p)), "ku_classify_batch")
+        return {"calls": calls[:n], "taxa": taxa, "hits": hits[:n]}
+
+    def lookup_device(self, d_seqs, n_bytes, d_taxa, flags=0, stream=None):
+        o = Opts(flags, 1, 0, 0)
+        _chk(lib().ku_lookup_device(self.h, d_seqs, n_bytes, C.byref(o), d_taxa, stream), "ku_lookup_device")
+
+    def resolve_device(self, d_seqs, d_off, d_len, n_reads, d_calls, d_taxa, d_hits=None, flags=0, min_hits=1,
+                       max_read_len=0, stream=None):
+        o = Opts(flags, min_hits, max_read_len, 0)
+        _chk(lib().ku_resolve_device(self.h, d_seqs, d_off, d_len, n_reads, C.byref(o), d_calls, d_taxa, d_hits,
+                                     stream), "ku_resolve_device")
+
+    def classify_batch_device(self, d_seqs, n_bytes, d_off, d_len, n_reads, d_calls, d_taxa, d_hits=None, flags=0,
+                              min_hits=1, max_read_len=0, stream=None):
+        o = Opts(flags, min_hits, max_read_len, 0)
+        _chk(lib().ku_classify_batch_device(self.h, d_seqs, n_bytes, d_off, d_len, n_reads, C.byref(o), d_calls,
+                                            d_taxa, d_hits, stream), "ku_classify_batch_device")
+
+    def synchronize(self):
+        _chk(lib().ku_ctx_synchronize(self.h), "ku_ctx_synchronize")
+
+    def counts(self):
+        d = CountsDims()
+        _chk(lib().ku_counts_dims_get(self.h, C.byref(d)), "ku_counts_dims_get")
+        ns, nn = d.n_slots, d.n_nodes
+        out = {"slot_taxid": np.zeros(ns, dtype=np.uint32), "n_kmers": np.zeros(ns, dtype=np.uint64),
+               "registers": np.zeros((ns, KU_HLL_M), dtype=np.uint8), "node_taxid": np.zeros(nn, dtype=np.uint32),
+               "n_reads": np.zeros(nn, dtype=np.uint64)}
+        _chk(lib().ku_counts_export(self.h, _p(out["slot_taxid"], u32p), _p(out["n_kmers"], u64p),
+                                    _p(out["registers"], u8p), _p(out["node_taxid"], u32p), _p(out["n_reads"], u64p)),
+             "ku_counts_export")
+        return out
+
+    def counts_device_ptrs(self):
+        r, k, n = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nb, ns, nn = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().ku_counts_device_ptrs(self.h, C.byref(r), C.byref(nb), C.byref(k), C.byref(ns), C.byref(n),
+                                         C.byref(nn)), "ku_counts_device_ptrs")
+        return {"registers": r.value, "register_bytes": nb.value, "n_kmers": k.value, "n_slots": ns.value,
+                "n_reads": n.value, "n_nodes": nn.value}
+
+
+def hll_cardinality(registers, n_observed, p=12):
+    r = np.ascontiguousarray(registers, dtype=np.uint8)
+    return lib().ku_hll_cardinality(_p(r, u8p), p, int(n_observed))
+
+
+def hitlist_string(taxa):
+    t = np.ascontiguousarray(taxa, dtype=np.uint32)
+    buf = C.create_string_buffer(24 * len(t) + 16)
+    n = lib().ku_hitlist_string(_p(t, u32p), len(t), buf)
+    return buf.raw[:n].decode()
+
+
+def format_kraken(buf, off, lens, ids, k, calls, taxa=None, hits=None, flags=0):
+    arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    calls = np.ascontiguousarray(calls, dtype=np.uint32)
+    idbuf = b"".join(i.encode() + b"\0" for i in ids)
+    out, n = C.c_void_p(), C.c_size_t()
+    _chk(lib().ku_format_kraken(arr.ctypes.data, _p(off, u64p), _p(lens, u32p), len(lens), idbuf, k,
+                                _p(calls, u32p), _p(taxa, u32p), _p(hits, u32p), flags, C.byref(out), C.byref(n)),
+         "ku_format_kraken")
+    s = C.string_at(out, n.value).decode()
+    lib().ku_free(out)
+    return s
+
+
+def report(tax: Tax, counts: dict, counts_path=None):
+    out, n = C.c_void_p(), C.c_size_t()
+    regs = np.ascontiguousarray(counts["registers"], dtype=np.uint8)
+    _chk(lib().ku_report(tax.h, counts_path.encode() if counts_path else None, _p(counts["slot_taxid"], u32p),
+                         _p(counts["n_kmers"], u64p), _p(regs, u8p), len(counts["slot_taxid"]),
+                         _p(counts["node_taxid"], u32p), _p(counts["n_reads"], u64p), len(counts["node_taxid"]),
+                         C.byref(out), C.byref(n)), "ku_report")
+    s = C.string_at(out, n.value).decode()
+    lib().ku_free(out)
+    return s

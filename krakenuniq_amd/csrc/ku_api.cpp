@@ -1,0 +1,699 @@
+// ku_api.cpp -- C-ABI entry points (include/krakenuniq_amd.h): host-side database /
+// taxonomy objects and the per-GPU context that owns the resident shard, the dense
+// taxonomy tables and the per-taxon run state.  Compiled with hipcc together with
+// ku_kernels.hip into libkrakenuniq_amd.so.  No CPU classification path exists
+// here: every compute entry point needs a usable gfx950 device.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ku_host.h"
+#include "ku_internal.h"
+
+// ---------------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+void ku_set_error(const std::string &s) { g_last_error = s; }
+static int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(e_ == hipErrorOutOfMemory ? KU_ENOMEM : KU_EHIP,                             \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                          \
+  } while (0)
+#define KU_TRY(expr)            \
+  do {                          \
+    int s_ = (expr);            \
+    if (s_ != KU_OK) return s_; \
+  } while (0)
+
+extern "C" const char *ku_strerror(int status) {
+  switch (status) {
+    case KU_OK: return "ok";
+    case KU_EINVAL: return "invalid argument";
+    case KU_EDATA: return "malformed database / index / taxonomy data";
+    case KU_ENOINPUT: return "cannot open input";
+    case KU_ENOMEM: return "out of memory";
+    case KU_EHIP: return "HIP runtime error or no usable gfx950 device";
+    case KU_ESTATE: return "call order violated";
+    case KU_EUNSUP: return "not supported by this build";
+    default: return "unknown status";
+  }
+}
+extern "C" const char *ku_last_error(void) { return g_last_error.c_str(); }
+extern "C" int ku_abi_version(void) { return KU_ABI_VERSION; }
+extern "C" int ku_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---------------------------------------------------------------------------- ku_db
+struct ku_db {
+  const uint8_t *pairs = nullptr;
+  const uint64_t *offsets = nullptr;
+  ku_db_info info{};
+  void *map_kdb = nullptr, *map_idx = nullptr;
+  size_t map_kdb_sz = 0, map_idx_sz = 0;
+};
+
+static void *map_file(const char *path, size_t *sz) {
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) return nullptr;
+  struct stat st;
+  if (fstat(fd, &st) != 0) { close(fd); return nullptr; }
+  void *p = st.st_size ? mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : MAP_FAILED;
+  close(fd);
+  if (p == MAP_FAILED) return nullptr;
+  *sz = (size_t)st.st_size;
+  return p;
+}
+
+static int db_validate(ku_db *db) {
+  const ku_db_info &i = db->info;
+  if (i.k < 1 || i.k > 31) return fail(KU_EDATA, "k must be in [1,31]");
+  // KrakenDB::bin_key computes its mask in 32-bit int (krakendb.cpp:204): nt <= 15
+  if (i.nt < 1 || i.nt > 15 || i.nt > i.k) return fail(KU_EDATA, "minimizer length must be in [1,min(15,k)]");
+  if (i.idx_type != 1 && i.idx_type != 2) return fail(KU_EDATA, "illegal Kraken DB index format");
+  return KU_OK;
+}
+
+extern "C" int ku_db_open(const char *kdb_path, const char *idx_path, ku_db **out) {
+  if (!kdb_path || !idx_path || !out) return fail(KU_EINVAL, "ku_db_open: null argument");
+  *out = nullptr;
+  ku_db *db = new ku_db();
+  db->map_kdb = map_file(kdb_path, &db->map_kdb_sz);
+  if (!db->map_kdb) { delete db; return fail(KU_ENOINPUT, std::string("can't open ") + kdb_path); }
+  db->map_idx = map_file(idx_path, &db->map_idx_sz);
+  if (!db->map_idx) { ku_db_close(db); return fail(KU_ENOINPUT, std::string("can't open ") + idx_path); }
+  const uint8_t *kp = (const uint8_t *)db->map_kdb, *ip = (const uint8_t *)db->map_idx;
+  // krakendb.cpp:67-77
+  if (db->map_kdb_sz < 72 || memcmp(kp, "JFLISTDN", 8) != 0) {
+    ku_db_close(db);
+    return fail(KU_EDATA, "database in improper format");
+  }
+  uint64_t key_bits, val_len, key_ct;
+  memcpy(&key_bits, kp + 8, 8);
+  memcpy(&val_len, kp + 16, 8);
+  memcpy(&key_ct, kp + 48, 8);
+  if (val_len != 4) { ku_db_close(db); return fail(KU_EDATA, "can only handle 4 byte DB values"); }
+  if (key_bits == 0 || key_bits > 62 || (key_bits & 1)) { ku_db_close(db); return fail(KU_EDATA, "unsupported key_bits"); }
+  size_t hdr = 72 + 2 * (4 + 8 * key_bits);  // krakendb.cpp:177
+  db->info.k = (uint32_t)(key_bits / 2);
+  db->info.key_len = (uint32_t)(key_bits / 8 + !!(key_bits % 8));
+  db->info.key_ct = key_ct;
+  if (db->map_kdb_sz < hdr + key_ct * (db->info.key_len + 4)) { ku_db_close(db); return fail(KU_EDATA, "database file truncated"); }
+  db->pairs = kp + hdr;
+  // krakendb.cpp:534-544
+  if (db->map_idx_sz < 8) { ku_db_close(db); return fail(KU_EDATA, "illegal Kraken DB index format"); }
+  if (memcmp(ip, "KRAKIDX", 7) == 0) db->info.idx_type = 1;
+  else if (memcmp(ip, "KRAKIX2", 7) == 0) db->info.idx_type = 2;
+  else { ku_db_close(db); return fail(KU_EDATA, "illegal Kraken DB index format"); }
+  db->info.nt = ip[7];
+  int st = db_validate(db);
+  if (st != KU_OK) { ku_db_close(db); return st; }
+  db->info.n_bins = 1ull << (2 * db->info.nt);
+  if (db->map_idx_sz < 8 + 8 * (db->info.n_bins + 1)) { ku_db_close(db); return fail(KU_EDATA, "index file truncated"); }
+  db->offsets = (const uint64_t *)(ip + 8);
+  if (db->offsets[db->info.n_bins] != key_ct) { ku_db_close(db); return fail(KU_EDATA, "index does not match database (last offset != key_ct)"); }
+  *out = db;
+  return KU_OK;
+}
+
+extern "C" int ku_db_wrap(const void *pairs, uint64_t key_ct, uint32_t k, const uint64_t *offsets, uint32_t nt,
+                          uint32_t idx_type, ku_db **out) {
+  if (!out || (!pairs && key_ct) || !offsets) return fail(KU_EINVAL, "ku_db_wrap: null argument");
+  ku_db *db = new ku_db();
+  db->pairs = (const uint8_t *)pairs;
+  db->offsets = offsets;
+  db->info.k = k; db->info.nt = nt; db->info.idx_type = idx_type;
+  db->info.key_len = (2 * k + 7) / 8;
+  db->info.key_ct = key_ct;
+  int st = db_validate(db);
+  if (st != KU_OK) { delete db; return st; }
+  db->info.n_bins = 1ull << (2 * nt);
+  *out = db;
+  return KU_OK;
+}
+
+extern "C" void ku_db_close(ku_db *db) {
+  if (!db) return;
+  if (db->map_kdb) munmap(db->map_kdb, db->map_kdb_sz);
+  if (db->map_idx) munmap(db->map_idx, db->map_idx_sz);
+  delete db;
+}
+
+extern "C" int ku_db_get_info(const ku_db *db, ku_db_info *out) {
+  if (!db || !out) return fail(KU_EINVAL, "ku_db_get_info: null argument");
+  *out = db->info;
+  return KU_OK;
+}
+
+extern "C" int ku_db_shard_plan(const ku_db *db, uint32_t n_shards, uint64_t *bounds) {
+  if (!db || !bounds || n_shards == 0) return fail(KU_EINVAL, "ku_db_shard_plan: bad argument");
+  const uint64_t nb = db->info.n_bins, ps = db->info.key_len + 4;
+  auto cost = [&](uint64_t b) { return 8 * b + ps * db->offsets[b]; };  // bytes of bins [0, b)
+  const uint64_t total = cost(nb);
+  bounds[0] = 0;
+  for (uint32_t s = 1; s < n_shards; ++s) {
+    // smallest b with cost(b) >= total * s / n_shards (monotone in b)
+    unsigned __int128 target = (unsigned __int128)total * s / n_shards;
+    uint64_t lo = bounds[s - 1], hi = nb;
+    while (lo < hi) {
+      uint64_t mid = lo + (hi - lo) / 2;
+      if ((unsigned __int128)cost(mid) < target) lo = mid + 1; else hi = mid;
+    }
+    bounds[s] = lo;
+  }
+  bounds[n_shards] = nb;
+  return KU_OK;
+}
+
+extern "C" int ku_db_chunk_plan(const ku_db *db, uint64_t max_bytes, uint64_t *bounds, uint32_t cap,
+                                uint32_t *n_chunks) {
+  if (!db || !bounds || !n_chunks) return fail(KU_EINVAL, "ku_db_chunk_plan: null argument");
+  const uint64_t nb = db->info.n_bins, ps = db->info.key_len + 4;
+  uint64_t idx_pos = 0;
+  uint32_t n = 0;
+  bounds[0] = 0;
+  uint64_t last_dbx = 0;
+  while (idx_pos < nb) {
+    // KrakenDB::upper_bound (krakendb.cpp:430-461): first bin that no longer fits
+    uint64_t first = idx_pos, count = nb - idx_pos;
+    const uint64_t orig = idx_pos, data0 = db->offsets[orig];
+    while (count > 0) {
+      uint64_t step = count / 2, it = first + step;
+      uint64_t size_index = (it + 1 - orig) * 8;
+      uint64_t size_data = (db->offsets[it + 1] - data0) * ps;
+      if (size_index + size_data + 8 <= max_bytes) { first = it + 1; count -= step + 1; }
+      else count = step;
+    }
+    if (first == idx_pos) return fail(KU_EINVAL, "preload size too small for the largest minimizer bin");
+    idx_pos = first;
+    uint64_t dbx = db->offsets[idx_pos];
+    if (dbx == last_dbx) continue;  // chunk without k-mers is skipped (krakendb.cpp:497-498)
+    last_dbx = dbx;
+    ++n;
+    if (n <= cap) bounds[n] = idx_pos;
+  }
+  *n_chunks = n;
+  return n <= cap ? KU_OK : fail(KU_EINVAL, "ku_db_chunk_plan: bounds array too small");
+}
+
+// ---------------------------------------------------------------------------- ku_tax
+extern "C" int ku_tax_open(const char *path, ku_tax **out) {
+  if (!path || !out) return fail(KU_EINVAL, "ku_tax_open: null argument");
+  *out = nullptr;
+  FILE *f = fopen(path, "r");
+  if (!f) return fail(KU_ENOINPUT, std::string("unable to open taxonomy index file ") + path);
+  ku_tax *t = new ku_tax();
+  // taxdb.hpp:581-597: "id <ws> parent <tab> name <tab> rank-to-end-of-line"
+  char *line = nullptr;
+  size_t lcap = 0;
+  ssize_t ll;
+  while ((ll = getline(&line, &lcap, f)) > 0) {
+    if (line[ll - 1] == '\n') line[--ll] = 0;
+    if (ll == 0) continue;
+    char *p = line, *end;
+    unsigned long id = strtoul(p, &end, 10);
+    if (end == p) continue;
+    p = end;
+    unsigned long par = strtoul(p, &end, 10);
+    if (end == p) continue;
+    p = end;
+    if (*p) ++p;
+    char *tab = strchr(p, '\t');
+    std::string name, rank;
+    if (tab) { name.assign(p, tab - p); rank.assign(tab + 1); } else name.assign(p);
+    if ((uint32_t)id > 1 && id == par) {  // taxdb.hpp:583-586: fatal in the reference
+      free(line); fclose(f); delete t;
+      return fail(KU_EDATA, "taxDB: the parent of " + std::to_string(id) + " is itself");
+    }
+    t->add((uint32_t)id, (uint32_t)par, name, rank);
+  }
+  free(line);
+  fclose(f);
+  t->add(0, 0, "unclassified", "no rank");  // taxdb.hpp:599
+  t->finish();
+  *out = t;
+  return KU_OK;
+}
+
+extern "C" int ku_tax_from_arrays(const uint32_t *ids, const uint32_t *parents, uint64_t n, ku_tax **out) {
+  if (!out || (n && (!ids || !parents))) return fail(KU_EINVAL, "ku_tax_from_arrays: null argument");
+  ku_tax *t = new ku_tax();
+  for (uint64_t i = 0; i < n; ++i) t->add(ids[i], parents[i], "", "");
+  t->add(0, 0, "unclassified", "no rank");
+  t->finish();
+  *out = t;
+  return KU_OK;
+}
+extern "C" void ku_tax_close(ku_tax *t) { delete t; }
+extern "C" uint64_t ku_tax_size(const ku_tax *t) { return t ? t->ids.size() : 0; }
+extern "C" uint32_t ku_tax_parent(const ku_tax *t, uint32_t taxid) {
+  if (!t || taxid == 0) return KU_AMBIG;  // getParentMap skips key 0 (taxdb.hpp:388-389)
+  auto it = t->row.find(taxid);
+  return it == t->row.end() ? KU_AMBIG : t->parent_map[it->second];
+}
+
+// ---------------------------------------------------------------------------- ku_ctx
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return KU_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return KU_ENOMEM; }
+      want = bytes;
+    }
+    cap = want;
+    return KU_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ku_ctx {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  // DB shard
+  bool db_loaded = false, db_owned = false, tax_set = false;
+  uint32_t *d_pairs = nullptr;
+  uint64_t *d_offsets = nullptr;
+  bool offsets_owned = false;
+  KuDbDev db{};
+  std::vector<uint32_t> values;  // ascending distinct non-zero raw taxids of the shard
+  // taxonomy tables
+  std::vector<uint32_t> h_node_taxid, h_slot_taxid;
+  uint32_t *d_node_parent = nullptr, *d_node_slot = nullptr, *d_node_taxid = nullptr, *d_slot_node = nullptr,
+           *d_slot_taxid = nullptr;
+  KuTaxDev tax{};
+  // run state
+  KuCountsDev cnt{};
+  // scratch for the host-buffer entry point
+  DevBuf b_seqs, b_off, b_len, b_calls, b_taxa, b_hits, b_ws;
+  uint32_t *d_scalar = nullptr;
+};
+
+static int ctx_activate(ku_ctx *ctx) {
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(KU_EHIP, "hipSetDevice failed");
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_create(int device, ku_ctx **out) {
+  if (!out) return fail(KU_EINVAL, "ku_ctx_create: null argument");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KU_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(KU_EINVAL, "device index out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(KU_EHIP, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  ku_ctx *ctx = new ku_ctx();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void **)&ctx->d_scalar, 64));
+  *out = ctx;
+  return KU_OK;
+}
+
+static void ctx_free_db(ku_ctx *ctx) {
+  if (ctx->db_owned && ctx->d_pairs) (void)hipFree(ctx->d_pairs);
+  if (ctx->offsets_owned && ctx->d_offsets) (void)hipFree(ctx->d_offsets);
+  ctx->d_pairs = nullptr; ctx->d_offsets = nullptr;
+  ctx->db_loaded = ctx->db_owned = ctx->offsets_owned = false;
+}
+static void ctx_free_tax(ku_ctx *ctx) {
+  for (uint32_t **p : {&ctx->d_node_parent, &ctx->d_node_slot, &ctx->d_node_taxid, &ctx->d_slot_node, &ctx->d_slot_taxid}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  if (ctx->cnt.registers) (void)hipFree(ctx->cnt.registers);
+  if (ctx->cnt.n_kmers) (void)hipFree(ctx->cnt.n_kmers);
+  if (ctx->cnt.n_reads) (void)hipFree(ctx->cnt.n_reads);
+  ctx->cnt = KuCountsDev{};
+  ctx->tax_set = false;
+}
+
+extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx_free_db(ctx);
+  ctx_free_tax(ctx);
+  for (DevBuf *b : {&ctx->b_seqs, &ctx->b_off, &ctx->b_len, &ctx->b_calls, &ctx->b_taxa, &ctx->b_hits, &ctx->b_ws}) b->release();
+  if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// distinct values of the resident shard via a 2^32-bit bitmap (512 MiB scratch)
+static int ctx_scan_values(ku_ctx *ctx) {
+  ctx->values.clear();
+  uint32_t *d_bitmap = nullptr, *d_list = nullptr, *d_count = ctx->d_scalar;
+  const uint32_t cap = 1u << 24;
+  HIP_TRY(hipMalloc((void **)&d_bitmap, 1ull << 29));
+  if (hipMalloc((void **)&d_list, (size_t)cap * 4) != hipSuccess) { (void)hipFree(d_bitmap); return fail(KU_ENOMEM, "hipMalloc values list"); }
+  int st = KU_OK;
+  uint32_t count = 0;
+  if (hipMemsetAsync(d_bitmap, 0, 1ull << 29, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(d_count, 0, 4, ctx->stream) != hipSuccess)
+    st = fail(KU_EHIP, "memset failed");
+  if (st == KU_OK) st = ku_launch_mark_values(ctx->d_pairs, ctx->db.n_pairs, d_bitmap, ctx->stream);
+  if (st == KU_OK) st = ku_launch_collect_values(d_bitmap, d_list, cap, d_count, ctx->stream);
+  if (st == KU_OK && hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = fail(KU_EHIP, "memcpy failed");
+  if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(KU_EHIP, "value scan kernel failed");
+  if (st == KU_OK && count > cap) st = fail(KU_EUNSUP, "more than 2^24 distinct taxids in the database");
+  if (st == KU_OK) {
+    ctx->values.resize(count);
+    if (count && hipMemcpy(ctx->values.data(), d_list, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) st = fail(KU_EHIP, "memcpy failed");
+    std::sort(ctx->values.begin(), ctx->values.end());
+    if (!ctx->values.empty() && ctx->values[0] == 0) ctx->values.erase(ctx->values.begin());
+  }
+  (void)hipFree(d_bitmap);
+  (void)hipFree(d_list);
+  return st;
+}
+
+static void fill_db_dev(ku_ctx *ctx, uint64_t n_pairs, uint64_t pair_base, uint32_t k, uint32_t nt, uint32_t idx_type,
+                        uint64_t bin_lo, uint64_t bin_hi) {
+  ctx->db.pairs = ctx->d_pairs;
+  ctx->db.offsets = ctx->d_offsets;
+  ctx->db.pair_base = pair_base;
+  ctx->db.n_pairs = n_pairs;
+  ctx->db.bin_lo = bin_lo;
+  ctx->db.bin_hi = bin_hi;
+  ctx->db.k = k;
+  ctx->db.nt = nt;
+  const uint64_t INDEX2_XOR_MASK = 0xe37e28c4271b5a2dULL;  // krakendb.cpp:45
+  ctx->db.xor_mask = idx_type == 1 ? 0u : (uint32_t)(INDEX2_XOR_MASK & ((1ull << (2 * nt)) - 1));
+}
+
+extern "C" int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
+  if (!ctx || !db) return fail(KU_EINVAL, "ku_ctx_load_db: null argument");
+  if (bin_lo > bin_hi || bin_hi > db->info.n_bins) return fail(KU_EINVAL, "bin range out of bounds");
+  KU_TRY(ctx_activate(ctx));
+  ctx_free_tax(ctx);
+  ctx_free_db(ctx);
+  const uint64_t p0 = db->offsets[bin_lo], p1 = db->offsets[bin_hi], np = p1 - p0;
+  const uint32_t kl = db->info.key_len, ps = kl + 4;
+  HIP_TRY(hipMalloc((void **)&ctx->d_pairs, std::max<uint64_t>(np, 1) * 12));
+  ctx->db_owned = true;
+  if (kl == 8) {
+    if (np) HIP_TRY(hipMemcpy(ctx->d_pairs, db->pairs + p0 * 12, np * 12, hipMemcpyHostToDevice));
+  } else if (np) {
+    void *d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_raw, np * ps));
+    hipError_t e = hipMemcpy(d_raw, db->pairs + p0 * ps, np * ps, hipMemcpyHostToDevice);
+    int st = e == hipSuccess ? ku_launch_repack((const uint8_t *)d_raw, np, kl, ctx->d_pairs, ctx->stream) : KU_EHIP;
+    if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
+    (void)hipFree(d_raw);
+    if (st != KU_OK) return fail(st, "pair repack failed");
+  }
+  const uint64_t no = bin_hi - bin_lo + 1;
+  HIP_TRY(hipMalloc((void **)&ctx->d_offsets, no * 8));
+  ctx->offsets_owned = true;
+  HIP_TRY(hipMemcpy(ctx->d_offsets, db->offsets + bin_lo, no * 8, hipMemcpyHostToDevice));
+  fill_db_dev(ctx, np, p0, db->info.k, db->info.nt, db->info.idx_type, bin_lo, bin_hi);
+  ctx->db_loaded = true;
+  return ctx_scan_values(ctx);
+}
+
+extern "C" int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, const uint64_t *d_offsets, uint32_t k,
+                               uint32_t nt, uint32_t idx_type, uint64_t bin_lo, uint64_t bin_hi) {
+  if (!ctx || (!d_pairs && n_pairs) || !d_offsets) return fail(KU_EINVAL, "ku_ctx_adopt_db: null argument");
+  if (k < 1 || k > 31 || nt < 1 || nt > 15 || nt > k || (idx_type != 1 && idx_type != 2) || bin_lo > bin_hi ||
+      bin_hi > (1ull << (2 * nt)))
+    return fail(KU_EINVAL, "ku_ctx_adopt_db: bad geometry");
+  KU_TRY(ctx_activate(ctx));
+  ctx_free_tax(ctx);
+  ctx_free_db(ctx);
+  ctx->d_pairs = (uint32_t *)d_pairs;
+  ctx->d_offsets = const_cast<uint64_t *>(d_offsets);
+  uint64_t pair_base = 0;
+  HIP_TRY(hipMemcpy(&pair_base, d_offsets, 8, hipMemcpyDeviceToHost));
+  fill_db_dev(ctx, n_pairs, pair_base, k, nt, idx_type, bin_lo, bin_hi);
+  ctx->db_loaded = true;
+  return ctx_scan_values(ctx);
+}
+
+extern "C" int ku_ctx_db_values(ku_ctx *ctx, uint32_t *out, uint64_t *n) {
+  if (!ctx || !n) return fail(KU_EINVAL, "ku_ctx_db_values: null argument");
+  if (!ctx->db_loaded) return fail(KU_ESTATE, "no database loaded");
+  if (out) {
+    if (*n < ctx->values.size()) return fail(KU_EINVAL, "output array too small");
+    if (!ctx->values.empty()) memcpy(out, ctx->values.data(), ctx->values.size() * 4);
+  }
+  *n = ctx->values.size();
+  return KU_OK;
+}
+
+template <typename T> static int upload(T **dst, const std::vector<T> &src) {
+  HIP_TRY(hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_t *all_values, uint64_t n_values) {
+  if (!ctx || !tax) return fail(KU_EINVAL, "ku_ctx_set_taxonomy: null argument");
+  if (!ctx->db_loaded) return fail(KU_ESTATE, "load a database before the taxonomy");
+  if (ctx->tax_set) return fail(KU_ESTATE, "taxonomy already set for this shard (values are remapped once)");
+  KU_TRY(ctx_activate(ctx));
+  // slot table: 0 + ascending distinct DB values (over all shards when given)
+  std::vector<uint32_t> slots;
+  slots.push_back(0);
+  if (all_values) {
+    for (uint64_t i = 0; i < n_values; ++i) if (all_values[i]) slots.push_back(all_values[i]);
+    std::sort(slots.begin() + 1, slots.end());
+    slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+    if (!std::includes(slots.begin(), slots.end(), ctx->values.begin(), ctx->values.end()))
+      return fail(KU_EINVAL, "all_values does not cover this shard's values");
+  } else {
+    slots.insert(slots.end(), ctx->values.begin(), ctx->values.end());
+  }
+  // node universe: taxDB ids U DB values U {0, 1}, ascending => node 0 = taxid 0, node 1 = taxid 1
+  std::vector<uint32_t> nodes(tax->ids);
+  nodes.insert(nodes.end(), slots.begin(), slots.end());
+  nodes.push_back(0);
+  nodes.push_back(1);
+  std::sort(nodes.begin(), nodes.end());
+  nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+  auto node_of = [&](uint32_t taxid) { return (uint32_t)(std::lower_bound(nodes.begin(), nodes.end(), taxid) - nodes.begin()); };
+  std::vector<uint32_t> node_parent(nodes.size(), 0), node_slot(nodes.size(), 0), slot_node(slots.size(), 0);
+  for (size_t i = 0; i < tax->ids.size(); ++i) {
+    uint32_t p = tax->parent_map[i];  // Parent_map semantics: 0 = none
+    if (tax->ids[i] != 0 && p != 0) node_parent[node_of(tax->ids[i])] = node_of(p);
+  }
+  for (size_t s = 1; s < slots.size(); ++s) {
+    uint32_t nd = node_of(slots[s]);
+    slot_node[s] = nd;
+    node_slot[nd] = (uint32_t)s;
+  }
+  ctx_free_tax(ctx);
+  ctx->h_node_taxid = nodes;
+  ctx->h_slot_taxid = slots;
+  KU_TRY(upload(&ctx->d_node_parent, node_parent));
+  KU_TRY(upload(&ctx->d_node_slot, node_slot));
+  KU_TRY(upload(&ctx->d_node_taxid, nodes));
+  KU_TRY(upload(&ctx->d_slot_node, slot_node));
+  KU_TRY(upload(&ctx->d_slot_taxid, slots));
+  ctx->tax.node_parent = ctx->d_node_parent;
+  ctx->tax.node_slot = ctx->d_node_slot;
+  ctx->tax.node_taxid = ctx->d_node_taxid;
+  ctx->tax.slot_node = ctx->d_slot_node;
+  ctx->tax.slot_taxid = ctx->d_slot_taxid;
+  ctx->tax.n_nodes = (uint32_t)nodes.size();
+  ctx->tax.n_slots = (uint32_t)slots.size();
+  ctx->tax.node_one = 1;
+  // raw taxid -> slot id, in place
+  HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, 4, ctx->stream));
+  KU_TRY(ku_launch_remap_values(ctx->d_pairs, ctx->db.n_pairs, ctx->d_slot_taxid, ctx->tax.n_slots, ctx->d_scalar, ctx->stream));
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, ctx->d_scalar, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (err) return fail(KU_EDATA, "internal: " + std::to_string(err) + " DB values missing from the slot table");
+  // per-taxon state
+  HIP_TRY(hipMalloc((void **)&ctx->cnt.registers, (size_t)slots.size() * KU_HLL_M));
+  HIP_TRY(hipMalloc((void **)&ctx->cnt.n_kmers, slots.size() * 8));
+  HIP_TRY(hipMalloc((void **)&ctx->cnt.n_reads, nodes.size() * 8));
+  ctx->tax_set = true;
+  return ku_ctx_reset_counts(ctx);
+}
+
+extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
+  if (!ctx || !ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  KU_TRY(ctx_activate(ctx));
+  HIP_TRY(hipMemsetAsync(ctx->cnt.registers, 0, (size_t)ctx->tax.n_slots * KU_HLL_M, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->cnt.n_kmers, 0, (size_t)ctx->tax.n_slots * 8, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->cnt.n_reads, 0, (size_t)ctx->tax.n_nodes * 8, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *counts, uint64_t *n) {
+  if (!ctx || !n) return fail(KU_EINVAL, "ku_ctx_count_taxons: null argument");
+  if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  KU_TRY(ctx_activate(ctx));
+  const uint32_t ns = ctx->tax.n_slots;
+  unsigned long long *d_c = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_c, (size_t)ns * 8));
+  std::vector<unsigned long long> h(ns);
+  int st = KU_OK;
+  if (hipMemsetAsync(d_c, 0, (size_t)ns * 8, ctx->stream) != hipSuccess) st = KU_EHIP;
+  if (st == KU_OK) st = ku_launch_count_slots(ctx->d_pairs, ctx->db.n_pairs, d_c, ns, ctx->stream);
+  if (st == KU_OK && hipMemcpyAsync(h.data(), d_c, (size_t)ns * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = KU_EHIP;
+  if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
+  (void)hipFree(d_c);
+  if (st != KU_OK) return fail(st, "count_taxons kernel failed");
+  uint64_t m = 0;
+  for (uint32_t s = 0; s < ns; ++s) if (h[s]) ++m;
+  if (taxids && counts) {
+    if (*n < m) return fail(KU_EINVAL, "output arrays too small");
+    uint64_t j = 0;
+    for (uint32_t s = 0; s < ns; ++s) if (h[s]) { taxids[j] = ctx->h_slot_taxid[s]; counts[j] = h[s]; ++j; }
+  }
+  *n = m;
+  return KU_OK;
+}
+
+// ---------------------------------------------------------------------------- classification
+static int check_ready(ku_ctx *ctx) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  if (!ctx->db_loaded) return fail(KU_ESTATE, "no database loaded");
+  if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  return ctx_activate(ctx);
+}
+
+extern "C" int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const ku_opts *opts,
+                                uint32_t *d_taxa, void *stream) {
+  KU_TRY(check_ready(ctx));
+  if (n_bytes && (!d_seqs || !d_taxa)) return fail(KU_EINVAL, "ku_lookup_device: null buffer");
+  const uint32_t flags = opts ? opts->flags : 0;
+  // quick mode counts only the scanned prefix of each read -> accounted in the resolve stage
+  const bool counts = !(flags & (KU_F_NO_COUNTS | KU_F_QUICK));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int st = ku_launch_lookup(ctx->db, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_taxa, counts, ctx->n_cu, s);
+  return st == KU_OK ? KU_OK : fail(st, "lookup kernel launch failed");
+}
+
+extern "C" int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
+                                 uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls, uint32_t *d_taxa,
+                                 uint32_t *d_hits, void *stream) {
+  KU_TRY(check_ready(ctx));
+  if (n_reads && (!d_seq_off || !d_seq_len || !d_calls || !d_taxa)) return fail(KU_EINVAL, "ku_resolve_device: null buffer");
+  const uint32_t flags = opts ? opts->flags : 0;
+  if ((flags & KU_F_QUICK) && !d_seqs) return fail(KU_EINVAL, "quick mode needs the sequence buffer");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  uint32_t max_len = opts ? opts->max_read_len : 0;
+  if (max_len == 0 && n_reads) {
+    KU_TRY(ku_launch_max_len(d_seq_len, n_reads, ctx->d_scalar + 4, s));
+    HIP_TRY(hipMemcpyAsync(&max_len, ctx->d_scalar + 4, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  uint64_t ws = (flags & KU_F_QUICK) ? 0 : ku_resolve_workspace_bytes(max_len, ctx->db.k, ctx->n_cu);
+  if (ws > ctx->b_ws.cap) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ctx->b_ws.reserve(ws) != KU_OK) return fail(KU_ENOMEM, "resolve workspace allocation failed");
+  }
+  if (ws) HIP_TRY(hipMemsetAsync(ctx->b_ws.p, 0, ws, s));
+  int st = ku_launch_resolve(ctx->db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, flags,
+                             opts ? opts->min_hits : 1, max_len, d_calls, d_taxa, d_hits, ctx->b_ws.p, ctx->b_ws.cap,
+                             ctx->n_cu, s);
+  return st == KU_OK ? KU_OK : fail(st, "resolve kernel launch failed");
+}
+
+extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
+                                        const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
+                                        uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream) {
+  KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, opts, d_taxa, stream));
+  return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, opts, d_calls, d_taxa, d_hits, stream);
+}
+
+extern "C" int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                                 const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                                 uint32_t *taxa, uint32_t *hits) {
+  KU_TRY(check_ready(ctx));
+  if ((n_bytes && !seqs) || (n_reads && (!seq_off || !seq_len || !calls))) return fail(KU_EINVAL, "ku_classify_batch: null buffer");
+  if (n_reads == 0) return KU_OK;
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  if (o.max_read_len == 0) for (uint64_t i = 0; i < n_reads; ++i) o.max_read_len = std::max(o.max_read_len, seq_len[i]);
+  for (uint64_t i = 0; i < n_reads; ++i)
+    if (seq_off[i] + seq_len[i] > n_bytes) return fail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
+  if (ctx->b_seqs.reserve(n_bytes + 16) || ctx->b_off.reserve(n_reads * 8) || ctx->b_len.reserve(n_reads * 4) ||
+      ctx->b_calls.reserve(n_reads * 4) || ctx->b_taxa.reserve((n_bytes + 16) * 4) || ctx->b_hits.reserve(n_reads * 4))
+    return fail(KU_ENOMEM, "device batch buffers");
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->b_seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_off.p, seq_off, n_reads * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_len.p, seq_len, n_reads * 4, hipMemcpyHostToDevice, s));
+  KU_TRY(ku_classify_batch_device(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
+                                  n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
+                                  (uint32_t *)ctx->b_hits.p, s));
+  HIP_TRY(hipMemcpyAsync(calls, ctx->b_calls.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  if (taxa) HIP_TRY(hipMemcpyAsync(taxa, ctx->b_taxa.p, n_bytes * 4, hipMemcpyDeviceToHost, s));
+  if (hits) HIP_TRY(hipMemcpyAsync(hits, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_synchronize(ku_ctx *ctx) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  KU_TRY(ctx_activate(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return KU_OK;
+}
+
+// ---------------------------------------------------------------------------- counts
+extern "C" int ku_counts_dims_get(ku_ctx *ctx, ku_counts_dims *out) {
+  if (!ctx || !out) return fail(KU_EINVAL, "ku_counts_dims_get: null argument");
+  if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  out->n_slots = ctx->tax.n_slots;
+  out->n_nodes = ctx->tax.n_nodes;
+  return KU_OK;
+}
+
+extern "C" int ku_counts_export(ku_ctx *ctx, uint32_t *slot_taxid, uint64_t *n_kmers, uint8_t *registers,
+                                uint32_t *node_taxid, uint64_t *n_reads) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  KU_TRY(ctx_activate(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const size_t ns = ctx->tax.n_slots, nn = ctx->tax.n_nodes;
+  if (slot_taxid) memcpy(slot_taxid, ctx->h_slot_taxid.data(), ns * 4);
+  if (node_taxid) memcpy(node_taxid, ctx->h_node_taxid.data(), nn * 4);
+  if (n_kmers) HIP_TRY(hipMemcpy(n_kmers, ctx->cnt.n_kmers, ns * 8, hipMemcpyDeviceToHost));
+  if (registers) HIP_TRY(hipMemcpy(registers, ctx->cnt.registers, ns * KU_HLL_M, hipMemcpyDeviceToHost));
+  if (n_reads) HIP_TRY(hipMemcpy(n_reads, ctx->cnt.n_reads, nn * 8, hipMemcpyDeviceToHost));
+  return KU_OK;
+}
+
+extern "C" int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_register_bytes,
+                                     uint64_t **d_n_kmers, uint64_t *n_slots, uint64_t **d_n_reads, uint64_t *n_nodes) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  if (d_registers) *d_registers = ctx->cnt.registers;
+  if (n_register_bytes) *n_register_bytes = (uint64_t)ctx->tax.n_slots * KU_HLL_M;
+  if (d_n_kmers) *d_n_kmers = (uint64_t *)ctx->cnt.n_kmers;
+  if (n_slots) *n_slots = ctx->tax.n_slots;
+  if (d_n_reads) *d_n_reads = (uint64_t *)ctx->cnt.n_reads;
+  if (n_nodes) *n_nodes = ctx->tax.n_nodes;
+  return KU_OK;
+}

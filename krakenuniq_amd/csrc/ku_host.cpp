@@ -1,0 +1,264 @@
+// ku_host.cpp -- host-side arithmetic and text of the classify boundary: the Ertl
+// cardinality estimator (double, once per report row), the Kraken output line and
+// the report.  The reference does these on the host as well (SURVEY.md 8a A11, A15,
+// A18); nothing here classifies reads.
+#include "ku_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// ---------------------------------------------------------------------------- HLL estimator
+// sigma / tau series of Ertl's improved estimator (hyperloglogplus.cpp:373-387,408-422)
+static double ertl_sigma(double x) {
+  if (x == 1.0) return INFINITY;
+  double prev, sig = x, y = 1.0;
+  do {
+    prev = sig;
+    x *= x;
+    sig += x * y;
+    y += y;
+  } while (sig != prev);
+  return sig;
+}
+static double ertl_tau(double x) {
+  if (x == 0.0 || x == 1.0) return 0.0;
+  double prev, y = 1.0, t = 1 - x;
+  do {
+    prev = t;
+    x = std::sqrt(x);
+    y /= 2.0;
+    t -= std::pow(1 - x, 2) * y;
+  } while (t != prev);
+  return t / 3.0;
+}
+
+extern "C" uint64_t ku_hll_cardinality(const uint8_t *M, uint32_t p, uint64_t n_observed) {
+  // hyperloglogplus.cpp:722-753 on dense registers: q = 64 - p, m = 2^p
+  if (!M || p < 4 || p > 18) return 0;
+  const uint32_t m = 1u << p, q = 64 - p;
+  std::vector<int> C(q + 2, 0);
+  for (uint32_t i = 0; i < m; ++i) C[std::min<uint32_t>(M[i], q + 1)]++;
+  double den = m * ertl_tau(1.0 - double(C[q + 1]) / double(m));
+  for (int k = (int)q; k >= 1; --k) {
+    den += C[k];
+    den *= 0.5;
+  }
+  den += m * ertl_sigma(double(C[0]) / double(m));
+  double est = (m / (2.0 * std::log(2))) * m / den;
+  if (double(n_observed) < est) return n_observed;  // use_n_observed = true (hyperloglogplus.hpp:78)
+  return (uint64_t)std::llround(est);
+}
+
+// ---------------------------------------------------------------------------- Kraken lines
+static inline char *put_u64(char *p, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+
+extern "C" size_t ku_hitlist_string(const uint32_t *taxa, size_t n, char *buf) {
+  // classify.cpp:826-861; "0:0" for a read without k-mers (:994-995)
+  if (n == 0) { memcpy(buf, "0:0", 3); return 3; }
+  char *p = buf;
+  size_t i = 0;
+  while (i < n) {
+    size_t j = i + 1;
+    while (j < n && taxa[j] == taxa[i]) ++j;
+    if (taxa[i] == KU_AMBIG) *p++ = 'A'; else p = put_u64(p, taxa[i]);
+    *p++ = ':';
+    p = put_u64(p, j - i);
+    if (j < n) *p++ = ' ';
+    i = j;
+  }
+  return (size_t)(p - buf);
+}
+
+extern "C" int ku_format_kraken(const char *seqs, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
+                                const char *ids, uint32_t k, const uint32_t *calls, const uint32_t *taxa,
+                                const uint32_t *hits, uint32_t flags, char **out, size_t *out_len) {
+  if (!out || !out_len || (n_reads && (!seq_off || !seq_len || !ids || !calls))) { ku_set_error("ku_format_kraken: null argument"); return KU_EINVAL; }
+  const bool quick = flags & KU_P_QUICK, only_c = flags & KU_P_ONLY_CLASSIFIED, pseq = flags & KU_P_SEQUENCE;
+  if ((!quick && !taxa) || (quick && !hits) || (pseq && !seqs)) { ku_set_error("ku_format_kraken: missing array for the requested columns"); return KU_EINVAL; }
+  size_t cap = 1 << 16, len = 0;
+  char *buf = (char *)malloc(cap);
+  if (!buf) return KU_ENOMEM;
+  const char *id = ids;
+  for (uint64_t r = 0; r < n_reads; ++r) {
+    size_t idl = strlen(id);
+    const uint32_t L = seq_len[r];
+    const size_t n = L >= k ? L - k + 1 : 0;
+    size_t need = idl + 64 + 24 * n + (pseq ? L + 1 : 0);
+    if (len + need > cap) {
+      while (len + need > cap) cap *= 2;
+      char *nb = (char *)realloc(buf, cap);
+      if (!nb) { free(buf); return KU_ENOMEM; }
+      buf = nb;
+    }
+    const uint32_t call = calls[r];
+    if (!(call == 0 && only_c)) {  // classify.cpp:980-987
+      char *p = buf + len;
+      *p++ = call ? 'C' : 'U';
+      *p++ = '\t';
+      memcpy(p, id, idl); p += idl;
+      *p++ = '\t';
+      p = put_u64(p, call);
+      *p++ = '\t';
+      p = put_u64(p, L);
+      *p++ = '\t';
+      if (quick) { *p++ = 'Q'; *p++ = ':'; p = put_u64(p, hits[r]); }
+      else p += ku_hitlist_string(taxa + seq_off[r], n, p);
+      if (pseq) { *p++ = '\t'; memcpy(p, seqs + seq_off[r], L); p += L; }
+      *p++ = '\n';
+      len = (size_t)(p - buf);
+    }
+    id += idl + 1;
+  }
+  *out = buf;
+  *out_len = len;
+  return KU_OK;
+}
+
+extern "C" void ku_free(void *p) { free(p); }
+
+// ---------------------------------------------------------------------------- report
+namespace {
+struct Clade {
+  uint64_t reads = 0, kmers = 0;
+  std::vector<uint8_t> regs;  // dense p=12 registers of the merged sketch (empty until first k-mer source)
+  bool present = false;
+};
+struct Sb {
+  std::string s;
+  void printf(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(tmp, sizeof(tmp), fmt, ap);
+    va_end(ap);
+    if (n > 0) s.append(tmp, (size_t)std::min<int>(n, (int)sizeof(tmp) - 1));
+  }
+};
+}  // namespace
+
+extern "C" int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_taxid, const uint64_t *n_kmers,
+                         const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads,
+                         uint64_t n_nodes, char **out, size_t *out_len) {
+  if (!tax || !out || !out_len || (n_slots && (!slot_taxid || !n_kmers || !registers)) || (n_nodes && (!node_taxid || !n_reads))) {
+    ku_set_error("ku_report: null argument");
+    return KU_EINVAL;
+  }
+  const size_t nt = tax->ids.size();
+  // taxon_counts: taxid -> (n_reads, n_kmers, sketch); an entry exists when either count is non-zero
+  struct TaxCount { uint64_t reads = 0, kmers = 0; const uint8_t *regs = nullptr; };
+  std::unordered_map<uint32_t, TaxCount> tc;
+  for (uint64_t s = 0; s < n_slots; ++s)
+    if (n_kmers[s]) { auto &e = tc[slot_taxid[s]]; e.kmers = n_kmers[s]; e.regs = registers + s * KU_HLL_M; }
+  for (uint64_t i = 0; i < n_nodes; ++i)
+    if (n_reads[i]) tc[node_taxid[i]].reads = n_reads[i];
+  // genome sizes: readGenomeSizes (taxdb.hpp:867-885).  "while(!eof){in >> id >> size; set(id,size);}" applies
+  // the LAST pair twice when the file ends in whitespace (the failed extraction leaves both values unchanged).
+  std::vector<uint64_t> gsize(nt, 0), gchild(nt, 0);
+  auto set_genome_size = [&](uint32_t id, uint64_t size) {  // taxdb.hpp:850-865
+    auto it = tax->row.find(id);
+    if (it == tax->row.end()) return;
+    gsize[it->second] += size;
+    for (int64_t q = tax->parent_row(it->second); q >= 0; q = tax->parent_row((size_t)q)) gchild[q] += size;
+  };
+  if (counts_path) {
+    FILE *f = fopen(counts_path, "r");
+    if (!f) { ku_set_error(std::string("unable to open file ") + counts_path); return KU_ENOINPUT; }
+    std::string data;
+    char tmp[65536];
+    size_t got;
+    while ((got = fread(tmp, 1, sizeof(tmp), f)) > 0) data.append(tmp, got);
+    fclose(f);
+    const char *p = data.c_str();
+    unsigned long long id = 0, size = 0;
+    bool have = false, trailing = false;
+    for (;;) {
+      char *e1, *e2;
+      unsigned long long a = strtoull(p, &e1, 10);
+      if (e1 == p) break;
+      unsigned long long b = strtoull(e1, &e2, 10);
+      if (e2 == e1) break;
+      id = a; size = b; have = true; p = e2;
+      trailing = *p != 0;
+      set_genome_size((uint32_t)id, size);
+    }
+    if (have && trailing) set_genome_size((uint32_t)id, size);
+  }
+  // clade roll-up (taxdb.hpp:928-973): every counted taxon contributes to itself and all ancestors
+  std::vector<Clade> clade(nt);
+  for (auto &kv : tc) {
+    auto it = tax->row.find(kv.first);
+    if (it == tax->row.end()) continue;  // "No entry for X in database!"
+    for (int64_t q = it->second; q >= 0; q = tax->parent_row((size_t)q)) {
+      Clade &c = clade[q];
+      c.present = true;
+      c.reads += kv.second.reads;
+      c.kmers += kv.second.kmers;
+      if (kv.second.regs) {
+        if (c.regs.empty()) c.regs.assign(kv.second.regs, kv.second.regs + KU_HLL_M);
+        else for (int i = 0; i < KU_HLL_M; ++i) c.regs[i] = std::max(c.regs[i], kv.second.regs[i]);
+      }
+    }
+  }
+  // children lists
+  std::vector<std::vector<uint32_t>> kids(nt);
+  for (size_t i = 0; i < nt; ++i) { int64_t p = tax->parent_row(i); if (p >= 0) kids[p].push_back((uint32_t)i); }
+  uint64_t total = 0;
+  const uint32_t roots[3] = {0u, 1u, 0xFFFFFFFFu};  // taxdb.hpp:1004
+  for (uint32_t r : roots) { auto it = tax->row.find(r); if (it != tax->row.end() && clade[it->second].present) total += clade[it->second].reads; }
+  Sb sb;
+  if (total) {
+    sb.s += "%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n";  // classify.cpp:305-314
+    static const std::vector<uint8_t> zero_regs(KU_HLL_M, 0);
+    // iterative DFS (taxdb.hpp:1049-1076)
+    struct Frame { uint32_t row; unsigned depth; };
+    std::vector<Frame> stack;
+    for (int i = 2; i >= 0; --i) { auto it = tax->row.find(roots[i]); if (it != tax->row.end()) stack.push_back({it->second, 0}); }
+    while (!stack.empty()) {
+      Frame fr = stack.back();
+      stack.pop_back();
+      const Clade &c = clade[fr.row];
+      if (!c.present || c.reads == 0) continue;
+      const uint8_t *regs = c.regs.empty() ? zero_regs.data() : c.regs.data();
+      const uint64_t uniq = ku_hll_cardinality(regs, KU_HLL_P, c.kmers);
+      volatile double gs = double(gsize[fr.row] + gchild[fr.row]);
+      volatile double kc = double(c.kmers), un = double(uniq);
+      auto ti = tc.find(tax->ids[fr.row]);
+      const uint64_t tax_reads = ti == tc.end() ? 0 : ti->second.reads;
+      sb.printf("%.4g\t", 100.0 * double(c.reads) / double(total));
+      sb.printf("%llu\t%llu\t%llu\t", (unsigned long long)c.reads, (unsigned long long)tax_reads, (unsigned long long)uniq);
+      sb.printf("%.3g\t", kc / un);
+      if (gs == 0) sb.s += "NA\t"; else sb.printf("%.4g\t", un / gs);
+      if (tax->ids[fr.row] == 0xFFFFFFFFu) sb.s += "-1\t"; else sb.printf("%d\t", (int32_t)tax->ids[fr.row]);
+      sb.s += tax->ranks[fr.row];
+      sb.s += '\t';
+      sb.s.append(2 * fr.depth, ' ');
+      sb.s += tax->names[fr.row];
+      sb.s += '\n';
+      std::vector<uint32_t> ch;
+      for (uint32_t x : kids[fr.row]) if (clade[x].present) ch.push_back(x);
+      // descending (reads, kmers) (readcounts.hpp:90-98); ties: ascending taxid
+      std::sort(ch.begin(), ch.end(), [&](uint32_t a, uint32_t b) {
+        if (clade[a].reads != clade[b].reads) return clade[a].reads > clade[b].reads;
+        if (clade[a].kmers != clade[b].kmers) return clade[a].kmers > clade[b].kmers;
+        return tax->ids[a] < tax->ids[b];
+      });
+      for (auto it = ch.rbegin(); it != ch.rend(); ++it) stack.push_back({*it, fr.depth + 1});
+    }
+  }
+  char *buf = (char *)malloc(sb.s.size() + 1);
+  if (!buf) return KU_ENOMEM;
+  memcpy(buf, sb.s.c_str(), sb.s.size() + 1);
+  *out = buf;
+  *out_len = sb.s.size();
+  return KU_OK;
+}

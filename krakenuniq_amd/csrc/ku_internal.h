@@ -1,0 +1,65 @@
+// ku_internal.h -- structures shared by the C-ABI host code (ku_api.cpp) and the
+// gfx950 kernels (ku_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/krakenuniq_amd.h"
+
+// Device view of the resident DB shard.  Pairs keep the reference's on-disk
+// 12-byte AoS record (8-byte LE key | 4-byte value, krakendb.cpp:176) so key and
+// value of a probe arrive in the same cache line; after ku_ctx_set_taxonomy the
+// value dword holds a *slot id* (rank of the taxid among the distinct DB values,
+// 0 = taxid 0) instead of the raw taxid.
+struct KuDbDev {
+  const uint32_t *pairs;    // 3 dwords per pair: key_lo, key_hi, slot
+  const uint64_t *offsets;  // bin_hi - bin_lo + 1 global pair indices
+  uint64_t pair_base;       // global index of pairs[0]
+  uint64_t n_pairs;
+  uint64_t bin_lo, bin_hi;  // owned minimizer range [bin_lo, bin_hi)
+  uint32_t k, nt;
+  uint32_t xor_mask;        // INDEX2_XOR_MASK & (4^nt - 1), 0 for KRAKIDX
+  uint32_t pad;
+};
+
+// Dense taxonomy tables (all uint32, device memory).
+//   node  = rank of a taxid in sorted(taxDB ids U DB values U {0}); node 0 = taxid 0
+//   slot  = rank of a taxid in sorted(DB values U {0});             slot 0 = taxid 0
+struct KuTaxDev {
+  const uint32_t *node_parent;  // Parent_map in node space (0 = none)
+  const uint32_t *node_slot;    // slot of the node's taxid, 0 if it is not a DB value
+  const uint32_t *node_taxid;
+  const uint32_t *slot_node;
+  const uint32_t *slot_taxid;
+  uint32_t n_nodes, n_slots;    // n_slots includes slot 0
+  uint32_t node_one;            // node of taxid 1 (0xFFFFFFFF if absent)
+  uint32_t pad;
+};
+
+// Per-taxon run state (device).
+struct KuCountsDev {
+  uint8_t *registers;                 // n_slots * 4096, dense HLL p = 12
+  unsigned long long *n_kmers;        // n_slots
+  unsigned long long *n_reads;        // n_nodes
+};
+
+// launch wrappers implemented in ku_kernels.hip (all asynchronous on `stream`)
+int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
+                     uint32_t *d_taxa, bool do_counts, int n_cu, hipStream_t stream);
+int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
+                      const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads, uint32_t flags,
+                      uint32_t min_hits, uint32_t max_read_len, uint32_t *d_calls, uint32_t *d_taxa,
+                      uint32_t *d_hits, void *d_workspace, uint64_t workspace_bytes, int n_cu,
+                      hipStream_t stream);
+uint64_t ku_resolve_workspace_bytes(uint32_t max_read_len, uint32_t k, int n_cu);
+int ku_launch_max_len(const uint32_t *d_seq_len, uint64_t n_reads, uint32_t *d_out, hipStream_t stream);
+// DB preparation
+int ku_launch_repack(const uint8_t *d_raw, uint64_t n_pairs, uint32_t key_len, uint32_t *d_pairs,
+                     hipStream_t stream);
+int ku_launch_mark_values(const uint32_t *d_pairs, uint64_t n_pairs, uint32_t *d_bitmap, hipStream_t stream);
+int ku_launch_collect_values(const uint32_t *d_bitmap, uint32_t *d_out, uint32_t cap, uint32_t *d_count,
+                             hipStream_t stream);
+int ku_launch_remap_values(uint32_t *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_taxid, uint32_t n_slots,
+                           uint32_t *d_err, hipStream_t stream);
+int ku_launch_count_slots(const uint32_t *d_pairs, uint64_t n_pairs, unsigned long long *d_counts,
+                          uint32_t n_slots, hipStream_t stream);

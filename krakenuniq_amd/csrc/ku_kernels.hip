@@ -1,0 +1,783 @@
+// ku_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the KrakenUniq
+// classify hot path.  Integer / byte work bounded by HBM gathers; no MFMA.
+//
+//   ku_lookup_kernel    rows A1-A6 + A12/A13 of SURVEY.md 8(a):
+//                       KmerScanner (krakenutil.cpp:237-282), canonical form
+//                       (krakendb.cpp:218-246), minimizer bin key (:200-215),
+//                       idx pair fetch (:268-269), in-bin search (:280-299),
+//                       ReadCounts::add_kmer -> HLL register max + n_kmers
+//                       (readcounts.hpp:71-74, hyperloglogplus.cpp:485-523)
+//   ku_resolve_kernel   rows A7-A9: hit_counts, resolve_tree, lca
+//                       (classify.cpp:941-968, krakenutil.cpp:90-118,149-200)
+//   ku_quick_kernel     quick mode (-q/-m, classify.cpp:943-944,962-963)
+//   DB preparation      repack / distinct values / slot remap / count_taxons
+//                       (krakendb.cpp:90-113)
+//
+// Work decomposition of the lookup kernel is FLAT: one lane per k-mer start
+// position of the concatenated read buffer (reads are separated by >= 1
+// non-ACGT byte, so every k-mer that would span two reads is "ambiguous" by
+// construction and costs nothing).  That keeps all 64 lanes busy for 150 bp,
+// paired 301 bp and 10 kbp reads alike, makes the taxa[] stores perfectly
+// coalesced, and puts neighbouring lanes on neighbouring k-mers -- which share
+// their minimizer bin ~(k-nt+1)/2 times in a row, so the idx and pair gathers
+// of a wave collapse onto a handful of cache lines.
+#include "ku_internal.h"
+
+#define KU_THREADS 256
+#define KU_ITEMS 4
+#define KU_TILE (KU_THREADS * KU_ITEMS)   // k-mer start positions per block iteration
+#define KU_PACKW ((KU_TILE + 64) / 16)    // 16-base words staged per tile (covers TILE + 63 bases)
+#define KU_CT_LOG2 9                      // per-block LDS counter table (n_kmers / n_reads aggregation)
+#define KU_CT_CAP (1 << KU_CT_LOG2)
+
+// ----------------------------------------------------------------------------
+// small device helpers
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ku_fmix64(uint64_t key) {  // hyperloglogplus.cpp:830-838
+  key += 1;
+  key ^= key >> 33;
+  key *= 0xff51afd7ed558ccdULL;
+  key ^= key >> 33;
+  key *= 0xc4ceb9fe1a85ec53ULL;
+  key ^= key >> 33;
+  return key;
+}
+
+// reverse complement of the n-mer held in the low 2n bits (krakendb.cpp:218-225):
+// full bit reversal (v_bfrev_b32 x2) + swap inside every 2-bit group == reversal
+// of the 2-bit groups; complement is bitwise NOT in this encoding.
+__device__ __forceinline__ uint64_t ku_revcomp64(uint64_t x, uint32_t n) {
+  uint64_t r = __builtin_bitreverse64(x);
+  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+  return (~r) >> (64 - 2 * n);
+}
+__device__ __forceinline__ uint32_t ku_revcomp32(uint32_t x, uint32_t n) {
+  uint32_t r = __builtin_bitreverse32(x);
+  r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+  return (~r) >> (32 - 2 * n);
+}
+
+// LDS-aggregated counters: id -> count, flushed to a global uint64 array.
+__device__ __forceinline__ void ku_ct_add(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t id, uint32_t n,
+                                          unsigned long long *global) {
+  uint32_t h = (id * 2654435761u) >> (32 - KU_CT_LOG2);
+#pragma unroll 1
+  for (int probe = 0; probe < 8; ++probe) {
+    uint32_t cur = __hip_atomic_load(&ct_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cur == 0) {
+      uint32_t old = atomicCAS(&ct_key[h], 0u, id + 1);
+      cur = old == 0 ? id + 1 : old;
+    }
+    if (cur == id + 1) {
+      atomicAdd(&ct_cnt[h], n);
+      return;
+    }
+    h = (h + 1) & (KU_CT_CAP - 1);
+  }
+  atomicAdd(&global[id], (unsigned long long)n);
+}
+__device__ __forceinline__ void ku_ct_clear(uint32_t *ct_key, uint32_t *ct_cnt) {
+  for (int i = threadIdx.x; i < KU_CT_CAP; i += blockDim.x) {
+    ct_key[i] = 0;
+    ct_cnt[i] = 0;
+  }
+}
+__device__ __forceinline__ void ku_ct_flush(uint32_t *ct_key, uint32_t *ct_cnt, unsigned long long *global) {
+  for (int i = threadIdx.x; i < KU_CT_CAP; i += blockDim.x) {
+    uint32_t kk = ct_key[i];
+    if (kk) atomicAdd(&global[kk - 1], (unsigned long long)ct_cnt[i]);
+  }
+}
+
+// HLL register update: M[slot][idx] = max(M, rank) (hyperloglogplus.cpp:508-522, p = 12).
+// The plain pre-check load may be stale (other CUs' updates are not visible in
+// this CU's L1) -- stale values are only ever too small, so the worst case is a
+// redundant CAS, never a lost update.
+__device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot, uint64_t canon) {
+  uint64_t h = ku_fmix64(canon);
+  uint32_t idx = (uint32_t)(h >> (64 - KU_HLL_P));
+  uint64_t rest = h << KU_HLL_P;
+  uint32_t rank = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KU_HLL_P + 1);
+  uint8_t *r = registers + (size_t)slot * KU_HLL_M + idx;
+  if (*r < rank) {
+    uint32_t *w = (uint32_t *)((uintptr_t)r & ~(uintptr_t)3);
+    uint32_t sh = ((uint32_t)(uintptr_t)r & 3u) * 8;
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (((old >> sh) & 0xffu) < rank) {
+      uint32_t nw = (old & ~(0xffu << sh)) | (rank << sh);
+      uint32_t prev = atomicCAS(w, old, nw);
+      if (prev == old) break;
+      old = prev;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// ku_lookup_kernel
+// ----------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) KuPair {  // the on-disk record (krakendb.cpp:176)
+  uint32_t key_lo, key_hi, slot;
+};
+
+// ASCII -> (2-bit code, valid): A/a=0 C/c=1 G/g=2 T/t=3 (krakenutil.cpp:252-263)
+__device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &word, uint32_t &amb) {
+  uint32_t c = b & 0xDFu;
+  uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
+  uint32_t valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+  word |= code << (30 - 2 * j);
+  amb |= (valid ^ 1u) << (15 - j);
+}
+
+template <bool DO_COUNTS>
+__global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
+                                                               const uint8_t *__restrict__ seqs,
+                                                               uint64_t n_bytes, uint32_t *__restrict__ taxa) {
+  // 16 bases per word, MSB first (base 16w in bits 31..30): a k-mer is a
+  // funnel shift over three consecutive words.
+  __shared__ uint32_t s_codes[KU_PACKW + 4];
+  __shared__ uint32_t s_amb[(KU_PACKW + 4) / 2 + 2];  // 32 bases per word, MSB first
+  __shared__ uint32_t s_mm[KU_TILE + 64];             // scrambled canonical m-mer per start position
+  __shared__ uint32_t s_ctk[KU_CT_CAP];
+  __shared__ uint32_t s_ctc[KU_CT_CAP];
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t k = db.k, m = db.nt;
+  const uint32_t w = k - m + 1;  // m-mers per k-mer (krakendb.cpp:208)
+  const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
+  const bool aligned = (((uintptr_t)seqs) & 15u) == 0;
+  uint16_t *s_amb16 = reinterpret_cast<uint16_t *>(s_amb);
+
+  if (DO_COUNTS) ku_ct_clear(s_ctk, s_ctc);
+
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t tile0 = tile * KU_TILE;
+    __syncthreads();  // previous iteration's LDS readers are done
+    // ---- stage 1: ASCII -> packed 2-bit codes + ambiguity bits (16 bases per lane)
+    if (tid < KU_PACKW + 4) {
+      uint64_t b0 = tile0 + 16ull * tid;
+      uint32_t word = 0, amb = 0;
+      if (tid >= KU_PACKW || b0 >= n_bytes) {
+        amb = 0xFFFFu;
+      } else if (aligned && b0 + 16 <= n_bytes) {
+        uint4 v = *reinterpret_cast<const uint4 *>(seqs + b0);
+        uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) ku_pack_byte((d[q] >> (8 * j)) & 0xffu, 4 * q + j, word, amb);
+      } else {
+        for (uint32_t j = 0; j < 16; ++j) {
+          uint32_t b = (b0 + j < n_bytes) ? seqs[b0 + j] : (uint32_t)'N';
+          ku_pack_byte(b, j, word, amb);
+        }
+      }
+      s_codes[tid] = word;
+      s_amb16[tid ^ 1u] = (uint16_t)amb;  // even word -> high half (little-endian uint16 view)
+    }
+    __syncthreads();
+
+    // ---- stage 2: forward k-mer, ambiguity, canonical form, m-mer value per position
+    uint64_t canon[KU_ITEMS];
+    bool ok[KU_ITEMS];       // k-mer is unambiguous, inside the buffer and (after stage 3) owned by this shard
+    bool foreign[KU_ITEMS];  // unambiguous but its bin belongs to another shard
+#pragma unroll
+    for (int j = 0; j <= KU_ITEMS; ++j) {
+      uint32_t p = j * KU_THREADS + tid;
+      if (j == KU_ITEMS && p >= KU_TILE + w - 1) break;
+      uint32_t wi = p >> 4, sh = (p & 15u) * 2;
+      uint64_t hi = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
+      uint64_t x = sh ? ((hi << sh) | (uint64_t)(s_codes[wi + 2] >> (32 - sh))) : hi;  // 32 bases from p
+      // m-mer starting at p, canonical, scrambled (krakendb.cpp:209)
+      uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
+      uint32_t mrc = ku_revcomp32(mm, m);
+      s_mm[p] = (mm < mrc ? mm : mrc) ^ db.xor_mask;
+      if (j < KU_ITEMS) {
+        uint64_t fwd = x >> (64 - 2 * k);
+        uint64_t rc = ku_revcomp64(fwd, k);
+        canon[j] = fwd < rc ? fwd : rc;
+        uint32_t ai = p >> 5, as = p & 31u;
+        uint64_t a = (((uint64_t)s_amb[ai] << 32) | s_amb[ai + 1]) << as;
+        ok[j] = (a >> (64 - k)) == 0 && (tile0 + p + k <= n_bytes);
+        foreign[j] = false;
+      }
+    }
+    __syncthreads();
+
+    // ---- stage 3: minimizer = sliding-window minimum of the m-mer values, idx fetch
+    uint32_t n_b[KU_ITEMS];          // bin size
+    const uint32_t *bp[KU_ITEMS];    // first pair of the bin
+#pragma unroll
+    for (int j = 0; j < KU_ITEMS; ++j) {
+      uint32_t p = j * KU_THREADS + tid;
+      n_b[j] = 0;
+      bp[j] = db.pairs;
+      if (ok[j]) {
+        uint32_t mn = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
+        uint64_t bin = mn;
+        if (bin >= db.bin_lo && bin < db.bin_hi) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
+          const uint64_t *o = db.offsets + (bin - db.bin_lo);
+          uint64_t lo = o[0], hi = o[1];
+          n_b[j] = (uint32_t)(hi - lo);
+          bp[j] = db.pairs + 3 * (lo - db.pair_base);
+        } else {
+          ok[j] = false;  // another shard owns this k-mer (and accounts its miss)
+          foreign[j] = true;
+        }
+      }
+    }
+
+    // ---- stage 4: in-bin binary search, KU_ITEMS probes in flight per lane
+    uint32_t lo[KU_ITEMS], hi[KU_ITEMS], slot[KU_ITEMS];
+#pragma unroll
+    for (int j = 0; j < KU_ITEMS; ++j) {
+      lo[j] = 0;
+      hi[j] = n_b[j];
+      slot[j] = 0;
+    }
+    bool any = true;
+    while (any) {
+      any = false;
+      KuPair pr[KU_ITEMS];
+      uint32_t mid[KU_ITEMS];
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        mid[j] = (lo[j] + hi[j]) >> 1;
+        if (lo[j] < hi[j]) pr[j] = reinterpret_cast<const KuPair *>(bp[j])[mid[j]];  // one 12-byte load: key + value
+      }
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        if (lo[j] < hi[j]) {
+          uint64_t key = ((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo;
+          if (key == canon[j]) {
+            slot[j] = pr[j].slot;
+            lo[j] = hi[j];
+          } else if (key < canon[j]) {
+            lo[j] = mid[j] + 1;
+          } else {
+            hi[j] = mid[j];
+          }
+          any |= lo[j] < hi[j];
+        }
+      }
+    }
+
+    // ---- stage 5: per-taxon accounting (classify.cpp:939) + coalesced store
+#pragma unroll
+    for (int j = 0; j < KU_ITEMS; ++j) {
+      uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
+      if (DO_COUNTS && ok[j]) {
+        ku_hll_update(cnt.registers, slot[j], canon[j]);
+        ku_ct_add(s_ctk, s_ctc, slot[j], 1, cnt.n_kmers);
+      }
+      if (pos < n_bytes) {
+        // ambiguous -> KU_AMBIG on every shard; not owned -> 0 (the owner's value wins the max-reduce)
+        taxa[pos] = ok[j] ? slot[j] : (foreign[j] ? 0u : KU_AMBIG);
+      }
+    }
+  }
+  if (DO_COUNTS) {
+    __syncthreads();
+    ku_ct_flush(s_ctk, s_ctc, cnt.n_kmers);
+  }
+}
+
+int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
+                     uint32_t *d_taxa, bool do_counts, int n_cu, hipStream_t stream) {
+  if (n_bytes == 0) return KU_OK;
+  uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
+  uint64_t max_blocks = (uint64_t)n_cu * 8;
+  unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
+  if (do_counts)
+    hipLaunchKernelGGL(ku_lookup_kernel<true>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
+                       d_taxa);
+  else
+    hipLaunchKernelGGL(ku_lookup_kernel<false>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
+                       d_taxa);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// ----------------------------------------------------------------------------
+// ku_resolve_kernel: one group (wave or block) per read
+// ----------------------------------------------------------------------------
+// MODE 0: GROUP 64,  LDS table of 512 entries    -> reads with n_kmers <= 384
+// MODE 1: GROUP 256, LDS table of 16384 entries  -> n_kmers <= 12288
+// MODE 2: GROUP 256, table in global workspace   -> anything longer
+// Table entry: key = slot + 1 (0 = empty); cnt word = hit count (MODE 0/1: low 16
+// bits, the root-path score is accumulated in the high 16 bits; MODE 2: separate
+// score array).
+template <int MODE> struct KuResolveCfg;
+template <> struct KuResolveCfg<0> { static constexpr int GROUP = 64, CAP_LOG2 = 9, MAX_N = 384; };
+template <> struct KuResolveCfg<1> { static constexpr int GROUP = 256, CAP_LOG2 = 14, MAX_N = 12288; };
+template <> struct KuResolveCfg<2> { static constexpr int GROUP = 256, CAP_LOG2 = 0, MAX_N = 0x7fffffff; };
+
+template <int GROUP> __device__ __forceinline__ uint32_t ku_group_max(uint32_t v, uint32_t *s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  if (GROUP > 64) {
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = s_red[0];
+#pragma unroll
+    for (int i = 1; i < GROUP / 64; ++i) v = max(v, s_red[i]);
+  }
+  return v;
+}
+template <int GROUP> __device__ __forceinline__ uint32_t ku_group_min(uint32_t v, uint32_t *s_red) {
+  return ~ku_group_max<GROUP>(~v, s_red);
+}
+template <int GROUP> __device__ __forceinline__ uint32_t ku_group_sum(uint32_t v, uint32_t *s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+  if (GROUP > 64) {
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = 0;
+#pragma unroll
+    for (int i = 0; i < GROUP / 64; ++i) v += s_red[i];
+  }
+  return v;
+}
+
+// lca() in node space (krakenutil.cpp:90-118).  Nodes are ranks of taxids in a
+// sorted universe that always contains 0 and 1, so "taxid > 1" == "node > 1".
+__device__ uint32_t ku_lca_nodes(const uint32_t *__restrict__ parent, uint32_t a, uint32_t b) {
+  if (a == 0 || b == 0) return a ? a : b;
+  // path(a) is walked once per candidate of b's path: O(depth^2), depth <= ~40, ties only
+  for (uint32_t guard_b = 0; b > 1 && guard_b < 4096; ++guard_b) {
+    uint32_t x = a;
+    for (uint32_t guard_a = 0; x > 1 && guard_a < 4096; ++guard_a) {
+      if (x == b) return b;
+      x = parent[x];
+    }
+    b = parent[b];
+  }
+  return 1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
+    KuTaxDev tax, KuCountsDev cnt, uint32_t k, const uint64_t *__restrict__ seq_off,
+    const uint32_t *__restrict__ seq_len, uint64_t n_reads, uint32_t min_n, uint32_t flags,
+    uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t *__restrict__ hits_out, uint32_t *ws,
+    uint32_t ws_cap_log2) {
+  using Cfg = KuResolveCfg<MODE>;
+  constexpr int GROUP = Cfg::GROUP;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  __shared__ uint32_t s_red[4];
+  __shared__ uint32_t s_n_list;
+  __shared__ uint32_t s_bcast;
+  __shared__ uint32_t s_ctk[KU_CT_CAP];
+  __shared__ uint32_t s_ctc[KU_CT_CAP];
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t cap_log2 = MODE == 2 ? ws_cap_log2 : (uint32_t)Cfg::CAP_LOG2;
+  const uint32_t cap = 1u << cap_log2;
+  uint32_t *t_key, *t_cnt, *t_score, *t_list;
+  if (MODE == 2) {
+    uint32_t *base = ws + (size_t)blockIdx.x * 4 * cap;
+    t_key = base;
+    t_cnt = base + cap;
+    t_score = base + 2 * (size_t)cap;
+    t_list = base + 3 * (size_t)cap;
+  } else {
+    t_key = smem;
+    t_cnt = smem + cap;
+    t_score = nullptr;
+    t_list = smem + 2 * cap;  // uint16 entries
+  }
+  uint16_t *t_list16 = reinterpret_cast<uint16_t *>(t_list);
+  const bool do_counts = !(flags & KU_F_NO_COUNTS);
+  const bool keep_slots = (flags & KU_F_KEEP_SLOTS) != 0;
+
+  ku_ct_clear(s_ctk, s_ctc);
+  for (uint32_t i = tid; i < cap; i += GROUP) {
+    t_key[i] = 0;
+    t_cnt[i] = 0;
+    if (MODE == 2) t_score[i] = 0;
+  }
+  __syncthreads();
+
+  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    if (n < min_n || n > (uint32_t)Cfg::MAX_N) continue;  // another MODE's launch handles it
+    const uint64_t off = seq_off[r];
+    if (tid == 0) s_n_list = 0;
+    // ---- hit_counts[taxon]++ (classify.cpp:941-942)
+    for (uint32_t i = tid; i < n; i += GROUP) {
+      uint32_t s = taxa[off + i];
+      if (s != 0 && s != KU_AMBIG) {
+        uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
+        for (;;) {
+          uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (cur == 0) {
+            uint32_t old = atomicCAS(&t_key[h], 0u, s + 1);
+            cur = old == 0 ? s + 1 : old;
+          }
+          if (cur == s + 1) {
+            atomicAdd(&t_cnt[h], 1u);
+            break;
+          }
+          h = (h + 1) & (cap - 1);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- compact the occupied entries so that every distinct taxon gets its own lane
+    for (uint32_t i = tid; i < cap; i += GROUP) {
+      if (t_key[i]) {
+        uint32_t e = atomicAdd(&s_n_list, 1u);
+        if (MODE == 2) t_list[e] = i; else t_list16[e] = (uint16_t)i;
+      }
+    }
+    __syncthreads();
+    const uint32_t n_list = s_n_list;
+    uint32_t call_node = 0;
+    if (n_list > 0) {
+      // ---- score(t) = sum of hit counts on t's root path (krakenutil.cpp:157-177)
+      uint32_t my_max = 0;
+      for (uint32_t e = tid; e < n_list; e += GROUP) {
+        uint32_t pos = MODE == 2 ? t_list[e] : (uint32_t)t_list16[e];
+        uint32_t node = tax.slot_node[t_key[pos] - 1];
+        uint32_t score = 0;
+        for (uint32_t guard = 0; node > 0 && guard < 4096; ++guard) {
+          uint32_t s = tax.node_slot[node];
+          if (s) {
+            uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
+            for (;;) {
+              uint32_t cur = t_key[h];
+              if (cur == s + 1) {
+                score += MODE == 2 ? t_cnt[h] : (t_cnt[h] & 0xffffu);
+                break;
+              }
+              if (cur == 0) break;
+              h = (h + 1) & (cap - 1);
+            }
+          }
+          node = tax.node_parent[node];
+        }
+        if (MODE == 2) t_score[pos] = score; else atomicAdd(&t_cnt[pos], score << 16);
+        my_max = max(my_max, score);
+      }
+      const uint32_t max_score = ku_group_max<GROUP>(my_max, s_red);
+      __syncthreads();
+      // ---- winner; ties -> fold lca() over the tied taxa in ascending taxid (= slot) order
+      uint32_t last = 0;  // slots are >= 1
+      bool first = true;
+      for (;;) {
+        uint32_t my_min = 0xFFFFFFFFu;
+        for (uint32_t e = tid; e < n_list; e += GROUP) {
+          uint32_t pos = MODE == 2 ? t_list[e] : (uint32_t)t_list16[e];
+          uint32_t sc = MODE == 2 ? t_score[pos] : (t_cnt[pos] >> 16);
+          uint32_t s = t_key[pos] - 1;
+          if (sc == max_score && s > last) my_min = min(my_min, s);
+        }
+        uint32_t next = ku_group_min<GROUP>(my_min, s_red);
+        if (next == 0xFFFFFFFFu) break;
+        if (tid == 0) {
+          uint32_t node = tax.slot_node[next];
+          s_bcast = first ? node : ku_lca_nodes(tax.node_parent, s_bcast, node);
+        }
+        first = false;
+        last = next;
+        __syncthreads();
+      }
+      __syncthreads();
+      call_node = s_bcast;
+      __syncthreads();
+      // ---- reset the used entries for the next read
+      for (uint32_t e = tid; e < n_list; e += GROUP) {
+        uint32_t pos = MODE == 2 ? t_list[e] : (uint32_t)t_list16[e];
+        t_key[pos] = 0;
+        t_cnt[pos] = 0;
+        if (MODE == 2) t_score[pos] = 0;
+      }
+    }
+    if (tid == 0) {
+      calls[r] = tax.node_taxid[call_node];
+      if (hits_out) hits_out[r] = 0;
+      if (do_counts) ku_ct_add(s_ctk, s_ctc, call_node, 1, cnt.n_reads);  // incrementReadCount (classify.cpp:968)
+    }
+    // ---- slot -> taxid for the hit string
+    if (!keep_slots) {
+      for (uint32_t i = tid; i < n; i += GROUP) {
+        uint32_t s = taxa[off + i];
+        if (s != 0 && s != KU_AMBIG) taxa[off + i] = tax.slot_taxid[s];
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  ku_ct_flush(s_ctk, s_ctc, cnt.n_reads);
+}
+
+// canonical k-mer straight from ASCII (quick mode only; positions known non-ambiguous)
+__device__ __forceinline__ uint64_t ku_canon_from_ascii(const uint8_t *p, uint32_t k) {
+  uint64_t fwd = 0;
+  for (uint32_t i = 0; i < k; ++i) {
+    uint32_t c = p[i] & 0xDFu;
+    fwd = (fwd << 2) | (((c >> 1) ^ (c >> 2)) & 3u);
+  }
+  uint64_t rc = ku_revcomp64(fwd, k);
+  return fwd < rc ? fwd : rc;
+}
+
+// Quick mode (classify.cpp:943-944,962-963): stop at the min_hits-th hit, call =
+// its taxon; only the k-mers scanned up to and including that one are counted.
+__global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev cnt, uint32_t k,
+                                                      const uint8_t *__restrict__ seqs,
+                                                      const uint64_t *__restrict__ seq_off,
+                                                      const uint32_t *__restrict__ seq_len, uint64_t n_reads,
+                                                      uint32_t flags, uint32_t min_hits,
+                                                      uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa,
+                                                      uint32_t *__restrict__ hits_out) {
+  __shared__ uint32_t s_ctk[KU_CT_CAP];
+  __shared__ uint32_t s_ctc[KU_CT_CAP];
+  __shared__ uint32_t s_ckk[KU_CT_CAP];
+  __shared__ uint32_t s_ckc[KU_CT_CAP];
+  const uint32_t tid = threadIdx.x;
+  const bool do_counts = !(flags & KU_F_NO_COUNTS);
+  const bool keep_slots = (flags & KU_F_KEEP_SLOTS) != 0;
+  ku_ct_clear(s_ctk, s_ctc);
+  ku_ct_clear(s_ckk, s_ckc);
+  __syncthreads();
+  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t off = seq_off[r];
+    uint32_t total = 0, call_slot = 0;
+    uint32_t stop = n;  // exclusive end of the scanned prefix
+    for (uint32_t base = 0; base < n; base += 64) {
+      uint32_t i = base + tid;
+      uint32_t s = i < n ? taxa[off + i] : 0;
+      bool hit = s != 0 && s != KU_AMBIG;
+      unsigned long long mask = __ballot(hit);
+      uint32_t c = (uint32_t)__popcll(mask);
+      if (total + c >= min_hits) {
+        uint32_t need = min_hits - total;  // >= 1
+        uint32_t before = (uint32_t)__popcll(mask & ((1ull << tid) - 1ull));
+        bool is_stop = hit && before + 1 == need;
+        unsigned long long sm = __ballot(is_stop);
+        uint32_t lane = (uint32_t)__ffsll((long long)sm) - 1;
+        call_slot = (uint32_t)__shfl((int)s, (int)lane);
+        stop = base + lane + 1;
+        total = min_hits;
+        break;
+      }
+      total += c;
+    }
+    if (do_counts) {
+      for (uint32_t i = tid; i < stop; i += 64) {
+        uint32_t s = taxa[off + i];
+        if (s != KU_AMBIG) {
+          ku_hll_update(cnt.registers, s, ku_canon_from_ascii(seqs + off + i, k));
+          ku_ct_add(s_ckk, s_ckc, s, 1, cnt.n_kmers);
+        }
+      }
+    }
+    uint32_t call_node = (total >= min_hits) ? tax.slot_node[call_slot] : 0;
+    if (tid == 0) {
+      calls[r] = tax.node_taxid[call_node];
+      if (hits_out) hits_out[r] = total;
+      if (do_counts) ku_ct_add(s_ctk, s_ctc, call_node, 1, cnt.n_reads);
+    }
+    if (!keep_slots) {
+      for (uint32_t i = tid; i < n; i += 64) {
+        uint32_t s = taxa[off + i];
+        if (s != 0 && s != KU_AMBIG) taxa[off + i] = tax.slot_taxid[s];
+      }
+    }
+  }
+  __syncthreads();
+  ku_ct_flush(s_ctk, s_ctc, cnt.n_reads);
+  ku_ct_flush(s_ckk, s_ckc, cnt.n_kmers);
+}
+
+static inline uint32_t ku_ceil_log2(uint64_t v) {
+  uint32_t l = 0;
+  while ((1ull << l) < v) ++l;
+  return l;
+}
+
+uint64_t ku_resolve_workspace_bytes(uint32_t max_read_len, uint32_t k, int n_cu) {
+  uint32_t n = max_read_len >= k ? max_read_len - k + 1 : 0;
+  if (n <= (uint32_t)KuResolveCfg<1>::MAX_N) return 0;
+  uint32_t cap_log2 = ku_ceil_log2(2ull * n);
+  uint64_t blocks = (uint64_t)(n_cu < 64 ? n_cu : 64);
+  return blocks * 4ull * (1ull << cap_log2) * sizeof(uint32_t);
+}
+
+int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
+                      const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads, uint32_t flags,
+                      uint32_t min_hits, uint32_t max_read_len, uint32_t *d_calls, uint32_t *d_taxa,
+                      uint32_t *d_hits, void *d_workspace, uint64_t workspace_bytes, int n_cu,
+                      hipStream_t stream) {
+  if (n_reads == 0) return KU_OK;
+  const uint32_t k = db.k;
+  const uint32_t max_n = max_read_len >= k ? max_read_len - k + 1 : 0;
+  if (flags & KU_F_QUICK) {
+    uint64_t mb = (uint64_t)n_cu * 16;
+    unsigned grid = (unsigned)(n_reads < mb ? n_reads : mb);
+    hipLaunchKernelGGL(ku_quick_kernel, dim3(grid), dim3(64), 0, stream, tax, cnt, k, d_seqs, d_seq_off, d_seq_len,
+                       n_reads, flags, min_hits ? min_hits : 1u, d_calls, d_taxa, d_hits);
+    return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+  }
+  {  // MODE 0: every read with n <= 384 (incl. reads shorter than k)
+    uint64_t mb = (uint64_t)n_cu * 16;
+    unsigned grid = (unsigned)(n_reads < mb ? n_reads : mb);
+    size_t lds = (2u << KuResolveCfg<0>::CAP_LOG2) * 4 + KuResolveCfg<0>::MAX_N * 2 + 64;
+    hipLaunchKernelGGL(ku_resolve_kernel<0>, dim3(grid), dim3(64), lds, stream, tax, cnt, k, d_seq_off, d_seq_len,
+                       n_reads, 0u, flags, d_calls, d_taxa, d_hits, (uint32_t *)nullptr, 0u);
+  }
+  if (max_n > (uint32_t)KuResolveCfg<0>::MAX_N) {
+    uint64_t mb = (uint64_t)n_cu;
+    unsigned grid = (unsigned)(n_reads < mb ? n_reads : mb);
+    size_t lds = (2u << KuResolveCfg<1>::CAP_LOG2) * 4 + KuResolveCfg<1>::MAX_N * 2 + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(ku_resolve_kernel<1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(ku_resolve_kernel<1>, dim3(grid), dim3(256), lds, stream, tax, cnt, k, d_seq_off, d_seq_len,
+                       n_reads, (uint32_t)KuResolveCfg<0>::MAX_N + 1, flags, d_calls, d_taxa, d_hits,
+                       (uint32_t *)nullptr, 0u);
+  }
+  if (max_n > (uint32_t)KuResolveCfg<1>::MAX_N) {
+    uint32_t cap_log2 = ku_ceil_log2(2ull * max_n);
+    uint64_t blocks = (uint64_t)(n_cu < 64 ? n_cu : 64);
+    if (workspace_bytes < blocks * 4ull * (1ull << cap_log2) * sizeof(uint32_t) || !d_workspace) return KU_ENOMEM;
+    unsigned grid = (unsigned)(n_reads < blocks ? n_reads : blocks);
+    hipLaunchKernelGGL(ku_resolve_kernel<2>, dim3(grid), dim3(256), 0, stream, tax, cnt, k, d_seq_off, d_seq_len,
+                       n_reads, (uint32_t)KuResolveCfg<1>::MAX_N + 1, flags, d_calls, d_taxa, d_hits,
+                       (uint32_t *)d_workspace, cap_log2);
+  }
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// ----------------------------------------------------------------------------
+// small utility kernels
+// ----------------------------------------------------------------------------
+__global__ void ku_max_len_kernel(const uint32_t *__restrict__ len, uint64_t n, uint32_t *out) {
+  uint32_t m = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    m = max(m, len[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+int ku_launch_max_len(const uint32_t *d_seq_len, uint64_t n_reads, uint32_t *d_out, hipStream_t stream) {
+  if (hipMemsetAsync(d_out, 0, 4, stream) != hipSuccess) return KU_EHIP;
+  if (n_reads == 0) return KU_OK;
+  uint64_t nb = (n_reads + 255) / 256;
+  hipLaunchKernelGGL(ku_max_len_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, stream, d_seq_len,
+                     n_reads, d_out);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// on-disk pairs with key_len < 8 (k < 29) -> the fixed 12-byte record the kernels use
+__global__ void ku_repack_kernel(const uint8_t *__restrict__ raw, uint64_t n, uint32_t key_len,
+                                 uint32_t *__restrict__ out) {
+  const uint32_t ps = key_len + 4;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint8_t *p = raw + i * ps;
+    uint64_t key = 0;
+    for (uint32_t b = 0; b < key_len; ++b) key |= (uint64_t)p[b] << (8 * b);
+    uint32_t val = 0;
+    for (uint32_t b = 0; b < 4; ++b) val |= (uint32_t)p[key_len + b] << (8 * b);
+    out[3 * i] = (uint32_t)key;
+    out[3 * i + 1] = (uint32_t)(key >> 32);
+    out[3 * i + 2] = val;
+  }
+}
+int ku_launch_repack(const uint8_t *d_raw, uint64_t n_pairs, uint32_t key_len, uint32_t *d_pairs,
+                     hipStream_t stream) {
+  if (n_pairs == 0) return KU_OK;
+  uint64_t nb = (n_pairs + 255) / 256;
+  hipLaunchKernelGGL(ku_repack_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, d_raw, n_pairs,
+                     key_len, d_pairs);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// distinct DB values: 2^32-bit bitmap (512 MiB scratch), then compaction
+__global__ void ku_mark_values_kernel(const uint32_t *__restrict__ pairs, uint64_t n, uint32_t *bitmap) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t v = pairs[3 * i + 2];
+    uint32_t bit = 1u << (v & 31u);
+    if (!(bitmap[v >> 5] & bit)) atomicOr(&bitmap[v >> 5], bit);
+  }
+}
+int ku_launch_mark_values(const uint32_t *d_pairs, uint64_t n_pairs, uint32_t *d_bitmap, hipStream_t stream) {
+  if (n_pairs == 0) return KU_OK;
+  uint64_t nb = (n_pairs + 255) / 256;
+  hipLaunchKernelGGL(ku_mark_values_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, d_pairs,
+                     n_pairs, d_bitmap);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+__global__ void ku_collect_values_kernel(const uint32_t *__restrict__ bitmap, uint32_t *out, uint32_t cap,
+                                         uint32_t *count) {
+  const uint64_t n_words = 1ull << 27;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t wv = bitmap[i];
+    while (wv) {
+      uint32_t b = (uint32_t)__ffs((int)wv) - 1;
+      wv &= wv - 1;
+      uint32_t e = atomicAdd(count, 1u);
+      if (e < cap) out[e] = (uint32_t)(i << 5) | b;
+    }
+  }
+}
+int ku_launch_collect_values(const uint32_t *d_bitmap, uint32_t *d_out, uint32_t cap, uint32_t *d_count,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(ku_collect_values_kernel, dim3(4096), dim3(256), 0, stream, d_bitmap, d_out, cap, d_count);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// raw taxid -> slot id (rank in the ascending slot table; 0 stays 0)
+__global__ void ku_remap_values_kernel(uint32_t *pairs, uint64_t n, const uint32_t *__restrict__ slot_taxid,
+                                       uint32_t n_slots, uint32_t *err) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t v = pairs[3 * i + 2];
+    if (v == 0) continue;
+    uint32_t lo = 1, hi = n_slots;  // slot_taxid[0] = 0
+    while (lo < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (slot_taxid[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n_slots && slot_taxid[lo] == v) pairs[3 * i + 2] = lo;
+    else { pairs[3 * i + 2] = 0; atomicAdd(err, 1u); }
+  }
+}
+int ku_launch_remap_values(uint32_t *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_taxid, uint32_t n_slots,
+                           uint32_t *d_err, hipStream_t stream) {
+  if (n_pairs == 0) return KU_OK;
+  uint64_t nb = (n_pairs + 255) / 256;
+  hipLaunchKernelGGL(ku_remap_values_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream, d_pairs,
+                     n_pairs, d_slot_taxid, n_slots, d_err);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// count_taxons (krakendb.cpp:90-113) over slot ids
+__global__ __launch_bounds__(256) void ku_count_slots_kernel(const uint32_t *__restrict__ pairs, uint64_t n,
+                                                             unsigned long long *counts) {
+  __shared__ uint32_t s_ctk[KU_CT_CAP];
+  __shared__ uint32_t s_ctc[KU_CT_CAP];
+  ku_ct_clear(s_ctk, s_ctc);
+  __syncthreads();
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    ku_ct_add(s_ctk, s_ctc, pairs[3 * i + 2], 1, counts);
+  __syncthreads();
+  ku_ct_flush(s_ctk, s_ctc, counts);
+}
+int ku_launch_count_slots(const uint32_t *d_pairs, uint64_t n_pairs, unsigned long long *d_counts, uint32_t,
+                          hipStream_t stream) {
+  if (n_pairs == 0) return KU_OK;
+  uint64_t nb = (n_pairs + 255) / 256;
+  hipLaunchKernelGGL(ku_count_slots_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, stream, d_pairs,
+                     n_pairs, d_counts);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}

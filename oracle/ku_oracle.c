@@ -695,6 +695,12 @@ typedef struct {
   size_t n, cap;
 } ko_cmap;
 
+/* Test knob: 1 (default) = the reference's behaviour (sketches start sparse);
+ * 0 = every sketch is dense from the start -- the "dense p=12 registers only"
+ * model the GPU path implements (HLL section). */
+static int g_hll_sparse = 1;
+void ko_set_hll_sparse(int sparse) { g_hll_sparse = sparse; }
+
 static void cmap_init(ko_cmap *m) { memset(m, 0, sizeof(*m)); u32map_init(&m->idx, 64); }
 static ko_counts *cmap_get(ko_cmap *m, uint32_t taxid) { /* unordered_map::operator[] */
   int isnew;
@@ -708,7 +714,7 @@ static ko_counts *cmap_get(ko_cmap *m, uint32_t taxid) { /* unordered_map::opera
     *slot = (uint32_t)m->n;
     m->taxids[m->n] = taxid;
     m->c[m->n].n_reads = 0; m->c[m->n].n_kmers = 0;
-    m->c[m->n].hll = ko_hll_new(12, 1); /* hyperloglogplus.hpp:87 defaults; -p is a no-op */
+    m->c[m->n].hll = ko_hll_new(12, g_hll_sparse); /* hyperloglogplus.hpp:87 defaults; -p is a no-op */
     m->n++;
   }
   return &m->c[*slot];
@@ -1061,7 +1067,7 @@ char *ko_run_report(const ko_run *r, const char *taxdb_path, const char *counts_
     int64_t row = tax_row(t, r->global.taxids[i]);
     if (row < 0) continue; /* "No entry for X in database!" */
     for (int64_t q = row; q >= 0; q = tax_parent_row(t, (size_t)q)) {
-      if (!rc.has_clade[q]) { rc.has_clade[q] = 1; rc.clade_hll[q] = ko_hll_new(12, 1); }
+      if (!rc.has_clade[q]) { rc.has_clade[q] = 1; rc.clade_hll[q] = ko_hll_new(12, g_hll_sparse); }
       rc.clade_reads[q] += r->global.c[i].n_reads;
       rc.clade_kmers[q] += r->global.c[i].n_kmers;
       ko_hll_merge(rc.clade_hll[q], r->global.c[i].hll);

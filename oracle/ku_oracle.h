@@ -87,6 +87,8 @@ uint32_t ko_classify_read(const ko_db *db, const ko_tax *tax, const char *seq, s
 /* classify.cpp:826-861; returns bytes written (no NUL counted), buf must hold 24*n+8 */
 size_t ko_hitlist_string(const uint32_t *taxa, const uint8_t *ambig, size_t n, char *buf);
 
+/* test knob: 0 = all sketches dense from the start (the GPU path's model), 1 = reference behaviour */
+void ko_set_hll_sparse(int sparse);
 typedef struct ko_run ko_run;
 /* work_unit_nt: classify.cpp:38 (500000). threads>1 uses OpenMP over work units. */
 ko_run *ko_run_new(const ko_db *db, const ko_tax *tax, uint64_t work_unit_nt, int quick,

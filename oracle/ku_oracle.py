@@ -81,6 +81,7 @@ def lib():
         "ko_run_sketch": (C.c_void_p, [C.c_void_p, C.c_size_t]),
         "ko_run_report": (C.c_void_p, [C.c_void_p, C.c_char_p, C.c_char_p]),
         "ko_free": (None, [C.c_void_p]),
+        "ko_set_hll_sparse": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -266,6 +267,11 @@ class Run:
         s = C.string_at(p).decode()
         lib().ko_free(p)
         return s
+
+
+def set_hll_sparse(sparse: bool):
+    """False = sketches dense from the start (the GPU path's HLL model); True = reference behaviour."""
+    lib().ko_set_hll_sparse(int(sparse))
 
 
 def hitlist(taxa, ambig):

@@ -1,0 +1,279 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and against the
+golden outputs captured from the compiled reference.  Bit-exact for everything
+integer: calls, per-k-mer codes, hit strings, n_kmers, n_reads, HLL registers."""
+import os
+
+import numpy as np
+import pytest
+
+from krakenuniq_amd import capi, synth
+from oracle import ku_oracle as ko
+
+from gpu_common import (assert_same_classification, assert_same_counts, make_ctx, oracle_flat, random_db,
+                        valid_mask)
+
+pytestmark = pytest.mark.gpu
+K = 31
+
+
+@pytest.fixture(scope="module")
+def f1(golden):
+    d = os.path.join(golden, "f1")
+    ctx, cdb, ctax = make_ctx(d)
+    return {"dir": d, "ctx": ctx, "cdb": cdb, "ctax": ctax,
+            "odb": ko.Db(f"{d}/database.kdb", f"{d}/database.idx"), "otax": ko.Tax(f"{d}/taxDB")}
+
+
+def rows(text):
+    return sorted(text.strip("\n").split("\n"))
+
+
+def test_loaded_native_library():
+    assert capi.lib().ku_device_count() >= 1
+    assert os.path.exists(capi.LIB_PATH)
+
+
+def test_f1_matches_reference_output_and_oracle_state(f1):
+    d = f1["dir"]
+    ids, seqs = synth.read_seqfile(f"{d}/reads.fq")
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    # the reference's own output file, byte for byte
+    assert capi.format_kraken(buf, off, lens, ids, K, gpu["calls"], taxa=gpu["taxa"]) == open(f"{d}/out.tsv").read()
+    counts = ctx.counts()
+    assert_same_counts(counts, run)
+    # report: identical to the oracle run with dense sketches; reference's report within 3 sigma on kmers
+    ko.set_hll_sparse(False)
+    try:
+        run_d = ko.Run(f1["odb"], f1["otax"])
+        run_d.classify(seqs)
+        want = run_d.report(f"{d}/taxDB", f"{d}/database.kdb.counts")
+    finally:
+        ko.set_hll_sparse(True)
+    got = capi.report(f1["ctax"], counts, f"{d}/database.kdb.counts")
+    assert got == want
+    ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{d}/report.tsv").read().strip().split("\n")}
+    for ln in got.strip().split("\n"):
+        f = ln.split("\t")
+        r = ref[f[6]]
+        assert f[:3] == r[:3] and f[6:] == r[6:]
+        if f[3] != "kmers":
+            assert abs(int(f[3]) - int(r[3])) <= max(2, 3 * 0.01625 * int(r[3]))
+
+
+def test_f1_counts_accumulate_over_batches(f1):
+    """two batches == one batch (the global taxon_counts merge, classify.cpp:541-544)"""
+    ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    for part in (seqs[:300], seqs[300:]):
+        buf, off, lens = ko.pack_reads(part)
+        ctx.classify_batch(buf, off, lens)
+    run = ko.Run(f1["odb"], f1["otax"])
+    run.classify(seqs)
+    assert_same_counts(ctx.counts(), run)
+
+
+def test_f1_quick_mode(f1):
+    d = f1["dir"]
+    ids, seqs = synth.read_seqfile(f"{d}/reads.fq")
+    for mh in (1, 2, 5):
+        run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs, quick=True, min_hits=mh)
+        ctx = f1["ctx"]
+        ctx.reset_counts()
+        gpu = ctx.classify_batch(buf, off, lens, flags=capi.KU_F_QUICK, min_hits=mh)
+        assert_same_classification(gpu, res, taxa, off, lens, K, quick=True)
+        assert_same_counts(ctx.counts(), run)
+        if mh == 2:
+            assert capi.format_kraken(buf, off, lens, ids, K, gpu["calls"], hits=gpu["hits"],
+                                      flags=capi.KU_P_QUICK) == open(f"{d}/out_quick.tsv").read()
+
+
+def test_f2_edge_reads(golden, f1):
+    d = os.path.join(golden, "f2")
+    ids, seqs = synth.read_seqfile(f"{d}/edge.fa")
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    assert capi.format_kraken(buf, off, lens, ids, K, gpu["calls"], taxa=gpu["taxa"]) == open(f"{d}/out.tsv").read()
+    assert_same_counts(ctx.counts(), run)
+
+
+def test_f4_paired_merged(golden, f1):
+    d = os.path.join(golden, "f4")
+    ids, seqs = synth.read_seqfile(f"{d}/merged.fa")
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert capi.format_kraken(buf, off, lens, ids, K, gpu["calls"], taxa=gpu["taxa"]) == open(f"{d}/out.tsv").read()
+    assert_same_counts(ctx.counts(), run)
+
+
+def test_f7_legacy_unscrambled_index(golden, f1):
+    d = os.path.join(golden, "f7")
+    ctx, _, _ = make_ctx(d)
+    ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert capi.format_kraken(buf, off, lens, ids, K, gpu["calls"], taxa=gpu["taxa"]) == open(f"{d}/out.tsv").read()
+
+
+def test_count_taxons_equals_counts_file(f1):
+    t, c = f1["ctx"].count_taxons()
+    want = open(f"{f1['dir']}/database.kdb.counts").read()
+    assert "".join(f"{a}\t{b}\n" for a, b in zip(t.tolist(), c.tolist())) == want
+
+
+def test_db_values(f1):
+    _, vals, *_ = synth.read_db(f1["dir"])
+    want = np.unique(vals[vals != 0])
+    assert (f1["ctx"].db_values() == want).all()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_sharded_lookup_merges_to_unsharded(f1, n_shards):
+    """Minimizer-range shards (the 8-GPU layout, here one after another on one GPU): per-k-mer slots merged with
+    max (exactly one shard is non-zero, classify.cpp:447), resolve once, owner-computes counts summed."""
+    d = f1["dir"]
+    ids, seqs = synth.read_seqfile(f"{d}/reads.fq")
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    import torch
+    dev = torch.device("cuda:0")
+    bounds = f1["cdb"].shard_plan(n_shards)
+    all_values = f1["ctx"].db_values()
+    t_seq = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    merged = None
+    ctxs = []
+    for s in range(n_shards):
+        ctx, _, _ = make_ctx(cdb=f1["cdb"], ctax=f1["ctax"], shard=(int(bounds[s]), int(bounds[s + 1])),
+                             all_values=all_values)
+        t_taxa = torch.zeros(len(buf), dtype=torch.int32, device=dev)
+        ctx.lookup_device(t_seq.data_ptr(), len(buf), t_taxa.data_ptr(), flags=capi.KU_F_KEEP_SLOTS)
+        ctx.synchronize()
+        u = t_taxa.view(torch.int32).cpu().numpy().view(np.uint32)
+        merged = u if merged is None else np.maximum(merged, u)
+        ctxs.append(ctx)
+    # exactly one shard may be non-zero per k-mer -> max == the owner's value; resolve on shard 0's context
+    t_m = torch.from_numpy(merged.view(np.int32)).to(dev)
+    t_calls = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+    ctxs[0].resolve_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), len(lens), t_calls.data_ptr(),
+                           t_m.data_ptr(), max_read_len=int(lens.max()))
+    ctxs[0].synchronize()
+    gpu = {"calls": t_calls.cpu().numpy().view(np.uint32), "taxa": t_m.cpu().numpy().view(np.uint32)}
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    # reduce the per-shard state: max on registers, sum on counters
+    cs = [c.counts() for c in ctxs]
+    tot = dict(cs[0])
+    tot["registers"] = np.maximum.reduce([c["registers"] for c in cs])
+    tot["n_kmers"] = np.sum([c["n_kmers"] for c in cs], axis=0)
+    tot["n_reads"] = np.sum([c["n_reads"] for c in cs], axis=0)
+    assert_same_counts(tot, run)
+
+
+def test_device_api_with_torch_buffers(f1):
+    import torch
+    dev = torch.device("cuda:0")
+    ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    t_seq = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    t_taxa = torch.zeros(len(buf), dtype=torch.int32, device=dev)
+    t_calls = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.classify_batch_device(t_seq.data_ptr(), len(buf), t_off.data_ptr(), t_len.data_ptr(), len(lens),
+                              t_calls.data_ptr(), t_taxa.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    gpu = {"calls": t_calls.cpu().numpy().view(np.uint32), "taxa": t_taxa.cpu().numpy().view(np.uint32)}
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    assert_same_counts(ctx.counts(), run)
+
+
+@pytest.mark.parametrize("k,nt", [(31, 9), (31, 13), (31, 15), (25, 6), (21, 12), (31, 1)])
+def test_random_db_geometries(k, nt):
+    """other (k, nt): key_len < 8 repack path (k=21, 25), nt=15 (30-bit minimizers), degenerate nt=1"""
+    rng = np.random.default_rng(100 * k + nt)
+    db = random_db(rng, k=k, nt=nt, glen=2500)
+    raw = np.zeros(len(db["kmers"]) * ((2 * k + 7) // 8 + 4), dtype=np.uint8)
+    kl = (2 * k + 7) // 8
+    rec = raw.reshape(-1, kl + 4)
+    kb = db["kmers"].astype("<u8").view(np.uint8).reshape(-1, 8)
+    rec[:, :kl] = kb[:, :kl]
+    rec[:, kl:] = db["vals"].astype("<u4").view(np.uint8).reshape(-1, 4)
+    ids, par = db["tax"].arrays()
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=k, offsets=db["offsets"], nt=nt)
+    otax = ko.Tax(ids=ids, parents=par)
+    cdb = capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=k, offsets=db["offsets"], nt=nt)
+    ctax = capi.Tax(ids=ids, parents=par)
+    ctx, _, _ = make_ctx(cdb=cdb, ctax=ctax)
+    reads, _ = synth.sample_reads(db["genomes"], 400, 150, rng, n_rate=0.002)
+    reads += [b"", b"ACGT", reads[0][:k], reads[1][:k - 1]]
+    run, res, buf, off, lens, taxa = oracle_flat(odb, otax, reads)
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, k)
+    assert_same_counts(ctx.counts(), run)
+
+
+def test_long_and_huge_reads(f1):
+    """10 kbp reads (block-per-read resolve, LDS table) and one > 12288-k-mer read (global-memory table)"""
+    rng = np.random.default_rng(5)
+    db = random_db(rng, n_genomes=12, glen=30000, nt=10)
+    ids, par = db["tax"].arrays()
+    raw = db["pairs"].view(np.uint8)
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=10)
+    otax = ko.Tax(ids=ids, parents=par)
+    ctx, _, _ = make_ctx(cdb=capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=10),
+                         ctax=capi.Tax(ids=ids, parents=par))
+    reads, _ = synth.sample_reads(db["genomes"], 24, 10000, rng, frac_random=0.1)
+    # chimeras touch many taxa; one read longer than 12288 k-mers
+    g = list(db["genomes"].values())
+    chim = b"".join(synth.codes_to_ascii(x[i * 700:(i + 1) * 700]) for i, x in enumerate(g))
+    reads += [chim, chim + reads[0] + chim[::-1], reads[1][:400], reads[2][:150], b"ACGTN" * 10]
+    run, res, buf, off, lens, taxa = oracle_flat(odb, otax, reads)
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    assert_same_counts(ctx.counts(), run)
+
+
+def test_revcomp_invariance_property(f1):
+    """size-independent property: a read and its reverse complement get the same call and mirrored hit list"""
+    ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
+    comp = bytes.maketrans(b"ACGTacgtN", b"TGCAtgcaN")
+    rc = [s.translate(comp)[::-1] for s in seqs]
+    ctx = f1["ctx"]
+    b1, o1, l1 = ko.pack_reads(seqs)
+    b2, o2, l2 = ko.pack_reads(rc)
+    g1 = ctx.classify_batch(b1, o1, l1)
+    g2 = ctx.classify_batch(b2, o2, l2)
+    assert (g1["calls"] == g2["calls"]).all()
+    for o, l in zip(o1.tolist(), l1.tolist()):
+        if l >= K:
+            n = l - K + 1
+            assert (g1["taxa"][o:o + n] == g2["taxa"][o:o + n][::-1]).all()
+
+
+def test_errors_are_reported_not_swallowed(f1):
+    ctx = capi.Ctx(0)
+    buf, off, lens = ko.pack_reads([b"ACGT" * 20])
+    with pytest.raises(capi.KuError) as e:
+        ctx.classify_batch(buf, off, lens)
+    assert e.value.status == -6
+    ctx.load_db(f1["cdb"])
+    with pytest.raises(capi.KuError):
+        ctx.classify_batch(buf, off, lens)  # taxonomy missing
+    ctx.set_taxonomy(f1["ctax"])
+    bad_len = lens.copy()
+    bad_len[0] = 1000
+    with pytest.raises(capi.KuError) as e:
+        ctx.classify_batch(buf, off, bad_len)
+    assert e.value.status == -1
