@@ -100,6 +100,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C krakenuniq_amd/csrc` "
                               "(or __graft_entry__.build()); there is no fallback path")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+        # Importing torch first makes this library bind to the runtime torch uses, so torch tensors, RCCL
+        # and our kernels share one device context; loading ours first leaves torch with "No HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the ABI symbol is not exported
