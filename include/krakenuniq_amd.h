@@ -182,6 +182,12 @@ int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_seq_off
                       uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls, uint32_t *d_taxa,
                       uint32_t *d_hits, void *stream);
 int ku_ctx_synchronize(ku_ctx *ctx);
+/* Measurement aid (bench.py roofline): runs the scan + minimizer + idx stages only
+ * and returns, for the k-mers this context owns, stats_out[4] = { lookups,
+ * sum over lookups of ceil(log2(n_bin + 1)), lookups into non-empty bins,
+ * sum of n_bin } -- the inputs of the algorithmic-bytes model
+ * B(q) = 16 + 12 * ceil(log2(n_bin + 1)) + 4.  Blocking. */
+int ku_lookup_stats_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint64_t *stats_out, void *stream);
 
 /* ------------------------------------------------------------------ per-taxon state
  * Export of the run's `taxon_counts` (classify.cpp:78): one row per slot

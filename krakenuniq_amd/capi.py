@@ -78,6 +78,7 @@ SIGNATURES = {
     "ku_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Opts),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ku_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "ku_lookup_stats_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, C.c_void_p]),
     "ku_counts_dims_get": (C.c_int, [C.c_void_p, C.POINTER(CountsDims)]),
     "ku_counts_export": (C.c_int, [C.c_void_p, u32p, u64p, u8p, u32p, u64p]),
     "ku_counts_device_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p), u64p,
@@ -140,8 +141,8 @@ class Db:
         _chk(lib().ku_db_get_info(self.h, C.byref(self.info)), "ku_db_get_info")
 
     def close(self):
-        if self.h:
-            lib().ku_db_close(self.h)
+        if self.h and _lib is not None:
+            _lib.ku_db_close(self.h)
             self.h = C.c_void_p()
 
     __del__ = close
@@ -172,8 +173,8 @@ class Tax:
                  "ku_tax_from_arrays")
 
     def close(self):
-        if self.h:
-            lib().ku_tax_close(self.h)
+        if self.h and _lib is not None:
+            _lib.ku_tax_close(self.h)
             self.h = C.c_void_p()
 
     __del__ = close
@@ -194,8 +195,8 @@ class Ctx:
         self._keep = []
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().ku_ctx_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ku_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
     __del__ = close
@@ -268,6 +269,11 @@ class Ctx:
         o = Opts(flags, min_hits, max_read_len, 0)
         _chk(lib().ku_classify_batch_device(self.h, d_seqs, n_bytes, d_off, d_len, n_reads, C.byref(o), d_calls,
                                             d_taxa, d_hits, stream), "ku_classify_batch_device")
+
+    def lookup_stats_device(self, d_seqs, n_bytes, stream=None):
+        out = np.zeros(4, dtype=np.uint64)
+        _chk(lib().ku_lookup_stats_device(self.h, d_seqs, n_bytes, _p(out, u64p), stream), "ku_lookup_stats_device")
+        return {"lookups": int(out[0]), "sum_ceil_log2": int(out[1]), "nonempty": int(out[2]), "sum_nb": int(out[3])}
 
     def synchronize(self):
         _chk(lib().ku_ctx_synchronize(self.h), "ku_ctx_synchronize")

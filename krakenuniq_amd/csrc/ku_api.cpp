@@ -594,6 +594,20 @@ extern "C" int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
   return st == KU_OK ? KU_OK : fail(st, "lookup kernel launch failed");
 }
 
+extern "C" int ku_lookup_stats_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint64_t *stats_out,
+                                      void *stream) {
+  KU_TRY(check_ready(ctx));
+  if (!stats_out || (n_bytes && !d_seqs)) return fail(KU_EINVAL, "ku_lookup_stats_device: null argument");
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  unsigned long long *d_stats = (unsigned long long *)(ctx->d_scalar + 8);  // 32 bytes at offset 32
+  HIP_TRY(hipMemsetAsync(d_stats, 0, 32, s));
+  int st = ku_launch_lookup_stats(ctx->db, (const uint8_t *)d_seqs, n_bytes, d_stats, ctx->n_cu, s);
+  if (st != KU_OK) return fail(st, "stats kernel launch failed");
+  HIP_TRY(hipMemcpyAsync(stats_out, d_stats, 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return KU_OK;
+}
+
 extern "C" int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
                                  uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls, uint32_t *d_taxa,
                                  uint32_t *d_hits, void *stream) {

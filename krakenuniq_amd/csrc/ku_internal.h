@@ -46,6 +46,8 @@ struct KuCountsDev {
 // launch wrappers implemented in ku_kernels.hip (all asynchronous on `stream`)
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
                      uint32_t *d_taxa, bool do_counts, int n_cu, hipStream_t stream);
+int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
+                           int n_cu, hipStream_t stream);
 int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
                       const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads, uint32_t flags,
                       uint32_t min_hits, uint32_t max_read_len, uint32_t *d_calls, uint32_t *d_taxa,

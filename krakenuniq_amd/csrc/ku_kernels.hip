@@ -128,10 +128,17 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
   amb |= (valid ^ 1u) << (15 - j);
 }
 
-template <bool DO_COUNTS>
+// MODE 0: lookup only; MODE 1: lookup + per-taxon accounting; MODE 2: measurement
+// only -- no search, accumulates {queries, sum ceil(log2(n_b+1)), queries into
+// non-empty bins, sum n_b} into stats[4] (the algorithmic-bytes model of
+// SURVEY.md 8(d), DESIGN.md "Roofline").
+template <int MODE>
 __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
                                                                const uint8_t *__restrict__ seqs,
-                                                               uint64_t n_bytes, uint32_t *__restrict__ taxa) {
+                                                               uint64_t n_bytes, uint32_t *__restrict__ taxa,
+                                                               unsigned long long *stats) {
+  constexpr bool DO_COUNTS = MODE == 1;
+  unsigned long long st_q = 0, st_lg = 0, st_ne = 0, st_nb = 0;
   // 16 bases per word, MSB first (base 16w in bits 31..30): a k-mer is a
   // funnel shift over three consecutive words.
   __shared__ uint32_t s_codes[KU_PACKW + 4];
@@ -227,6 +234,17 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
       }
     }
 
+    if (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j)
+        if (ok[j]) {
+          st_q += 1;
+          st_lg += n_b[j] ? 32 - __builtin_clz(n_b[j]) : 0;
+          st_ne += n_b[j] != 0;
+          st_nb += n_b[j];
+        }
+      continue;
+    }
     // ---- stage 4: in-bin binary search, KU_ITEMS probes in flight per lane
     uint32_t lo[KU_ITEMS], hi[KU_ITEMS], slot[KU_ITEMS];
 #pragma unroll
@@ -280,6 +298,15 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
     __syncthreads();
     ku_ct_flush(s_ctk, s_ctc, cnt.n_kmers);
   }
+  if (MODE == 2) {
+    unsigned long long v[4] = {st_q, st_lg, st_ne, st_nb};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+      if ((tid & 63) == 0 && v[i]) atomicAdd(&stats[i], v[i]);
+    }
+  }
 }
 
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
@@ -289,11 +316,22 @@ int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d
   uint64_t max_blocks = (uint64_t)n_cu * 8;
   unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
   if (do_counts)
-    hipLaunchKernelGGL(ku_lookup_kernel<true>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
-                       d_taxa);
+    hipLaunchKernelGGL(ku_lookup_kernel<1>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
+                       d_taxa, (unsigned long long *)nullptr);
   else
-    hipLaunchKernelGGL(ku_lookup_kernel<false>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
-                       d_taxa);
+    hipLaunchKernelGGL(ku_lookup_kernel<0>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
+                       d_taxa, (unsigned long long *)nullptr);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
+                           int n_cu, hipStream_t stream) {
+  if (n_bytes == 0) return KU_OK;
+  uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
+  uint64_t max_blocks = (uint64_t)n_cu * 8;
+  unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
+  hipLaunchKernelGGL(ku_lookup_kernel<2>, dim3(grid), dim3(KU_THREADS), 0, stream, db, KuCountsDev{}, d_seqs, n_bytes,
+                     (uint32_t *)nullptr, d_stats);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

@@ -1,0 +1,86 @@
+"""Multi-GPU orchestration of the classify hot path (torch.distributed; backend
+"nccl" == RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+The reference shards its database only *in time* (--preload-size chunk mode,
+src/krakendb.cpp:411-526, src/classify.cpp:566-791) and merges per-k-mer taxa with
+"non-zero wins" (src/classify.cpp:445-452).  Here the same minimizer-range shards
+live on different GPUs at once:
+
+  replicas  every rank holds the whole DB and classifies its own reads; the only
+            exchange is the end-of-run merge of the per-taxon state
+            (HLL registers: MAX, n_kmers / n_reads: SUM)  == taxon_counts[t] += local[t]
+            (src/classify.cpp:541-544) across ranks.
+  sharded   rank r holds the bins [bounds[r], bounds[r+1]); every rank scans the same
+            read batch and looks up only the k-mers it owns (is_minimizer_in_chunk);
+            per-k-mer slot ids are merged with all_reduce(MAX) (exactly one rank is
+            non-zero per k-mer, ambiguous k-mers are 0xFFFFFFFF = -1 on every rank),
+            each rank then resolves its own slice of the reads.  HLL / n_kmers are
+            owner-computes (the bin owner also accounts the misses), merged as above.
+
+All functions take plain torch tensors so the same code runs under gloo on CPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def read_slice(n_reads: int, rank: int, world_size: int):
+    """contiguous slice of a broadcast batch that `rank` resolves"""
+    per = (n_reads + world_size - 1) // world_size
+    lo = min(rank * per, n_reads)
+    return lo, min(lo + per, n_reads)
+
+
+def allgather_values(local_values: np.ndarray, device) -> np.ndarray:
+    """union of the distinct DB taxids of all shards, ascending (so every rank numbers slots alike)"""
+    rank, ws = world()
+    if ws == 1:
+        return np.asarray(local_values, dtype=np.uint32)
+    n = torch.tensor([len(local_values)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    m = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros(max(m, 1), dtype=torch.int64, device=device)
+    pad[:len(local_values)] = torch.from_numpy(np.asarray(local_values, dtype=np.int64)).to(device)
+    parts = [torch.zeros_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad)
+    vals = np.concatenate([p[:int(s.item())].cpu().numpy() for p, s in zip(parts, sizes)])
+    return np.unique(vals).astype(np.uint32)
+
+
+def merge_taxa_max(taxa_i32: torch.Tensor) -> torch.Tensor:
+    """in-place MAX all-reduce of per-k-mer slot ids viewed as int32 (non-zero wins; KU_AMBIG == -1 everywhere)"""
+    _, ws = world()
+    if ws > 1:
+        dist.all_reduce(taxa_i32, op=dist.ReduceOp.MAX)
+    return taxa_i32
+
+
+def reduce_state(registers_u8: torch.Tensor, n_kmers_i64: torch.Tensor, n_reads_i64: torch.Tensor):
+    """end-of-run merge of the per-taxon state across ranks: returns (registers, n_kmers, n_reads) copies"""
+    _, ws = world()
+    r, k, n = registers_u8.clone(), n_kmers_i64.clone(), n_reads_i64.clone()
+    if ws > 1:
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return r, k, n
+
+
+def quantile_bin_bounds(sample_bins: torch.Tensor, n_bins: int, world_size: int) -> np.ndarray:
+    """shard bounds from a sample of bin keys (every rank draws the same sample -> same plan)"""
+    b = np.zeros(world_size + 1, dtype=np.uint64)
+    b[-1] = n_bins
+    if world_size > 1:
+        q = torch.quantile(sample_bins.to(torch.float64), torch.linspace(0, 1, world_size + 1,
+                                                                         dtype=torch.float64)[1:-1].to(sample_bins.device))
+        b[1:-1] = np.ceil(q.cpu().numpy()).astype(np.uint64)
+    return b

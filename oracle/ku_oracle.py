@@ -111,8 +111,8 @@ class Hll:
         self.p = p
 
     def __del__(self):
-        if self._own and self.h:
-            lib().ko_hll_free(self.h)
+        if self._own and self.h and _lib is not None:
+            _lib.ko_hll_free(self.h)
             self.h = None
 
     def insert(self, x: int):
@@ -162,8 +162,8 @@ class Tax:
             self.h = lib().ko_tax_from_arrays(_p(ids, u32p), _p(parents, u32p), len(ids))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ko_tax_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ko_tax_free(self.h)
             self.h = None
 
     def parent(self, t):
@@ -194,8 +194,8 @@ class Db:
         self.key_ct = lib().ko_db_key_ct(self.h)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ko_db_close(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ko_db_close(self.h)
             self.h = None
 
     def query(self, canon):
@@ -228,8 +228,8 @@ class Run:
         self.quick = quick
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ko_run_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ko_run_free(self.h)
             self.h = None
 
     def classify(self, seqs, want_taxa=True):
