@@ -109,8 +109,10 @@ int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_h
  * d_pairs = n_pairs 12-byte (8-byte LE key, 4-byte LE taxid) records of the
  * bins [bin_lo, bin_hi); d_offsets = bin_hi - bin_lo + 1 uint64 *global* pair
  * indices whose first entry is the global index of d_pairs[0].  The buffers
- * stay owned by the caller and must outlive the context; values are remapped
- * in place by ku_ctx_set_taxonomy. */
+ * stay owned by the caller; d_pairs is remapped in place (taxid -> slot id) and
+ * consumed by ku_ctx_set_taxonomy (it builds the probe table from it) and may be
+ * released afterwards unless the context runs with KU_LAYOUT=sorted; d_offsets
+ * must outlive the context. */
 int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, const uint64_t *d_offsets, uint32_t k,
                     uint32_t nt, uint32_t idx_type, uint64_t bin_lo, uint64_t bin_hi);
 /* Distinct non-zero taxids stored in the resident shard, ascending (what

@@ -293,6 +293,10 @@ struct ku_ctx {
   hipStream_t stream = nullptr;
   // DB shard
   bool db_loaded = false, db_owned = false, tax_set = false;
+  bool hash_layout = true;   // KU_LAYOUT=sorted keeps the on-disk order + binary search (A/B and fallback for HBM-tight shards)
+  double load_factor = 0.5;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
+  void *d_table = nullptr;
+  uint64_t n_dup = 0;
   uint32_t *d_pairs = nullptr;
   uint64_t *d_offsets = nullptr;
   bool offsets_owned = false;
@@ -331,11 +335,18 @@ extern "C" int ku_ctx_create(int device, ku_ctx **out) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void **)&ctx->d_scalar, 64));
+  if (const char *e = getenv("KU_LAYOUT")) ctx->hash_layout = strcmp(e, "sorted") != 0;
+  if (const char *e = getenv("KU_LOAD_FACTOR")) {
+    double f = atof(e);
+    if (f >= 0.05 && f <= 0.9) ctx->load_factor = f;
+  }
   *out = ctx;
   return KU_OK;
 }
 
 static void ctx_free_db(ku_ctx *ctx) {
+  if (ctx->d_table) (void)hipFree(ctx->d_table);
+  ctx->d_table = nullptr;
   if (ctx->db_owned && ctx->d_pairs) (void)hipFree(ctx->d_pairs);
   if (ctx->offsets_owned && ctx->d_offsets) (void)hipFree(ctx->d_offsets);
   ctx->d_pairs = nullptr; ctx->d_offsets = nullptr;
@@ -396,6 +407,8 @@ static int ctx_scan_values(ku_ctx *ctx) {
 static void fill_db_dev(ku_ctx *ctx, uint64_t n_pairs, uint64_t pair_base, uint32_t k, uint32_t nt, uint32_t idx_type,
                         uint64_t bin_lo, uint64_t bin_hi) {
   ctx->db.pairs = ctx->d_pairs;
+  ctx->db.table = nullptr;
+  ctx->db.n_lines = 0;
   ctx->db.offsets = ctx->d_offsets;
   ctx->db.pair_base = pair_base;
   ctx->db.n_pairs = n_pairs;
@@ -530,6 +543,25 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
   HIP_TRY(hipMemcpyAsync(&err, ctx->d_scalar, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (err) return fail(KU_EDATA, "internal: " + std::to_string(err) + " DB values missing from the slot table");
+  if (ctx->hash_layout) {
+    // re-lay the shard out as the open-addressing table the lookup kernel probes; the 12-byte
+    // pairs are only the build input: owned copies are released, adopted buffers go back to the caller.
+    uint64_t n_lines = (uint64_t)((double)ctx->db.n_pairs / ctx->load_factor / 9.0) + 1;
+    HIP_TRY(hipMalloc(&ctx->d_table, n_lines * 128));
+    unsigned long long *d_dup = (unsigned long long *)(ctx->d_scalar + 2);
+    HIP_TRY(hipMemsetAsync(d_dup, 0, 8, ctx->stream));
+    KU_TRY(ku_launch_build_table(ctx->d_pairs, ctx->db.n_pairs, ctx->d_table, n_lines, d_dup, ctx->stream));
+    unsigned long long dup = 0;
+    HIP_TRY(hipMemcpyAsync(&dup, d_dup, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_dup = dup;
+    ctx->db.table = (const uint4 *)ctx->d_table;
+    ctx->db.n_lines = n_lines;
+    if (ctx->db_owned) (void)hipFree(ctx->d_pairs);
+    ctx->d_pairs = nullptr;
+    ctx->db_owned = false;
+    ctx->db.pairs = nullptr;
+  }
   // per-taxon state
   HIP_TRY(hipMalloc((void **)&ctx->cnt.registers, (size_t)slots.size() * KU_HLL_M));
   HIP_TRY(hipMalloc((void **)&ctx->cnt.n_kmers, slots.size() * 8));
@@ -558,7 +590,9 @@ extern "C" int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *coun
   std::vector<unsigned long long> h(ns);
   int st = KU_OK;
   if (hipMemsetAsync(d_c, 0, (size_t)ns * 8, ctx->stream) != hipSuccess) st = KU_EHIP;
-  if (st == KU_OK) st = ku_launch_count_slots(ctx->d_pairs, ctx->db.n_pairs, d_c, ns, ctx->stream);
+  if (st == KU_OK)
+    st = ctx->db.table ? ku_launch_count_table(ctx->d_table, ctx->db.n_lines, d_c, ctx->stream)
+                       : ku_launch_count_slots(ctx->d_pairs, ctx->db.n_pairs, d_c, ns, ctx->stream);
   if (st == KU_OK && hipMemcpyAsync(h.data(), d_c, (size_t)ns * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = KU_EHIP;
   if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
   (void)hipFree(d_c);

@@ -12,7 +12,9 @@
 // value dword holds a *slot id* (rank of the taxid among the distinct DB values,
 // 0 = taxid 0) instead of the raw taxid.
 struct KuDbDev {
-  const uint32_t *pairs;    // 3 dwords per pair: key_lo, key_hi, slot
+  const uint32_t *pairs;    // sorted layout: 3 dwords per pair: key_lo, key_hi, slot (nullptr once the table is built)
+  const uint4 *table;       // hash layout: n_lines buckets of 128 B (20-byte tag header + 9 x 12-byte entries)
+  uint64_t n_lines;         // 128-byte lines in the table
   const uint64_t *offsets;  // bin_hi - bin_lo + 1 global pair indices
   uint64_t pair_base;       // global index of pairs[0]
   uint64_t n_pairs;
@@ -63,5 +65,8 @@ int ku_launch_collect_values(const uint32_t *d_bitmap, uint32_t *d_out, uint32_t
                              hipStream_t stream);
 int ku_launch_remap_values(uint32_t *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_taxid, uint32_t n_slots,
                            uint32_t *d_err, hipStream_t stream);
+int ku_launch_build_table(const uint32_t *d_pairs, uint64_t n_pairs, void *d_table, uint64_t n_lines,
+                          unsigned long long *d_dup, hipStream_t stream);
+int ku_launch_count_table(const void *d_table, uint64_t n_lines, unsigned long long *d_counts, hipStream_t stream);
 int ku_launch_count_slots(const uint32_t *d_pairs, uint64_t n_pairs, unsigned long long *d_counts,
                           uint32_t n_slots, hipStream_t stream);

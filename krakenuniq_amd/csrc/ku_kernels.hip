@@ -23,6 +23,8 @@
 // of a wave collapse onto a handful of cache lines.
 #include "ku_internal.h"
 
+#include <cstdlib>
+
 #define KU_THREADS 256
 #define KU_ITEMS 4
 #define KU_TILE (KU_THREADS * KU_ITEMS)   // k-mer start positions per block iteration
@@ -57,35 +59,55 @@ __device__ __forceinline__ uint32_t ku_revcomp32(uint32_t x, uint32_t n) {
   return (~r) >> (32 - 2 * n);
 }
 
-// LDS-aggregated counters: id -> count, flushed to a global uint64 array.
-__device__ __forceinline__ void ku_ct_add(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t id, uint32_t n,
+// LDS-aggregated counters: id -> count, flushed to a global uint64 array.  `used` counts occupied
+// entries; callers flush + clear at a block-uniform point once the table is half full
+// (ku_ct_maybe_flush), so the 8-probe fallback to a global atomic stays rare whatever the
+// number of distinct taxa a block meets.
+template <int LOG2 = KU_CT_LOG2>
+__device__ __forceinline__ void ku_ct_add(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t *used, uint32_t id, uint32_t n,
                                           unsigned long long *global) {
-  uint32_t h = (id * 2654435761u) >> (32 - KU_CT_LOG2);
+  uint32_t h = (id * 2654435761u) >> (32 - LOG2);
 #pragma unroll 1
   for (int probe = 0; probe < 8; ++probe) {
     uint32_t cur = __hip_atomic_load(&ct_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (cur == 0) {
       uint32_t old = atomicCAS(&ct_key[h], 0u, id + 1);
+      if (old == 0) atomicAdd(used, 1u);
       cur = old == 0 ? id + 1 : old;
     }
     if (cur == id + 1) {
       atomicAdd(&ct_cnt[h], n);
       return;
     }
-    h = (h + 1) & (KU_CT_CAP - 1);
+    h = (h + 1) & ((1u << LOG2) - 1);
   }
   atomicAdd(&global[id], (unsigned long long)n);
 }
-__device__ __forceinline__ void ku_ct_clear(uint32_t *ct_key, uint32_t *ct_cnt) {
-  for (int i = threadIdx.x; i < KU_CT_CAP; i += blockDim.x) {
+template <int LOG2 = KU_CT_LOG2>
+__device__ __forceinline__ void ku_ct_clear(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t *used) {
+  for (int i = threadIdx.x; i < (1 << LOG2); i += blockDim.x) {
     ct_key[i] = 0;
     ct_cnt[i] = 0;
   }
+  if (threadIdx.x == 0) *used = 0;
 }
+template <int LOG2 = KU_CT_LOG2>
 __device__ __forceinline__ void ku_ct_flush(uint32_t *ct_key, uint32_t *ct_cnt, unsigned long long *global) {
-  for (int i = threadIdx.x; i < KU_CT_CAP; i += blockDim.x) {
+  for (int i = threadIdx.x; i < (1 << LOG2); i += blockDim.x) {
     uint32_t kk = ct_key[i];
     if (kk) atomicAdd(&global[kk - 1], (unsigned long long)ct_cnt[i]);
+  }
+}
+// call at a point every thread of the block reaches, after a __syncthreads()
+template <int LOG2 = KU_CT_LOG2>
+__device__ __forceinline__ void ku_ct_maybe_flush(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t *used,
+                                                  unsigned long long *global) {
+  if (*used > (1u << LOG2) / 2) {  // block-uniform (read after the barrier)
+    __syncthreads();
+    ku_ct_flush<LOG2>(ct_key, ct_cnt, global);
+    __syncthreads();
+    ku_ct_clear<LOG2>(ct_key, ct_cnt, used);
+    __syncthreads();
   }
 }
 
@@ -93,8 +115,8 @@ __device__ __forceinline__ void ku_ct_flush(uint32_t *ct_key, uint32_t *ct_cnt, 
 // The plain pre-check load may be stale (other CUs' updates are not visible in
 // this CU's L1) -- stale values are only ever too small, so the worst case is a
 // redundant CAS, never a lost update.
-__device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot, uint64_t canon) {
-  uint64_t h = ku_fmix64(canon);
+__device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot, uint64_t h) {
+  // h = ku_fmix64(canonical k-mer)
   uint32_t idx = (uint32_t)(h >> (64 - KU_HLL_P));
   uint64_t rest = h << KU_HLL_P;
   uint32_t rank = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KU_HLL_P + 1);
@@ -128,24 +150,66 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
   amb |= (valid ^ 1u) << (15 - j);
 }
 
+// Hash layout (LAYOUT 1, default): at upload time the shard's pairs are re-laid out as a bucketised hash table,
+// one bucket per 128-byte line:
+//     dword 0      count (low 16 bits) | tag 0 (high 16 bits)
+//     dwords 1..4  tags 1..8, two 16-bit tags per dword
+//     dwords 5..31 nine 12-byte entries {key_lo, key_hi, slot}
+// MI355X moves 128 B per L2 miss and sustains ~48 G random line fetches/s whatever the access width
+// (scripts/calib_gather.hip), so a lookup costs the number of distinct lines it touches -- and, per wave, the
+// number of *dependent* round trips of its slowest lane.  The sorted-bin binary search touches ~2.5 lines in ~8
+// dependent probes; here the 20-byte header answers "which entry, if any" in ONE round trip (16-bit tags, false
+// positive rate 9 * 2^-16), the entry itself is then an L1/L2 hit in the same line.  A bucket that received more
+// than 9 keys has count > 9 and spills into the following line(s) (1.7 % of the buckets at load factor 0.5).
+#define KU_LINE_DWORDS 32
+#define KU_LINE_SLOTS 9
+__device__ __forceinline__ uint64_t ku_table_line(uint64_t h, uint64_t n_lines) {
+  // h = fmix64(kmer + 1) (the HLL hash, reused): line from its low 40 bits, tag from bits 59..44
+  return __umul64hi((h << 24) | (h >> 40), n_lines);
+}
+__device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) { return (uint32_t)(h >> 44) & 0xFFFFu; }
+// bit i set <=> tag i of the header equals `tag` (i < min(count, 9))
+__device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32_t tag) {
+  const uint32_t cnt = h4.x & 0xFFFFu;
+  const uint32_t n = cnt < KU_LINE_SLOTS ? cnt : KU_LINE_SLOTS;
+  uint32_t m = 0;
+  m |= ((h4.x >> 16) == tag) << 0;
+  m |= ((h4.y & 0xFFFFu) == tag) << 1;
+  m |= ((h4.y >> 16) == tag) << 2;
+  m |= ((h4.z & 0xFFFFu) == tag) << 3;
+  m |= ((h4.z >> 16) == tag) << 4;
+  m |= ((h4.w & 0xFFFFu) == tag) << 5;
+  m |= ((h4.w >> 16) == tag) << 6;
+  m |= ((h1 & 0xFFFFu) == tag) << 7;
+  m |= ((h1 >> 16) == tag) << 8;
+  return m & ((1u << n) - 1u);
+}
+
 // MODE 0: lookup only; MODE 1: lookup + per-taxon accounting; MODE 2: measurement
 // only -- no search, accumulates {queries, sum ceil(log2(n_b+1)), queries into
 // non-empty bins, sum n_b} into stats[4] (the algorithmic-bytes model of
 // SURVEY.md 8(d), DESIGN.md "Roofline").
-template <int MODE>
+// LAYOUT 0: sorted bins + binary search (the on-disk order); LAYOUT 1: hash table.
+// SHARDED: the context owns a strict sub-range of the minimizer bins, so the minimizer of
+// every k-mer is needed for the ownership test (always needed by LAYOUT 0 and MODE 2).
+template <int MODE, int LAYOUT, bool SHARDED>
 __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
                                                                const uint8_t *__restrict__ seqs,
                                                                uint64_t n_bytes, uint32_t *__restrict__ taxa,
-                                                               unsigned long long *stats) {
+                                                               unsigned long long *stats, uint32_t ablate) {
+  // `ablate` is a measurement knob (env KU_ABLATE, scripts/ablate_lookup.py): bit0 skip the table/bin probe,
+  // bit1 skip the HLL update, bit2 skip the n_kmers counter, bit3 skip the taxa store.  0 in production.
   constexpr bool DO_COUNTS = MODE == 1;
+  constexpr bool NEED_MIN = SHARDED || LAYOUT == 0 || MODE == 2;
   unsigned long long st_q = 0, st_lg = 0, st_ne = 0, st_nb = 0;
   // 16 bases per word, MSB first (base 16w in bits 31..30): a k-mer is a
   // funnel shift over three consecutive words.
   __shared__ uint32_t s_codes[KU_PACKW + 4];
-  __shared__ uint32_t s_amb[(KU_PACKW + 4) / 2 + 2];  // 32 bases per word, MSB first
-  __shared__ uint32_t s_mm[KU_TILE + 64];             // scrambled canonical m-mer per start position
+  __shared__ uint32_t s_amb[(KU_PACKW + 4) / 2 + 2];       // 32 bases per word, MSB first
+  __shared__ uint32_t s_mm[NEED_MIN ? KU_TILE + 64 : 1];   // scrambled canonical m-mer per start position
   __shared__ uint32_t s_ctk[KU_CT_CAP];
   __shared__ uint32_t s_ctc[KU_CT_CAP];
+  __shared__ uint32_t s_ctu;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t k = db.k, m = db.nt;
@@ -154,11 +218,12 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
   const bool aligned = (((uintptr_t)seqs) & 15u) == 0;
   uint16_t *s_amb16 = reinterpret_cast<uint16_t *>(s_amb);
 
-  if (DO_COUNTS) ku_ct_clear(s_ctk, s_ctc);
+  if (DO_COUNTS) ku_ct_clear(s_ctk, s_ctc, &s_ctu);
 
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t tile0 = tile * KU_TILE;
     __syncthreads();  // previous iteration's LDS readers are done
+    if (DO_COUNTS) ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, cnt.n_kmers);
     // ---- stage 1: ASCII -> packed 2-bit codes + ambiguity bits (16 bases per lane)
     if (tid < KU_PACKW + 4) {
       uint64_t b0 = tile0 + 16ull * tid;
@@ -183,21 +248,22 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
     }
     __syncthreads();
 
-    // ---- stage 2: forward k-mer, ambiguity, canonical form, m-mer value per position
+    // ---- stage 2: forward k-mer, ambiguity, canonical form (+ m-mer value) per position
     uint64_t canon[KU_ITEMS];
     bool ok[KU_ITEMS];       // k-mer is unambiguous, inside the buffer and (after stage 3) owned by this shard
     bool foreign[KU_ITEMS];  // unambiguous but its bin belongs to another shard
 #pragma unroll
     for (int j = 0; j <= KU_ITEMS; ++j) {
       uint32_t p = j * KU_THREADS + tid;
-      if (j == KU_ITEMS && p >= KU_TILE + w - 1) break;
+      if (j == KU_ITEMS && (!NEED_MIN || p >= KU_TILE + w - 1)) break;
       uint32_t wi = p >> 4, sh = (p & 15u) * 2;
       uint64_t hi = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
       uint64_t x = sh ? ((hi << sh) | (uint64_t)(s_codes[wi + 2] >> (32 - sh))) : hi;  // 32 bases from p
-      // m-mer starting at p, canonical, scrambled (krakendb.cpp:209)
-      uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
-      uint32_t mrc = ku_revcomp32(mm, m);
-      s_mm[p] = (mm < mrc ? mm : mrc) ^ db.xor_mask;
+      if (NEED_MIN) {  // m-mer starting at p, canonical, scrambled (krakendb.cpp:209)
+        uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
+        uint32_t mrc = ku_revcomp32(mm, m);
+        s_mm[p] = (mm < mrc ? mm : mrc) ^ db.xor_mask;
+      }
       if (j < KU_ITEMS) {
         uint64_t fwd = x >> (64 - 2 * k);
         uint64_t rc = ku_revcomp64(fwd, k);
@@ -208,28 +274,32 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
         foreign[j] = false;
       }
     }
-    __syncthreads();
 
-    // ---- stage 3: minimizer = sliding-window minimum of the m-mer values, idx fetch
-    uint32_t n_b[KU_ITEMS];          // bin size
-    const uint32_t *bp[KU_ITEMS];    // first pair of the bin
+    // ---- stage 3: minimizer = sliding-window minimum of the m-mer values; ownership; idx fetch
+    uint32_t n_b[KU_ITEMS];          // bin size (LAYOUT 0 / MODE 2)
+    const uint32_t *bp[KU_ITEMS];    // first pair of the bin (LAYOUT 0)
+    if (NEED_MIN) {
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < KU_ITEMS; ++j) {
-      uint32_t p = j * KU_THREADS + tid;
-      n_b[j] = 0;
-      bp[j] = db.pairs;
-      if (ok[j]) {
-        uint32_t mn = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
-        uint64_t bin = mn;
-        if (bin >= db.bin_lo && bin < db.bin_hi) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
-          const uint64_t *o = db.offsets + (bin - db.bin_lo);
-          uint64_t lo = o[0], hi = o[1];
-          n_b[j] = (uint32_t)(hi - lo);
-          bp[j] = db.pairs + 3 * (lo - db.pair_base);
-        } else {
-          ok[j] = false;  // another shard owns this k-mer (and accounts its miss)
-          foreign[j] = true;
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        uint32_t p = j * KU_THREADS + tid;
+        n_b[j] = 0;
+        bp[j] = db.pairs;
+        if (ok[j]) {
+          uint32_t mn = 0xFFFFFFFFu;
+          for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
+          uint64_t bin = mn;
+          if (bin >= db.bin_lo && bin < db.bin_hi) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
+            if (LAYOUT == 0 || MODE == 2) {
+              const uint64_t *o = db.offsets + (bin - db.bin_lo);
+              uint64_t lo = o[0], hi = o[1];
+              n_b[j] = (uint32_t)(hi - lo);
+              bp[j] = db.pairs + 3 * (lo - db.pair_base);
+            }
+          } else {
+            ok[j] = false;  // another shard owns this k-mer (and accounts its miss)
+            foreign[j] = true;
+          }
         }
       }
     }
@@ -245,37 +315,114 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
         }
       continue;
     }
-    // ---- stage 4: in-bin binary search, KU_ITEMS probes in flight per lane
-    uint32_t lo[KU_ITEMS], hi[KU_ITEMS], slot[KU_ITEMS];
-#pragma unroll
-    for (int j = 0; j < KU_ITEMS; ++j) {
-      lo[j] = 0;
-      hi[j] = n_b[j];
-      slot[j] = 0;
-    }
-    bool any = true;
-    while (any) {
-      any = false;
-      KuPair pr[KU_ITEMS];
-      uint32_t mid[KU_ITEMS];
+
+    // ---- stage 4: the lookup proper, KU_ITEMS independent probes in flight per lane
+    uint32_t slot[KU_ITEMS];
+    uint64_t hh[KU_ITEMS];  // fmix64(kmer + 1): table position and HLL index/rank
+    if (LAYOUT == 1) {
+      const uint32_t *lp[KU_ITEMS];  // the bucket (line) being examined
+      uint32_t tag[KU_ITEMS], cand[KU_ITEMS];
+      bool act[KU_ITEMS], ovf[KU_ITEMS];
+      uint4 h4[KU_ITEMS];
+      uint32_t h1[KU_ITEMS];
+      const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
-        mid[j] = (lo[j] + hi[j]) >> 1;
-        if (lo[j] < hi[j]) pr[j] = reinterpret_cast<const KuPair *>(bp[j])[mid[j]];  // one 12-byte load: key + value
+        hh[j] = ku_fmix64(canon[j]);
+        lp[j] = tab + ku_table_line(hh[j], db.n_lines) * KU_LINE_DWORDS;
+        tag[j] = ku_table_tag(hh[j]);
+        slot[j] = 0;
+        act[j] = ok[j] && !(ablate & 1u);
       }
+      // round trip 1: the 20-byte bucket headers of all items
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j)
+        if (act[j]) {
+          h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
+          h1[j] = lp[j][4];
+        }
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
-        if (lo[j] < hi[j]) {
-          uint64_t key = ((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo;
-          if (key == canon[j]) {
+        cand[j] = 0;
+        ovf[j] = false;
+        if (act[j]) {
+          cand[j] = ku_tag_matches(h4[j], h1[j], tag[j]);
+          ovf[j] = (h4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+          act[j] = cand[j] != 0 || ovf[j];
+        }
+      }
+      // round trip 2 (same line: L1/L2 hit): the first candidate entry of every item
+      KuPair pr[KU_ITEMS];
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j)
+        if (cand[j]) pr[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j)
+        if (cand[j]) {
+          if ((((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo) == canon[j]) {
             slot[j] = pr[j].slot;
-            lo[j] = hi[j];
-          } else if (key < canon[j]) {
-            lo[j] = mid[j] + 1;
+            act[j] = false;
           } else {
-            hi[j] = mid[j];
+            cand[j] &= cand[j] - 1;
+            act[j] = cand[j] != 0 || ovf[j];
           }
-          any |= lo[j] < hi[j];
+        }
+      // rare tail: further tag matches in the bucket (false positives) and spilled buckets
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        while (act[j]) {
+          if (cand[j]) {
+            KuPair e = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+            cand[j] &= cand[j] - 1;
+            if ((((uint64_t)e.key_hi << 32) | e.key_lo) == canon[j]) {
+              slot[j] = e.slot;
+              act[j] = false;
+            }
+          } else if (ovf[j]) {
+            lp[j] += KU_LINE_DWORDS;
+            if (lp[j] == tab + db.n_lines * KU_LINE_DWORDS) lp[j] = tab;
+            uint4 a4 = *reinterpret_cast<const uint4 *>(lp[j]);
+            uint32_t a1 = lp[j][4];
+            cand[j] = ku_tag_matches(a4, a1, tag[j]);
+            ovf[j] = (a4.x & 0xFFFFu) > KU_LINE_SLOTS;
+          } else {
+            act[j] = false;  // miss
+          }
+        }
+      }
+    } else {
+      uint32_t lo[KU_ITEMS], hi[KU_ITEMS];
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        lo[j] = 0;
+        hi[j] = (ablate & 1u) ? 0 : n_b[j];
+        slot[j] = 0;
+        if (DO_COUNTS) hh[j] = ku_fmix64(canon[j]);
+      }
+      bool any = true;
+      while (any) {
+        any = false;
+        KuPair pr[KU_ITEMS];
+        uint32_t mid[KU_ITEMS];
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          mid[j] = (lo[j] + hi[j]) >> 1;
+          if (lo[j] < hi[j]) pr[j] = reinterpret_cast<const KuPair *>(bp[j])[mid[j]];  // one 12-byte load: key + value
+        }
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          if (lo[j] < hi[j]) {
+            uint64_t key = ((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo;
+            if (key == canon[j]) {
+              slot[j] = pr[j].slot;
+              lo[j] = hi[j];
+            } else if (key < canon[j]) {
+              lo[j] = mid[j] + 1;
+            } else {
+              hi[j] = mid[j];
+            }
+            any |= lo[j] < hi[j];
+          }
         }
       }
     }
@@ -285,10 +432,10 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
     for (int j = 0; j < KU_ITEMS; ++j) {
       uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
       if (DO_COUNTS && ok[j]) {
-        ku_hll_update(cnt.registers, slot[j], canon[j]);
-        ku_ct_add(s_ctk, s_ctc, slot[j], 1, cnt.n_kmers);
+        if (!(ablate & 2u)) ku_hll_update(cnt.registers, slot[j], hh[j]);
+        if (!(ablate & 4u)) ku_ct_add(s_ctk, s_ctc, &s_ctu, slot[j], 1, cnt.n_kmers);
       }
-      if (pos < n_bytes) {
+      if (pos < n_bytes && !(ablate & 8u)) {
         // ambiguous -> KU_AMBIG on every shard; not owned -> 0 (the owner's value wins the max-reduce)
         taxa[pos] = ok[j] ? slot[j] : (foreign[j] ? 0u : KU_AMBIG);
       }
@@ -309,29 +456,116 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
   }
 }
 
+static unsigned ku_lookup_grid(uint64_t n_bytes, int n_cu) {
+  uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
+  uint64_t max_blocks = (uint64_t)n_cu * 8;
+  return (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
+}
+
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
                      uint32_t *d_taxa, bool do_counts, int n_cu, hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
-  uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
-  uint64_t max_blocks = (uint64_t)n_cu * 8;
-  unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
-  if (do_counts)
-    hipLaunchKernelGGL(ku_lookup_kernel<1>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
-                       d_taxa, (unsigned long long *)nullptr);
-  else
-    hipLaunchKernelGGL(ku_lookup_kernel<0>, dim3(grid), dim3(KU_THREADS), 0, stream, db, cnt, d_seqs, n_bytes,
-                       d_taxa, (unsigned long long *)nullptr);
+  const dim3 grid(ku_lookup_grid(n_bytes, n_cu)), block(KU_THREADS);
+  unsigned long long *ns = nullptr;
+  const bool sharded = !(db.bin_lo == 0 && db.bin_hi == (1ull << (2 * db.nt)));
+  const char *ab = getenv("KU_ABLATE");
+  const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
+#define KU_LAUNCH(M, L, S) hipLaunchKernelGGL((ku_lookup_kernel<M, L, S>), grid, block, 0, stream, db, cnt, d_seqs, n_bytes, d_taxa, ns, ablate)
+  if (db.table) {
+    if (do_counts) { if (sharded) KU_LAUNCH(1, 1, true); else KU_LAUNCH(1, 1, false); }
+    else { if (sharded) KU_LAUNCH(0, 1, true); else KU_LAUNCH(0, 1, false); }
+  } else {
+    if (do_counts) KU_LAUNCH(1, 0, true); else KU_LAUNCH(0, 0, true);
+  }
+#undef KU_LAUNCH
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
 int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
                            int n_cu, hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
-  uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
-  uint64_t max_blocks = (uint64_t)n_cu * 8;
-  unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
-  hipLaunchKernelGGL(ku_lookup_kernel<2>, dim3(grid), dim3(KU_THREADS), 0, stream, db, KuCountsDev{}, d_seqs, n_bytes,
-                     (uint32_t *)nullptr, d_stats);
+  hipLaunchKernelGGL((ku_lookup_kernel<2, 0, true>), dim3(ku_lookup_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream,
+                     db, KuCountsDev{}, d_seqs, n_bytes, (uint32_t *)nullptr, d_stats, 0u);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// hash-table construction from the (already slot-remapped) 12-byte pairs
+__global__ void ku_build_table_kernel(const uint32_t *__restrict__ pairs, uint64_t n, uint32_t *table, uint64_t n_lines,
+                                      unsigned long long *n_spilled) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t klo = pairs[3 * i], khi = pairs[3 * i + 1], val = pairs[3 * i + 2];
+    const uint64_t h = ku_fmix64(((uint64_t)khi << 32) | klo);
+    const uint32_t tag = ku_table_tag(h);
+    uint64_t line = ku_table_line(h, n_lines);
+    for (uint32_t hops = 0;; ++hops) {
+      uint32_t *lp = table + line * KU_LINE_DWORDS;
+      // claim the next free entry of the bucket: count lives in the low half of dword 0
+      uint32_t w0 = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int got = -1;
+      for (;;) {
+        uint32_t c = w0 & 0xFFFFu;
+        if (c >= KU_LINE_SLOTS) {
+          // full: make sure the bucket is marked "spilled" (count = 10) before moving on.  The CAS can also lose
+          // against a tag-0 atomicOr, so retry until the mark is visible.
+          while ((w0 & 0xFFFFu) == KU_LINE_SLOTS) {
+            uint32_t prev = atomicCAS(lp, w0, w0 + 1);
+            if (prev == w0) break;
+            w0 = prev;
+          }
+          break;
+        }
+        uint32_t prev = atomicCAS(lp, w0, w0 + 1);
+        if (prev == w0) { got = (int)c; break; }
+        w0 = prev;
+      }
+      if (got >= 0) {
+        if (got == 0) atomicOr(lp, tag << 16);
+        else atomicOr(lp + ((got + 1) >> 1), (got & 1) ? tag : tag << 16);
+        uint32_t *e = lp + 5 + 3 * got;
+        e[0] = klo; e[1] = khi; e[2] = val;
+        if (hops) atomicAdd(n_spilled, 1ull);
+        break;
+      }
+      line = line + 1 == n_lines ? 0 : line + 1;
+    }
+  }
+}
+int ku_launch_build_table(const uint32_t *d_pairs, uint64_t n_pairs, void *d_table, uint64_t n_lines,
+                          unsigned long long *d_spilled, hipStream_t stream) {
+  if (hipMemsetAsync(d_table, 0, n_lines * 128, stream) != hipSuccess) return KU_EHIP;
+  if (n_pairs == 0) return KU_OK;
+  uint64_t nb = (n_pairs + 255) / 256;
+  hipLaunchKernelGGL(ku_build_table_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, d_pairs,
+                     n_pairs, (uint32_t *)d_table, n_lines, d_spilled);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// count_taxons over the table entries (hash layout)
+__global__ __launch_bounds__(256) void ku_count_table_kernel(const uint32_t *__restrict__ table, uint64_t n_lines,
+                                                             unsigned long long *counts) {
+  __shared__ uint32_t s_ctk[KU_CT_CAP];
+  __shared__ uint32_t s_ctc[KU_CT_CAP];
+  __shared__ uint32_t s_ctu;
+  ku_ct_clear(s_ctk, s_ctc, &s_ctu);
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < n_lines; base += stride) {
+    uint64_t l = base + threadIdx.x;
+    if (l < n_lines) {
+      const uint32_t *lp = table + l * KU_LINE_DWORDS;
+      uint32_t c = lp[0] & 0xFFFFu;
+      if (c > KU_LINE_SLOTS) c = KU_LINE_SLOTS;
+      for (uint32_t i = 0; i < c; ++i) ku_ct_add(s_ctk, s_ctc, &s_ctu, lp[5 + 3 * i + 2], 1, counts);
+    }
+    __syncthreads();
+    ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, counts);
+  }
+  __syncthreads();
+  ku_ct_flush(s_ctk, s_ctc, counts);
+}
+int ku_launch_count_table(const void *d_table, uint64_t n_lines, unsigned long long *d_counts, hipStream_t stream) {
+  hipLaunchKernelGGL(ku_count_table_kernel, dim3(2048), dim3(256), 0, stream, (const uint32_t *)d_table, n_lines,
+                     d_counts);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
@@ -407,8 +641,10 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
   __shared__ uint32_t s_red[4];
   __shared__ uint32_t s_n_list;
   __shared__ uint32_t s_bcast;
-  __shared__ uint32_t s_ctk[KU_CT_CAP];
-  __shared__ uint32_t s_ctc[KU_CT_CAP];
+  constexpr int RCT = 7;  // n_reads counter table: 128 entries keep the block's LDS at ~6 KB (occupancy)
+  __shared__ uint32_t s_ctk[1 << RCT];
+  __shared__ uint32_t s_ctc[1 << RCT];
+  __shared__ uint32_t s_ctu;
 
   const uint32_t tid = threadIdx.x;
   const uint32_t cap_log2 = MODE == 2 ? ws_cap_log2 : (uint32_t)Cfg::CAP_LOG2;
@@ -430,7 +666,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
   const bool do_counts = !(flags & KU_F_NO_COUNTS);
   const bool keep_slots = (flags & KU_F_KEEP_SLOTS) != 0;
 
-  ku_ct_clear(s_ctk, s_ctc);
+  ku_ct_clear<RCT>(s_ctk, s_ctc, &s_ctu);
   for (uint32_t i = tid; i < cap; i += GROUP) {
     t_key[i] = 0;
     t_cnt[i] = 0;
@@ -443,24 +679,58 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     const uint32_t n = len >= k ? len - k + 1 : 0;
     if (n < min_n || n > (uint32_t)Cfg::MAX_N) continue;  // another MODE's launch handles it
     const uint64_t off = seq_off[r];
+    ku_ct_maybe_flush<RCT>(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
     if (tid == 0) s_n_list = 0;
+    uint32_t call_node = 0;
+    bool resolved = false;
+    // MODE 0 keeps the read's codes in registers (<= 6 per lane) and short-cuts the common case of at most
+    // one distinct hit taxon: resolve_tree() then returns that taxon (or 0) without any tree walk.
+    constexpr int NV = MODE == 0 ? (Cfg::MAX_N + 63) / 64 : 1;
+    uint32_t v[NV];
+    if (MODE == 0) {
+      uint32_t mine = 0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        uint32_t i = c * 64 + tid;
+        v[c] = i < n ? taxa[off + i] : 0u;
+        if (v[c] == KU_AMBIG) v[c] = 0;  // ambiguous k-mers carry no hit
+        if (mine == 0) mine = v[c];
+      }
+      unsigned long long bal = __ballot(mine != 0);
+      uint32_t first = bal ? (uint32_t)__shfl((int)mine, __ffsll((long long)bal) - 1) : 0u;
+      bool diff = false;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) diff |= (v[c] != 0 && v[c] != first);
+      if (!__any(diff)) {
+        resolved = true;
+        call_node = first ? tax.slot_node[first] : 0u;
+      }
+    }
+    if (!resolved) {
     // ---- hit_counts[taxon]++ (classify.cpp:941-942)
-    for (uint32_t i = tid; i < n; i += GROUP) {
-      uint32_t s = taxa[off + i];
-      if (s != 0 && s != KU_AMBIG) {
-        uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
-        for (;;) {
-          uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (cur == 0) {
-            uint32_t old = atomicCAS(&t_key[h], 0u, s + 1);
-            cur = old == 0 ? s + 1 : old;
-          }
-          if (cur == s + 1) {
-            atomicAdd(&t_cnt[h], 1u);
-            break;
-          }
-          h = (h + 1) & (cap - 1);
+    auto table_insert = [&](uint32_t s) {
+      uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
+      for (;;) {
+        uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == 0) {
+          uint32_t old = atomicCAS(&t_key[h], 0u, s + 1);
+          cur = old == 0 ? s + 1 : old;
         }
+        if (cur == s + 1) {
+          atomicAdd(&t_cnt[h], 1u);
+          break;
+        }
+        h = (h + 1) & (cap - 1);
+      }
+    };
+    if (MODE == 0) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c)
+        if (v[c] != 0) table_insert(v[c]);
+    } else {
+      for (uint32_t i = tid; i < n; i += GROUP) {
+        uint32_t s = taxa[off + i];
+        if (s != 0 && s != KU_AMBIG) table_insert(s);
       }
     }
     __syncthreads();
@@ -473,7 +743,6 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     }
     __syncthreads();
     const uint32_t n_list = s_n_list;
-    uint32_t call_node = 0;
     if (n_list > 0) {
       // ---- score(t) = sum of hit counts on t's root path (krakenutil.cpp:157-177)
       uint32_t my_max = 0;
@@ -534,22 +803,31 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
         if (MODE == 2) t_score[pos] = 0;
       }
     }
+    }  // !resolved
     if (tid == 0) {
       calls[r] = tax.node_taxid[call_node];
       if (hits_out) hits_out[r] = 0;
-      if (do_counts) ku_ct_add(s_ctk, s_ctc, call_node, 1, cnt.n_reads);  // incrementReadCount (classify.cpp:968)
+      if (do_counts) ku_ct_add<RCT>(s_ctk, s_ctc, &s_ctu, call_node, 1, cnt.n_reads);  // incrementReadCount (classify.cpp:968)
     }
     // ---- slot -> taxid for the hit string
     if (!keep_slots) {
-      for (uint32_t i = tid; i < n; i += GROUP) {
-        uint32_t s = taxa[off + i];
-        if (s != 0 && s != KU_AMBIG) taxa[off + i] = tax.slot_taxid[s];
+      if (MODE == 0) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          uint32_t i = c * 64 + tid;
+          if (i < n && v[c] != 0) taxa[off + i] = tax.slot_taxid[v[c]];
+        }
+      } else {
+        for (uint32_t i = tid; i < n; i += GROUP) {
+          uint32_t s = taxa[off + i];
+          if (s != 0 && s != KU_AMBIG) taxa[off + i] = tax.slot_taxid[s];
+        }
       }
     }
     __syncthreads();
   }
   __syncthreads();
-  ku_ct_flush(s_ctk, s_ctc, cnt.n_reads);
+  ku_ct_flush<RCT>(s_ctk, s_ctc, cnt.n_reads);
 }
 
 // canonical k-mer straight from ASCII (quick mode only; positions known non-ambiguous)
@@ -576,16 +854,20 @@ __global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev 
   __shared__ uint32_t s_ctc[KU_CT_CAP];
   __shared__ uint32_t s_ckk[KU_CT_CAP];
   __shared__ uint32_t s_ckc[KU_CT_CAP];
+  __shared__ uint32_t s_ctu, s_cku;
   const uint32_t tid = threadIdx.x;
   const bool do_counts = !(flags & KU_F_NO_COUNTS);
   const bool keep_slots = (flags & KU_F_KEEP_SLOTS) != 0;
-  ku_ct_clear(s_ctk, s_ctc);
-  ku_ct_clear(s_ckk, s_ckc);
+  ku_ct_clear(s_ctk, s_ctc, &s_ctu);
+  ku_ct_clear(s_ckk, s_ckc, &s_cku);
   __syncthreads();
   for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
     const uint32_t len = seq_len[r];
     const uint32_t n = len >= k ? len - k + 1 : 0;
     const uint64_t off = seq_off[r];
+    __syncthreads();
+    ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
+    ku_ct_maybe_flush(s_ckk, s_ckc, &s_cku, cnt.n_kmers);
     uint32_t total = 0, call_slot = 0;
     uint32_t stop = n;  // exclusive end of the scanned prefix
     for (uint32_t base = 0; base < n; base += 64) {
@@ -611,8 +893,8 @@ __global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev 
       for (uint32_t i = tid; i < stop; i += 64) {
         uint32_t s = taxa[off + i];
         if (s != KU_AMBIG) {
-          ku_hll_update(cnt.registers, s, ku_canon_from_ascii(seqs + off + i, k));
-          ku_ct_add(s_ckk, s_ckc, s, 1, cnt.n_kmers);
+          ku_hll_update(cnt.registers, s, ku_fmix64(ku_canon_from_ascii(seqs + off + i, k)));
+          ku_ct_add(s_ckk, s_ckc, &s_cku, s, 1, cnt.n_kmers);
         }
       }
     }
@@ -620,7 +902,7 @@ __global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev 
     if (tid == 0) {
       calls[r] = tax.node_taxid[call_node];
       if (hits_out) hits_out[r] = total;
-      if (do_counts) ku_ct_add(s_ctk, s_ctc, call_node, 1, cnt.n_reads);
+      if (do_counts) ku_ct_add(s_ctk, s_ctc, &s_ctu, call_node, 1, cnt.n_reads);
     }
     if (!keep_slots) {
       for (uint32_t i = tid; i < n; i += 64) {
@@ -664,7 +946,7 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
     return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
   }
   {  // MODE 0: every read with n <= 384 (incl. reads shorter than k)
-    uint64_t mb = (uint64_t)n_cu * 16;
+    uint64_t mb = (uint64_t)n_cu * 24;
     unsigned grid = (unsigned)(n_reads < mb ? n_reads : mb);
     size_t lds = (2u << KuResolveCfg<0>::CAP_LOG2) * 4 + KuResolveCfg<0>::MAX_N * 2 + 64;
     hipLaunchKernelGGL(ku_resolve_kernel<0>, dim3(grid), dim3(64), lds, stream, tax, cnt, k, d_seq_off, d_seq_len,
@@ -804,10 +1086,16 @@ __global__ __launch_bounds__(256) void ku_count_slots_kernel(const uint32_t *__r
                                                              unsigned long long *counts) {
   __shared__ uint32_t s_ctk[KU_CT_CAP];
   __shared__ uint32_t s_ctc[KU_CT_CAP];
-  ku_ct_clear(s_ctk, s_ctc);
+  __shared__ uint32_t s_ctu;
+  ku_ct_clear(s_ctk, s_ctc, &s_ctu);
   __syncthreads();
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    ku_ct_add(s_ctk, s_ctc, pairs[3 * i + 2], 1, counts);
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < n; base += stride) {  // block-uniform trip count
+    uint64_t i = base + threadIdx.x;
+    if (i < n) ku_ct_add(s_ctk, s_ctc, &s_ctu, pairs[3 * i + 2], 1, counts);
+    __syncthreads();
+    ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, counts);
+  }
   __syncthreads();
   ku_ct_flush(s_ctk, s_ctc, counts);
 }

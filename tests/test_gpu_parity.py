@@ -277,3 +277,24 @@ def test_errors_are_reported_not_swallowed(f1):
     with pytest.raises(capi.KuError) as e:
         ctx.classify_batch(buf, off, bad_len)
     assert e.value.status == -1
+
+
+def test_hash_table_spilled_buckets(monkeypatch):
+    """load factor 0.95: many buckets spill into the following lines; every DB k-mer must still be found"""
+    monkeypatch.setenv("KU_LOAD_FACTOR", "0.9")
+    rng = np.random.default_rng(77)
+    db = random_db(rng, n_genomes=8, glen=6000, nt=8)
+    ids, par = db["tax"].arrays()
+    raw = db["pairs"].view(np.uint8)
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=8)
+    otax = ko.Tax(ids=ids, parents=par)
+    ctx, _, _ = make_ctx(cdb=capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=8),
+                         ctax=capi.Tax(ids=ids, parents=par))
+    reads = [synth.codes_to_ascii(g) for g in db["genomes"].values()]  # whole genomes: every k-mer is a DB hit
+    reads += synth.sample_reads(db["genomes"], 300, 150, rng)[0]
+    run, res, buf, off, lens, taxa = oracle_flat(odb, otax, reads)
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    assert_same_counts(ctx.counts(), run)
+    t, c = ctx.count_taxons()
+    assert int(c.sum()) == len(db["kmers"])
