@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkrakenuniq_amd.so")
+LIB_PATH = os.environ.get("KU_LIB") or os.path.join(_HERE, "libkrakenuniq_amd.so")  # KU_LIB: tuning experiments only
 
 KU_AMBIG = 0xFFFFFFFF
 KU_HLL_M = 4096

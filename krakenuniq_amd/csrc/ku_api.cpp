@@ -294,7 +294,7 @@ struct ku_ctx {
   // DB shard
   bool db_loaded = false, db_owned = false, tax_set = false;
   bool hash_layout = true;   // KU_LAYOUT=sorted keeps the on-disk order + binary search (A/B and fallback for HBM-tight shards)
-  double load_factor = 0.5;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
+  double load_factor = 0.4;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
   void *d_table = nullptr;
   uint64_t n_dup = 0;
   uint32_t *d_pairs = nullptr;
@@ -550,7 +550,8 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
     HIP_TRY(hipMalloc(&ctx->d_table, n_lines * 128));
     unsigned long long *d_dup = (unsigned long long *)(ctx->d_scalar + 2);
     HIP_TRY(hipMemsetAsync(d_dup, 0, 8, ctx->stream));
-    KU_TRY(ku_launch_build_table(ctx->d_pairs, ctx->db.n_pairs, ctx->d_table, n_lines, d_dup, ctx->stream));
+    KU_TRY(ku_launch_build_table(ctx->d_pairs, ctx->db.n_pairs, ctx->d_table, n_lines, ctx->db.k, ctx->db.nt,
+                                 ctx->db.xor_mask, d_dup, ctx->stream));
     unsigned long long dup = 0;
     HIP_TRY(hipMemcpyAsync(&dup, d_dup, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

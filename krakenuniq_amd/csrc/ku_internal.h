@@ -65,8 +65,8 @@ int ku_launch_collect_values(const uint32_t *d_bitmap, uint32_t *d_out, uint32_t
                              hipStream_t stream);
 int ku_launch_remap_values(uint32_t *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_taxid, uint32_t n_slots,
                            uint32_t *d_err, hipStream_t stream);
-int ku_launch_build_table(const uint32_t *d_pairs, uint64_t n_pairs, void *d_table, uint64_t n_lines,
-                          unsigned long long *d_dup, hipStream_t stream);
+int ku_launch_build_table(const uint32_t *d_pairs, uint64_t n_pairs, void *d_table, uint64_t n_lines, uint32_t k,
+                          uint32_t m, uint32_t xor_mask, unsigned long long *d_spilled, hipStream_t stream);
 int ku_launch_count_table(const void *d_table, uint64_t n_lines, unsigned long long *d_counts, hipStream_t stream);
 int ku_launch_count_slots(const uint32_t *d_pairs, uint64_t n_pairs, unsigned long long *d_counts,
                           uint32_t n_slots, hipStream_t stream);

@@ -26,7 +26,9 @@
 #include <cstdlib>
 
 #define KU_THREADS 256
-#define KU_ITEMS 4
+#ifndef KU_ITEMS
+#define KU_ITEMS 3
+#endif
 #define KU_TILE (KU_THREADS * KU_ITEMS)   // k-mer start positions per block iteration
 #define KU_PACKW ((KU_TILE + 64) / 16)    // 16-base words staged per tile (covers TILE + 63 bases)
 #define KU_CT_LOG2 9                      // per-block LDS counter table (n_kmers / n_reads aggregation)
@@ -163,11 +165,9 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
 // than 9 keys has count > 9 and spills into the following line(s) (1.7 % of the buckets at load factor 0.5).
 #define KU_LINE_DWORDS 32
 #define KU_LINE_SLOTS 9
-__device__ __forceinline__ uint64_t ku_table_line(uint64_t h, uint64_t n_lines) {
-  // h = fmix64(kmer + 1) (the HLL hash, reused): line from its low 40 bits, tag from bits 59..44
-  return __umul64hi((h << 24) | (h >> 40), n_lines);
-}
-__device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) { return (uint32_t)(h >> 44) & 0xFFFFu; }
+// 16-bit entry tag from h = fmix64(kmer + 1) (the HLL hash, reused; the HLL consumes bits 63..52 and the
+// leading zeros below them, the tag takes bits 43..28)
+__device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) { return (uint32_t)(h >> 28) & 0xFFFFu; }
 // bit i set <=> tag i of the header equals `tag` (i < min(count, 9))
 __device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32_t tag) {
   const uint32_t cnt = h4.x & 0xFFFFu;
@@ -185,6 +185,70 @@ __device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32
   return m & ((1u << n) - 1u);
 }
 
+// Locality-aware bucket choice.  Consecutive k-mers of a read share their minimizer *occurrence* ~(k-nt+1)/2
+// times in a row.  The bucket of a k-mer is therefore derived not from the k-mer itself but from its "locus
+// key": (minimizer value, the KU_FLANK bases next to the minimizer occurrence on the longer side, a coarse
+// offset class) -- all taken on the strand where the minimizer m-mer is canonical, so both strands of a locus
+// agree.  The ~5 overlapping k-mers that share a locus key share one 128-byte bucket: a wave's 64 consecutive
+// k-mers touch ~20 lines instead of 64.  The key is a pure function of the canonical k-mer (first minimum in
+// the canonical k-mer's frame on ties), so build and lookup agree by construction; which k-mers share a bucket
+// only affects speed, never results.
+#define KU_FLANK 8
+#define KU_OFFCLASS 5
+__device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint64_t c_rc, uint32_t k, uint32_t m, uint32_t xor_mask,
+                                                 uint32_t &bin) {
+  const uint32_t w = k - m + 1;
+  const uint32_t mask = (1u << (2 * m)) - 1u;  // m <= 15
+  uint32_t best = 0xFFFFFFFFu, a = 0;
+  bool plus = true;
+  for (uint32_t j = 0; j < w; ++j) {  // j = offset of the m-mer from the left (most significant) end of c
+    uint32_t mm = (uint32_t)(c >> (2 * (k - m - j))) & mask;
+    uint32_t rcmm = ku_revcomp32(mm, m);
+    uint32_t v = (mm < rcmm ? mm : rcmm) ^ xor_mask;
+    bool lt = v < best;
+    best = lt ? v : best;
+    a = lt ? j : a;
+    plus = lt ? (mm <= rcmm) : plus;
+  }
+  bin = best;
+  const uint64_t cp = plus ? c : c_rc;            // strand on which the minimizer occurrence is canonical
+  const uint32_t ap = plus ? a : w - 1 - a;       // its offset on that strand
+  const uint32_t left = ap, right = w - 1 - ap;
+  const bool use_r = right >= left;
+  const uint32_t side = use_r ? right : left;
+  const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
+  // right flank = offsets [ap+m, ap+m+flen), left flank = [ap-flen, ap)
+  const uint32_t end = use_r ? ap + m + flen : ap;  // one past the flank's last base
+  const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
+  return ((uint64_t)best << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
+}
+__device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lines) {
+  uint64_t g = (locus ^ (locus >> 31)) * 0x9E3779B97F4A7C15ULL;
+  g = (g ^ (g >> 29)) * 0xBF58476D1CE4E5B9ULL;
+  return __umul64hi(g ^ (g >> 32), n_lines);
+}
+
+// Sliding-window minimum with the position of the first minimum, for KU_ITEMS windows at once (independent
+// chains -> the LDS reads pipeline).  Window t-th element of item j = s_mm[base[j] + dj[j] * t]; the result packs
+// (value << 5) | t, valid while the values have <= 27 bits (minimizer length <= 13).  W > 0: compile-time window
+// length (fully unrolled), W == 0: run-time length w.
+template <int W>
+__device__ __forceinline__ void ku_window_argmin(const uint32_t *s_mm, const int32_t (&base)[KU_ITEMS],
+                                                 const int32_t (&dj)[KU_ITEMS], uint32_t w, uint32_t (&out)[KU_ITEMS]) {
+#pragma unroll
+  for (int j = 0; j < KU_ITEMS; ++j) out[j] = 0xFFFFFFFFu;
+  if (W > 0) {
+#pragma unroll
+    for (int t = 0; t < W; ++t)
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) out[j] = min(out[j], (s_mm[base[j] + dj[j] * t] << 5) | (uint32_t)t);
+  } else {
+    for (uint32_t t = 0; t < w; ++t)
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) out[j] = min(out[j], (s_mm[base[j] + dj[j] * (int32_t)t] << 5) | t);
+  }
+}
+
 // MODE 0: lookup only; MODE 1: lookup + per-taxon accounting; MODE 2: measurement
 // only -- no search, accumulates {queries, sum ceil(log2(n_b+1)), queries into
 // non-empty bins, sum n_b} into stats[4] (the algorithmic-bytes model of
@@ -200,7 +264,7 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
   // `ablate` is a measurement knob (env KU_ABLATE, scripts/ablate_lookup.py): bit0 skip the table/bin probe,
   // bit1 skip the HLL update, bit2 skip the n_kmers counter, bit3 skip the taxa store.  0 in production.
   constexpr bool DO_COUNTS = MODE == 1;
-  constexpr bool NEED_MIN = SHARDED || LAYOUT == 0 || MODE == 2;
+  constexpr bool NEED_MIN = true;  // every variant uses the LDS sliding-window minimizer (bin, and for LAYOUT 1 its position)
   unsigned long long st_q = 0, st_lg = 0, st_ne = 0, st_nb = 0;
   // 16 bases per word, MSB first (base 16w in bits 31..30): a k-mer is a
   // funnel shift over three consecutive words.
@@ -249,7 +313,8 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
     __syncthreads();
 
     // ---- stage 2: forward k-mer, ambiguity, canonical form (+ m-mer value) per position
-    uint64_t canon[KU_ITEMS];
+    uint64_t canon[KU_ITEMS], canon_rc[KU_ITEMS];
+    bool is_fwd[KU_ITEMS];   // the read-strand k-mer is the canonical one
     bool ok[KU_ITEMS];       // k-mer is unambiguous, inside the buffer and (after stage 3) owned by this shard
     bool foreign[KU_ITEMS];  // unambiguous but its bin belongs to another shard
 #pragma unroll
@@ -267,7 +332,9 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
       if (j < KU_ITEMS) {
         uint64_t fwd = x >> (64 - 2 * k);
         uint64_t rc = ku_revcomp64(fwd, k);
-        canon[j] = fwd < rc ? fwd : rc;
+        canon[j] = fwd <= rc ? fwd : rc;
+        canon_rc[j] = fwd <= rc ? rc : fwd;
+        is_fwd[j] = fwd <= rc;
         uint32_t ai = p >> 5, as = p & 31u;
         uint64_t a = (((uint64_t)s_amb[ai] << 32) | s_amb[ai + 1]) << as;
         ok[j] = (a >> (64 - k)) == 0 && (tile0 + p + k <= n_bytes);
@@ -278,16 +345,67 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
     // ---- stage 3: minimizer = sliding-window minimum of the m-mer values; ownership; idx fetch
     uint32_t n_b[KU_ITEMS];          // bin size (LAYOUT 0 / MODE 2)
     const uint32_t *bp[KU_ITEMS];    // first pair of the bin (LAYOUT 0)
+    uint64_t locus[KU_ITEMS];        // locus key (LAYOUT 1), see ku_locus_key()
     if (NEED_MIN) {
       __syncthreads();
+      uint32_t packed[KU_ITEMS];  // (minimum << 5) | first offset, canonical k-mer frame (LAYOUT 1, m <= 13)
+      if (LAYOUT == 1 && MODE != 2 && m <= 13) {
+        int32_t base[KU_ITEMS], dj[KU_ITEMS];
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          base[j] = (int32_t)(j * KU_THREADS + tid) + (is_fwd[j] ? 0 : (int32_t)w - 1);
+          dj[j] = is_fwd[j] ? 1 : -1;
+        }
+        switch (w) {  // block-uniform; the common geometries get fully unrolled windows
+          case 19: ku_window_argmin<19>(s_mm, base, dj, w, packed); break;  // k = 31, nt = 13
+          case 20: ku_window_argmin<20>(s_mm, base, dj, w, packed); break;  // k = 31, nt = 12
+          case 25: ku_window_argmin<25>(s_mm, base, dj, w, packed); break;  // k = 31, nt = 7
+          default: ku_window_argmin<0>(s_mm, base, dj, w, packed); break;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         uint32_t p = j * KU_THREADS + tid;
         n_b[j] = 0;
-        bp[j] = db.pairs;
         if (ok[j]) {
           uint32_t mn = 0xFFFFFFFFu;
-          for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
+          if (LAYOUT == 1 && MODE != 2) {
+            // minimum AND its first position in the canonical k-mer's frame (offset t from the left end of the
+            // canonical k-mer = read offset t for a forward-canonical k-mer, w-1-t otherwise) -- must agree with
+            // ku_locus_key(), which the table build evaluates on the stored canonical k-mer
+            const int32_t j0 = is_fwd[j] ? 0 : (int32_t)w - 1, dj = is_fwd[j] ? 1 : -1;
+            uint32_t a = 0;
+            if (m <= 13) {  // (value << 5 | offset) fits 32 bits: one min per m-mer, done above for all items
+              a = packed[j] & 31u;
+              mn = packed[j] >> 5;
+            } else {
+              for (uint32_t t = 0; t < w; ++t) {
+                uint32_t vv = s_mm[p + j0 + dj * (int32_t)t];
+                bool lt = vv < mn;
+                mn = lt ? vv : mn;
+                a = lt ? t : a;
+              }
+            }
+            // orientation of the minimizer occurrence: forward read m-mer at read offset jr
+            const uint32_t jr = is_fwd[j] ? a : w - 1 - a, q = p + jr;
+            const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
+            const uint64_t two = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
+            const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
+            const uint32_t rcm = ku_revcomp32(mmf, m);
+            const bool plus = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
+            const uint64_t cp = plus ? canon[j] : canon_rc[j];
+            const uint32_t ap = plus ? a : w - 1 - a;
+            const uint32_t left = ap, right = w - 1 - ap;
+            const bool use_r = right >= left;
+            const uint32_t side = use_r ? right : left;
+            const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
+            const uint32_t end = use_r ? ap + m + flen : ap;
+            const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
+            locus[j] = ((uint64_t)mn << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) |
+                       (uint32_t)use_r;
+          } else {
+            for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
+          }
           uint64_t bin = mn;
           if (bin >= db.bin_lo && bin < db.bin_hi) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
             if (LAYOUT == 0 || MODE == 2) {
@@ -329,7 +447,7 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         hh[j] = ku_fmix64(canon[j]);
-        lp[j] = tab + ku_table_line(hh[j], db.n_lines) * KU_LINE_DWORDS;
+        lp[j] = tab + ku_locus_line(ok[j] ? locus[j] : 0, db.n_lines) * KU_LINE_DWORDS;
         tag[j] = ku_table_tag(hh[j]);
         slot[j] = 0;
         act[j] = ok[j] && !(ablate & 1u);
@@ -491,12 +609,13 @@ int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_
 
 // hash-table construction from the (already slot-remapped) 12-byte pairs
 __global__ void ku_build_table_kernel(const uint32_t *__restrict__ pairs, uint64_t n, uint32_t *table, uint64_t n_lines,
-                                      unsigned long long *n_spilled) {
+                                      uint32_t k, uint32_t m, uint32_t xor_mask, unsigned long long *n_spilled) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t klo = pairs[3 * i], khi = pairs[3 * i + 1], val = pairs[3 * i + 2];
-    const uint64_t h = ku_fmix64(((uint64_t)khi << 32) | klo);
-    const uint32_t tag = ku_table_tag(h);
-    uint64_t line = ku_table_line(h, n_lines);
+    const uint64_t key = ((uint64_t)khi << 32) | klo;
+    const uint32_t tag = ku_table_tag(ku_fmix64(key));
+    uint32_t bin;
+    uint64_t line = ku_locus_line(ku_locus_key(key, ku_revcomp64(key, k), k, m, xor_mask, bin), n_lines);
     for (uint32_t hops = 0;; ++hops) {
       uint32_t *lp = table + line * KU_LINE_DWORDS;
       // claim the next free entry of the bucket: count lives in the low half of dword 0
@@ -530,13 +649,13 @@ __global__ void ku_build_table_kernel(const uint32_t *__restrict__ pairs, uint64
     }
   }
 }
-int ku_launch_build_table(const uint32_t *d_pairs, uint64_t n_pairs, void *d_table, uint64_t n_lines,
-                          unsigned long long *d_spilled, hipStream_t stream) {
+int ku_launch_build_table(const uint32_t *d_pairs, uint64_t n_pairs, void *d_table, uint64_t n_lines, uint32_t k,
+                          uint32_t m, uint32_t xor_mask, unsigned long long *d_spilled, hipStream_t stream) {
   if (hipMemsetAsync(d_table, 0, n_lines * 128, stream) != hipSuccess) return KU_EHIP;
   if (n_pairs == 0) return KU_OK;
   uint64_t nb = (n_pairs + 255) / 256;
   hipLaunchKernelGGL(ku_build_table_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, stream, d_pairs,
-                     n_pairs, (uint32_t *)d_table, n_lines, d_spilled);
+                     n_pairs, (uint32_t *)d_table, n_lines, k, m, xor_mask, d_spilled);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

@@ -291,6 +291,7 @@ def test_hash_table_spilled_buckets(monkeypatch):
     ctx, _, _ = make_ctx(cdb=capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=8),
                          ctax=capi.Tax(ids=ids, parents=par))
     reads = [synth.codes_to_ascii(g) for g in db["genomes"].values()]  # whole genomes: every k-mer is a DB hit
+    reads += [synth.codes_to_ascii(synth.revcomp_codes(g)) for g in db["genomes"].values()]  # ... on both strands
     reads += synth.sample_reads(db["genomes"], 300, 150, rng)[0]
     run, res, buf, off, lens, taxa = oracle_flat(odb, otax, reads)
     gpu = ctx.classify_batch(buf, off, lens)
