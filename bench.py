@@ -134,11 +134,19 @@ def main():
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     if ws != a.gpus and ws > 1:
         a.gpus = ws
+    # debugging aid for 1-GPU boxes: KU_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and KU_BENCH_BACKEND=gloo
+    # replaces RCCL, so the N > 1 code path can be exercised without N GPUs (numbers are then meaningless)
+    if os.environ.get("KU_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("KU_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from krakenuniq_amd import capi, dist as kdist, synth_torch
 
     k = 31

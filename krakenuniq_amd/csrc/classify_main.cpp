@@ -1,0 +1,403 @@
+// classify_main.cpp -- drop-in for the reference's `classify` executable (src/classify.cpp), host side only:
+// flag parsing, FASTA/FASTQ(+gz) ingest, batching, output files, stderr summary, report.  Every per-read
+// computation goes through the C ABI (include/krakenuniq_amd.h) to the HIP kernels; there is no CPU
+// classification path in this program.
+//
+// Honoured getopt string (src/classify.cpp:1074): d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:
+//   -d kdb  -i idx  -a taxDB            as the reference (one database; a second -d/-i is KU_EUNSUP)
+//   -o file|off|-                       Kraken output ("-" and "off" both disable it, src/classify.cpp:234-235)
+//   -r file|off                         report, opened in APPEND mode like the reference (:286)
+//   -C/-U file                          classified / unclassified reads;  -c only classified lines;  -s print sequence
+//   -q -m N                             quick mode
+//   -t N                                accepted (must be > 0); the GPU replaces the OpenMP team
+//   -u N                                accepted (must be > 0); sets the ingest batch size in nt (default 256 Mi)
+//   -M, -x SIZE                         accepted: the database is always resident in HBM (SIZE is parsed and checked)
+//   -p N                                accepted and ignored exactly like the reference
+//   -I file                             UID mapping: not built here -> exit 70 with a message
+// Extension: env KU_DEVICE selects the GPU (default 0).
+#include <getopt.h>
+#include <sys/time.h>
+#include <sysexits.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cerrno>
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/krakenuniq_amd.h"
+
+static void die(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3), noreturn));
+static void die(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "classify: ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  exit(code);
+}
+static int exit_code_of(int st) {
+  switch (st) {
+    case KU_EINVAL: return EX_USAGE;
+    case KU_EDATA: return EX_DATAERR;
+    case KU_ENOINPUT: return EX_NOINPUT;
+    case KU_ENOMEM: return EX_OSERR;
+    default: return EX_SOFTWARE;
+  }
+}
+#define KU_CHECK(call)                                                              \
+  do {                                                                              \
+    int st_ = (call);                                                               \
+    if (st_ != KU_OK) die(exit_code_of(st_), "%s: %s", ku_strerror(st_), ku_last_error()); \
+  } while (0)
+
+static void usage(int code) {  // text of src/classify.cpp:1164-1189
+  fprintf(stderr,
+          "Usage: classify [options] <fasta/fastq file(s)>\n\n"
+          "Options: (*mandatory)\n"
+          "* -d filename      Kraken DB filename\n"
+          "* -i filename      Kraken DB index filename\n"
+          "  -o filename      Output file for Kraken output\n"
+          "  -r filename      Output file for Kraken report output\n"
+          "  -a filename      TaxDB\n"
+          "  -I filename      UID to TaxId map\n"
+          "  -p #             Precision for unique k-mer counting, between 10 and 18\n"
+          "  -t #             Number of threads\n"
+          "  -u #             Thread work unit size (in bp)\n"
+          "  -q               Quick operation\n"
+          "  -m #             Minimum hit count (ignored w/o -q)\n"
+          "  -C filename      Print classified sequences\n"
+          "  -U filename      Print unclassified sequences\n"
+          "  -c               Only include classified reads in output\n"
+          "  -M               Preload database files\n"
+          "  -x size          Preload database files using x amount of RAM (e.g. 10G)\n"
+          "  -s               Print read sequence in Kraken output\n"
+          "  -h               Print this message\n\n"
+          "Kraken output is to standard output by default.\n");
+  exit(code);
+}
+
+// parse_human_readable_size (src/krakenutil.cpp:30-55)
+static uint64_t parse_size(const char *s) {
+  char *end = nullptr;
+  errno = 0;
+  unsigned long long x = strtoull(s, &end, 10);
+  if (errno || end == s) return 0;
+  int sh;
+  switch (*end) {
+    case 'k': case 'K': sh = 10; break;
+    case 'm': case 'M': sh = 20; break;
+    case 'g': case 'G': sh = 30; break;
+    case 0: sh = 0; break;
+    default: return 0;
+  }
+  if (x > (UINT64_MAX >> sh)) return 0;
+  return (uint64_t)x << sh;
+}
+
+// ---- output sink: plain file, stdout, or gzip when the name ends in .gz (src/classify.cpp:133-148)
+struct Sink {
+  FILE *f = nullptr;
+  gzFile g = nullptr;
+  bool open(const std::string &name, bool append = false) {
+    if (name == "-") { f = stdout; return true; }
+    if (name.size() > 3 && name.compare(name.size() - 3, 3, ".gz") == 0) { g = gzopen(name.c_str(), "wb"); return g != nullptr; }
+    f = fopen(name.c_str(), append ? "a" : "w");
+    return f != nullptr;
+  }
+  void write(const char *p, size_t n) {
+    if (!n) return;
+    if (g) { if (gzwrite(g, p, (unsigned)n) <= 0) die(EX_OSERR, "gz write error"); }
+    else if (f && fwrite(p, 1, n, f) != n) die(EX_OSERR, "write error: %s", strerror(errno));
+  }
+  void close() {
+    if (g) gzclose(g);
+    if (f && f != stdout) fclose(f);
+    if (f == stdout) fflush(stdout);
+    f = nullptr; g = nullptr;
+  }
+};
+
+// ---- FASTA/FASTQ reader with the record semantics of src/seqreader.cpp:26-133 (gz transparently via zlib)
+struct Reader {
+  gzFile g = nullptr;
+  bool fastq = false, valid = true;
+  std::string pending;  // FASTA look-ahead header line
+  bool have_pending = false;
+  std::vector<char> buf;
+  size_t pos = 0, len = 0;
+  bool eof = false;
+  void open(const char *path) {
+    g = gzopen(path, "rb");
+    if (!g) die(EX_NOINPUT, "can't open %s", path);
+    gzbuffer(g, 1 << 20);
+    buf.resize(1 << 22);
+    int c = peek();
+    fastq = c == '@';  // determine_input_file_type (src/classify.cpp:377-388)
+  }
+  bool fill() {
+    if (eof) return false;
+    int n = gzread(g, buf.data(), (unsigned)buf.size());
+    if (n <= 0) { eof = true; len = pos = 0; return false; }
+    len = (size_t)n; pos = 0;
+    return true;
+  }
+  int peek() { if (pos >= len && !fill()) return -1; return (unsigned char)buf[pos]; }
+  bool getline(std::string &line) {  // without the '\n'; false at EOF with nothing read
+    line.clear();
+    bool any = false;
+    for (;;) {
+      if (pos >= len && !fill()) return any;
+      any = true;
+      const char *s = buf.data() + pos;
+      const char *nl = (const char *)memchr(s, '\n', len - pos);
+      if (nl) { line.append(s, nl - s); pos += (nl - s) + 1; return true; }
+      line.append(s, len - pos);
+      pos = len;
+    }
+  }
+  // returns false when the stream is exhausted / malformed (reader->is_valid() == false)
+  bool next(std::string &header, std::string &seq, std::string &quals) {
+    header.clear(); seq.clear(); quals.clear();
+    std::string line;
+    if (fastq) {
+      if (!valid || !getline(line) || line.empty()) { valid = false; return false; }
+      if (line[0] != '@') {
+        if (line[0] != '\r') fprintf(stderr, "classify: malformed fastq file - sequence header (%s)\n", line.c_str());
+        valid = false; return false;
+      }
+      header = line.substr(1);
+      getline(seq);
+      if (!getline(line) || line.empty() || line[0] != '+') {
+        if (line.empty() || line[0] != '\r') fprintf(stderr, "classify: malformed fastq file - quality header (%s)\n", line.c_str());
+        valid = false; return false;
+      }
+      getline(quals);
+      return true;
+    }
+    if (have_pending) { line = pending; have_pending = false; }
+    else if (!getline(line)) { valid = false; return false; }
+    if (line.empty() || line[0] != '>') {
+      fprintf(stderr, "classify: malformed fasta file - expected header char > not found\n");
+      valid = false; return false;
+    }
+    header = line.substr(1);
+    while (getline(line)) {
+      if (!line.empty() && line[0] == '>') { pending = line; have_pending = true; break; }
+      seq += line;
+    }
+    return true;
+  }
+  void close() { if (g) gzclose(g); g = nullptr; }
+};
+
+static double seconds_between(const timeval &a, const timeval &b) {
+  return (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_usec - a.tv_usec) / 1e6;
+}
+
+int main(int argc, char **argv) {
+  std::vector<std::string> dbs, idxs;
+  std::string kraken_out, report_out, taxdb, cls_out, ucls_out;
+  bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
+  uint32_t min_hits = 1;
+  uint64_t unit_nt = 256ull << 20;
+  if (argc > 1 && strcmp(argv[1], "-h") == 0) usage(0);
+  int opt;
+  while ((opt = getopt(argc, argv, "d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:")) != -1) {
+    long long sig;
+    switch (opt) {
+      case 'd': dbs.push_back(optarg); break;
+      case 'i': idxs.push_back(optarg); break;
+      case 't':
+        sig = atoll(optarg);
+        if (sig <= 0) die(EX_USAGE, "can't use nonpositive thread count");
+        break;
+      case 'p': break;  // HLL_PRECISION only selects report columns in the reference; the sketch is p = 12
+      case 'q': quick = true; break;
+      case 'm':
+        sig = atoll(optarg);
+        if (sig <= 0) die(EX_USAGE, "can't use nonpositive minimum hit count");
+        min_hits = (uint32_t)sig;
+        break;
+      case 'c': only_classified = true; break;
+      case 'C': print_cls = true; cls_out = optarg; break;
+      case 'U': print_ucls = true; ucls_out = optarg; break;
+      case 'o': kraken_out = optarg; break;
+      case 'r': report_out = optarg; break;
+      case 's': print_seq = true; break;
+      case 'a': taxdb = optarg; break;
+      case 'u':
+        sig = atoll(optarg);
+        if (sig <= 0) die(EX_USAGE, "can't use nonpositive work unit size");
+        unit_nt = (uint64_t)sig < (1ull << 20) ? (1ull << 20) : (uint64_t)sig;  // GPU batches: at least 1 Mi nt
+        break;
+      case 'M': populate = true; break;
+      case 'x':
+        populate = true;
+        if (parse_size(optarg) == 0) die(EX_USAGE, "can't parse preload size %s", optarg);
+        break;
+      case 'I': die(EX_SOFTWARE, "UID mapping (-I) is not built into the MI355X classify (see DESIGN.md)");
+      case 'n': break;
+      default: usage(EX_USAGE);
+    }
+  }
+  if (dbs.empty()) { fprintf(stderr, "Missing mandatory option -d\n"); usage(EX_USAGE); }
+  if (idxs.empty()) { fprintf(stderr, "Missing mandatory option -i\n"); usage(EX_USAGE); }
+  if (dbs.size() > 1 || idxs.size() > 1) die(EX_SOFTWARE, "hierarchical multi-database classification is not built into the MI355X classify");
+  if (optind == argc && !populate) fprintf(stderr, "No sequence data files specified\n");
+  if (taxdb.empty()) { fprintf(stderr, "TaxDB argument is required!\n"); return 1; }  // src/classify.cpp:221-222
+
+  fprintf(stderr, " Database %s\n", dbs[0].c_str());
+  ku_db *db = nullptr;
+  KU_CHECK(ku_db_open(dbs[0].c_str(), idxs[0].c_str(), &db));
+  ku_db_info info;
+  KU_CHECK(ku_db_get_info(db, &info));
+  fprintf(stderr, "Loaded database with %" PRIu64 " keys with k of %u [val_len 4, key_len %u].\n", info.key_ct, info.k, info.key_len);
+  ku_tax *tax = nullptr;
+  KU_CHECK(ku_tax_open(taxdb.c_str(), &tax));
+  ku_ctx *ctx = nullptr;
+  const char *dev_env = getenv("KU_DEVICE");
+  KU_CHECK(ku_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx));
+  KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
+  KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
+
+  Sink s_kraken, s_cls, s_ucls;
+  bool print_kraken = true;
+  if (!kraken_out.empty()) {
+    if (kraken_out == "off" || kraken_out == "-") print_kraken = false;
+    else {
+      fprintf(stderr, "Writing Kraken output to %s\n", kraken_out.c_str());
+      if (!s_kraken.open(kraken_out)) die(EX_OSERR, "can't open %s", kraken_out.c_str());
+    }
+  } else s_kraken.open("-");
+  if (print_cls && !s_cls.open(cls_out)) die(EX_OSERR, "can't open %s", cls_out.c_str());
+  if (print_ucls && !s_ucls.open(ucls_out)) die(EX_OSERR, "can't open %s", ucls_out.c_str());
+
+  unsigned long long total_sequences = 0, total_classified = 0, total_bases = 0;
+  timeval tv1, tv2;
+  gettimeofday(&tv1, nullptr);
+  ku_opts opts = {quick ? KU_F_QUICK : 0u, min_hits, 0, 0};
+  const uint32_t pflags = (only_classified ? KU_P_ONLY_CLASSIFIED : 0u) | (print_seq ? KU_P_SEQUENCE : 0u) | (quick ? KU_P_QUICK : 0u);
+
+  std::string seqs, ids, headers, quals_all;
+  std::vector<uint64_t> off, hoff, qoff;
+  std::vector<uint32_t> len, calls, taxa, hits;
+  for (int fi = optind; fi < argc; ++fi) {
+    Reader rd;
+    rd.open(argv[fi]);
+    std::string header, seq, quals;
+    bool more = true;
+    while (more) {
+      seqs.clear(); ids.clear(); headers.clear(); quals_all.clear();
+      off.clear(); len.clear(); hoff.clear(); qoff.clear();
+      uint64_t nt = 0;
+      while (nt < unit_nt) {
+        if (!rd.next(header, seq, quals)) { more = false; break; }
+        off.push_back(seqs.size());
+        len.push_back((uint32_t)seq.size());
+        seqs += seq;
+        seqs += '\n';  // separator required by the C ABI (any non-ACGT byte)
+        size_t e = header.find_first_of(" \t\r\v\f");  // id = header up to first whitespace (src/seqreader.cpp:57-58)
+        ids.append(header, 0, e == std::string::npos ? header.size() : e);
+        ids.push_back('\0');
+        if (print_cls || print_ucls) {
+          hoff.push_back(headers.size()); headers += header; headers.push_back('\0');
+          qoff.push_back(quals_all.size()); quals_all += quals; quals_all.push_back('\0');
+        }
+        nt += seq.size();
+      }
+      const uint64_t n = off.size();
+      if (nt == 0) break;  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
+      calls.assign(n, 0); hits.assign(n, 0); taxa.assign(seqs.size(), 0);
+      opts.max_read_len = 0;
+      KU_CHECK(ku_classify_batch(ctx, seqs.data(), seqs.size(), off.data(), len.data(), n, &opts, calls.data(),
+                                 taxa.data(), hits.data()));
+      for (uint64_t i = 0; i < n; ++i) total_classified += calls[i] != 0;
+      if (print_kraken) {
+        char *text = nullptr; size_t tn = 0;
+        KU_CHECK(ku_format_kraken(seqs.data(), off.data(), len.data(), n, ids.data(), info.k, calls.data(), taxa.data(),
+                                  hits.data(), pflags, &text, &tn));
+        s_kraken.write(text, tn);
+        ku_free(text);
+      }
+      if (print_cls || print_ucls) {  // print_sequence (src/classify.cpp:794-805)
+        std::string rec;
+        for (uint64_t i = 0; i < n; ++i) {
+          Sink &sk = calls[i] ? s_cls : s_ucls;
+          if (calls[i] ? !print_cls : !print_ucls) continue;
+          rec.clear();
+          rec += rd.fastq ? '@' : '>';
+          rec += headers.c_str() + hoff[i];
+          rec += '\n';
+          rec.append(seqs, off[i], len[i]);
+          rec += '\n';
+          if (rd.fastq) { rec += "+\n"; rec += quals_all.c_str() + qoff[i]; rec += '\n'; }
+          sk.write(rec.data(), rec.size());
+        }
+      }
+      total_sequences += n;
+      total_bases += nt;
+      fprintf(stderr, "\r Processed %llu sequences (%.2f%% classified)", total_sequences, total_classified * 100.0 / total_sequences);
+    }
+    rd.close();
+  }
+  gettimeofday(&tv2, nullptr);
+  {  // report_stats (src/classify.cpp:361-375)
+    double seconds = seconds_between(tv1, tv2);
+    fprintf(stderr, "\r");
+    fprintf(stderr, "%llu sequences (%.2f Mbp) processed in %.3fs (%.1f Kseq/m, %.2f Mbp/m).\n", total_sequences,
+            total_bases / 1.0e6, seconds, total_sequences / 1.0e3 / (seconds / 60), total_bases / 1.0e6 / (seconds / 60));
+    fprintf(stderr, "  %llu sequences classified (%.2f%%)\n", total_classified, total_classified * 100.0 / total_sequences);
+    fprintf(stderr, "  %llu sequences unclassified (%.2f%%)\n", total_sequences - total_classified,
+            (total_sequences - total_classified) * 100.0 / total_sequences);
+  }
+  s_kraken.close(); s_cls.close(); s_ucls.close();
+
+  if (!report_out.empty() && report_out != "off") {
+    gettimeofday(&tv1, nullptr);
+    fprintf(stderr, "Writing report file to %s  ..\n", report_out.c_str());
+    // database.kdb.counts: regenerate when missing or empty (src/classify.cpp:263-285)
+    const std::string cname = dbs[0] + ".counts";
+    bool good = false;
+    if (FILE *cf = fopen(cname.c_str(), "r")) { good = fgetc(cf) != EOF; fclose(cf); if (!good) fprintf(stderr, "Kmer counts file is empty - trying to regenerate ...\n"); }
+    if (!good) {
+      fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
+      uint64_t nc = 0;
+      KU_CHECK(ku_ctx_count_taxons(ctx, nullptr, nullptr, &nc));
+      std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
+      uint64_t cap = nc;
+      KU_CHECK(ku_ctx_count_taxons(ctx, ct.data(), cc.data(), &cap));
+      FILE *cf = fopen(cname.c_str(), "w");
+      if (!cf) die(EX_OSERR, "can't write %s", cname.c_str());
+      for (uint64_t i = 0; i < cap; ++i) fprintf(cf, "%u\t%" PRIu64 "\n", ct[i], cc[i]);
+      fclose(cf);
+    }
+    ku_counts_dims d;
+    KU_CHECK(ku_counts_dims_get(ctx, &d));
+    std::vector<uint32_t> st(d.n_slots), ntx(d.n_nodes);
+    std::vector<uint64_t> nk(d.n_slots), nr(d.n_nodes);
+    std::vector<uint8_t> regs(d.n_slots * (size_t)KU_HLL_M);
+    KU_CHECK(ku_counts_export(ctx, st.data(), nk.data(), regs.data(), ntx.data(), nr.data()));
+    char *text = nullptr; size_t tn = 0;
+    KU_CHECK(ku_report(tax, cname.c_str(), st.data(), nk.data(), regs.data(), d.n_slots, ntx.data(), nr.data(), d.n_nodes, &text, &tn));
+    if (tn == 0) fprintf(stderr, "total number of reads is zero - not creating a report!\n");
+    Sink rs;
+    if (!rs.open(report_out, /*append=*/true)) die(EX_OSERR, "can't open %s", report_out.c_str());
+    rs.write(text, tn);
+    rs.close();
+    ku_free(text);
+    gettimeofday(&tv2, nullptr);
+    fprintf(stderr, "Report finished in %.3f seconds.\n", seconds_between(tv1, tv2));
+  }
+  fprintf(stderr, "Finishing up ...\n");
+  ku_ctx_destroy(ctx);
+  ku_tax_close(tax);
+  ku_db_close(db);
+  return 0;
+}

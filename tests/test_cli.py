@@ -1,0 +1,103 @@
+"""The drop-in `classify` executable (krakenuniq_amd/bin/classify): flag handling and exit codes on CPU,
+byte-identical outputs against the reference's golden files on the GPU."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "krakenuniq_amd", "bin", "classify")
+F1 = os.path.join(ROOT, "tests", "golden", "f1")
+DB = ["-d", f"{F1}/database.kdb", "-i", f"{F1}/database.idx", "-a", f"{F1}/taxDB"]
+
+
+def run(args, **kw):
+    return subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+
+
+def rows(text):
+    return sorted(text.strip("\n").split("\n"))
+
+
+def test_usage_and_exit_codes():
+    assert os.path.exists(BIN), "build with make -C krakenuniq_amd/csrc"
+    r = run([])
+    assert r.returncode == 64 and b"Missing mandatory option -d" in r.stderr  # EX_USAGE (classify.cpp:1151-1154)
+    assert run(["-h"]).returncode == 0
+    for bad in (["-t", "0"], ["-m", "0"], ["-u", "-5"], ["-x", "12Q"]):
+        r = run(["-d", "x", "-i", "y"] + bad)
+        assert r.returncode == 64, bad
+    r = run(["-d", "x", "-i", "y", "r.fq"])
+    assert r.returncode == 1 and b"TaxDB argument is required" in r.stderr  # classify.cpp:221-222
+    r = run(["-d", "/nonexistent.kdb", "-i", f"{F1}/database.idx", "-a", f"{F1}/taxDB", "r.fq"])
+    assert r.returncode == 66  # EX_NOINPUT
+    r = run(["-d", f"{F1}/taxDB", "-i", f"{F1}/database.idx", "-a", f"{F1}/taxDB", "r.fq"])
+    assert r.returncode == 65  # EX_DATAERR: not a JFLISTDN file
+    assert run(DB + ["-I", "uid.map", "r.fq"]).returncode == 70
+    assert run(DB + ["-d", "second.kdb", "r.fq"]).returncode == 70
+
+
+@pytest.mark.gpu
+def test_outputs_match_reference(tmp_path):
+    shutil_db = tmp_path / "db"
+    shutil_db.mkdir()
+    for fn in ("database.kdb", "database.idx", "taxDB"):  # private copy: the CLI (re)writes database.kdb.counts
+        (shutil_db / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
+    db = ["-d", f"{shutil_db}/database.kdb", "-i", f"{shutil_db}/database.idx", "-a", f"{shutil_db}/taxDB"]
+    out, rep = tmp_path / "out.tsv", tmp_path / "report.tsv"
+    rep.write_text("# header written by the wrapper\n")  # the report is opened in append mode (classify.cpp:286)
+    r = run(db + ["-t", "4", "-M", "-p", "14", "-o", str(out), "-r", str(rep), f"{F1}/reads.fq"])
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+    assert (shutil_db / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
+    text = rep.read_text()
+    assert text.startswith("# header written by the wrapper\n%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n")
+    ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{F1}/report.tsv").read().strip().split("\n")}
+    got = text.strip().split("\n")[1:]
+    assert len(got) == len(ref)
+    for ln in got:
+        f = ln.split("\t")
+        assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
+        if f[3] != "kmers":
+            assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
+    err = r.stderr.decode()
+    assert "1000 sequences (0.15 Mbp) processed in" in err and "sequences classified (74.10%)" in err
+    # stdout default, quick mode, -c, -s, gz output, -o off
+    r = run(db + ["-q", "-m", "2", f"{F1}/reads.fq"])
+    assert r.stdout == open(f"{F1}/out_quick.tsv", "rb").read()
+    assert run(db + ["-c", f"{F1}/reads.fq"]).stdout == open(f"{F1}/out_c.tsv", "rb").read()
+    assert run(db + ["-s", f"{F1}/reads.fq"]).stdout == open(f"{F1}/out_s.tsv", "rb").read()
+    gz = tmp_path / "out.tsv.gz"
+    assert run(db + ["-o", str(gz), f"{F1}/reads.fq"]).returncode == 0
+    assert gzip.open(gz).read() == open(f"{F1}/out.tsv", "rb").read()
+    r = run(db + ["-o", "off", f"{F1}/reads.fq"])
+    assert r.returncode == 0 and r.stdout == b""
+    # -u splits the input into several batches: same output, same per-taxon state
+    r = run(db + ["-u", "1", "-o", str(out), "-r", str(tmp_path / "r2.tsv"), f"{F1}/reads.fq"])
+    assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+    assert rows((tmp_path / "r2.tsv").read_text()) == rows("\n".join(got) + "\n" + text.split("\n")[1])
+
+
+@pytest.mark.gpu
+def test_fasta_paired_edge_and_read_files(tmp_path):
+    g = os.path.join(ROOT, "tests", "golden")
+    r = run(DB + [f"{g}/f2/edge.fa"])
+    assert r.returncode == 0 and r.stdout == open(f"{g}/f2/out.tsv", "rb").read()
+    r = run(DB + [f"{g}/f4/merged.fa"])
+    assert r.stdout == open(f"{g}/f4/out.tsv", "rb").read()
+    # gz input and two input files in one run
+    gzp = tmp_path / "edge.fa.gz"
+    with gzip.open(gzp, "wb") as f:
+        f.write(open(f"{g}/f2/edge.fa", "rb").read())
+    r = run(DB + [str(gzp), f"{g}/f4/merged.fa"])
+    assert r.stdout == open(f"{g}/f2/out.tsv", "rb").read() + open(f"{g}/f4/out.tsv", "rb").read()
+    # -C / -U: classified and unclassified reads as FASTQ records
+    c, u = tmp_path / "c.fq", tmp_path / "u.fq"
+    r = run(DB + ["-o", "off", "-C", str(c), "-U", str(u), f"{F1}/reads.fq"])
+    assert r.returncode == 0
+    calls = {ln.split("\t")[1]: ln[0] for ln in open(f"{F1}/out.tsv").read().strip().split("\n")}
+    src = open(f"{F1}/reads.fq").read().split("\n")
+    want_c = "".join("\n".join(src[i:i + 4]) + "\n" for i in range(0, len(src) - 1, 4) if calls[src[i][1:]] == "C")
+    want_u = "".join("\n".join(src[i:i + 4]) + "\n" for i in range(0, len(src) - 1, 4) if calls[src[i][1:]] == "U")
+    assert c.read_text() == want_c and u.read_text() == want_u
