@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--genome-len", type=int, default=310_000)
     ap.add_argument("--nt", type=int, default=13)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas")
+    ap.add_argument("--paired", action="store_true", help="configs[3]-style reads: mate1 + 'N' + mate2 (2 x read-len + 1)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--keep-tmp", action="store_true")
@@ -175,6 +176,19 @@ def main():
     ctx.set_taxonomy(ctax, all_values)
     # reads: own batch per rank (replicas) or the same batch on every rank (sharded)
     d_seqs, d_off, d_len, _ = db.sample_reads(a.reads, a.read_len, seed=1 if sharded else 1 + rank)
+    if a.paired:  # read_merger.pl semantics: seq1 . "N" . seq2 (scripts/read_merger.pl:187-191)
+        m2, _, _, _ = db.sample_reads(a.reads, a.read_len, seed=1001 if sharded else 1001 + rank)
+        L = a.read_len
+        merged = torch.empty((a.reads, 2 * L + 2), dtype=torch.uint8, device=dev)
+        merged[:, :L] = d_seqs.view(a.reads, L + 1)[:, :L]
+        merged[:, L] = 78
+        merged[:, L + 1:2 * L + 1] = m2.view(a.reads, L + 1)[:, :L]
+        merged[:, 2 * L + 1] = 10
+        d_seqs = merged.reshape(-1)
+        d_off = torch.arange(a.reads, device=dev, dtype=torch.int64) * (2 * L + 2)
+        d_len = torch.full((a.reads,), 2 * L + 1, dtype=torch.int32, device=dev)
+        a.read_len = 2 * L + 1
+        del m2, merged
     n_bytes = d_seqs.numel()
     d_taxa = torch.zeros(n_bytes, dtype=torch.int32, device=dev)
     d_calls = torch.zeros(a.reads, dtype=torch.int32, device=dev)
@@ -182,6 +196,7 @@ def main():
     build_s = time.time() - t_build
 
     # a dedicated (non-null) torch stream: kernels, RCCL collectives and the timing events all live on it
+    torch.cuda.synchronize()  # inputs were produced on the default stream: finish them before switching streams
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
@@ -254,12 +269,19 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    default_cfg = (a.reads == 10_000_000 and a.species == 2000 and a.genome_len == 310_000 and a.nt == 13
+                   and not a.paired and a.read_len == 150)
+    if default_cfg and ws == 1:
+        workload = "configs[1]: 8 GB MiniKraken-style DB (k=31), 10M synthetic 150 bp reads, 1xMI355X"
+    else:
+        workload = (f"{'configs[1] ' if default_cfg else ''}synthetic DB ({a.species} taxa x {a.genome_len} bp, nt={a.nt}), "
+                    f"{a.reads} {'paired 2x' + str((a.read_len - 1) // 2) if a.paired else str(a.read_len)} bp reads per GPU "
+                    f"per step, {a.mode} x{ws}")
     result = {
         "metric": "Mreads/s (150 bp)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": ws, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1]: 8 GB MiniKraken-style DB (k=31), 10M synthetic 150 bp reads, 1xMI355X"
-                   if ws == 1 else f"configs[1] DB, {a.mode}, {a.reads} reads/GPU/step",
+        "config": {"workload": workload,
                    "db_pairs_per_gpu": db.n_pairs, "db_bytes_per_gpu": db.n_pairs * 12 + db.offsets.numel() * 8,
                    "k": k, "nt": a.nt, "taxa": a.species, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
                    "parallelism": f"{a.mode}{ws}", "db_build_s": round(build_s, 1)},
