@@ -26,6 +26,9 @@
 #include <cstdlib>
 
 #define KU_THREADS 256
+#ifndef KU_MIN_WAVES
+#define KU_MIN_WAVES 4  // waves per SIMD the lookup kernel is compiled for (<= 128 VGPRs)
+#endif
 #ifndef KU_ITEMS
 #define KU_ITEMS 3
 #endif
@@ -223,29 +226,39 @@ __device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint64_t c_rc, uint
   return ((uint64_t)best << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
 }
 __device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lines) {
-  uint64_t g = (locus ^ (locus >> 31)) * 0x9E3779B97F4A7C15ULL;
-  g = (g ^ (g >> 29)) * 0xBF58476D1CE4E5B9ULL;
-  return __umul64hi(g ^ (g >> 32), n_lines);
+  // 32-bit mixing (v_mul_lo/hi_u32 are quarter-rate on CDNA; 64-bit multiplies cost four of them each);
+  // n_lines < 2^32 is enforced at table construction (512 GiB of table per shard)
+  uint32_t g = (uint32_t)locus * 0x9E3779B1u ^ __builtin_rotateleft32((uint32_t)(locus >> 32) * 0x85EBCA77u, 15);
+  g ^= g >> 15;
+  g *= 0x2C1B3C6Du;
+  g ^= g >> 13;
+  return __umulhi(g, (uint32_t)n_lines);
 }
 
-// Sliding-window minimum with the position of the first minimum, for KU_ITEMS windows at once (independent
-// chains -> the LDS reads pipeline).  Window t-th element of item j = s_mm[base[j] + dj[j] * t]; the result packs
-// (value << 5) | t, valid while the values have <= 27 bits (minimizer length <= 13).  W > 0: compile-time window
-// length (fully unrolled), W == 0: run-time length w.
+// Sliding-window minimum with the position of the minimum, for KU_ITEMS windows at once (independent chains ->
+// the LDS reads pipeline).  s_mm holds the m-mer values PRE-SHIFTED by 5 bits (low 5 bits zero, values <= 27
+// bits, i.e. minimizer length <= 13) and biased by +1.  Every lane reads its window forward (conflict-free across lanes) and
+// minimises  s_mm[t] + sgn * t  in one v_mad_i32_i24 + v_min_u32 per element:
+//   sgn = +1: ties resolve to the smallest t (first minimum), result = value + t
+//   sgn = -1: ties resolve to the largest t (last minimum),   result = value - t   (a borrow from the value
+//             field keeps the order: value1 < value2  =>  value1 - t1 < value2 - t2 because values are 32 apart)
+// W > 0: compile-time window length (fully unrolled), W == 0: run-time length w.
 template <int W>
-__device__ __forceinline__ void ku_window_argmin(const uint32_t *s_mm, const int32_t (&base)[KU_ITEMS],
-                                                 const int32_t (&dj)[KU_ITEMS], uint32_t w, uint32_t (&out)[KU_ITEMS]) {
+__device__ __forceinline__ void ku_window_argmin(const uint32_t *s_mm, const uint32_t (&base)[KU_ITEMS],
+                                                 const int32_t (&sgn)[KU_ITEMS], uint32_t w,
+                                                 uint32_t (&out)[KU_ITEMS]) {
 #pragma unroll
   for (int j = 0; j < KU_ITEMS; ++j) out[j] = 0xFFFFFFFFu;
   if (W > 0) {
 #pragma unroll
     for (int t = 0; t < W; ++t)
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) out[j] = min(out[j], (s_mm[base[j] + dj[j] * t] << 5) | (uint32_t)t);
+      for (int j = 0; j < KU_ITEMS; ++j) out[j] = min(out[j], s_mm[base[j] + t] + (uint32_t)(sgn[j] * t));
   } else {
     for (uint32_t t = 0; t < w; ++t)
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) out[j] = min(out[j], (s_mm[base[j] + dj[j] * (int32_t)t] << 5) | t);
+      for (int j = 0; j < KU_ITEMS; ++j)
+        out[j] = min(out[j], s_mm[base[j] + t] + (uint32_t)(sgn[j] * (int32_t)t));
   }
 }
 
@@ -257,7 +270,7 @@ __device__ __forceinline__ void ku_window_argmin(const uint32_t *s_mm, const int
 // SHARDED: the context owns a strict sub-range of the minimizer bins, so the minimizer of
 // every k-mer is needed for the ownership test (always needed by LAYOUT 0 and MODE 2).
 template <int MODE, int LAYOUT, bool SHARDED>
-__global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
+__global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
                                                                const uint8_t *__restrict__ seqs,
                                                                uint64_t n_bytes, uint32_t *__restrict__ taxa,
                                                                unsigned long long *stats, uint32_t ablate) {
@@ -280,6 +293,9 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
   const uint32_t w = k - m + 1;  // m-mers per k-mer (krakendb.cpp:208)
   const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
   const bool aligned = (((uintptr_t)seqs) & 15u) == 0;
+  // LAYOUT 1 with nt <= 13 keeps the m-mer values pre-shifted by 5 bits in LDS (ku_window_argmin)
+  const uint32_t mm_shift = (LAYOUT == 1 && MODE != 2 && m <= 13) ? 5u : 0u;
+  const uint32_t mm_bias = mm_shift ? 1u : 0u;  // value + 1: the field never underflows when an offset is subtracted
   uint16_t *s_amb16 = reinterpret_cast<uint16_t *>(s_amb);
 
   if (DO_COUNTS) ku_ct_clear(s_ctk, s_ctc, &s_ctu);
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
       if (NEED_MIN) {  // m-mer starting at p, canonical, scrambled (krakendb.cpp:209)
         uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
         uint32_t mrc = ku_revcomp32(mm, m);
-        s_mm[p] = (mm < mrc ? mm : mrc) ^ db.xor_mask;
+        s_mm[p] = (((mm < mrc ? mm : mrc) ^ db.xor_mask) + mm_bias) << mm_shift;
       }
       if (j < KU_ITEMS) {
         uint64_t fwd = x >> (64 - 2 * k);
@@ -350,17 +366,26 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
       __syncthreads();
       uint32_t packed[KU_ITEMS];  // (minimum << 5) | first offset, canonical k-mer frame (LAYOUT 1, m <= 13)
       if (LAYOUT == 1 && MODE != 2 && m <= 13) {
-        int32_t base[KU_ITEMS], dj[KU_ITEMS];
+        uint32_t base[KU_ITEMS], r[KU_ITEMS];
+        int32_t sgn[KU_ITEMS];
 #pragma unroll
         for (int j = 0; j < KU_ITEMS; ++j) {
-          base[j] = (int32_t)(j * KU_THREADS + tid) + (is_fwd[j] ? 0 : (int32_t)w - 1);
-          dj[j] = is_fwd[j] ? 1 : -1;
+          base[j] = j * KU_THREADS + tid;
+          sgn[j] = is_fwd[j] ? 1 : -1;
         }
         switch (w) {  // block-uniform; the common geometries get fully unrolled windows
-          case 19: ku_window_argmin<19>(s_mm, base, dj, w, packed); break;  // k = 31, nt = 13
-          case 20: ku_window_argmin<20>(s_mm, base, dj, w, packed); break;  // k = 31, nt = 12
-          case 25: ku_window_argmin<25>(s_mm, base, dj, w, packed); break;  // k = 31, nt = 7
-          default: ku_window_argmin<0>(s_mm, base, dj, w, packed); break;
+          case 19: ku_window_argmin<19>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 13
+          case 20: ku_window_argmin<20>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 12
+          case 25: ku_window_argmin<25>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 7
+          default: ku_window_argmin<0>(s_mm, base, sgn, w, r); break;
+        }
+        // offset in the canonical k-mer's frame: read offset t when the read strand is canonical, else w-1-t
+        // (the first minimum there is the LAST one in read order)
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          uint32_t t = is_fwd[j] ? (r[j] & 31u) : ((0u - r[j]) & 31u);
+          uint32_t val = (is_fwd[j] ? (r[j] >> 5) : ((r[j] + 31u) >> 5)) - 1u;  // undo the +1 bias
+          packed[j] = (val << 5) | (is_fwd[j] ? t : w - 1 - t);
         }
       }
 #pragma unroll
@@ -485,26 +510,44 @@ __global__ __launch_bounds__(KU_THREADS) void ku_lookup_kernel(KuDbDev db, KuCou
             act[j] = cand[j] != 0 || ovf[j];
           }
         }
-      // rare tail: further tag matches in the bucket (false positives) and spilled buckets
+      // rare tail: further tag matches in the bucket (false positives) and spilled buckets; the items of a
+      // lane advance in lockstep so their round trips overlap
+      bool any = false;
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
-        while (act[j]) {
-          if (cand[j]) {
-            KuPair e = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
-            cand[j] &= cand[j] - 1;
-            if ((((uint64_t)e.key_hi << 32) | e.key_lo) == canon[j]) {
-              slot[j] = e.slot;
-              act[j] = false;
+      for (int j = 0; j < KU_ITEMS; ++j) any |= act[j];
+      while (any) {
+        any = false;
+        KuPair e[KU_ITEMS];
+        uint4 a4[KU_ITEMS];
+        uint32_t a1[KU_ITEMS];
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          if (act[j]) {
+            if (cand[j]) {
+              e[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+            } else {  // ovf[j]: continue in the next line
+              lp[j] += KU_LINE_DWORDS;
+              if (lp[j] == tab + db.n_lines * KU_LINE_DWORDS) lp[j] = tab;
+              a4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
+              a1[j] = lp[j][4];
             }
-          } else if (ovf[j]) {
-            lp[j] += KU_LINE_DWORDS;
-            if (lp[j] == tab + db.n_lines * KU_LINE_DWORDS) lp[j] = tab;
-            uint4 a4 = *reinterpret_cast<const uint4 *>(lp[j]);
-            uint32_t a1 = lp[j][4];
-            cand[j] = ku_tag_matches(a4, a1, tag[j]);
-            ovf[j] = (a4.x & 0xFFFFu) > KU_LINE_SLOTS;
-          } else {
-            act[j] = false;  // miss
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          if (act[j]) {
+            if (cand[j]) {
+              cand[j] &= cand[j] - 1;
+              if ((((uint64_t)e[j].key_hi << 32) | e[j].key_lo) == canon[j]) {
+                slot[j] = e[j].slot;
+                act[j] = false;
+              }
+            } else {
+              cand[j] = ku_tag_matches(a4[j], a1[j], tag[j]);
+              ovf[j] = (a4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+            }
+            if (act[j]) act[j] = cand[j] != 0 || ovf[j];
+            any |= act[j];
           }
         }
       }
