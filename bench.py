@@ -283,7 +283,7 @@ def main():
         "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": workload,
                    "db_pairs_per_gpu": db.n_pairs, "db_bytes_per_gpu": db.n_pairs * 12 + db.offsets.numel() * 8,
-                   "k": k, "nt": a.nt, "taxa": a.species, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
+                   "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
                    "parallelism": f"{a.mode}{ws}", "db_build_s": round(build_s, 1)},
         "roofline": {"bound": "hbm", "kernel": "ku_lookup_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

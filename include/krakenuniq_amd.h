@@ -111,10 +111,15 @@ int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_h
  * indices whose first entry is the global index of d_pairs[0].  The buffers
  * stay owned by the caller; d_pairs is remapped in place (taxid -> slot id) and
  * consumed by ku_ctx_set_taxonomy (it builds the probe table from it) and may be
- * released afterwards unless the context runs with KU_LAYOUT=sorted; d_offsets
- * must outlive the context. */
+ * released afterwards unless ku_ctx_db_layout reports the sorted layout;
+ * d_offsets must outlive the context. */
 int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, const uint64_t *d_offsets, uint32_t k,
                     uint32_t nt, uint32_t idx_type, uint64_t bin_lo, uint64_t bin_hi);
+/* Which in-HBM layout the shard ended up in after ku_ctx_set_taxonomy: *is_hash = 1 for the bucketised probe
+ * table (default), 0 for the sorted on-disk order + binary search (KU_LAYOUT=sorted, or the automatic fallback
+ * when the table does not fit: an adopted d_pairs buffer then stays in use).  *resident_bytes = table or pairs
+ * + offsets. */
+int ku_ctx_db_layout(ku_ctx *ctx, uint32_t *is_hash, uint64_t *resident_bytes);
 /* Distinct non-zero taxids stored in the resident shard, ascending (what
  * KrakenDB::count_taxons enumerates, krakendb.cpp:90-113).  Call with out = NULL
  * to get *n. */

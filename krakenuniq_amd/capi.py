@@ -66,6 +66,7 @@ SIGNATURES = {
     "ku_ctx_load_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ku_ctx_adopt_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint64, C.c_uint64]),
+    "ku_ctx_db_layout": (C.c_int, [C.c_void_p, u32p, u64p]),
     "ku_ctx_db_values": (C.c_int, [C.c_void_p, u32p, u64p]),
     "ku_ctx_set_taxonomy": (C.c_int, [C.c_void_p, C.c_void_p, u32p, C.c_uint64]),
     "ku_ctx_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
@@ -212,6 +213,11 @@ class Ctx:
         self._keep.append(keep)
         _chk(lib().ku_ctx_adopt_db(self.h, d_pairs_ptr, n_pairs, d_offsets_ptr, k, nt, idx_type, bin_lo, bin_hi),
              "ku_ctx_adopt_db")
+
+    def db_layout(self):
+        h, b = C.c_uint32(), C.c_uint64()
+        _chk(lib().ku_ctx_db_layout(self.h, C.byref(h), C.byref(b)), "ku_ctx_db_layout")
+        return {"hash": bool(h.value), "resident_bytes": b.value}
 
     def db_values(self):
         n = C.c_uint64()

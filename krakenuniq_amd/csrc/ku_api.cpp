@@ -294,9 +294,10 @@ struct ku_ctx {
   // DB shard
   bool db_loaded = false, db_owned = false, tax_set = false;
   bool hash_layout = true;   // KU_LAYOUT=sorted keeps the on-disk order + binary search (A/B and fallback for HBM-tight shards)
-  double load_factor = 0.4;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
+  double load_factor = 0.3;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
   void *d_table = nullptr;
   uint64_t n_dup = 0;
+  uint64_t table_lines = 0;
   uint32_t *d_pairs = nullptr;
   uint64_t *d_offsets = nullptr;
   bool offsets_owned = false;
@@ -468,6 +469,16 @@ extern "C" int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, con
   return ctx_scan_values(ctx);
 }
 
+extern "C" int ku_ctx_db_layout(ku_ctx *ctx, uint32_t *is_hash, uint64_t *resident_bytes) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  if (!ctx->db_loaded) return fail(KU_ESTATE, "no database loaded");
+  const bool hash = ctx->db.table != nullptr;
+  if (is_hash) *is_hash = hash ? 1u : 0u;
+  if (resident_bytes)
+    *resident_bytes = (hash ? ctx->db.n_lines * 128 : ctx->db.n_pairs * 12) + (ctx->db.bin_hi - ctx->db.bin_lo + 1) * 8;
+  return KU_OK;
+}
+
 extern "C" int ku_ctx_db_values(ku_ctx *ctx, uint32_t *out, uint64_t *n) {
   if (!ctx || !n) return fail(KU_EINVAL, "ku_ctx_db_values: null argument");
   if (!ctx->db_loaded) return fail(KU_ESTATE, "no database loaded");
@@ -546,8 +557,22 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
   if (ctx->hash_layout) {
     // re-lay the shard out as the open-addressing table the lookup kernel probes; the 12-byte
     // pairs are only the build input: owned copies are released, adopted buffers go back to the caller.
-    uint64_t n_lines = (uint64_t)((double)ctx->db.n_pairs / ctx->load_factor / 9.0) + 1;
-    HIP_TRY(hipMalloc(&ctx->d_table, n_lines * 128));
+    // preferred load factor first (fewest spilled buckets = fewest dependent round trips); denser tables when
+    // HBM is short; the sorted on-disk layout (no extra memory) as the last resort
+    uint64_t n_lines = 0;
+    for (double lf : {ctx->load_factor, 0.45, 0.6, 0.8}) {
+      if (lf < ctx->load_factor) continue;
+      n_lines = (uint64_t)((double)ctx->db.n_pairs / lf / 9.0) + 1;
+      if (n_lines >= (1ull << 32)) { n_lines = 0; continue; }  // ku_locus_line() reduces to 32 bits
+      if (hipMalloc(&ctx->d_table, n_lines * 128) == hipSuccess) { ctx->table_lines = n_lines; break; }
+      (void)hipGetLastError();
+      ctx->d_table = nullptr;
+      n_lines = 0;
+    }
+    if (!ctx->d_table) ctx->hash_layout = false;  // keep the sorted pairs resident and binary-search them
+  }
+  if (ctx->hash_layout) {
+    const uint64_t n_lines = ctx->table_lines;
     unsigned long long *d_dup = (unsigned long long *)(ctx->d_scalar + 2);
     HIP_TRY(hipMemsetAsync(d_dup, 0, 8, ctx->stream));
     KU_TRY(ku_launch_build_table(ctx->d_pairs, ctx->db.n_pairs, ctx->d_table, n_lines, ctx->db.k, ctx->db.nt,

@@ -197,7 +197,9 @@ __device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32
 // the canonical k-mer's frame on ties), so build and lookup agree by construction; which k-mers share a bucket
 // only affects speed, never results.
 #define KU_FLANK 8
-#define KU_OFFCLASS 5
+#ifndef KU_OFFCLASS
+#define KU_OFFCLASS 4  // offsets per locus class: 4 measured best (3: 25.7, 4: 25.3, 5: 26.8, 8: 28.1 ms at load 0.3)
+#endif
 __device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint64_t c_rc, uint32_t k, uint32_t m, uint32_t xor_mask,
                                                  uint32_t &bin) {
   const uint32_t w = k - m + 1;
