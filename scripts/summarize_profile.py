@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>_{stats,pmc*} (scripts/profile_bench.sh) into profiles/<tag>_kernel_stats.csv,
+profiles/<tag>_pmc_summary.json and profiles/lookup_traffic.json.   usage: scripts/summarize_profile.py <tag> <rev>"""
+import collections, csv, glob, json, sys
+tag, rev = sys.argv[1], sys.argv[2]
+out = {}
+for f in sorted(glob.glob(f'gpurun_out/{tag}_pmc*/runc/*counter_collection.csv')):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        kn = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        agg[(kn, r['Counter_Name'])].append(float(r['Counter_Value']))
+    for (kn, c), v in agg.items():
+        vv = v[1:] if len(v) > 1 else v   # first dispatch = untimed warm-up step
+        out.setdefault(kn, {})[c] = {"per_launch_mean": sum(vv) / len(vv), "launches": len(vv)}
+json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1, sort_keys=True)
+rows = list(csv.reader(open(glob.glob(f'gpurun_out/{tag}_stats/runc/*kernel_stats.csv')[0])))
+with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
+    w = csv.writer(f); w.writerow(rows[0])
+    for r in rows[1:]:
+        if 'ku_' in r[0] or float(r[4]) >= 1.0:
+            w.writerow([r[0][:160]] + r[1:])
+for r in rows[1:]:
+    if 'ku_' in r[0]: print(r[0][:44], 'calls', r[1], 'avg_ns', r[3])
+lk = next(v for k, v in out.items() if k.startswith('ku_lookup_kernel<1'))
+kname = next(k for k in out if k.startswith('ku_lookup_kernel<1'))
+fetch_kb, write_kb = lk['FETCH_SIZE']['per_launch_mean'], lk['WRITE_SIZE']['per_launch_mean']
+j = {"reads": 10000000, "nt": 13, "species": 2000, "kernel": kname, "kernel_rev": rev,
+     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+     "correction": "gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM; scripts/calib_gather.hip: a random "
+                   "16-B gather moves one 128-B line): read bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 as is (uncalibrated)",
+     "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024)}
+json.dump(j, open('profiles/lookup_traffic.json', 'w'), indent=1)
+print({k: '%.4g' % v['per_launch_mean'] for k, v in lk.items()})
+print('traffic GB', j['hbm_bytes_per_launch'] / 1e9)
