@@ -219,17 +219,28 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
+    fused = not sharded and os.environ.get("KU_NO_FUSED") is None and (a.read_len - k + 1) <= 192 and ctx.db_layout()["hash"]
+
     def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        ctx.lookup_device(d_seqs.data_ptr(), n_bytes, d_taxa.data_ptr(),
-                          flags=capi.KU_F_KEEP_SLOTS if sharded else 0, stream=stream)
-        if i is not None:
-            ev[i][1].record()
-        if sharded:
-            kdist.merge_taxa_max(d_taxa)
-        ctx.resolve_device(d_seqs.data_ptr(), d_off[r_lo:].data_ptr(), d_len[r_lo:].data_ptr(), r_hi - r_lo,
-                           d_calls[r_lo:].data_ptr(), d_taxa.data_ptr(), max_read_len=a.read_len, stream=stream)
+        if fused:
+            # short reads, whole DB resident: ONE fused kernel (wave per read) does lookup + counts + resolve
+            if i is not None:
+                ev[i][0].record()
+            ctx.classify_batch_device(d_seqs.data_ptr(), n_bytes, d_off.data_ptr(), d_len.data_ptr(), a.reads,
+                                      d_calls.data_ptr(), d_taxa.data_ptr(), max_read_len=a.read_len, stream=stream)
+            if i is not None:
+                ev[i][1].record()
+        else:
+            if i is not None:
+                ev[i][0].record()
+            ctx.lookup_device(d_seqs.data_ptr(), n_bytes, d_taxa.data_ptr(),
+                              flags=capi.KU_F_KEEP_SLOTS if sharded else 0, stream=stream)
+            if i is not None:
+                ev[i][1].record()
+            if sharded:
+                kdist.merge_taxa_max(d_taxa)
+            ctx.resolve_device(d_seqs.data_ptr(), d_off[r_lo:].data_ptr(), d_len[r_lo:].data_ptr(), r_hi - r_lo,
+                               d_calls[r_lo:].data_ptr(), d_taxa.data_ptr(), max_read_len=a.read_len, stream=stream)
         if ws > 1:
             kdist.reduce_state(st_regs, st_kmers, st_reads)
 
@@ -265,7 +276,8 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("reads") == a.reads and tj.get("nt") == a.nt and tj.get("species") == a.species:
+            if (tj.get("reads") == a.reads and tj.get("nt") == a.nt and tj.get("species") == a.species
+                    and tj.get("kernel", "").startswith("ku_classify_short" if fused else "ku_lookup")):
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -285,7 +297,7 @@ def main():
                    "db_pairs_per_gpu": db.n_pairs, "db_bytes_per_gpu": db.n_pairs * 12 + db.offsets.numel() * 8,
                    "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
                    "parallelism": f"{a.mode}{ws}", "db_build_s": round(build_s, 1)},
-        "roofline": {"bound": "hbm", "kernel": "ku_lookup_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "ku_classify_short_kernel (fused lookup+resolve)" if fused else "ku_lookup_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_algo, "lookups_per_launch": stats["lookups"],
                      "mean_ceil_log2_bin": round(stats["sum_ceil_log2"] / max(stats["lookups"], 1), 3),

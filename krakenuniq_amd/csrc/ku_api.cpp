@@ -697,6 +697,30 @@ extern "C" int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t
 extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
                                         const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
                                         uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream) {
+  KU_TRY(check_ready(ctx));
+  const uint32_t flags = opts ? opts->flags : 0;
+  // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
+  const uint32_t short_max = getenv("KU_NO_FUSED") ? 0 : ku_short_max_kmers(ctx->db);
+  if (short_max && !(flags & KU_F_QUICK) && n_reads) {
+    if (!d_seqs || !d_seq_off || !d_seq_len || !d_calls || !d_taxa) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t max_len = opts ? opts->max_read_len : 0;
+    if (max_len == 0) {
+      KU_TRY(ku_launch_max_len(d_seq_len, n_reads, ctx->d_scalar + 4, s));
+      HIP_TRY(hipMemcpyAsync(&max_len, ctx->d_scalar + 4, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    const uint32_t max_n = max_len >= ctx->db.k ? max_len - ctx->db.k + 1 : 0;
+    if (max_n <= short_max) {
+      int st = ku_launch_classify_short(ctx->db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len,
+                                        n_reads, max_n, flags, d_calls, d_taxa, d_hits, ctx->n_cu, s);
+      return st == KU_OK ? KU_OK : fail(st, "fused short-read kernel launch failed");
+    }
+    ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+    o.max_read_len = max_len;
+    KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, &o, d_taxa, stream));
+    return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, &o, d_calls, d_taxa, d_hits, stream);
+  }
   KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, opts, d_taxa, stream));
   return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, opts, d_calls, d_taxa, d_hits, stream);
 }

@@ -21,9 +21,9 @@
 // coalesced, and puts neighbouring lanes on neighbouring k-mers -- which share
 // their minimizer bin ~(k-nt+1)/2 times in a row, so the idx and pair gathers
 // of a wave collapse onto a handful of cache lines.
-#include "ku_internal.h"
-
 #include <cstdlib>
+
+#include "ku_device.h"
 
 #define KU_THREADS 256
 #ifndef KU_MIN_WAVES
@@ -34,235 +34,6 @@
 #endif
 #define KU_TILE (KU_THREADS * KU_ITEMS)   // k-mer start positions per block iteration
 #define KU_PACKW ((KU_TILE + 64) / 16)    // 16-base words staged per tile (covers TILE + 63 bases)
-#define KU_CT_LOG2 9                      // per-block LDS counter table (n_kmers / n_reads aggregation)
-#define KU_CT_CAP (1 << KU_CT_LOG2)
-
-// ----------------------------------------------------------------------------
-// small device helpers
-// ----------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t ku_fmix64(uint64_t key) {  // hyperloglogplus.cpp:830-838
-  key += 1;
-  key ^= key >> 33;
-  key *= 0xff51afd7ed558ccdULL;
-  key ^= key >> 33;
-  key *= 0xc4ceb9fe1a85ec53ULL;
-  key ^= key >> 33;
-  return key;
-}
-
-// reverse complement of the n-mer held in the low 2n bits (krakendb.cpp:218-225):
-// full bit reversal (v_bfrev_b32 x2) + swap inside every 2-bit group == reversal
-// of the 2-bit groups; complement is bitwise NOT in this encoding.
-__device__ __forceinline__ uint64_t ku_revcomp64(uint64_t x, uint32_t n) {
-  uint64_t r = __builtin_bitreverse64(x);
-  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
-  return (~r) >> (64 - 2 * n);
-}
-__device__ __forceinline__ uint32_t ku_revcomp32(uint32_t x, uint32_t n) {
-  uint32_t r = __builtin_bitreverse32(x);
-  r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-  return (~r) >> (32 - 2 * n);
-}
-
-// LDS-aggregated counters: id -> count, flushed to a global uint64 array.  `used` counts occupied
-// entries; callers flush + clear at a block-uniform point once the table is half full
-// (ku_ct_maybe_flush), so the 8-probe fallback to a global atomic stays rare whatever the
-// number of distinct taxa a block meets.
-template <int LOG2 = KU_CT_LOG2>
-__device__ __forceinline__ void ku_ct_add(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t *used, uint32_t id, uint32_t n,
-                                          unsigned long long *global) {
-  uint32_t h = (id * 2654435761u) >> (32 - LOG2);
-#pragma unroll 1
-  for (int probe = 0; probe < 8; ++probe) {
-    uint32_t cur = __hip_atomic_load(&ct_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (cur == 0) {
-      uint32_t old = atomicCAS(&ct_key[h], 0u, id + 1);
-      if (old == 0) atomicAdd(used, 1u);
-      cur = old == 0 ? id + 1 : old;
-    }
-    if (cur == id + 1) {
-      atomicAdd(&ct_cnt[h], n);
-      return;
-    }
-    h = (h + 1) & ((1u << LOG2) - 1);
-  }
-  atomicAdd(&global[id], (unsigned long long)n);
-}
-template <int LOG2 = KU_CT_LOG2>
-__device__ __forceinline__ void ku_ct_clear(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t *used) {
-  for (int i = threadIdx.x; i < (1 << LOG2); i += blockDim.x) {
-    ct_key[i] = 0;
-    ct_cnt[i] = 0;
-  }
-  if (threadIdx.x == 0) *used = 0;
-}
-template <int LOG2 = KU_CT_LOG2>
-__device__ __forceinline__ void ku_ct_flush(uint32_t *ct_key, uint32_t *ct_cnt, unsigned long long *global) {
-  for (int i = threadIdx.x; i < (1 << LOG2); i += blockDim.x) {
-    uint32_t kk = ct_key[i];
-    if (kk) atomicAdd(&global[kk - 1], (unsigned long long)ct_cnt[i]);
-  }
-}
-// call at a point every thread of the block reaches, after a __syncthreads()
-template <int LOG2 = KU_CT_LOG2>
-__device__ __forceinline__ void ku_ct_maybe_flush(uint32_t *ct_key, uint32_t *ct_cnt, uint32_t *used,
-                                                  unsigned long long *global) {
-  if (*used > (1u << LOG2) / 2) {  // block-uniform (read after the barrier)
-    __syncthreads();
-    ku_ct_flush<LOG2>(ct_key, ct_cnt, global);
-    __syncthreads();
-    ku_ct_clear<LOG2>(ct_key, ct_cnt, used);
-    __syncthreads();
-  }
-}
-
-// HLL register update: M[slot][idx] = max(M, rank) (hyperloglogplus.cpp:508-522, p = 12).
-// The plain pre-check load may be stale (other CUs' updates are not visible in
-// this CU's L1) -- stale values are only ever too small, so the worst case is a
-// redundant CAS, never a lost update.
-__device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot, uint64_t h) {
-  // h = ku_fmix64(canonical k-mer)
-  uint32_t idx = (uint32_t)(h >> (64 - KU_HLL_P));
-  uint64_t rest = h << KU_HLL_P;
-  uint32_t rank = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KU_HLL_P + 1);
-  uint8_t *r = registers + (size_t)slot * KU_HLL_M + idx;
-  if (*r < rank) {
-    uint32_t *w = (uint32_t *)((uintptr_t)r & ~(uintptr_t)3);
-    uint32_t sh = ((uint32_t)(uintptr_t)r & 3u) * 8;
-    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (((old >> sh) & 0xffu) < rank) {
-      uint32_t nw = (old & ~(0xffu << sh)) | (rank << sh);
-      uint32_t prev = atomicCAS(w, old, nw);
-      if (prev == old) break;
-      old = prev;
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// ku_lookup_kernel
-// ----------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) KuPair {  // the on-disk record (krakendb.cpp:176)
-  uint32_t key_lo, key_hi, slot;
-};
-
-// ASCII -> (2-bit code, valid): A/a=0 C/c=1 G/g=2 T/t=3 (krakenutil.cpp:252-263)
-__device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &word, uint32_t &amb) {
-  uint32_t c = b & 0xDFu;
-  uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
-  uint32_t valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
-  word |= code << (30 - 2 * j);
-  amb |= (valid ^ 1u) << (15 - j);
-}
-
-// Hash layout (LAYOUT 1, default): at upload time the shard's pairs are re-laid out as a bucketised hash table,
-// one bucket per 128-byte line:
-//     dword 0      count (low 16 bits) | tag 0 (high 16 bits)
-//     dwords 1..4  tags 1..8, two 16-bit tags per dword
-//     dwords 5..31 nine 12-byte entries {key_lo, key_hi, slot}
-// MI355X moves 128 B per L2 miss and sustains ~48 G random line fetches/s whatever the access width
-// (scripts/calib_gather.hip), so a lookup costs the number of distinct lines it touches -- and, per wave, the
-// number of *dependent* round trips of its slowest lane.  The sorted-bin binary search touches ~2.5 lines in ~8
-// dependent probes; here the 20-byte header answers "which entry, if any" in ONE round trip (16-bit tags, false
-// positive rate 9 * 2^-16), the entry itself is then an L1/L2 hit in the same line.  A bucket that received more
-// than 9 keys has count > 9 and spills into the following line(s) (1.7 % of the buckets at load factor 0.5).
-#define KU_LINE_DWORDS 32
-#define KU_LINE_SLOTS 9
-// 16-bit entry tag from h = fmix64(kmer + 1) (the HLL hash, reused; the HLL consumes bits 63..52 and the
-// leading zeros below them, the tag takes bits 43..28)
-__device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) { return (uint32_t)(h >> 28) & 0xFFFFu; }
-// bit i set <=> tag i of the header equals `tag` (i < min(count, 9))
-__device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32_t tag) {
-  const uint32_t cnt = h4.x & 0xFFFFu;
-  const uint32_t n = cnt < KU_LINE_SLOTS ? cnt : KU_LINE_SLOTS;
-  uint32_t m = 0;
-  m |= ((h4.x >> 16) == tag) << 0;
-  m |= ((h4.y & 0xFFFFu) == tag) << 1;
-  m |= ((h4.y >> 16) == tag) << 2;
-  m |= ((h4.z & 0xFFFFu) == tag) << 3;
-  m |= ((h4.z >> 16) == tag) << 4;
-  m |= ((h4.w & 0xFFFFu) == tag) << 5;
-  m |= ((h4.w >> 16) == tag) << 6;
-  m |= ((h1 & 0xFFFFu) == tag) << 7;
-  m |= ((h1 >> 16) == tag) << 8;
-  return m & ((1u << n) - 1u);
-}
-
-// Locality-aware bucket choice.  Consecutive k-mers of a read share their minimizer *occurrence* ~(k-nt+1)/2
-// times in a row.  The bucket of a k-mer is therefore derived not from the k-mer itself but from its "locus
-// key": (minimizer value, the KU_FLANK bases next to the minimizer occurrence on the longer side, a coarse
-// offset class) -- all taken on the strand where the minimizer m-mer is canonical, so both strands of a locus
-// agree.  The ~5 overlapping k-mers that share a locus key share one 128-byte bucket: a wave's 64 consecutive
-// k-mers touch ~20 lines instead of 64.  The key is a pure function of the canonical k-mer (first minimum in
-// the canonical k-mer's frame on ties), so build and lookup agree by construction; which k-mers share a bucket
-// only affects speed, never results.
-#define KU_FLANK 8
-#ifndef KU_OFFCLASS
-#define KU_OFFCLASS 4  // offsets per locus class: 4 measured best (3: 25.7, 4: 25.3, 5: 26.8, 8: 28.1 ms at load 0.3)
-#endif
-__device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint64_t c_rc, uint32_t k, uint32_t m, uint32_t xor_mask,
-                                                 uint32_t &bin) {
-  const uint32_t w = k - m + 1;
-  const uint32_t mask = (1u << (2 * m)) - 1u;  // m <= 15
-  uint32_t best = 0xFFFFFFFFu, a = 0;
-  bool plus = true;
-  for (uint32_t j = 0; j < w; ++j) {  // j = offset of the m-mer from the left (most significant) end of c
-    uint32_t mm = (uint32_t)(c >> (2 * (k - m - j))) & mask;
-    uint32_t rcmm = ku_revcomp32(mm, m);
-    uint32_t v = (mm < rcmm ? mm : rcmm) ^ xor_mask;
-    bool lt = v < best;
-    best = lt ? v : best;
-    a = lt ? j : a;
-    plus = lt ? (mm <= rcmm) : plus;
-  }
-  bin = best;
-  const uint64_t cp = plus ? c : c_rc;            // strand on which the minimizer occurrence is canonical
-  const uint32_t ap = plus ? a : w - 1 - a;       // its offset on that strand
-  const uint32_t left = ap, right = w - 1 - ap;
-  const bool use_r = right >= left;
-  const uint32_t side = use_r ? right : left;
-  const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
-  // right flank = offsets [ap+m, ap+m+flen), left flank = [ap-flen, ap)
-  const uint32_t end = use_r ? ap + m + flen : ap;  // one past the flank's last base
-  const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
-  return ((uint64_t)best << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
-}
-__device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lines) {
-  // 32-bit mixing (v_mul_lo/hi_u32 are quarter-rate on CDNA; 64-bit multiplies cost four of them each);
-  // n_lines < 2^32 is enforced at table construction (512 GiB of table per shard)
-  uint32_t g = (uint32_t)locus * 0x9E3779B1u ^ __builtin_rotateleft32((uint32_t)(locus >> 32) * 0x85EBCA77u, 15);
-  g ^= g >> 15;
-  g *= 0x2C1B3C6Du;
-  g ^= g >> 13;
-  return __umulhi(g, (uint32_t)n_lines);
-}
-
-// Sliding-window minimum with the position of the minimum, for KU_ITEMS windows at once (independent chains ->
-// the LDS reads pipeline).  s_mm holds the m-mer values PRE-SHIFTED by 5 bits (low 5 bits zero, values <= 27
-// bits, i.e. minimizer length <= 13) and biased by +1.  Every lane reads its window forward (conflict-free across lanes) and
-// minimises  s_mm[t] + sgn * t  in one v_mad_i32_i24 + v_min_u32 per element:
-//   sgn = +1: ties resolve to the smallest t (first minimum), result = value + t
-//   sgn = -1: ties resolve to the largest t (last minimum),   result = value - t   (a borrow from the value
-//             field keeps the order: value1 < value2  =>  value1 - t1 < value2 - t2 because values are 32 apart)
-// W > 0: compile-time window length (fully unrolled), W == 0: run-time length w.
-template <int W>
-__device__ __forceinline__ void ku_window_argmin(const uint32_t *s_mm, const uint32_t (&base)[KU_ITEMS],
-                                                 const int32_t (&sgn)[KU_ITEMS], uint32_t w,
-                                                 uint32_t (&out)[KU_ITEMS]) {
-#pragma unroll
-  for (int j = 0; j < KU_ITEMS; ++j) out[j] = 0xFFFFFFFFu;
-  if (W > 0) {
-#pragma unroll
-    for (int t = 0; t < W; ++t)
-#pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) out[j] = min(out[j], s_mm[base[j] + t] + (uint32_t)(sgn[j] * t));
-  } else {
-    for (uint32_t t = 0; t < w; ++t)
-#pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j)
-        out[j] = min(out[j], s_mm[base[j] + t] + (uint32_t)(sgn[j] * (int32_t)t));
-  }
-}
 
 // MODE 0: lookup only; MODE 1: lookup + per-taxon accounting; MODE 2: measurement
 // only -- no search, accumulates {queries, sum ceil(log2(n_b+1)), queries into
@@ -376,10 +147,10 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
           sgn[j] = is_fwd[j] ? 1 : -1;
         }
         switch (w) {  // block-uniform; the common geometries get fully unrolled windows
-          case 19: ku_window_argmin<19>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 13
-          case 20: ku_window_argmin<20>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 12
-          case 25: ku_window_argmin<25>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 7
-          default: ku_window_argmin<0>(s_mm, base, sgn, w, r); break;
+          case 19: ku_window_argmin<19, KU_ITEMS>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 13
+          case 20: ku_window_argmin<20, KU_ITEMS>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 12
+          case 25: ku_window_argmin<25, KU_ITEMS>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 7
+          default: ku_window_argmin<0, KU_ITEMS>(s_mm, base, sgn, w, r); break;
         }
         // offset in the canonical k-mer's frame: read offset t when the read strand is canonical, else w-1-t
         // (the first minimum there is the LAST one in read order)
@@ -775,22 +546,6 @@ template <int GROUP> __device__ __forceinline__ uint32_t ku_group_sum(uint32_t v
     for (int i = 0; i < GROUP / 64; ++i) v += s_red[i];
   }
   return v;
-}
-
-// lca() in node space (krakenutil.cpp:90-118).  Nodes are ranks of taxids in a
-// sorted universe that always contains 0 and 1, so "taxid > 1" == "node > 1".
-__device__ uint32_t ku_lca_nodes(const uint32_t *__restrict__ parent, uint32_t a, uint32_t b) {
-  if (a == 0 || b == 0) return a ? a : b;
-  // path(a) is walked once per candidate of b's path: O(depth^2), depth <= ~40, ties only
-  for (uint32_t guard_b = 0; b > 1 && guard_b < 4096; ++guard_b) {
-    uint32_t x = a;
-    for (uint32_t guard_a = 0; x > 1 && guard_a < 4096; ++guard_a) {
-      if (x == b) return b;
-      x = parent[x];
-    }
-    b = parent[b];
-  }
-  return 1;
 }
 
 template <int MODE>

@@ -1,0 +1,442 @@
+// ku_short.hip -- fused classification of SHORT reads: one wavefront per read, from ASCII to call.
+//
+// The flat kernel (ku_kernels.hip) + the resolve kernel are the general path (any read length, sharded mode,
+// sorted layout).  For the headline workload -- 100-300 bp reads against the resident probe table -- this kernel
+// does the whole of classify_sequence (src/classify.cpp:897-968) inside one wave64:
+//   ASCII -> 2-bit codes (wave-private LDS) -> canonical k-mers, minimizer + locus key -> bucket probe
+//   -> HLL / n_kmers -> hit_counts + resolve_tree + lca entirely from registers / wave-private LDS -> call,
+//   per-k-mer taxids (coalesced store), n_reads.
+// There is no block-level barrier anywhere: the 4 waves of a block are independent, so a wave that waits for
+// HBM never holds the others back, the per-k-mer codes never make a round trip through HBM between a lookup and a
+// resolve kernel, and no lane is spent on the separator bytes between reads.
+// Eligibility (checked by the launcher): hash layout, whole bin range resident (not a shard), no quick mode,
+// every read of the batch has at most 64 * ITEMS k-mers (ITEMS = 2 or 3: reads up to 222 bp at k = 31; paired
+// 2 x 150 and longer reads take the flat lookup + resolve kernels).
+#include <cstdlib>
+
+#include "ku_device.h"
+
+#define KS_WAVES 4  // reads in flight per 256-thread block
+
+template <int ITEMS> struct KsGeom {
+  static constexpr int MAXN = 64 * ITEMS;                      // k-mers per read
+  static constexpr int NWORDS = (MAXN + 31 + 15) / 16 + 3;     // 16-base code words (+ funnel slack)
+  static constexpr int NAMB = (NWORDS + 1) / 2 + 2;            // 32-base ambiguity words
+  static constexpr int NMM = MAXN + 64;                        // m-mer values
+  static constexpr int TCAP_LOG2 = ITEMS <= 2 ? 8 : (ITEMS <= 4 ? 9 : 10);  // resolve table >= 2 * MAXN
+  static constexpr int KCT_LOG2 = 8;                           // n_kmers counter table (per wave)
+  static constexpr int RCT_LOG2 = 6;                           // n_reads counter table (per wave)
+};
+
+// order the wave's own LDS traffic (hardware executes a wave's DS ops in order; this stops the compiler)
+__device__ __forceinline__ void ks_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LOG2>
+__device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32_t *used, unsigned long long *global,
+                                            uint32_t lane) {
+  ks_wave_sync();
+  for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
+    uint32_t kk = key[i];
+    if (kk) atomicAdd(&global[kk - 1], (unsigned long long)cnt[i]);
+    key[i] = 0;
+    cnt[i] = 0;
+  }
+  if (lane == 0) *used = 0;
+  ks_wave_sync();
+}
+
+template <int ITEMS, bool DO_COUNTS>
+__global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
+    KuDbDev db, KuTaxDev tax, KuCountsDev cnt, const uint8_t *__restrict__ seqs, uint64_t n_bytes,
+    const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, uint64_t n_reads,
+    uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t *__restrict__ hits_out, uint32_t keep_slots,
+    uint32_t ablate) {
+  // `ablate`: measurement knob (env KU_ABLATE): 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
+  // 32 skip resolve (call 0), 64 skip locus/minimizer stage (bucket 0).  0 in production.
+  using G = KsGeom<ITEMS>;
+  constexpr uint32_t TCAP = 1u << G::TCAP_LOG2;
+  __shared__ uint32_t s_codes[KS_WAVES][G::NWORDS];
+  __shared__ uint32_t s_amb[KS_WAVES][G::NAMB];
+  __shared__ uint32_t s_mm[KS_WAVES][G::NMM];
+  __shared__ uint32_t s_tkey[KS_WAVES][TCAP];   // resolve table: slot + 1
+  __shared__ uint32_t s_tcnt[KS_WAVES][TCAP];   // hit count (low 16) | root-path score (high 16)
+  __shared__ uint16_t s_tlist[KS_WAVES][G::MAXN];
+  __shared__ uint32_t s_kk[KS_WAVES][1 << G::KCT_LOG2], s_kc[KS_WAVES][1 << G::KCT_LOG2];
+  __shared__ uint32_t s_rk[KS_WAVES][1 << G::RCT_LOG2], s_rc[KS_WAVES][1 << G::RCT_LOG2];
+  __shared__ uint32_t s_misc[KS_WAVES][4];      // [0] n_kmers table fill, [1] n_reads table fill, [2] list length, [3] bcast
+
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  uint32_t *codes = s_codes[wv], *amb = s_amb[wv], *mmv = s_mm[wv];
+  uint32_t *t_key = s_tkey[wv], *t_cnt = s_tcnt[wv];
+  uint16_t *t_list = s_tlist[wv];
+  uint16_t *amb16 = reinterpret_cast<uint16_t *>(amb);
+  uint32_t *misc = s_misc[wv];
+  const uint32_t k = db.k, m = db.nt, w = k - m + 1;
+  const bool packed_ok = m <= 13;  // (value + 1) << 5 | offset fits 32 bits
+  const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
+
+  for (uint32_t i = lane; i < TCAP; i += 64) { t_key[i] = 0; t_cnt[i] = 0; }
+  for (uint32_t i = lane; i < (1u << G::KCT_LOG2); i += 64) { s_kk[wv][i] = 0; s_kc[wv][i] = 0; }
+  for (uint32_t i = lane; i < (1u << G::RCT_LOG2); i += 64) { s_rk[wv][i] = 0; s_rc[wv][i] = 0; }
+  if (lane < 4) misc[lane] = 0;
+  ks_wave_sync();
+
+  const uint64_t n_waves = (uint64_t)gridDim.x * KS_WAVES;
+  for (uint64_t r = (uint64_t)blockIdx.x * KS_WAVES + wv; r < n_reads; r += n_waves) {
+    const uint32_t len = seq_len[r];
+    const uint64_t off = seq_off[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    if (DO_COUNTS) {
+      if (misc[0] > (1u << G::KCT_LOG2) / 2) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
+      if (misc[1] > (1u << G::RCT_LOG2) / 2) ks_ct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], cnt.n_reads, lane);
+    }
+    uint32_t v[ITEMS];  // slot of every k-mer (0 = miss or ambiguous)
+    bool amb_k[ITEMS];  // ambiguous k-mer (reported as KU_AMBIG)
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { v[j] = 0; amb_k[j] = false; }
+
+    if (n > 0) {
+      // ---- stage 1: ASCII -> 2-bit codes + ambiguity bits, 16 bases per lane, wave-private LDS
+      static_assert(G::NWORDS <= 64, "one packing pass");
+      if (lane < (uint32_t)G::NWORDS) {
+        const uint32_t wi = lane, b0 = 16 * wi;
+        uint32_t word = 0, ab = 0xFFFFu;
+        if (b0 < len) {
+          ab = 0;
+          const uint64_t a = off + b0;
+          const uint64_t a0 = a & ~3ull;
+          if (a0 + 20 <= n_bytes) {  // 5 aligned dwords cover the 16 bytes at any alignment
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(seqs + a0);
+            const uint32_t sh = (uint32_t)(a & 3ull) * 8;
+            const uint32_t d[5] = {q[0], q[1], q[2], q[3], q[4]};
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x) {
+              uint32_t dw = sh ? ((d[x] >> sh) | (d[x + 1] << (32 - sh))) : d[x];
+#pragma unroll
+              for (uint32_t j = 0; j < 4; ++j) ku_pack_byte((dw >> (8 * j)) & 0xffu, 4 * x + j, word, ab);
+            }
+          } else {
+            for (uint32_t j = 0; j < 16; ++j) ku_pack_byte(a + j < n_bytes ? seqs[a + j] : (uint32_t)'N', j, word, ab);
+          }
+          const uint32_t valid = len - b0;  // bases of this word that belong to the read
+          if (valid < 16) ab |= (1u << (16 - valid)) - 1u;
+        }
+        codes[wi] = word;
+        amb16[wi ^ 1u] = (uint16_t)ab;
+      }
+      ks_wave_sync();
+
+      // ---- stage 2: k-mers, ambiguity, canonical form, m-mer values
+      uint64_t canon[ITEMS], canon_rc[ITEMS];
+      bool is_fwd[ITEMS], ok[ITEMS];
+#pragma unroll
+      for (int j = 0; j <= ITEMS; ++j) {
+        const uint32_t p = j * 64 + lane;
+        if (j == ITEMS && p >= n + w - 1) break;
+        const uint32_t wi = p >> 4, sh = (p & 15u) * 2;
+        const uint64_t hi = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
+        const uint64_t x = sh ? ((hi << sh) | (uint64_t)(codes[wi + 2] >> (32 - sh))) : hi;
+        const uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
+        const uint32_t mrc = ku_revcomp32(mm, m);
+        const uint32_t val = (mm < mrc ? mm : mrc) ^ db.xor_mask;
+        mmv[p] = packed_ok ? (val + 1u) << 5 : val;
+        if (j < ITEMS) {
+          const uint64_t fwd = x >> (64 - 2 * k);
+          const uint64_t rc = ku_revcomp64(fwd, k);
+          is_fwd[j] = fwd <= rc;
+          canon[j] = is_fwd[j] ? fwd : rc;
+          canon_rc[j] = is_fwd[j] ? rc : fwd;
+          const uint32_t ai = p >> 5, as = p & 31u;
+          const uint64_t a = (((uint64_t)amb[ai] << 32) | amb[ai + 1]) << as;
+          amb_k[j] = p < n && (a >> (64 - k)) != 0;
+          ok[j] = p < n && !amb_k[j];
+        }
+      }
+      ks_wave_sync();
+
+      // ---- stage 3: minimizer + its first position in the canonical k-mer's frame -> locus key (ku_locus_key)
+      uint32_t mn[ITEMS], aoff[ITEMS];
+      if (ablate & 64u) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { mn[j] = 0; aoff[j] = 0; }
+      } else if (packed_ok) {
+        uint32_t base[ITEMS], rr[ITEMS];
+        int32_t sgn[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { base[j] = j * 64 + lane; sgn[j] = is_fwd[j] ? 1 : -1; }
+        switch (w) {
+          case 19: ku_window_argmin<19, ITEMS>(mmv, base, sgn, w, rr); break;
+          case 20: ku_window_argmin<20, ITEMS>(mmv, base, sgn, w, rr); break;
+          case 25: ku_window_argmin<25, ITEMS>(mmv, base, sgn, w, rr); break;
+          default: ku_window_argmin<0, ITEMS>(mmv, base, sgn, w, rr); break;
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const uint32_t t = is_fwd[j] ? (rr[j] & 31u) : ((0u - rr[j]) & 31u);
+          mn[j] = (is_fwd[j] ? (rr[j] >> 5) : ((rr[j] + 31u) >> 5)) - 1u;
+          aoff[j] = is_fwd[j] ? t : w - 1 - t;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const uint32_t p = j * 64 + lane;
+          const int32_t j0 = is_fwd[j] ? 0 : (int32_t)w - 1, dj = is_fwd[j] ? 1 : -1;
+          mn[j] = 0xFFFFFFFFu;
+          aoff[j] = 0;
+          if (ok[j])
+            for (uint32_t t = 0; t < w; ++t) {
+              const uint32_t vv = mmv[p + j0 + dj * (int32_t)t];
+              const bool lt = vv < mn[j];
+              mn[j] = lt ? vv : mn[j];
+              aoff[j] = lt ? t : aoff[j];
+            }
+        }
+      }
+      const uint32_t *lp[ITEMS];
+      uint32_t tag[ITEMS], cand[ITEMS];
+      uint64_t hh[ITEMS];
+      bool act[ITEMS], ovf[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t p = j * 64 + lane;
+        const uint32_t a = aoff[j];
+        const uint32_t jr = is_fwd[j] ? a : w - 1 - a, q = (ok[j] ? p : 0) + jr;
+        const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
+        const uint64_t two = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
+        const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
+        const uint32_t rcm = ku_revcomp32(mmf, m);
+        const bool plus = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
+        const uint64_t cp = plus ? canon[j] : canon_rc[j];
+        const uint32_t ap = plus ? a : w - 1 - a;
+        const uint32_t left = ap, right = w - 1 - ap;
+        const bool use_r = right >= left;
+        const uint32_t side = use_r ? right : left;
+        const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
+        const uint32_t end = use_r ? ap + m + flen : ap;
+        const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
+        const uint64_t locus = ((uint64_t)mn[j] << 32) | ((uint64_t)flank << 12) | (flen << 8) |
+                               ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
+        hh[j] = ku_fmix64(canon[j]);
+        lp[j] = tab + ku_locus_line(ok[j] ? locus : 0, db.n_lines) * KU_LINE_DWORDS;
+        tag[j] = ku_table_tag(hh[j]);
+        act[j] = ok[j] && !(ablate & 1u);
+        if (ablate & 64u) lp[j] = tab;
+      }
+
+      // ---- stage 4: bucket probe (header round trip, entry in the same line, lockstep tail)
+      // header loads and the first-candidate entry load are issued for every lane (inactive lanes point at
+      // bucket 0): the instructions are issued per wave anyway, predicating them only costs exec-mask juggling
+      uint4 h4[ITEMS];
+      uint32_t h1[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
+        h1[j] = lp[j][4];
+      }
+      KuPair pr[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        cand[j] = act[j] ? ku_tag_matches(h4[j], h1[j], tag[j]) : 0u;
+        ovf[j] = act[j] && (h4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+        pr[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (cand[j] ? __builtin_ctz(cand[j]) : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const bool hit = cand[j] != 0 && (((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo) == canon[j];
+        v[j] = hit ? pr[j].slot : 0u;
+        cand[j] &= cand[j] - 1;  // no-op for 0
+        act[j] = !hit && (cand[j] != 0 || ovf[j]);
+      }
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) any |= act[j];
+      while (any) {
+        any = false;
+        KuPair e[ITEMS];
+        uint4 a4[ITEMS];
+        uint32_t a1[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          if (act[j]) {
+            if (cand[j]) {
+              e[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+            } else {
+              lp[j] += KU_LINE_DWORDS;
+              if (lp[j] == tab + db.n_lines * KU_LINE_DWORDS) lp[j] = tab;
+              a4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
+              a1[j] = lp[j][4];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          if (act[j]) {
+            if (cand[j]) {
+              cand[j] &= cand[j] - 1;
+              if ((((uint64_t)e[j].key_hi << 32) | e[j].key_lo) == canon[j]) {
+                v[j] = e[j].slot;
+                act[j] = false;
+              }
+            } else {
+              cand[j] = ku_tag_matches(a4[j], a1[j], tag[j]);
+              ovf[j] = (a4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+            }
+            if (act[j]) act[j] = cand[j] != 0 || ovf[j];
+            any |= act[j];
+          }
+        }
+      }
+
+      // ---- stage 5: ReadCounts::add_kmer for every unambiguous k-mer, misses included (classify.cpp:939)
+      if (DO_COUNTS) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+          if (ok[j]) {
+            if (!(ablate & 2u)) ku_hll_update(cnt.registers, v[j], hh[j]);
+            if (!(ablate & 4u)) ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], v[j], 1, cnt.n_kmers);
+          }
+      }
+    }
+
+    // ---- resolve_tree (krakenutil.cpp:149-200) from registers
+    uint32_t call_node = 0;
+    if (!(ablate & 32u)) {
+      uint32_t mine = 0;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j)
+        if (mine == 0) mine = v[j];
+      const unsigned long long bal = __ballot(mine != 0);
+      const uint32_t first = bal ? (uint32_t)__shfl((int)mine, __ffsll((long long)bal) - 1) : 0u;
+      bool diff = false;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) diff |= (v[j] != 0 && v[j] != first);
+      if (!__any(diff)) {
+        call_node = first ? tax.slot_node[first] : 0u;  // at most one distinct hit taxon
+      } else {
+        // hit_counts in the wave's LDS table
+        if (lane == 0) misc[2] = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+          if (v[j] != 0) {
+            uint32_t h = (v[j] * 2654435761u) >> (32 - G::TCAP_LOG2);
+            for (;;) {
+              uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (cur == 0) {
+                uint32_t old = atomicCAS(&t_key[h], 0u, v[j] + 1);
+                cur = old == 0 ? v[j] + 1 : old;
+              }
+              if (cur == v[j] + 1) {
+                atomicAdd(&t_cnt[h], 1u);
+                break;
+              }
+              h = (h + 1) & (TCAP - 1);
+            }
+          }
+        ks_wave_sync();
+        for (uint32_t i = lane; i < TCAP; i += 64)
+          if (t_key[i]) t_list[atomicAdd(&misc[2], 1u)] = (uint16_t)i;
+        ks_wave_sync();
+        const uint32_t n_list = misc[2];
+        // score(t) = sum of the hit counts on t's root path
+        uint32_t my_max = 0;
+        for (uint32_t e = lane; e < n_list; e += 64) {
+          const uint32_t pos = t_list[e];
+          uint32_t node = tax.slot_node[t_key[pos] - 1];
+          uint32_t score = 0;
+          for (uint32_t guard = 0; node > 0 && guard < 4096; ++guard) {
+            const uint32_t s = tax.node_slot[node];
+            if (s) {
+              uint32_t h = (s * 2654435761u) >> (32 - G::TCAP_LOG2);
+              for (;;) {
+                const uint32_t cur = t_key[h];
+                if (cur == s + 1) { score += t_cnt[h] & 0xffffu; break; }
+                if (cur == 0) break;
+                h = (h + 1) & (TCAP - 1);
+              }
+            }
+            node = tax.node_parent[node];
+          }
+          atomicAdd(&t_cnt[pos], score << 16);
+          my_max = max(my_max, score);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o));
+        ks_wave_sync();
+        // winner; ties -> fold lca() in ascending taxid (= slot) order
+        uint32_t last = 0, res = 0;
+        bool firstt = true;
+        for (;;) {
+          uint32_t my_min = 0xFFFFFFFFu;
+          for (uint32_t e = lane; e < n_list; e += 64) {
+            const uint32_t pos = t_list[e];
+            const uint32_t s = t_key[pos] - 1;
+            if ((t_cnt[pos] >> 16) == my_max && s > last) my_min = min(my_min, s);
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, o));
+          if (my_min == 0xFFFFFFFFu) break;
+          const uint32_t node = tax.slot_node[my_min];
+          res = firstt ? node : ku_lca_nodes(tax.node_parent, res, node);  // uniform: every lane computes the same
+          firstt = false;
+          last = my_min;
+        }
+        call_node = res;
+        ks_wave_sync();
+        for (uint32_t e = lane; e < n_list; e += 64) {
+          const uint32_t pos = t_list[e];
+          t_key[pos] = 0;
+          t_cnt[pos] = 0;
+        }
+        ks_wave_sync();
+      }
+    }
+
+    // ---- outputs
+    if (lane == 0) {
+      calls[r] = tax.node_taxid[call_node];
+      if (hits_out) hits_out[r] = 0;
+      if (DO_COUNTS) ku_ct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], call_node, 1, cnt.n_reads);
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const uint32_t p = j * 64 + lane;
+      if (p < n && !(ablate & 8u)) taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (keep_slots ? v[j] : tax.slot_taxid[v[j]]) : 0u);
+    }
+    ks_wave_sync();  // the next read reuses the wave's LDS arrays
+  }
+  if (DO_COUNTS) {
+    ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
+    ks_ct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], cnt.n_reads, lane);
+  }
+}
+
+// k-mers per read the fused kernel can take (0 = not eligible)
+uint32_t ku_short_max_kmers(const KuDbDev &db) {
+  const bool whole = db.bin_lo == 0 && db.bin_hi == (1ull << (2 * db.nt));
+  return (db.table && whole) ? 64 * 3 : 0;  // longer reads: the flat lookup + resolve kernels (register budget)
+}
+
+int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
+                             uint64_t n_bytes, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
+                             uint32_t max_kmers, uint32_t flags, uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits,
+                             int n_cu, hipStream_t stream) {
+  if (n_reads == 0) return KU_OK;
+  const bool counts = !(flags & KU_F_NO_COUNTS);
+  const uint32_t keep = (flags & KU_F_KEEP_SLOTS) ? 1u : 0u;
+  const char *ab = getenv("KU_ABLATE");
+  const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
+  const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * 8;
+  const dim3 grid((unsigned)(want < cap ? want : cap)), block(64 * KS_WAVES);
+#define KS_LAUNCH(I, C)                                                                                              \
+  hipLaunchKernelGGL((ku_classify_short_kernel<I, C>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes, d_seq_off, \
+                     d_seq_len, n_reads, d_calls, d_taxa, d_hits, keep, ablate)
+  if (max_kmers <= 128) { if (counts) KS_LAUNCH(2, true); else KS_LAUNCH(2, false); }
+  else if (max_kmers <= 192) { if (counts) KS_LAUNCH(3, true); else KS_LAUNCH(3, false); }
+  else return KU_EINVAL;
+#undef KS_LAUNCH
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}

@@ -30,6 +30,23 @@ for name, abl, flags in [("full", 0, 0), ("no counts (MODE 0)", 0, capi.KU_F_NO_
     os.environ["KU_ABLATE"] = str(abl)
     print(f"{name:34s} {t_lookup(flags):8.2f} ms", flush=True)
 os.environ["KU_ABLATE"] = "0"
+for name, abl in [("fused full", 0), ("fused no probe", 1), ("fused no HLL", 2), ("fused no n_kmers", 4), ("fused no store", 8),
+                  ("fused no resolve", 32), ("fused no window/locus", 64), ("fused no probe/counts/store/resolve", 47),
+                  ("fused scan only", 111)]:
+    os.environ["KU_ABLATE"] = str(abl)
+    ts = []
+    for i in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); ctx.classify_batch_device(d_seqs.data_ptr(), d_seqs.numel(), d_off.data_ptr(), d_len.data_ptr(), n_reads, d_calls.data_ptr(), d_taxa.data_ptr(), max_read_len=150, stream=s.cuda_stream); b.record()
+        torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    print(f"{name:38s} {min(ts[1:]):8.2f} ms", flush=True)
+os.environ["KU_ABLATE"] = "0"
+ts = []
+for i in range(4):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); ctx.classify_batch_device(d_seqs.data_ptr(), d_seqs.numel(), d_off.data_ptr(), d_len.data_ptr(), n_reads, d_calls.data_ptr(), d_taxa.data_ptr(), max_read_len=150, stream=s.cuda_stream); b.record()
+    torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+print(f"{'classify_batch_device (fused if eligible)':34s} {min(ts[1:]):8.2f} ms", flush=True)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ctx.lookup_device(d_seqs.data_ptr(), d_seqs.numel(), d_taxa.data_ptr(), stream=s.cuda_stream)
 a.record(); ctx.resolve_device(d_seqs.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), n_reads, d_calls.data_ptr(), d_taxa.data_ptr(), max_read_len=150, stream=s.cuda_stream); b.record()

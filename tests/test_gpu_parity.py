@@ -299,3 +299,29 @@ def test_hash_table_spilled_buckets(monkeypatch):
     assert_same_counts(ctx.counts(), run)
     t, c = ctx.count_taxons()
     assert int(c.sum()) == len(db["kmers"])
+
+
+@pytest.mark.parametrize("read_len,no_fused", [(100, False), (150, True), (200, False), (222, False), (223, False)])
+def test_fused_short_read_kernel_and_staged_path_agree(monkeypatch, read_len, no_fused):
+    """<= 128 k-mers -> fused<2>, <= 192 -> fused<3>, longer or KU_NO_FUSED -> flat lookup + resolve kernels"""
+    if no_fused:
+        monkeypatch.setenv("KU_NO_FUSED", "1")
+    rng = np.random.default_rng(read_len)
+    db = random_db(rng, n_genomes=8, glen=5000, nt=13)
+    ids, par = db["tax"].arrays()
+    raw = db["pairs"].view(np.uint8)
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=13)
+    otax = ko.Tax(ids=ids, parents=par)
+    ctx, _, _ = make_ctx(cdb=capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=31, offsets=db["offsets"], nt=13),
+                         ctax=capi.Tax(ids=ids, parents=par))
+    reads, _ = synth.sample_reads(db["genomes"], 600, read_len, rng, n_rate=0.004)
+    # chimeric reads give several distinct taxa per read (the LDS-table resolve path), plus degenerate lengths
+    g = list(db["genomes"].values())
+    for i in range(60):
+        a, b, c = (g[int(rng.integers(0, len(g)))] for _ in range(3))
+        reads.append(synth.codes_to_ascii(np.concatenate([a[:read_len // 3], b[100:100 + read_len // 3], c[200:200 + read_len // 3]])))
+    reads += [b"", b"ACGT", reads[0][:31], reads[1][:30], b"N" * 50]
+    run, res, buf, off, lens, taxa = oracle_flat(odb, otax, reads)
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    assert_same_counts(ctx.counts(), run)
