@@ -21,8 +21,8 @@ with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
             w.writerow([r[0][:160]] + r[1:])
 for r in rows[1:]:
     if 'ku_' in r[0]: print(r[0][:44], 'calls', r[1], 'avg_ns', r[3])
-lk = next(v for k, v in out.items() if k.startswith('ku_lookup_kernel<1'))
-kname = next(k for k in out if k.startswith('ku_lookup_kernel<1'))
+lk = next(v for k, v in out.items() if k.startswith(('ku_classify_short_kernel', 'ku_lookup_kernel<1')))
+kname = next(k for k in out if k.startswith(('ku_classify_short_kernel', 'ku_lookup_kernel<1')))
 fetch_kb, write_kb = lk['FETCH_SIZE']['per_launch_mean'], lk['WRITE_SIZE']['per_launch_mean']
 j = {"reads": 10000000, "nt": 13, "species": 2000, "kernel": kname, "kernel_rev": rev,
      "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
