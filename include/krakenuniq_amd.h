@@ -240,6 +240,9 @@ int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_t
               const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads,
               uint64_t n_nodes, char **out, size_t *out_len);
 void ku_free(void *p);
+/* Page-locked host memory for batch buffers (fast, truly asynchronous H2D / D2H in ku_classify_batch). */
+int ku_host_alloc(size_t bytes, void **out);
+void ku_host_free(void *p);
 
 #ifdef __cplusplus
 }

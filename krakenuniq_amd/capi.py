@@ -91,6 +91,8 @@ SIGNATURES = {
     "ku_report": (C.c_int, [C.c_void_p, C.c_char_p, u32p, u64p, u8p, C.c_uint64, u32p, u64p, C.c_uint64,
                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_free": (None, [C.c_void_p]),
+    "ku_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "ku_host_free": (None, [C.c_void_p]),
 }
 
 _lib = None

@@ -9,8 +9,9 @@
 //   -r file|off                         report, opened in APPEND mode like the reference (:286)
 //   -C/-U file                          classified / unclassified reads;  -c only classified lines;  -s print sequence
 //   -q -m N                             quick mode
-//   -t N                                accepted (must be > 0); the GPU replaces the OpenMP team
-//   -u N                                accepted (must be > 0); sets the ingest batch size in nt (default 256 Mi)
+//   -t N                                host threads formatting the output (must be > 0; default 4); the GPU replaces
+//                                       the OpenMP classification team
+//   -u N                                accepted (must be > 0); sets the ingest batch size in nt (default 64 Mi, at least 1 Mi)
 //   -M, -x SIZE                         accepted: the database is always resident in HBM (SIZE is parsed and checked)
 //   -p N                                accepted and ignored exactly like the reference
 //   -I file                             UID mapping: not built here -> exit 70 with a message
@@ -27,7 +28,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/krakenuniq_amd.h"
@@ -197,6 +202,67 @@ struct Reader {
   void close() { if (g) gzclose(g); g = nullptr; }
 };
 
+// ---- a batch of reads travelling through the pipeline; the two big arrays live in pinned host memory
+struct Batch {
+  char *seqs = nullptr;       // reads, each followed by '\n'
+  size_t seqs_len = 0, seqs_cap = 0;
+  uint32_t *taxa = nullptr;   // per-k-mer codes, parallel to seqs
+  size_t taxa_cap = 0;
+  std::string ids, headers, quals;
+  std::vector<uint64_t> off, idoff, hoff, qoff;
+  std::vector<uint32_t> len, calls, hits;
+  bool fastq = false;
+  uint64_t nt = 0;
+  void clear() {
+    seqs_len = 0; nt = 0;
+    ids.clear(); headers.clear(); quals.clear();
+    off.clear(); idoff.clear(); hoff.clear(); qoff.clear(); len.clear();
+  }
+  void append_seq(const std::string &sq) {
+    const size_t need = seqs_len + sq.size() + 1;
+    if (need > seqs_cap) {
+      size_t ncap = seqs_cap ? seqs_cap : (size_t)1 << 24;
+      while (ncap < need) ncap *= 2;
+      void *np = nullptr;
+      if (ku_host_alloc(ncap, &np) != KU_OK) die(EX_OSERR, "out of host memory");
+      if (seqs_len) memcpy(np, seqs, seqs_len);
+      if (seqs) ku_host_free(seqs);
+      seqs = (char *)np;
+      seqs_cap = ncap;
+    }
+    memcpy(seqs + seqs_len, sq.data(), sq.size());
+    seqs_len += sq.size();
+    seqs[seqs_len++] = '\n';
+  }
+  void reserve_taxa() {
+    if (seqs_len <= taxa_cap) return;
+    if (taxa) ku_host_free(taxa);
+    void *np = nullptr;
+    if (ku_host_alloc(seqs_cap * sizeof(uint32_t), &np) != KU_OK) die(EX_OSERR, "out of host memory");
+    taxa = (uint32_t *)np;
+    taxa_cap = seqs_cap;
+  }
+  void release() {
+    if (seqs) ku_host_free(seqs);
+    if (taxa) ku_host_free(taxa);
+    seqs = nullptr; taxa = nullptr;
+  }
+};
+
+struct Queue {  // unbounded MPSC-ish queue; the number of Batch objects bounds what is in flight
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Batch *> q;
+  void push(Batch *b) { { std::lock_guard<std::mutex> l(m); q.push_back(b); } cv.notify_one(); }
+  Batch *pop() {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return !q.empty(); });
+    Batch *b = q.front();
+    q.pop_front();
+    return b;
+  }
+};
+
 static double seconds_between(const timeval &a, const timeval &b) {
   return (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_usec - a.tv_usec) / 1e6;
 }
@@ -206,7 +272,8 @@ int main(int argc, char **argv) {
   std::string kraken_out, report_out, taxdb, cls_out, ucls_out;
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
-  uint64_t unit_nt = 256ull << 20;
+  uint64_t unit_nt = 64ull << 20;
+  int fmt_threads = 4;  // -t: host threads that format the Kraken lines (the GPU replaces the OpenMP team)
   if (argc > 1 && strcmp(argv[1], "-h") == 0) usage(0);
   int opt;
   while ((opt = getopt(argc, argv, "d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:")) != -1) {
@@ -217,6 +284,7 @@ int main(int argc, char **argv) {
       case 't':
         sig = atoll(optarg);
         if (sig <= 0) die(EX_USAGE, "can't use nonpositive thread count");
+        fmt_threads = (int)(sig > 64 ? 64 : sig);
         break;
       case 'p': break;  // HLL_PRECISION only selects report columns in the reference; the sketch is p = 12
       case 'q': quick = true; break;
@@ -282,71 +350,120 @@ int main(int argc, char **argv) {
   unsigned long long total_sequences = 0, total_classified = 0, total_bases = 0;
   timeval tv1, tv2;
   gettimeofday(&tv1, nullptr);
-  ku_opts opts = {quick ? KU_F_QUICK : 0u, min_hits, 0, 0};
+  const ku_opts base_opts = {quick ? KU_F_QUICK : 0u, min_hits, 0, 0};
   const uint32_t pflags = (only_classified ? KU_P_ONLY_CLASSIFIED : 0u) | (print_seq ? KU_P_SEQUENCE : 0u) | (quick ? KU_P_QUICK : 0u);
 
-  std::string seqs, ids, headers, quals_all;
-  std::vector<uint64_t> off, hoff, qoff;
-  std::vector<uint32_t> len, calls, taxa, hits;
-  for (int fi = optind; fi < argc; ++fi) {
-    Reader rd;
-    rd.open(argv[fi]);
+  // Three-stage host pipeline: reader thread (FASTA/FASTQ(+gz) -> pinned batch) | this thread
+  // (ku_classify_batch: H2D, kernels, D2H) | writer thread (Kraken lines formatted by `fmt_threads` helpers,
+  // files written in input order).  Batches circulate through two bounded queues.
+  const int n_batches = 3;
+  std::vector<Batch> pool(n_batches);
+  Queue free_q, parsed_q, done_q;
+  for (auto &bt : pool) free_q.push(&bt);
+  const bool keep_records = print_cls || print_ucls;
+
+  std::thread reader([&] {
     std::string header, seq, quals;
-    bool more = true;
-    while (more) {
-      seqs.clear(); ids.clear(); headers.clear(); quals_all.clear();
-      off.clear(); len.clear(); hoff.clear(); qoff.clear();
-      uint64_t nt = 0;
-      while (nt < unit_nt) {
-        if (!rd.next(header, seq, quals)) { more = false; break; }
-        off.push_back(seqs.size());
-        len.push_back((uint32_t)seq.size());
-        seqs += seq;
-        seqs += '\n';  // separator required by the C ABI (any non-ACGT byte)
-        size_t e = header.find_first_of(" \t\r\v\f");  // id = header up to first whitespace (src/seqreader.cpp:57-58)
-        ids.append(header, 0, e == std::string::npos ? header.size() : e);
-        ids.push_back('\0');
-        if (print_cls || print_ucls) {
-          hoff.push_back(headers.size()); headers += header; headers.push_back('\0');
-          qoff.push_back(quals_all.size()); quals_all += quals; quals_all.push_back('\0');
+    for (int fi = optind; fi < argc; ++fi) {
+      Reader rd;
+      rd.open(argv[fi]);
+      bool more = true;
+      while (more) {
+        Batch *bt = free_q.pop();
+        bt->clear();
+        bt->fastq = rd.fastq;
+        uint64_t nt = 0;
+        while (nt < unit_nt) {
+          if (!rd.next(header, seq, quals)) { more = false; break; }
+          bt->off.push_back(bt->seqs_len);
+          bt->len.push_back((uint32_t)seq.size());
+          bt->append_seq(seq);  // + '\n' separator required by the C ABI (any non-ACGT byte)
+          size_t e = header.find_first_of(" \t\r\v\f");  // id = header up to first whitespace (src/seqreader.cpp:57-58)
+          bt->idoff.push_back(bt->ids.size());
+          bt->ids.append(header, 0, e == std::string::npos ? header.size() : e);
+          bt->ids.push_back('\0');
+          if (keep_records) {
+            bt->hoff.push_back(bt->headers.size()); bt->headers += header; bt->headers.push_back('\0');
+            bt->qoff.push_back(bt->quals.size()); bt->quals += quals; bt->quals.push_back('\0');
+          }
+          nt += seq.size();
         }
-        nt += seq.size();
+        bt->nt = nt;
+        if (nt == 0) { free_q.push(bt); break; }  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
+        parsed_q.push(bt);
       }
-      const uint64_t n = off.size();
-      if (nt == 0) break;  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
-      calls.assign(n, 0); hits.assign(n, 0); taxa.assign(seqs.size(), 0);
-      opts.max_read_len = 0;
-      KU_CHECK(ku_classify_batch(ctx, seqs.data(), seqs.size(), off.data(), len.data(), n, &opts, calls.data(),
-                                 taxa.data(), hits.data()));
-      for (uint64_t i = 0; i < n; ++i) total_classified += calls[i] != 0;
+      rd.close();
+    }
+    parsed_q.push(nullptr);
+  });
+
+  std::thread writer([&] {
+    std::vector<std::string> parts(fmt_threads);
+    for (;;) {
+      Batch *bt = done_q.pop();
+      if (!bt) break;
+      const uint64_t n = bt->off.size();
       if (print_kraken) {
-        char *text = nullptr; size_t tn = 0;
-        KU_CHECK(ku_format_kraken(seqs.data(), off.data(), len.data(), n, ids.data(), info.k, calls.data(), taxa.data(),
-                                  hits.data(), pflags, &text, &tn));
-        s_kraken.write(text, tn);
-        ku_free(text);
+        // format disjoint read ranges in parallel, write them in order
+        std::vector<std::thread> helpers;
+        std::vector<int> status(fmt_threads, KU_OK);
+        for (int t = 0; t < fmt_threads; ++t) {
+          helpers.emplace_back([&, t] {
+            const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
+            parts[t].clear();
+            if (hi <= lo) return;
+            char *text = nullptr; size_t tn = 0;
+            status[t] = ku_format_kraken(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
+                                         bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->taxa,
+                                         bt->hits.data() + lo, pflags, &text, &tn);
+            if (status[t] == KU_OK) { parts[t].assign(text, tn); ku_free(text); }
+          });
+        }
+        for (auto &h : helpers) h.join();
+        for (int t = 0; t < fmt_threads; ++t) {
+          if (status[t] != KU_OK) die(exit_code_of(status[t]), "%s", ku_strerror(status[t]));
+          s_kraken.write(parts[t].data(), parts[t].size());
+        }
       }
-      if (print_cls || print_ucls) {  // print_sequence (src/classify.cpp:794-805)
+      if (keep_records) {  // print_sequence (src/classify.cpp:794-805)
         std::string rec;
         for (uint64_t i = 0; i < n; ++i) {
-          Sink &sk = calls[i] ? s_cls : s_ucls;
-          if (calls[i] ? !print_cls : !print_ucls) continue;
+          Sink &sk = bt->calls[i] ? s_cls : s_ucls;
+          if (bt->calls[i] ? !print_cls : !print_ucls) continue;
           rec.clear();
-          rec += rd.fastq ? '@' : '>';
-          rec += headers.c_str() + hoff[i];
+          rec += bt->fastq ? '@' : '>';
+          rec += bt->headers.c_str() + bt->hoff[i];
           rec += '\n';
-          rec.append(seqs, off[i], len[i]);
+          rec.append(bt->seqs + bt->off[i], bt->len[i]);
           rec += '\n';
-          if (rd.fastq) { rec += "+\n"; rec += quals_all.c_str() + qoff[i]; rec += '\n'; }
+          if (bt->fastq) { rec += "+\n"; rec += bt->quals.c_str() + bt->qoff[i]; rec += '\n'; }
           sk.write(rec.data(), rec.size());
         }
       }
+      for (uint64_t i = 0; i < n; ++i) total_classified += bt->calls[i] != 0;
       total_sequences += n;
-      total_bases += nt;
+      total_bases += bt->nt;
       fprintf(stderr, "\r Processed %llu sequences (%.2f%% classified)", total_sequences, total_classified * 100.0 / total_sequences);
+      free_q.push(bt);
     }
-    rd.close();
+  });
+
+  for (;;) {  // GPU stage
+    Batch *bt = parsed_q.pop();
+    if (!bt) break;
+    const uint64_t n = bt->off.size();
+    bt->calls.assign(n, 0);
+    bt->hits.assign(n, 0);
+    bt->reserve_taxa();
+    ku_opts opts = base_opts;
+    KU_CHECK(ku_classify_batch(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts, bt->calls.data(),
+                               bt->taxa, bt->hits.data()));
+    done_q.push(bt);
   }
+  done_q.push(nullptr);
+  reader.join();
+  writer.join();
+  for (auto &bt : pool) bt.release();
   gettimeofday(&tv2, nullptr);
   {  // report_stats (src/classify.cpp:361-375)
     double seconds = seconds_between(tv1, tv2);

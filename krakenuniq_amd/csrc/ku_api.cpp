@@ -60,6 +60,17 @@ extern "C" int ku_device_count(void) {
   return n;
 }
 
+extern "C" int ku_host_alloc(size_t bytes, void **out) {
+  if (!out) return fail(KU_EINVAL, "ku_host_alloc: null argument");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KU_ENOMEM : KU_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  return KU_OK;
+}
+extern "C" void ku_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 // ---------------------------------------------------------------------------- ku_db
 struct ku_db {
   const uint8_t *pairs = nullptr;

@@ -877,7 +877,7 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
     size_t lds = (2u << KuResolveCfg<1>::CAP_LOG2) * 4 + KuResolveCfg<1>::MAX_N * 2 + 64;
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(ku_resolve_kernel<1>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ku_resolve_kernel<1>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }

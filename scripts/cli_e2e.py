@@ -1,0 +1,21 @@
+"""End-to-end rate of the drop-in `classify` executable (host pipeline included): f1 reads replicated
+to N reads in /dev/shm, tiny DB.  python scripts/cli_e2e.py [n_million] [threads]"""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from krakenuniq_amd import synth
+n_m = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+thr = sys.argv[2] if len(sys.argv) > 2 else "8"
+ids, seqs = synth.read_seqfile(f"{ROOT}/tests/golden/f1/reads.fq")
+path = "/dev/shm/ku_big.fq"
+with open(path, "wb") as f:
+    for rep in range(n_m * 1000):
+        f.write(b"".join(b"@r%d_%d\n" % (rep, i) + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in enumerate(seqs)))
+db = f"{ROOT}/tests/golden/f1"
+for out in ("/dev/shm/ku_out.tsv", "off"):
+    t = time.time()
+    r = subprocess.run([f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB",
+                        "-t", thr, "-o", out, path], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+    line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l]
+    print(f"-o {out}: wall {time.time() - t:.2f}s rc={r.returncode}", line[-1] if line else r.stderr.decode()[-300:])
+os.remove(path)
