@@ -325,3 +325,55 @@ def test_fused_short_read_kernel_and_staged_path_agree(monkeypatch, read_len, no
     gpu = ctx.classify_batch(buf, off, lens)
     assert_same_classification(gpu, res, taxa, off, lens, K)
     assert_same_counts(ctx.counts(), run)
+
+
+@pytest.mark.parametrize("read_len", [150, 301, 1000])
+def test_adversarial_taxonomy_and_ties(read_len):
+    """DB values scattered over an irregular taxonomy (deep chain, orphans, a self-parent, taxids missing from
+    taxDB, pseudo-taxids >= 1e9): reads see many distinct taxa, equal root-path scores and LCA folds -- every
+    resolve path (ballot fast path, wave/block LDS table) against the oracle."""
+    rng = np.random.default_rng(1000 + read_len)
+    tax = synth.Taxonomy()
+    tax.add(1, 1, "root", "root")
+    ids = [1]
+    for i in range(60):                       # random tree
+        t = 10 + 3 * i
+        tax.add(t, ids[int(rng.integers(0, len(ids)))], f"n{t}", "no rank")
+        ids.append(t)
+    chain = ids[-1]
+    for i in range(45):                       # deep chain below the last node
+        t = 1000 + i
+        tax.add(t, chain, f"c{t}", "no rank")
+        chain = t
+        ids.append(t)
+    tax.add(5000, 4242, "orphan", "species")      # parent id has no entry
+    tax.add(5001, 5001, "selfparent", "species")  # handled as "no parent" (taxdb.hpp:421)
+    tax.add(1000000007, ids[5], "pseudo", "sequence")
+    ids += [5000, 5001, 1000000007]
+    absent = [777, 888]                       # DB values that taxDB does not know
+    genome = synth.procedural_genome(int(rng.integers(1, 1 << 30)), 1, 20000)
+    kmers = np.unique(synth.canonical(synth.kmers_forward(genome, K), K))
+    # taxon changes every ~40 k-mers along the genome order of first appearance -> reads span several taxa
+    fwd = synth.canonical(synth.kmers_forward(genome, K), K)
+    pool = np.array(ids + absent, dtype=np.uint32)
+    seg = pool[rng.integers(0, len(pool), len(fwd) // 40 + 1)]
+    val_of = {}
+    for i, km in enumerate(fwd.tolist()):
+        val_of.setdefault(km, int(seg[i // 40]))
+    vals = np.array([val_of[int(x)] for x in kmers.tolist()], dtype=np.uint32)
+    sk, sv, off = synth.sort_db(kmers, vals, K, 10)
+    raw = synth.pack_pairs(sk, sv).view(np.uint8)
+    tids, tpar = tax.arrays()
+    odb = ko.Db(pairs=raw, key_ct=len(sk), k=K, offsets=off, nt=10)
+    otax = ko.Tax(ids=tids, parents=tpar)
+    ctx, _, _ = make_ctx(cdb=capi.Db(pairs=raw, key_ct=len(sk), k=K, offsets=off, nt=10),
+                         ctax=capi.Tax(ids=tids, parents=tpar))
+    reads, _ = synth.sample_reads({1: genome}, 500, read_len, rng, frac_random=0.1)
+    run, res, buf, off_r, lens, taxa = oracle_flat(odb, otax, reads)
+    gpu = ctx.classify_batch(buf, off_r, lens)
+    assert_same_classification(gpu, res, taxa, off_r, lens, K)
+    assert_same_counts(ctx.counts(), run)
+    # the scenario really exercises ties / multi-taxon reads
+    multi = sum(1 for i in range(len(reads))
+                if len(set(res["taxa"][int(res["taxa_off"][i]):int(res["taxa_off"][i]) + int(res["n_slots"][i])].tolist()) - {0}) > 2)
+    assert multi > len(reads) // 4
