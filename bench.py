@@ -53,7 +53,6 @@ def parse():
     ap.add_argument("--paired", action="store_true", help="configs[3]-style reads: mate1 + 'N' + mate2 (2 x read-len + 1)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--keep-tmp", action="store_true")
     return ap.parse_args()
 
 
