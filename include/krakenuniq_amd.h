@@ -168,6 +168,23 @@ int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uin
                       const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                       uint32_t *taxa, uint32_t *hits);
 
+/* As ku_classify_batch, but the per-k-mer codes come back run-length encoded -- exactly the information
+ * hitlist_string prints (classify.cpp:826-861) at ~30 B instead of 4 B per base for a typical short read, which is
+ * what the PCIe link and the output formatter want.  Two steps so that the caller can size the buffer exactly:
+ * ku_classify_batch_rle classifies, encodes on the device and returns calls/hits, (run_off, run_cnt) per read and
+ * the batch's total *n_runs; ku_fetch_runs then copies that many runs out of the context (valid until the next
+ * batch call on it).  Read i owns runs[run_off[i] .. run_off[i] + run_cnt[i]); a run is {code, start}: code =
+ * taxid / 0 / KU_AMBIG, start = index of its first k-mer; its length is the next run's start (or the read's k-mer
+ * count) minus its own.  Reads shorter than k own no runs. */
+typedef struct ku_run {
+  uint32_t code;
+  uint32_t start;
+} ku_run;
+int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                          const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                          uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs);
+int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs);
+
 /* Same on device-resident buffers, asynchronous on `stream` (a hipStream_t
  * passed as void*; NULL = the context's own stream). */
 int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
@@ -231,6 +248,11 @@ size_t ku_hitlist_string(const uint32_t *taxa, size_t n, char *buf);
 int ku_format_kraken(const char *seqs, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
                      const char *ids, uint32_t k, const uint32_t *calls, const uint32_t *taxa,
                      const uint32_t *hits, uint32_t flags, char **out, size_t *out_len);
+/* ku_format_kraken fed with the run-length encoded codes of ku_classify_batch_rle (taxa -> runs/run_off/run_cnt). */
+int ku_format_kraken_rle(const char *seqs, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
+                         const char *ids, uint32_t k, const uint32_t *calls, const ku_run *runs,
+                         const uint64_t *run_off, const uint32_t *run_cnt, const uint32_t *hits, uint32_t flags,
+                         char **out, size_t *out_len);
 /* Report with the reference's default columns
  * "%  reads  taxReads  kmers  dup  cov  taxID  rank  taxName"
  * (TaxReport, taxdb.hpp:928-1123; classify.cpp:288-325).  counts_path =

@@ -39,6 +39,10 @@ class Opts(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class Run(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("start", C.c_uint32)]
+
+
 class CountsDims(C.Structure):
     _fields_ = [("n_slots", C.c_uint64), ("n_nodes", C.c_uint64)]
 
@@ -73,6 +77,9 @@ SIGNATURES = {
     "ku_ctx_reset_counts": (C.c_int, [C.c_void_p]),
     "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
                                     u32p, u32p, u32p]),
+    "ku_classify_batch_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p, u32p,
+                                        u64p, u32p, u64p]),
+    "ku_fetch_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "ku_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ku_lookup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Opts), C.c_void_p, C.c_void_p]),
@@ -88,6 +95,8 @@ SIGNATURES = {
     "ku_hitlist_string": (C.c_size_t, [u32p, C.c_size_t, C.c_char_p]),
     "ku_format_kraken": (C.c_int, [C.c_void_p, u64p, u32p, C.c_uint64, C.c_char_p, C.c_uint32, u32p, u32p, u32p,
                                    C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_format_kraken_rle": (C.c_int, [C.c_void_p, u64p, u32p, C.c_uint64, C.c_char_p, C.c_uint32, u32p, C.c_void_p, u64p, u32p,
+                                       u32p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_report": (C.c_int, [C.c_void_p, C.c_char_p, u32p, u64p, u8p, C.c_uint64, u32p, u64p, C.c_uint64,
                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_free": (None, [C.c_void_p]),
@@ -262,6 +271,25 @@ class Ctx:
                                      _p(calls, u32p), _p(taxa, u32p), _p(hits, u32p)), "ku_classify_batch")
         return {"calls": calls[:n], "taxa": taxa, "hits": hits[:n]}
 
+    def classify_batch_rle(self, buf, off, lens, flags=0, min_hits=1):
+        """Host-buffer entry point with run-length encoded per-k-mer codes (ku_classify_batch_rle + ku_fetch_runs)."""
+        arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        calls = np.zeros(max(n, 1), dtype=np.uint32)
+        hits = np.zeros(max(n, 1), dtype=np.uint32)
+        roff = np.zeros(max(n, 1), dtype=np.uint64)
+        rcnt = np.zeros(max(n, 1), dtype=np.uint32)
+        o = Opts(flags, min_hits, 0, 0)
+        total = C.c_uint64()
+        _chk(lib().ku_classify_batch_rle(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n, C.byref(o),
+                                         _p(calls, u32p), _p(hits, u32p), _p(roff, u64p), _p(rcnt, u32p),
+                                         C.byref(total)), "ku_classify_batch_rle")
+        runs = np.zeros((max(total.value, 1), 2), dtype=np.uint32)
+        _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
+        return {"calls": calls[:n], "hits": hits[:n], "runs": runs[:total.value], "run_off": roff[:n], "run_cnt": rcnt[:n]}
+
     def lookup_device(self, d_seqs, n_bytes, d_taxa, flags=0, stream=None):
         o = Opts(flags, 1, 0, 0)
         _chk(lib().ku_lookup_device(self.h, d_seqs, n_bytes, C.byref(o), d_taxa, stream), "ku_lookup_device")
@@ -329,6 +357,24 @@ def format_kraken(buf, off, lens, ids, k, calls, taxa=None, hits=None, flags=0):
     _chk(lib().ku_format_kraken(arr.ctypes.data, _p(off, u64p), _p(lens, u32p), len(lens), idbuf, k,
                                 _p(calls, u32p), _p(taxa, u32p), _p(hits, u32p), flags, C.byref(out), C.byref(n)),
          "ku_format_kraken")
+    s = C.string_at(out, n.value).decode()
+    lib().ku_free(out)
+    return s
+
+
+def format_kraken_rle(buf, off, lens, ids, k, res, flags=0):
+    arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    idbuf = b"".join(i.encode() + b"\0" for i in ids)
+    runs = np.ascontiguousarray(res["runs"], dtype=np.uint32)
+    out, n = C.c_void_p(), C.c_size_t()
+    _chk(lib().ku_format_kraken_rle(arr.ctypes.data, _p(off, u64p), _p(lens, u32p), len(lens), idbuf, k,
+                                    _p(np.ascontiguousarray(res["calls"], dtype=np.uint32), u32p), runs.ctypes.data,
+                                    _p(np.ascontiguousarray(res["run_off"], dtype=np.uint64), u64p),
+                                    _p(np.ascontiguousarray(res["run_cnt"], dtype=np.uint32), u32p),
+                                    _p(np.ascontiguousarray(res["hits"], dtype=np.uint32), u32p), flags,
+                                    C.byref(out), C.byref(n)), "ku_format_kraken_rle")
     s = C.string_at(out, n.value).decode()
     lib().ku_free(out)
     return s

@@ -206,11 +206,11 @@ struct Reader {
 struct Batch {
   char *seqs = nullptr;       // reads, each followed by '\n'
   size_t seqs_len = 0, seqs_cap = 0;
-  uint32_t *taxa = nullptr;   // per-k-mer codes, parallel to seqs
-  size_t taxa_cap = 0;
+  ku_run *runs = nullptr;     // run-length encoded per-k-mer codes (ku_classify_batch_rle)
+  size_t runs_cap = 0;
   std::string ids, headers, quals;
-  std::vector<uint64_t> off, idoff, hoff, qoff;
-  std::vector<uint32_t> len, calls, hits;
+  std::vector<uint64_t> off, idoff, hoff, qoff, run_off;
+  std::vector<uint32_t> len, calls, hits, run_cnt;
   bool fastq = false;
   uint64_t nt = 0;
   void clear() {
@@ -234,18 +234,20 @@ struct Batch {
     seqs_len += sq.size();
     seqs[seqs_len++] = '\n';
   }
-  void reserve_taxa() {
-    if (seqs_len <= taxa_cap) return;
-    if (taxa) ku_host_free(taxa);
+  void reserve_runs(size_t n) {
+    if (n <= runs_cap) return;
+    if (runs) ku_host_free(runs);
+    size_t ncap = runs_cap ? runs_cap : (size_t)1 << 20;
+    while (ncap < n) ncap *= 2;
     void *np = nullptr;
-    if (ku_host_alloc(seqs_cap * sizeof(uint32_t), &np) != KU_OK) die(EX_OSERR, "out of host memory");
-    taxa = (uint32_t *)np;
-    taxa_cap = seqs_cap;
+    if (ku_host_alloc(ncap * sizeof(ku_run), &np) != KU_OK) die(EX_OSERR, "out of host memory");
+    runs = (ku_run *)np;
+    runs_cap = ncap;
   }
   void release() {
     if (seqs) ku_host_free(seqs);
-    if (taxa) ku_host_free(taxa);
-    seqs = nullptr; taxa = nullptr;
+    if (runs) ku_host_free(runs);
+    seqs = nullptr; runs = nullptr;
   }
 };
 
@@ -354,7 +356,7 @@ int main(int argc, char **argv) {
   const uint32_t pflags = (only_classified ? KU_P_ONLY_CLASSIFIED : 0u) | (print_seq ? KU_P_SEQUENCE : 0u) | (quick ? KU_P_QUICK : 0u);
 
   // Three-stage host pipeline: reader thread (FASTA/FASTQ(+gz) -> pinned batch) | this thread
-  // (ku_classify_batch: H2D, kernels, D2H) | writer thread (Kraken lines formatted by `fmt_threads` helpers,
+  // (ku_classify_batch_rle: H2D, kernels, run-length encoding, D2H) | writer thread (Kraken lines formatted by `fmt_threads` helpers,
   // files written in input order).  Batches circulate through two bounded queues.
   const int n_batches = 3;
   std::vector<Batch> pool(n_batches);
@@ -413,9 +415,10 @@ int main(int argc, char **argv) {
             parts[t].clear();
             if (hi <= lo) return;
             char *text = nullptr; size_t tn = 0;
-            status[t] = ku_format_kraken(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
-                                         bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->taxa,
-                                         bt->hits.data() + lo, pflags, &text, &tn);
+            status[t] = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
+                                             bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
+                                             bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
+                                             pflags, &text, &tn);
             if (status[t] == KU_OK) { parts[t].assign(text, tn); ku_free(text); }
           });
         }
@@ -454,10 +457,16 @@ int main(int argc, char **argv) {
     const uint64_t n = bt->off.size();
     bt->calls.assign(n, 0);
     bt->hits.assign(n, 0);
-    bt->reserve_taxa();
+    bt->run_off.assign(n, 0);
+    bt->run_cnt.assign(n, 0);
     ku_opts opts = base_opts;
-    KU_CHECK(ku_classify_batch(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts, bt->calls.data(),
-                               bt->taxa, bt->hits.data()));
+    uint64_t n_runs = 0;
+    KU_CHECK(ku_classify_batch_rle(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
+                                   bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
+    if (print_kraken && !quick) {  // the runs only feed the Kraken lines
+      bt->reserve_runs(n_runs);
+      KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
+    }
     done_q.push(bt);
   }
   done_q.push(nullptr);

@@ -322,8 +322,9 @@ struct ku_ctx {
   // run state
   KuCountsDev cnt{};
   // scratch for the host-buffer entry point
-  DevBuf b_seqs, b_off, b_len, b_calls, b_taxa, b_hits, b_ws;
+  DevBuf b_seqs, b_off, b_len, b_calls, b_taxa, b_hits, b_ws, b_runs, b_roff, b_rcnt;
   uint32_t *d_scalar = nullptr;
+  uint64_t n_runs = 0;  // runs of the last ku_classify_batch_rle, still in b_runs
 };
 
 static int ctx_activate(ku_ctx *ctx) {
@@ -382,7 +383,9 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx_free_db(ctx);
   ctx_free_tax(ctx);
-  for (DevBuf *b : {&ctx->b_seqs, &ctx->b_off, &ctx->b_len, &ctx->b_calls, &ctx->b_taxa, &ctx->b_hits, &ctx->b_ws}) b->release();
+  for (DevBuf *b : {&ctx->b_seqs, &ctx->b_off, &ctx->b_len, &ctx->b_calls, &ctx->b_taxa, &ctx->b_hits, &ctx->b_ws, &ctx->b_runs,
+                    &ctx->b_roff, &ctx->b_rcnt})
+    b->release();
   if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -760,6 +763,65 @@ extern "C" int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes
   if (taxa) HIP_TRY(hipMemcpyAsync(taxa, ctx->b_taxa.p, n_bytes * 4, hipMemcpyDeviceToHost, s));
   if (hits) HIP_TRY(hipMemcpyAsync(hits, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return KU_OK;
+}
+
+extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                                     const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                                     uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
+  KU_TRY(check_ready(ctx));
+  if ((n_bytes && !seqs) || (n_reads && (!seq_off || !seq_len || !calls || !run_off || !run_cnt)) || !n_runs)
+    return fail(KU_EINVAL, "ku_classify_batch_rle: null buffer");
+  *n_runs = 0;
+  ctx->n_runs = 0;
+  if (n_reads == 0) return KU_OK;
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  o.flags &= ~KU_F_KEEP_SLOTS;
+  if (o.max_read_len == 0) for (uint64_t i = 0; i < n_reads; ++i) o.max_read_len = std::max(o.max_read_len, seq_len[i]);
+  for (uint64_t i = 0; i < n_reads; ++i)
+    if (seq_off[i] + seq_len[i] > n_bytes) return fail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
+  // a run needs at least one k-mer, so n_bytes bounds the number of runs: the device side cannot overflow
+  const uint64_t runs_cap = n_bytes + 1;
+  if (ctx->b_seqs.reserve(n_bytes + 16) || ctx->b_off.reserve(n_reads * 8) || ctx->b_len.reserve(n_reads * 4) ||
+      ctx->b_calls.reserve(n_reads * 4) || ctx->b_taxa.reserve((n_bytes + 16) * 4) || ctx->b_hits.reserve(n_reads * 4) ||
+      ctx->b_runs.reserve(runs_cap * 8) || ctx->b_roff.reserve(n_reads * 8) || ctx->b_rcnt.reserve(n_reads * 4))
+    return fail(KU_ENOMEM, "device batch buffers");
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(ctx->b_seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_off.p, seq_off, n_reads * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_len.p, seq_len, n_reads * 4, hipMemcpyHostToDevice, s));
+  KU_TRY(ku_classify_batch_device(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
+                                  n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
+                                  (uint32_t *)ctx->b_hits.p, s));
+  unsigned long long *d_counter = (unsigned long long *)(ctx->d_scalar + 2);
+  if (o.flags & KU_F_QUICK) {  // quick mode stops at the first hits: no per-k-mer codes, no runs
+    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_roff.p, 0, n_reads * 8, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_rcnt.p, 0, n_reads * 4, s));
+  } else {
+    KU_TRY(ku_launch_rle((const uint32_t *)ctx->b_taxa.p, ctx->db.k, (const uint64_t *)ctx->b_off.p,
+                         (const uint32_t *)ctx->b_len.p, n_reads, ctx->b_runs.p, runs_cap, d_counter,
+                         (uint64_t *)ctx->b_roff.p, (uint32_t *)ctx->b_rcnt.p, ctx->n_cu, s));
+  }
+  unsigned long long total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(calls, ctx->b_calls.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  if (hits) HIP_TRY(hipMemcpyAsync(hits, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(run_off, ctx->b_roff.p, n_reads * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(run_cnt, ctx->b_rcnt.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total > runs_cap) return fail(KU_EHIP, "run-length encoder overflowed its bound");
+  *n_runs = ctx->n_runs = total;
+  return KU_OK;
+}
+
+extern "C" int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs) {
+  if (!ctx) return fail(KU_EINVAL, "ku_fetch_runs: null context");
+  if (n_runs > ctx->n_runs) return fail(KU_EINVAL, "ku_fetch_runs: the last batch holds " + std::to_string(ctx->n_runs) + " runs");
+  if (n_runs == 0) return KU_OK;
+  if (!runs) return fail(KU_EINVAL, "ku_fetch_runs: null buffer");
+  HIP_TRY(hipMemcpyAsync(runs, ctx->b_runs.p, n_runs * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return KU_OK;
 }
 

@@ -124,6 +124,64 @@ extern "C" int ku_format_kraken(const char *seqs, const uint64_t *seq_off, const
   return KU_OK;
 }
 
+extern "C" int ku_format_kraken_rle(const char *seqs, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
+                                    const char *ids, uint32_t k, const uint32_t *calls, const ku_run *runs,
+                                    const uint64_t *run_off, const uint32_t *run_cnt, const uint32_t *hits,
+                                    uint32_t flags, char **out, size_t *out_len) {
+  if (!out || !out_len || (n_reads && (!seq_off || !seq_len || !ids || !calls))) { ku_set_error("ku_format_kraken_rle: null argument"); return KU_EINVAL; }
+  const bool quick = flags & KU_P_QUICK, only_c = flags & KU_P_ONLY_CLASSIFIED, pseq = flags & KU_P_SEQUENCE;
+  if ((!quick && n_reads && (!run_off || !run_cnt)) || (quick && !hits) || (pseq && !seqs)) { ku_set_error("ku_format_kraken_rle: missing array for the requested columns"); return KU_EINVAL; }
+  size_t cap = 1 << 16, len = 0;
+  char *buf = (char *)malloc(cap);
+  if (!buf) return KU_ENOMEM;
+  const char *id = ids;
+  for (uint64_t r = 0; r < n_reads; ++r) {
+    const size_t idl = strlen(id);
+    const uint32_t L = seq_len[r];
+    const uint32_t n = L >= k ? L - k + 1 : 0;
+    const uint32_t nr = quick ? 0 : run_cnt[r];
+    if (nr == 0xFFFFFFFFu || (nr && !runs)) { free(buf); ku_set_error("ku_format_kraken_rle: read " + std::to_string(r) + " has no valid runs"); return KU_EINVAL; }
+    size_t need = idl + 64 + 24 * (size_t)nr + (pseq ? L + 1 : 0);
+    if (len + need > cap) {
+      while (len + need > cap) cap *= 2;
+      char *nb = (char *)realloc(buf, cap);
+      if (!nb) { free(buf); return KU_ENOMEM; }
+      buf = nb;
+    }
+    const uint32_t call = calls[r];
+    if (!(call == 0 && only_c)) {
+      char *p = buf + len;
+      *p++ = call ? 'C' : 'U';
+      *p++ = '\t';
+      memcpy(p, id, idl); p += idl;
+      *p++ = '\t';
+      p = put_u64(p, call);
+      *p++ = '\t';
+      p = put_u64(p, L);
+      *p++ = '\t';
+      if (quick) { *p++ = 'Q'; *p++ = ':'; p = put_u64(p, hits[r]); }
+      else if (n == 0) { memcpy(p, "0:0", 3); p += 3; }
+      else {
+        const ku_run *rr = runs + run_off[r];
+        for (uint32_t j = 0; j < nr; ++j) {
+          const uint32_t end = j + 1 < nr ? rr[j + 1].start : n;
+          if (rr[j].code == KU_AMBIG) *p++ = 'A'; else p = put_u64(p, rr[j].code);
+          *p++ = ':';
+          p = put_u64(p, end - rr[j].start);
+          if (j + 1 < nr) *p++ = ' ';
+        }
+      }
+      if (pseq) { *p++ = '\t'; memcpy(p, seqs + seq_off[r], L); p += L; }
+      *p++ = '\n';
+      len = (size_t)(p - buf);
+    }
+    id += idl + 1;
+  }
+  *out = buf;
+  *out_len = len;
+  return KU_OK;
+}
+
 extern "C" void ku_free(void *p) { free(p); }
 
 // ---------------------------------------------------------------------------- report

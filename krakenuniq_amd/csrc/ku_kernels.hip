@@ -898,6 +898,69 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
 }
 
 // ----------------------------------------------------------------------------
+// ku_rle_kernel: run-length encoding of the per-k-mer codes (hitlist_string, classify.cpp:826-861)
+// ----------------------------------------------------------------------------
+// One wave per read.  A run is stored as {code, start index}; its length is the next run's start (or the
+// read's k-mer count) minus its own -- the host formatter recovers it.  Space for a read's runs is claimed
+// from a global bump counter, so `runs` is dense but not in read order; (run_off, run_cnt) say where.
+__global__ __launch_bounds__(64) void ku_rle_kernel(const uint32_t *__restrict__ taxa, uint32_t k,
+                                                    const uint64_t *__restrict__ seq_off,
+                                                    const uint32_t *__restrict__ seq_len, uint64_t n_reads,
+                                                    uint2 *runs, unsigned long long runs_cap, unsigned long long *counter,
+                                                    uint64_t *run_off, uint32_t *run_cnt) {
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t off = seq_off[r];
+    // pass 1: count the run starts
+    uint32_t total = 0, carry = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t i = base + lane;
+      const uint32_t v = i < n ? taxa[off + i] : 0u;
+      uint32_t prev = (uint32_t)__shfl_up((int)v, 1);
+      if (lane == 0) prev = carry;
+      const bool start = i < n && (i == 0 || v != prev);
+      total += (uint32_t)__popcll(__ballot(start));
+      carry = (uint32_t)__shfl((int)v, 63);
+    }
+    unsigned long long basep = 0;
+    if (lane == 0) {
+      basep = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+      run_off[r] = basep;
+      run_cnt[r] = basep + total <= runs_cap ? total : 0xFFFFFFFFu;  // overflow marker: caller retries bigger
+    }
+    basep = __shfl(basep, 0);
+    if (basep + total > runs_cap) continue;
+    // pass 2: write {code, start}
+    uint32_t done = 0;
+    carry = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t i = base + lane;
+      const uint32_t v = i < n ? taxa[off + i] : 0u;
+      uint32_t prev = (uint32_t)__shfl_up((int)v, 1);
+      if (lane == 0) prev = carry;
+      const bool start = i < n && (i == 0 || v != prev);
+      const unsigned long long m = __ballot(start);
+      if (start) runs[basep + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, i);
+      done += (uint32_t)__popcll(m);
+      carry = (uint32_t)__shfl((int)v, 63);
+    }
+  }
+}
+int ku_launch_rle(const uint32_t *d_taxa, uint32_t k, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
+                  uint64_t n_reads, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter, uint64_t *d_run_off,
+                  uint32_t *d_run_cnt, int n_cu, hipStream_t stream) {
+  if (hipMemsetAsync(d_counter, 0, 8, stream) != hipSuccess) return KU_EHIP;
+  if (n_reads == 0) return KU_OK;
+  const uint64_t cap = (uint64_t)n_cu * 32;
+  hipLaunchKernelGGL(ku_rle_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, d_taxa, k,
+                     d_seq_off, d_seq_len, n_reads, (uint2 *)d_runs, (unsigned long long)runs_cap, d_counter, d_run_off,
+                     d_run_cnt);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// ----------------------------------------------------------------------------
 // small utility kernels
 // ----------------------------------------------------------------------------
 __global__ void ku_max_len_kernel(const uint32_t *__restrict__ len, uint64_t n, uint32_t *out) {

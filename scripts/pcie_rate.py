@@ -19,3 +19,6 @@ for want in (True, False):
     ctx.classify_batch(buf, off, lens, want_taxa=want)
     t = time.time(); ctx.classify_batch(buf, off, lens, want_taxa=want); dt = time.time() - t
     print(f"ku_classify_batch host buffers, per-k-mer output {'on' if want else 'off'}: {n_reads / dt / 1e6:.1f} Mreads/s ({dt * 1e3:.1f} ms for {n_reads} reads)")
+ctx.classify_batch_rle(buf, off, lens)
+t = time.time(); r = ctx.classify_batch_rle(buf, off, lens); dt = time.time() - t
+print(f"ku_classify_batch_rle + ku_fetch_runs host buffers: {n_reads / dt / 1e6:.1f} Mreads/s ({dt * 1e3:.1f} ms, {len(r['runs']) / n_reads:.2f} runs/read)")

@@ -173,6 +173,42 @@ def test_format_kraken_edge_reads(golden, f1):
     assert capi.hitlist_string(np.zeros(0, dtype=np.uint32)) == "0:0"
 
 
+def _rle(taxa, off, lens, calls, k=31, shuffle=False):
+    """numpy model of ku_classify_batch_rle's output (runs in arbitrary per-read order when shuffle is set)."""
+    per_read = []
+    for o, L in zip(off.tolist(), lens.tolist()):
+        n = max(L - k + 1, 0)
+        t = taxa[o:o + n]
+        starts = np.flatnonzero(np.r_[True, t[1:] != t[:-1]]) if n else np.zeros(0, dtype=np.int64)
+        per_read.append(np.stack([t[starts], starts.astype(np.uint32)], axis=1).astype(np.uint32).reshape(-1, 2))
+    order = list(range(len(per_read)))
+    if shuffle:
+        order = order[::-1]
+    run_off, pos = np.zeros(len(per_read), dtype=np.uint64), 0
+    for i in order:
+        run_off[i] = pos
+        pos += len(per_read[i])
+    runs = np.concatenate([per_read[i] for i in order]) if per_read else np.zeros((0, 2), np.uint32)
+    return {"calls": calls, "hits": np.zeros(len(lens), np.uint32), "runs": runs, "run_off": run_off,
+            "run_cnt": np.array([len(x) for x in per_read], dtype=np.uint32)}
+
+
+@pytest.mark.parametrize("fixture,reads", [("f1", "f1/reads.fq"), ("f2", "f2/edge.fa"), ("f4", "f4/merged.fa")])
+def test_format_kraken_rle_reproduces_reference_output(golden, f1, fixture, reads):
+    ids, seqs = synth.read_seqfile(os.path.join(golden, reads))
+    _, res, buf, off, lens, taxa = _oracle_flat(f1["dir"], seqs)
+    d = os.path.join(golden, fixture)
+    for shuffle in (False, True):
+        rle = _rle(taxa, off, lens, res["calls"], shuffle=shuffle)
+        assert capi.format_kraken_rle(buf, off, lens, ids, 31, rle) == open(f"{d}/out.tsv").read()
+    if fixture == "f1":
+        assert capi.format_kraken_rle(buf, off, lens, ids, 31, rle, flags=capi.KU_P_ONLY_CLASSIFIED) == open(f"{d}/out_c.tsv").read()
+        assert capi.format_kraken_rle(buf, off, lens, ids, 31, rle, flags=capi.KU_P_SEQUENCE) == open(f"{d}/out_s.tsv").read()
+        _, resq, *_ = _oracle_flat(d, seqs, quick=True, min_hits=2)
+        q = dict(rle, calls=resq["calls"], hits=resq["hits"])
+        assert capi.format_kraken_rle(buf, off, lens, ids, 31, q, flags=capi.KU_P_QUICK) == open(f"{d}/out_quick.tsv").read()
+
+
 def _counts_from_oracle(run):
     """Oracle per-taxon state -> the arrays ku_counts_export would deliver (dense registers)."""
     c = run.counts()

@@ -245,6 +245,62 @@ def test_long_and_huge_reads(f1):
     assert_same_counts(ctx.counts(), run)
 
 
+def _decode_runs(rle, off, lens, n_bytes, k=K):
+    """runs -> flat per-k-mer codes laid out like ku_classify_batch's taxa (positions past n_kmers left 0)"""
+    taxa = np.zeros(n_bytes, dtype=np.uint32)
+    for i, (o, L) in enumerate(zip(off.tolist(), lens.tolist())):
+        n = max(L - k + 1, 0)
+        a, c = int(rle["run_off"][i]), int(rle["run_cnt"][i])
+        rr = rle["runs"][a:a + c]
+        assert (c == 0) == (n == 0)
+        if c:
+            assert rr[0, 1] == 0 and np.all(np.diff(rr[:, 1].astype(np.int64)) > 0) and rr[-1, 1] < n
+            assert np.all(rr[1:, 0] != rr[:-1, 0])  # maximal runs
+            taxa[o:o + n] = np.repeat(rr[:, 0], np.diff(np.r_[rr[:, 1], n]))
+    return taxa
+
+
+@pytest.mark.parametrize("fixture,reads", [("f1", "f1/reads.fq"), ("f2", "f2/edge.fa"), ("f4", "f4/merged.fa")])
+def test_rle_output_path_matches_reference_output(golden, f1, fixture, reads):
+    """ku_classify_batch_rle + ku_fetch_runs + ku_format_kraken_rle: the reference's Kraken file byte for byte, and
+    the same per-taxon state as the per-k-mer path"""
+    ids, seqs = synth.read_seqfile(os.path.join(golden, reads))
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    rle = ctx.classify_batch_rle(buf, off, lens)
+    assert int(rle["run_cnt"].sum()) == len(rle["runs"])
+    assert capi.format_kraken_rle(buf, off, lens, ids, K, rle) == open(os.path.join(golden, fixture, "out.tsv")).read()
+    dec = _decode_runs(rle, off, lens, len(taxa))
+    m = valid_mask(off, lens, K, len(taxa))
+    assert np.array_equal(dec[m], taxa[m]) and np.array_equal(rle["calls"], res["calls"])
+    assert_same_counts(ctx.counts(), run)
+    if fixture == "f1":
+        q = ctx.classify_batch_rle(buf, off, lens, flags=capi.KU_F_QUICK | capi.KU_F_NO_COUNTS, min_hits=2)
+        assert len(q["runs"]) == 0
+        assert capi.format_kraken_rle(buf, off, lens, ids, K, q, flags=capi.KU_P_QUICK) == open(f"{f1['dir']}/out_quick.tsv").read()
+    ctx.reset_counts()
+
+
+def test_rle_long_reads_and_empty_batch(f1):
+    """reads spanning many 64-k-mer strips, runs crossing strip boundaries, reads without k-mers, empty batch"""
+    rng = np.random.default_rng(11)
+    ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
+    long_reads = [b"".join(seqs[i:i + 40]) for i in range(0, 400, 40)] + [b"ACGT" * 5, b"", seqs[0][:31], seqs[1][:30] + b"N" + seqs[1][31:95]]
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], long_reads)
+    ctx = f1["ctx"]
+    ctx.reset_counts()
+    rle = ctx.classify_batch_rle(buf, off, lens)
+    dec = _decode_runs(rle, off, lens, len(taxa))
+    m = valid_mask(off, lens, K, len(taxa))
+    assert np.array_equal(dec[m], taxa[m]) and np.array_equal(rle["calls"], res["calls"])
+    names = [f"r{i}" for i in range(len(long_reads))]
+    assert capi.format_kraken_rle(buf, off, lens, names, K, rle) == capi.format_kraken(buf, off, lens, names, K, res["calls"], taxa=taxa)
+    empty = ctx.classify_batch_rle(b"", np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    assert len(empty["runs"]) == 0 and len(empty["calls"]) == 0
+    ctx.reset_counts()
+
+
 def test_revcomp_invariance_property(f1):
     """size-independent property: a read and its reverse complement get the same call and mirrored hit list"""
     ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
