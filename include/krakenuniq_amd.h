@@ -115,6 +115,13 @@ int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_h
  * d_offsets must outlive the context. */
 int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, const uint64_t *d_offsets, uint32_t k,
                     uint32_t nt, uint32_t idx_type, uint64_t bin_lo, uint64_t bin_hi);
+/* Hierarchical multi-database classification ("classify -d A.kdb -i A.idx -d B.kdb -i B.idx", classify.cpp:163-177,
+ * 928-936): every k-mer is searched in the databases in the order they were given and the first one that holds it
+ * supplies the taxon; the k-mer is then accounted once under that taxon (or under 0).  ku_ctx_add_db appends a
+ * whole database behind the one loaded with ku_ctx_load_db / ku_ctx_adopt_db; call it before ku_ctx_set_taxonomy.
+ * All databases must share k (classify.cpp:199-208; KU_EINVAL), minimizer lengths and index types may differ.
+ * Needs the first database resident as a whole (no minimizer-range shard: KU_EUNSUP); at most 8 databases. */
+int ku_ctx_add_db(ku_ctx *ctx, const ku_db *db);
 /* Which in-HBM layout the shard ended up in after ku_ctx_set_taxonomy: *is_hash = 1 for the bucketised probe
  * table (default), 0 for the sorted on-disk order + binary search (KU_LAYOUT=sorted, or the automatic fallback
  * when the table does not fit: an adopted d_pairs buffer then stays in use).  *resident_bytes = table or pairs
@@ -134,6 +141,8 @@ int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_t *all_valu
  * (KrakenDB::count_taxons, krakendb.cpp:90-113; classify.cpp:275-283), ascending
  * taxid, includes value 0 if present.  out arrays sized via n (NULL to query). */
 int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *counts, uint64_t *n);
+/* Same for the db_index-th database of a hierarchical run (0 = the first one); one .counts file per database. */
+int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *taxids, uint64_t *counts, uint64_t *n);
 /* zero HLL registers / n_kmers / n_reads (start of a run) */
 int ku_ctx_reset_counts(ku_ctx *ctx);
 
@@ -261,6 +270,11 @@ int ku_format_kraken_rle(const char *seqs, const uint64_t *seq_off, const uint32
 int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_taxid, const uint64_t *n_kmers,
               const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads,
               uint64_t n_nodes, char **out, size_t *out_len);
+/* Same with one counts file per database of a hierarchical run: genome sizes add up in the order given
+ * (readGenomeSizes once per database, classify.cpp:263-285; taxdb.hpp:850-885). */
+int ku_report_multi(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
+                    const uint64_t *n_kmers, const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid,
+                    const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
 void ku_free(void *p);
 /* Page-locked host memory for batch buffers (fast, truly asynchronous H2D / D2H in ku_classify_batch). */
 int ku_host_alloc(size_t bytes, void **out);

@@ -70,10 +70,12 @@ SIGNATURES = {
     "ku_ctx_load_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ku_ctx_adopt_db": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                   C.c_uint32, C.c_uint64, C.c_uint64]),
+    "ku_ctx_add_db": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ku_ctx_db_layout": (C.c_int, [C.c_void_p, u32p, u64p]),
     "ku_ctx_db_values": (C.c_int, [C.c_void_p, u32p, u64p]),
     "ku_ctx_set_taxonomy": (C.c_int, [C.c_void_p, C.c_void_p, u32p, C.c_uint64]),
     "ku_ctx_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
+    "ku_ctx_count_taxons_db": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p, u64p]),
     "ku_ctx_reset_counts": (C.c_int, [C.c_void_p]),
     "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
                                     u32p, u32p, u32p]),
@@ -99,6 +101,8 @@ SIGNATURES = {
                                        u32p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_report": (C.c_int, [C.c_void_p, C.c_char_p, u32p, u64p, u8p, C.c_uint64, u32p, u64p, C.c_uint64,
                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_report_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u8p, C.c_uint64, u32p, u64p,
+                                  C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_free": (None, [C.c_void_p]),
     "ku_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ku_host_free": (None, [C.c_void_p]),
@@ -218,6 +222,10 @@ class Ctx:
             bin_hi = db.info.n_bins
         _chk(lib().ku_ctx_load_db(self.h, db.h, bin_lo, bin_hi), "ku_ctx_load_db")
 
+    def add_db(self, db: Db):
+        """a further database of a hierarchical run, searched after the ones already resident"""
+        _chk(lib().ku_ctx_add_db(self.h, db.h), "ku_ctx_add_db")
+
     def adopt_db(self, d_pairs_ptr, n_pairs, d_offsets_ptr, k, nt, idx_type=2, bin_lo=0, bin_hi=None, keep=None):
         if bin_hi is None:
             bin_hi = 4 ** nt
@@ -245,13 +253,13 @@ class Ctx:
             v = np.ascontiguousarray(all_values, dtype=np.uint32)
             _chk(lib().ku_ctx_set_taxonomy(self.h, tax.h, _p(v, u32p), len(v)), "ku_ctx_set_taxonomy")
 
-    def count_taxons(self):
+    def count_taxons(self, db_index=0):
         n = C.c_uint64()
-        _chk(lib().ku_ctx_count_taxons(self.h, None, None, C.byref(n)), "ku_ctx_count_taxons")
+        _chk(lib().ku_ctx_count_taxons_db(self.h, db_index, None, None, C.byref(n)), "ku_ctx_count_taxons_db")
         t = np.zeros(max(n.value, 1), dtype=np.uint32)
         c = np.zeros(max(n.value, 1), dtype=np.uint64)
         n2 = C.c_uint64(len(t))
-        _chk(lib().ku_ctx_count_taxons(self.h, _p(t, u32p), _p(c, u64p), C.byref(n2)), "ku_ctx_count_taxons")
+        _chk(lib().ku_ctx_count_taxons_db(self.h, db_index, _p(t, u32p), _p(c, u64p), C.byref(n2)), "ku_ctx_count_taxons_db")
         return t[:n2.value], c[:n2.value]
 
     def reset_counts(self):
@@ -381,8 +389,18 @@ def format_kraken_rle(buf, off, lens, ids, k, res, flags=0):
 
 
 def report(tax: Tax, counts: dict, counts_path=None):
+    """counts_path: database.kdb.counts, or a list of them (one per database of a hierarchical run)"""
     out, n = C.c_void_p(), C.c_size_t()
     regs = np.ascontiguousarray(counts["registers"], dtype=np.uint8)
+    if isinstance(counts_path, (list, tuple)):
+        paths = (C.c_char_p * len(counts_path))(*[p.encode() for p in counts_path])
+        _chk(lib().ku_report_multi(tax.h, paths, len(counts_path), _p(counts["slot_taxid"], u32p),
+                                   _p(counts["n_kmers"], u64p), _p(regs, u8p), len(counts["slot_taxid"]),
+                                   _p(counts["node_taxid"], u32p), _p(counts["n_reads"], u64p),
+                                   len(counts["node_taxid"]), C.byref(out), C.byref(n)), "ku_report_multi")
+        s = C.string_at(out, n.value).decode()
+        lib().ku_free(out)
+        return s
     _chk(lib().ku_report(tax.h, counts_path.encode() if counts_path else None, _p(counts["slot_taxid"], u32p),
                          _p(counts["n_kmers"], u64p), _p(regs, u8p), len(counts["slot_taxid"]),
                          _p(counts["node_taxid"], u32p), _p(counts["n_reads"], u64p), len(counts["node_taxid"]),

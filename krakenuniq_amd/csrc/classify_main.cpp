@@ -319,22 +319,34 @@ int main(int argc, char **argv) {
   }
   if (dbs.empty()) { fprintf(stderr, "Missing mandatory option -d\n"); usage(EX_USAGE); }
   if (idxs.empty()) { fprintf(stderr, "Missing mandatory option -i\n"); usage(EX_USAGE); }
-  if (dbs.size() > 1 || idxs.size() > 1) die(EX_SOFTWARE, "hierarchical multi-database classification is not built into the MI355X classify");
+  if (dbs.size() != idxs.size()) die(EX_USAGE, "every -d needs its -i (%zu databases, %zu indexes)", dbs.size(), idxs.size());
+  if (dbs.size() > 8) die(EX_SOFTWARE, "at most 8 databases");
   if (optind == argc && !populate) fprintf(stderr, "No sequence data files specified\n");
   if (taxdb.empty()) { fprintf(stderr, "TaxDB argument is required!\n"); return 1; }  // src/classify.cpp:221-222
 
-  fprintf(stderr, " Database %s\n", dbs[0].c_str());
-  ku_db *db = nullptr;
-  KU_CHECK(ku_db_open(dbs[0].c_str(), idxs[0].c_str(), &db));
+  // hierarchical run: the databases are searched in command-line order (src/classify.cpp:163-177,928-936)
+  std::vector<ku_db *> db_handles(dbs.size(), nullptr);
   ku_db_info info;
-  KU_CHECK(ku_db_get_info(db, &info));
-  fprintf(stderr, "Loaded database with %" PRIu64 " keys with k of %u [val_len 4, key_len %u].\n", info.key_ct, info.k, info.key_len);
+  for (size_t i = 0; i < dbs.size(); ++i) {
+    fprintf(stderr, " Database %s\n", dbs[i].c_str());
+    KU_CHECK(ku_db_open(dbs[i].c_str(), idxs[i].c_str(), &db_handles[i]));
+    ku_db_info inf;
+    KU_CHECK(ku_db_get_info(db_handles[i], &inf));
+    fprintf(stderr, "Loaded database with %" PRIu64 " keys with k of %u [val_len 4, key_len %u].\n", inf.key_ct, inf.k, inf.key_len);
+    if (i == 0) info = inf;
+    else if (inf.k != info.k) {  // src/classify.cpp:199-208
+      fprintf(stderr, "Different k-mer sizes in databases 1 and %zu: %i vs %i!\n", i + 1, (int)info.k, (int)inf.k);
+      return 1;
+    }
+  }
+  ku_db *db = db_handles[0];
   ku_tax *tax = nullptr;
   KU_CHECK(ku_tax_open(taxdb.c_str(), &tax));
   ku_ctx *ctx = nullptr;
   const char *dev_env = getenv("KU_DEVICE");
   KU_CHECK(ku_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx));
   KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
+  for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
   KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
 
   Sink s_kraken, s_cls, s_ucls;
@@ -488,22 +500,28 @@ int main(int argc, char **argv) {
   if (!report_out.empty() && report_out != "off") {
     gettimeofday(&tv1, nullptr);
     fprintf(stderr, "Writing report file to %s  ..\n", report_out.c_str());
-    // database.kdb.counts: regenerate when missing or empty (src/classify.cpp:263-285)
-    const std::string cname = dbs[0] + ".counts";
-    bool good = false;
-    if (FILE *cf = fopen(cname.c_str(), "r")) { good = fgetc(cf) != EOF; fclose(cf); if (!good) fprintf(stderr, "Kmer counts file is empty - trying to regenerate ...\n"); }
-    if (!good) {
-      fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
-      uint64_t nc = 0;
-      KU_CHECK(ku_ctx_count_taxons(ctx, nullptr, nullptr, &nc));
-      std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
-      uint64_t cap = nc;
-      KU_CHECK(ku_ctx_count_taxons(ctx, ct.data(), cc.data(), &cap));
-      FILE *cf = fopen(cname.c_str(), "w");
-      if (!cf) die(EX_OSERR, "can't write %s", cname.c_str());
-      for (uint64_t i = 0; i < cap; ++i) fprintf(cf, "%u\t%" PRIu64 "\n", ct[i], cc[i]);
-      fclose(cf);
+    // database.kdb.counts, one per database: regenerate when missing or empty (src/classify.cpp:263-285)
+    std::vector<std::string> cnames;
+    for (size_t di = 0; di < dbs.size(); ++di) {
+      const std::string cname = dbs[di] + ".counts";
+      cnames.push_back(cname);
+      bool good = false;
+      if (FILE *cf = fopen(cname.c_str(), "r")) { good = fgetc(cf) != EOF; fclose(cf); if (!good) fprintf(stderr, "Kmer counts file is empty - trying to regenerate ...\n"); }
+      if (!good) {
+        fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
+        uint64_t nc = 0;
+        KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, nullptr, nullptr, &nc));
+        std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
+        uint64_t cap = nc;
+        KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, ct.data(), cc.data(), &cap));
+        FILE *cf = fopen(cname.c_str(), "w");
+        if (!cf) die(EX_OSERR, "can't write %s", cname.c_str());
+        for (uint64_t i = 0; i < cap; ++i) fprintf(cf, "%u\t%" PRIu64 "\n", ct[i], cc[i]);
+        fclose(cf);
+      }
     }
+    std::vector<const char *> cpaths;
+    for (const std::string &c : cnames) cpaths.push_back(c.c_str());
     ku_counts_dims d;
     KU_CHECK(ku_counts_dims_get(ctx, &d));
     std::vector<uint32_t> st(d.n_slots), ntx(d.n_nodes);
@@ -511,7 +529,8 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> regs(d.n_slots * (size_t)KU_HLL_M);
     KU_CHECK(ku_counts_export(ctx, st.data(), nk.data(), regs.data(), ntx.data(), nr.data()));
     char *text = nullptr; size_t tn = 0;
-    KU_CHECK(ku_report(tax, cname.c_str(), st.data(), nk.data(), regs.data(), d.n_slots, ntx.data(), nr.data(), d.n_nodes, &text, &tn));
+    KU_CHECK(ku_report_multi(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), regs.data(), d.n_slots, ntx.data(),
+                             nr.data(), d.n_nodes, &text, &tn));
     if (tn == 0) fprintf(stderr, "total number of reads is zero - not creating a report!\n");
     Sink rs;
     if (!rs.open(report_out, /*append=*/true)) die(EX_OSERR, "can't open %s", report_out.c_str());
@@ -524,6 +543,6 @@ int main(int argc, char **argv) {
   fprintf(stderr, "Finishing up ...\n");
   ku_ctx_destroy(ctx);
   ku_tax_close(tax);
-  ku_db_close(db);
+  for (ku_db *h : db_handles) ku_db_close(h);
   return 0;
 }

@@ -298,22 +298,28 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct ku_ctx {
-  int device = 0;
-  int n_cu = 256;
-  hipStream_t stream = nullptr;
-  // DB shard
-  bool db_loaded = false, db_owned = false, tax_set = false;
-  bool hash_layout = true;   // KU_LAYOUT=sorted keeps the on-disk order + binary search (A/B and fallback for HBM-tight shards)
-  double load_factor = 0.3;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
+// one resident database (shard): the 12-byte pairs until the taxonomy is set, the probe table afterwards
+struct DbStore {
+  bool db_owned = false, offsets_owned = false;
+  bool hash_layout = true;
   void *d_table = nullptr;
   uint64_t n_dup = 0;
   uint64_t table_lines = 0;
   uint32_t *d_pairs = nullptr;
   uint64_t *d_offsets = nullptr;
-  bool offsets_owned = false;
   KuDbDev db{};
   std::vector<uint32_t> values;  // ascending distinct non-zero raw taxids of the shard
+};
+
+struct ku_ctx {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  bool db_loaded = false, tax_set = false;
+  bool hash_layout = true;   // KU_LAYOUT=sorted keeps the on-disk order + binary search (A/B and fallback for HBM-tight shards)
+  double load_factor = 0.3;  // KU_LOAD_FACTOR: keys per bucket slot (9 slots per 128-byte line)
+  DbStore m;                   // the (first) database: the only one that may be a strict minimizer-range shard
+  std::vector<DbStore> extra;  // further whole databases of a hierarchical run, searched in order after `m`
   // taxonomy tables
   std::vector<uint32_t> h_node_taxid, h_slot_taxid;
   uint32_t *d_node_parent = nullptr, *d_node_slot = nullptr, *d_node_taxid = nullptr, *d_slot_node = nullptr,
@@ -357,13 +363,17 @@ extern "C" int ku_ctx_create(int device, ku_ctx **out) {
   return KU_OK;
 }
 
+static void store_free(DbStore &d) {
+  if (d.d_table) (void)hipFree(d.d_table);
+  if (d.db_owned && d.d_pairs) (void)hipFree(d.d_pairs);
+  if (d.offsets_owned && d.d_offsets) (void)hipFree(d.d_offsets);
+  d = DbStore{};
+}
 static void ctx_free_db(ku_ctx *ctx) {
-  if (ctx->d_table) (void)hipFree(ctx->d_table);
-  ctx->d_table = nullptr;
-  if (ctx->db_owned && ctx->d_pairs) (void)hipFree(ctx->d_pairs);
-  if (ctx->offsets_owned && ctx->d_offsets) (void)hipFree(ctx->d_offsets);
-  ctx->d_pairs = nullptr; ctx->d_offsets = nullptr;
-  ctx->db_loaded = ctx->db_owned = ctx->offsets_owned = false;
+  store_free(ctx->m);
+  for (DbStore &e : ctx->extra) store_free(e);
+  ctx->extra.clear();
+  ctx->db_loaded = false;
 }
 static void ctx_free_tax(ku_ctx *ctx) {
   for (uint32_t **p : {&ctx->d_node_parent, &ctx->d_node_slot, &ctx->d_node_taxid, &ctx->d_slot_node, &ctx->d_slot_taxid}) {
@@ -391,9 +401,9 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   delete ctx;
 }
 
-// distinct values of the resident shard via a 2^32-bit bitmap (512 MiB scratch)
-static int ctx_scan_values(ku_ctx *ctx) {
-  ctx->values.clear();
+// distinct values of a resident shard via a 2^32-bit bitmap (512 MiB scratch)
+static int store_scan_values(ku_ctx *ctx, DbStore &d) {
+  d.values.clear();
   uint32_t *d_bitmap = nullptr, *d_list = nullptr, *d_count = ctx->d_scalar;
   const uint32_t cap = 1u << 24;
   HIP_TRY(hipMalloc((void **)&d_bitmap, 1ull << 29));
@@ -403,36 +413,61 @@ static int ctx_scan_values(ku_ctx *ctx) {
   if (hipMemsetAsync(d_bitmap, 0, 1ull << 29, ctx->stream) != hipSuccess ||
       hipMemsetAsync(d_count, 0, 4, ctx->stream) != hipSuccess)
     st = fail(KU_EHIP, "memset failed");
-  if (st == KU_OK) st = ku_launch_mark_values(ctx->d_pairs, ctx->db.n_pairs, d_bitmap, ctx->stream);
+  if (st == KU_OK) st = ku_launch_mark_values(d.d_pairs, d.db.n_pairs, d_bitmap, ctx->stream);
   if (st == KU_OK) st = ku_launch_collect_values(d_bitmap, d_list, cap, d_count, ctx->stream);
   if (st == KU_OK && hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = fail(KU_EHIP, "memcpy failed");
   if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(KU_EHIP, "value scan kernel failed");
   if (st == KU_OK && count > cap) st = fail(KU_EUNSUP, "more than 2^24 distinct taxids in the database");
   if (st == KU_OK) {
-    ctx->values.resize(count);
-    if (count && hipMemcpy(ctx->values.data(), d_list, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) st = fail(KU_EHIP, "memcpy failed");
-    std::sort(ctx->values.begin(), ctx->values.end());
-    if (!ctx->values.empty() && ctx->values[0] == 0) ctx->values.erase(ctx->values.begin());
+    d.values.resize(count);
+    if (count && hipMemcpy(d.values.data(), d_list, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) st = fail(KU_EHIP, "memcpy failed");
+    std::sort(d.values.begin(), d.values.end());
+    if (!d.values.empty() && d.values[0] == 0) d.values.erase(d.values.begin());
   }
   (void)hipFree(d_bitmap);
   (void)hipFree(d_list);
   return st;
 }
 
-static void fill_db_dev(ku_ctx *ctx, uint64_t n_pairs, uint64_t pair_base, uint32_t k, uint32_t nt, uint32_t idx_type,
+static void fill_db_dev(DbStore &d, uint64_t n_pairs, uint64_t pair_base, uint32_t k, uint32_t nt, uint32_t idx_type,
                         uint64_t bin_lo, uint64_t bin_hi) {
-  ctx->db.pairs = ctx->d_pairs;
-  ctx->db.table = nullptr;
-  ctx->db.n_lines = 0;
-  ctx->db.offsets = ctx->d_offsets;
-  ctx->db.pair_base = pair_base;
-  ctx->db.n_pairs = n_pairs;
-  ctx->db.bin_lo = bin_lo;
-  ctx->db.bin_hi = bin_hi;
-  ctx->db.k = k;
-  ctx->db.nt = nt;
+  d.db.pairs = d.d_pairs;
+  d.db.table = nullptr;
+  d.db.n_lines = 0;
+  d.db.offsets = d.d_offsets;
+  d.db.pair_base = pair_base;
+  d.db.n_pairs = n_pairs;
+  d.db.bin_lo = bin_lo;
+  d.db.bin_hi = bin_hi;
+  d.db.k = k;
+  d.db.nt = nt;
   const uint64_t INDEX2_XOR_MASK = 0xe37e28c4271b5a2dULL;  // krakendb.cpp:45
-  ctx->db.xor_mask = idx_type == 1 ? 0u : (uint32_t)(INDEX2_XOR_MASK & ((1ull << (2 * nt)) - 1));
+  d.db.xor_mask = idx_type == 1 ? 0u : (uint32_t)(INDEX2_XOR_MASK & ((1ull << (2 * nt)) - 1));
+}
+
+// host KrakenDB bins [bin_lo, bin_hi) -> device pairs (12-byte form) + offsets slice
+static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
+  const uint64_t p0 = db->offsets[bin_lo], p1 = db->offsets[bin_hi], np = p1 - p0;
+  const uint32_t kl = db->info.key_len, ps = kl + 4;
+  HIP_TRY(hipMalloc((void **)&d.d_pairs, std::max<uint64_t>(np, 1) * 12));
+  d.db_owned = true;
+  if (kl == 8) {
+    if (np) HIP_TRY(hipMemcpy(d.d_pairs, db->pairs + p0 * 12, np * 12, hipMemcpyHostToDevice));
+  } else if (np) {
+    void *d_raw = nullptr;
+    HIP_TRY(hipMalloc(&d_raw, np * ps));
+    hipError_t e = hipMemcpy(d_raw, db->pairs + p0 * ps, np * ps, hipMemcpyHostToDevice);
+    int st = e == hipSuccess ? ku_launch_repack((const uint8_t *)d_raw, np, kl, d.d_pairs, ctx->stream) : KU_EHIP;
+    if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
+    (void)hipFree(d_raw);
+    if (st != KU_OK) return fail(st, "pair repack failed");
+  }
+  const uint64_t no = bin_hi - bin_lo + 1;
+  HIP_TRY(hipMalloc((void **)&d.d_offsets, no * 8));
+  d.offsets_owned = true;
+  HIP_TRY(hipMemcpy(d.d_offsets, db->offsets + bin_lo, no * 8, hipMemcpyHostToDevice));
+  fill_db_dev(d, np, p0, db->info.k, db->info.nt, db->info.idx_type, bin_lo, bin_hi);
+  return store_scan_values(ctx, d);
 }
 
 extern "C" int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
@@ -441,28 +476,26 @@ extern "C" int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uin
   KU_TRY(ctx_activate(ctx));
   ctx_free_tax(ctx);
   ctx_free_db(ctx);
-  const uint64_t p0 = db->offsets[bin_lo], p1 = db->offsets[bin_hi], np = p1 - p0;
-  const uint32_t kl = db->info.key_len, ps = kl + 4;
-  HIP_TRY(hipMalloc((void **)&ctx->d_pairs, std::max<uint64_t>(np, 1) * 12));
-  ctx->db_owned = true;
-  if (kl == 8) {
-    if (np) HIP_TRY(hipMemcpy(ctx->d_pairs, db->pairs + p0 * 12, np * 12, hipMemcpyHostToDevice));
-  } else if (np) {
-    void *d_raw = nullptr;
-    HIP_TRY(hipMalloc(&d_raw, np * ps));
-    hipError_t e = hipMemcpy(d_raw, db->pairs + p0 * ps, np * ps, hipMemcpyHostToDevice);
-    int st = e == hipSuccess ? ku_launch_repack((const uint8_t *)d_raw, np, kl, ctx->d_pairs, ctx->stream) : KU_EHIP;
-    if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
-    (void)hipFree(d_raw);
-    if (st != KU_OK) return fail(st, "pair repack failed");
-  }
-  const uint64_t no = bin_hi - bin_lo + 1;
-  HIP_TRY(hipMalloc((void **)&ctx->d_offsets, no * 8));
-  ctx->offsets_owned = true;
-  HIP_TRY(hipMemcpy(ctx->d_offsets, db->offsets + bin_lo, no * 8, hipMemcpyHostToDevice));
-  fill_db_dev(ctx, np, p0, db->info.k, db->info.nt, db->info.idx_type, bin_lo, bin_hi);
+  KU_TRY(store_upload(ctx, ctx->m, db, bin_lo, bin_hi));
   ctx->db_loaded = true;
-  return ctx_scan_values(ctx);
+  return KU_OK;
+}
+
+static bool store_whole(const DbStore &d) { return d.db.bin_lo == 0 && d.db.bin_hi == (1ull << (2 * d.db.nt)); }
+
+extern "C" int ku_ctx_add_db(ku_ctx *ctx, const ku_db *db) {
+  if (!ctx || !db) return fail(KU_EINVAL, "ku_ctx_add_db: null argument");
+  if (!ctx->db_loaded) return fail(KU_ESTATE, "load the first database before adding further ones");
+  if (ctx->tax_set) return fail(KU_ESTATE, "add every database before the taxonomy is set");
+  if (db->info.k != ctx->m.db.k)  // classify.cpp:199-208 "Different k-mer sizes in databases"
+    return fail(KU_EINVAL, "different k-mer sizes in the databases: " + std::to_string(ctx->m.db.k) + " vs " + std::to_string(db->info.k));
+  if (!store_whole(ctx->m)) return fail(KU_EUNSUP, "hierarchical multi-database runs need the first database resident as a whole");
+  if (ctx->extra.size() >= 7) return fail(KU_EUNSUP, "at most 8 databases");
+  KU_TRY(ctx_activate(ctx));
+  ctx->extra.emplace_back();
+  int st = store_upload(ctx, ctx->extra.back(), db, 0, db->info.n_bins);
+  if (st != KU_OK) { store_free(ctx->extra.back()); ctx->extra.pop_back(); }
+  return st;
 }
 
 extern "C" int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, const uint64_t *d_offsets, uint32_t k,
@@ -474,39 +507,95 @@ extern "C" int ku_ctx_adopt_db(ku_ctx *ctx, void *d_pairs, uint64_t n_pairs, con
   KU_TRY(ctx_activate(ctx));
   ctx_free_tax(ctx);
   ctx_free_db(ctx);
-  ctx->d_pairs = (uint32_t *)d_pairs;
-  ctx->d_offsets = const_cast<uint64_t *>(d_offsets);
+  ctx->m.d_pairs = (uint32_t *)d_pairs;
+  ctx->m.d_offsets = const_cast<uint64_t *>(d_offsets);
   uint64_t pair_base = 0;
   HIP_TRY(hipMemcpy(&pair_base, d_offsets, 8, hipMemcpyDeviceToHost));
-  fill_db_dev(ctx, n_pairs, pair_base, k, nt, idx_type, bin_lo, bin_hi);
+  fill_db_dev(ctx->m, n_pairs, pair_base, k, nt, idx_type, bin_lo, bin_hi);
   ctx->db_loaded = true;
-  return ctx_scan_values(ctx);
+  return store_scan_values(ctx, ctx->m);
 }
 
 extern "C" int ku_ctx_db_layout(ku_ctx *ctx, uint32_t *is_hash, uint64_t *resident_bytes) {
   if (!ctx) return fail(KU_EINVAL, "null context");
   if (!ctx->db_loaded) return fail(KU_ESTATE, "no database loaded");
-  const bool hash = ctx->db.table != nullptr;
+  const bool hash = ctx->m.db.table != nullptr;
   if (is_hash) *is_hash = hash ? 1u : 0u;
   if (resident_bytes)
-    *resident_bytes = (hash ? ctx->db.n_lines * 128 : ctx->db.n_pairs * 12) + (ctx->db.bin_hi - ctx->db.bin_lo + 1) * 8;
+    *resident_bytes = (hash ? ctx->m.db.n_lines * 128 : ctx->m.db.n_pairs * 12) + (ctx->m.db.bin_hi - ctx->m.db.bin_lo + 1) * 8;
   return KU_OK;
+}
+
+// ascending distinct non-zero taxids over every resident database
+static std::vector<uint32_t> ctx_all_values(const ku_ctx *ctx) {
+  std::vector<uint32_t> v(ctx->m.values);
+  for (const DbStore &e : ctx->extra) v.insert(v.end(), e.values.begin(), e.values.end());
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  return v;
 }
 
 extern "C" int ku_ctx_db_values(ku_ctx *ctx, uint32_t *out, uint64_t *n) {
   if (!ctx || !n) return fail(KU_EINVAL, "ku_ctx_db_values: null argument");
   if (!ctx->db_loaded) return fail(KU_ESTATE, "no database loaded");
+  const std::vector<uint32_t> v = ctx_all_values(ctx);
   if (out) {
-    if (*n < ctx->values.size()) return fail(KU_EINVAL, "output array too small");
-    if (!ctx->values.empty()) memcpy(out, ctx->values.data(), ctx->values.size() * 4);
+    if (*n < v.size()) return fail(KU_EINVAL, "output array too small");
+    if (!v.empty()) memcpy(out, v.data(), v.size() * 4);
   }
-  *n = ctx->values.size();
+  *n = v.size();
   return KU_OK;
 }
 
 template <typename T> static int upload(T **dst, const std::vector<T> &src) {
   HIP_TRY(hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
   if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return KU_OK;
+}
+
+// raw taxids -> slot ids in place, then the probe-table layout (needs ctx->tax / d_slot_taxid)
+static int store_finalize(ku_ctx *ctx, DbStore &d) {
+  HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, 4, ctx->stream));
+  KU_TRY(ku_launch_remap_values(d.d_pairs, d.db.n_pairs, ctx->d_slot_taxid, ctx->tax.n_slots, ctx->d_scalar, ctx->stream));
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, ctx->d_scalar, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (err) return fail(KU_EDATA, "internal: " + std::to_string(err) + " DB values missing from the slot table");
+  d.hash_layout = ctx->hash_layout;
+  if (d.hash_layout) {
+    // re-lay the shard out as the open-addressing table the lookup kernel probes (DESIGN.md 2); the 12-byte
+    // pairs are only the build input: owned copies are released, adopted buffers go back to the caller.
+    // preferred load factor first (fewest spilled buckets = fewest dependent round trips); denser tables when
+    // HBM is short; the sorted on-disk layout (no extra memory) as the last resort
+    uint64_t n_lines = 0;
+    for (double lf : {ctx->load_factor, 0.45, 0.6, 0.8}) {
+      if (lf < ctx->load_factor) continue;
+      n_lines = (uint64_t)((double)d.db.n_pairs / lf / 9.0) + 1;
+      if (n_lines >= (1ull << 32)) { n_lines = 0; continue; }  // ku_locus_line() reduces to 32 bits
+      if (hipMalloc(&d.d_table, n_lines * 128) == hipSuccess) { d.table_lines = n_lines; break; }
+      (void)hipGetLastError();
+      d.d_table = nullptr;
+      n_lines = 0;
+    }
+    if (!d.d_table) d.hash_layout = false;  // keep the sorted pairs resident and binary-search them
+  }
+  if (d.hash_layout) {
+    const uint64_t n_lines = d.table_lines;
+    unsigned long long *d_dup = (unsigned long long *)(ctx->d_scalar + 2);
+    HIP_TRY(hipMemsetAsync(d_dup, 0, 8, ctx->stream));
+    KU_TRY(ku_launch_build_table(d.d_pairs, d.db.n_pairs, d.d_table, n_lines, d.db.k, d.db.nt, d.db.xor_mask, d_dup,
+                                 ctx->stream));
+    unsigned long long dup = 0;
+    HIP_TRY(hipMemcpyAsync(&dup, d_dup, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    d.n_dup = dup;
+    d.db.table = (const uint4 *)d.d_table;
+    d.db.n_lines = n_lines;
+    if (d.db_owned) (void)hipFree(d.d_pairs);
+    d.d_pairs = nullptr;
+    d.db_owned = false;
+    d.db.pairs = nullptr;
+  }
   return KU_OK;
 }
 
@@ -522,10 +611,12 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
     for (uint64_t i = 0; i < n_values; ++i) if (all_values[i]) slots.push_back(all_values[i]);
     std::sort(slots.begin() + 1, slots.end());
     slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
-    if (!std::includes(slots.begin(), slots.end(), ctx->values.begin(), ctx->values.end()))
+    const std::vector<uint32_t> mine = ctx_all_values(ctx);
+    if (!std::includes(slots.begin(), slots.end(), mine.begin(), mine.end()))
       return fail(KU_EINVAL, "all_values does not cover this shard's values");
   } else {
-    slots.insert(slots.end(), ctx->values.begin(), ctx->values.end());
+    const std::vector<uint32_t> mine = ctx_all_values(ctx);
+    slots.insert(slots.end(), mine.begin(), mine.end());
   }
   // node universe: taxDB ids U DB values U {0, 1}, ascending => node 0 = taxid 0, node 1 = taxid 1
   std::vector<uint32_t> nodes(tax->ids);
@@ -561,47 +652,8 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
   ctx->tax.n_nodes = (uint32_t)nodes.size();
   ctx->tax.n_slots = (uint32_t)slots.size();
   ctx->tax.node_one = 1;
-  // raw taxid -> slot id, in place
-  HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, 4, ctx->stream));
-  KU_TRY(ku_launch_remap_values(ctx->d_pairs, ctx->db.n_pairs, ctx->d_slot_taxid, ctx->tax.n_slots, ctx->d_scalar, ctx->stream));
-  uint32_t err = 0;
-  HIP_TRY(hipMemcpyAsync(&err, ctx->d_scalar, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (err) return fail(KU_EDATA, "internal: " + std::to_string(err) + " DB values missing from the slot table");
-  if (ctx->hash_layout) {
-    // re-lay the shard out as the open-addressing table the lookup kernel probes (DESIGN.md 2); the 12-byte
-    // pairs are only the build input: owned copies are released, adopted buffers go back to the caller.
-    // preferred load factor first (fewest spilled buckets = fewest dependent round trips); denser tables when
-    // HBM is short; the sorted on-disk layout (no extra memory) as the last resort
-    uint64_t n_lines = 0;
-    for (double lf : {ctx->load_factor, 0.45, 0.6, 0.8}) {
-      if (lf < ctx->load_factor) continue;
-      n_lines = (uint64_t)((double)ctx->db.n_pairs / lf / 9.0) + 1;
-      if (n_lines >= (1ull << 32)) { n_lines = 0; continue; }  // ku_locus_line() reduces to 32 bits
-      if (hipMalloc(&ctx->d_table, n_lines * 128) == hipSuccess) { ctx->table_lines = n_lines; break; }
-      (void)hipGetLastError();
-      ctx->d_table = nullptr;
-      n_lines = 0;
-    }
-    if (!ctx->d_table) ctx->hash_layout = false;  // keep the sorted pairs resident and binary-search them
-  }
-  if (ctx->hash_layout) {
-    const uint64_t n_lines = ctx->table_lines;
-    unsigned long long *d_dup = (unsigned long long *)(ctx->d_scalar + 2);
-    HIP_TRY(hipMemsetAsync(d_dup, 0, 8, ctx->stream));
-    KU_TRY(ku_launch_build_table(ctx->d_pairs, ctx->db.n_pairs, ctx->d_table, n_lines, ctx->db.k, ctx->db.nt,
-                                 ctx->db.xor_mask, d_dup, ctx->stream));
-    unsigned long long dup = 0;
-    HIP_TRY(hipMemcpyAsync(&dup, d_dup, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->n_dup = dup;
-    ctx->db.table = (const uint4 *)ctx->d_table;
-    ctx->db.n_lines = n_lines;
-    if (ctx->db_owned) (void)hipFree(ctx->d_pairs);
-    ctx->d_pairs = nullptr;
-    ctx->db_owned = false;
-    ctx->db.pairs = nullptr;
-  }
+  KU_TRY(store_finalize(ctx, ctx->m));
+  for (DbStore &e : ctx->extra) KU_TRY(store_finalize(ctx, e));
   // per-taxon state
   HIP_TRY(hipMalloc((void **)&ctx->cnt.registers, (size_t)slots.size() * KU_HLL_M));
   HIP_TRY(hipMalloc((void **)&ctx->cnt.n_kmers, slots.size() * 8));
@@ -621,8 +673,14 @@ extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
 }
 
 extern "C" int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *counts, uint64_t *n) {
+  return ku_ctx_count_taxons_db(ctx, 0, taxids, counts, n);
+}
+
+extern "C" int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *taxids, uint64_t *counts, uint64_t *n) {
   if (!ctx || !n) return fail(KU_EINVAL, "ku_ctx_count_taxons: null argument");
   if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  if (db_index > ctx->extra.size()) return fail(KU_EINVAL, "database index out of range");
+  const DbStore &d = db_index ? ctx->extra[db_index - 1] : ctx->m;
   KU_TRY(ctx_activate(ctx));
   const uint32_t ns = ctx->tax.n_slots;
   unsigned long long *d_c = nullptr;
@@ -631,8 +689,8 @@ extern "C" int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *coun
   int st = KU_OK;
   if (hipMemsetAsync(d_c, 0, (size_t)ns * 8, ctx->stream) != hipSuccess) st = KU_EHIP;
   if (st == KU_OK)
-    st = ctx->db.table ? ku_launch_count_table(ctx->d_table, ctx->db.n_lines, d_c, ctx->stream)
-                       : ku_launch_count_slots(ctx->d_pairs, ctx->db.n_pairs, d_c, ns, ctx->stream);
+    st = d.db.table ? ku_launch_count_table(d.d_table, d.db.n_lines, d_c, ctx->stream)
+                    : ku_launch_count_slots(d.d_pairs, d.db.n_pairs, d_c, ns, ctx->stream);
   if (st == KU_OK && hipMemcpyAsync(h.data(), d_c, (size_t)ns * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = KU_EHIP;
   if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
   (void)hipFree(d_c);
@@ -664,8 +722,16 @@ extern "C" int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
   // quick mode counts only the scanned prefix of each read -> accounted in the resolve stage
   const bool counts = !(flags & (KU_F_NO_COUNTS | KU_F_QUICK));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  int st = ku_launch_lookup(ctx->db, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_taxa, counts, ctx->n_cu, s);
-  return st == KU_OK ? KU_OK : fail(st, "lookup kernel launch failed");
+  // hierarchical run: one pass per database in command-line order; later passes only search the positions that
+  // are still 0, the last one does the per-taxon accounting (classify.cpp:928-939)
+  const size_t nd = 1 + ctx->extra.size();
+  for (size_t i = 0; i < nd; ++i) {
+    const DbStore &d = i ? ctx->extra[i - 1] : ctx->m;
+    int st = ku_launch_lookup(d.db, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_taxa, counts && i + 1 == nd, i > 0,
+                              ctx->n_cu, s);
+    if (st != KU_OK) return fail(st, "lookup kernel launch failed");
+  }
+  return KU_OK;
 }
 
 extern "C" int ku_lookup_stats_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint64_t *stats_out,
@@ -675,7 +741,7 @@ extern "C" int ku_lookup_stats_device(ku_ctx *ctx, const void *d_seqs, uint64_t 
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   unsigned long long *d_stats = (unsigned long long *)(ctx->d_scalar + 8);  // 32 bytes at offset 32
   HIP_TRY(hipMemsetAsync(d_stats, 0, 32, s));
-  int st = ku_launch_lookup_stats(ctx->db, (const uint8_t *)d_seqs, n_bytes, d_stats, ctx->n_cu, s);
+  int st = ku_launch_lookup_stats(ctx->m.db, (const uint8_t *)d_seqs, n_bytes, d_stats, ctx->n_cu, s);
   if (st != KU_OK) return fail(st, "stats kernel launch failed");
   HIP_TRY(hipMemcpyAsync(stats_out, d_stats, 32, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -696,13 +762,13 @@ extern "C" int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t
     HIP_TRY(hipMemcpyAsync(&max_len, ctx->d_scalar + 4, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
-  uint64_t ws = (flags & KU_F_QUICK) ? 0 : ku_resolve_workspace_bytes(max_len, ctx->db.k, ctx->n_cu);
+  uint64_t ws = (flags & KU_F_QUICK) ? 0 : ku_resolve_workspace_bytes(max_len, ctx->m.db.k, ctx->n_cu);
   if (ws > ctx->b_ws.cap) {
     HIP_TRY(hipStreamSynchronize(s));
     if (ctx->b_ws.reserve(ws) != KU_OK) return fail(KU_ENOMEM, "resolve workspace allocation failed");
   }
   if (ws) HIP_TRY(hipMemsetAsync(ctx->b_ws.p, 0, ws, s));
-  int st = ku_launch_resolve(ctx->db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, flags,
+  int st = ku_launch_resolve(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, flags,
                              opts ? opts->min_hits : 1, max_len, d_calls, d_taxa, d_hits, ctx->b_ws.p, ctx->b_ws.cap,
                              ctx->n_cu, s);
   return st == KU_OK ? KU_OK : fail(st, "resolve kernel launch failed");
@@ -714,7 +780,7 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
   KU_TRY(check_ready(ctx));
   const uint32_t flags = opts ? opts->flags : 0;
   // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
-  const uint32_t short_max = getenv("KU_NO_FUSED") ? 0 : ku_short_max_kmers(ctx->db);
+  const uint32_t short_max = (getenv("KU_NO_FUSED") || !ctx->extra.empty()) ? 0 : ku_short_max_kmers(ctx->m.db);
   if (short_max && !(flags & KU_F_QUICK) && n_reads) {
     if (!d_seqs || !d_seq_off || !d_seq_len || !d_calls || !d_taxa) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -724,9 +790,9 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
       HIP_TRY(hipMemcpyAsync(&max_len, ctx->d_scalar + 4, 4, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
     }
-    const uint32_t max_n = max_len >= ctx->db.k ? max_len - ctx->db.k + 1 : 0;
+    const uint32_t max_n = max_len >= ctx->m.db.k ? max_len - ctx->m.db.k + 1 : 0;
     if (max_n <= short_max) {
-      int st = ku_launch_classify_short(ctx->db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len,
+      int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len,
                                         n_reads, max_n, flags, d_calls, d_taxa, d_hits, ctx->n_cu, s);
       return st == KU_OK ? KU_OK : fail(st, "fused short-read kernel launch failed");
     }
@@ -799,7 +865,7 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
     HIP_TRY(hipMemsetAsync(ctx->b_roff.p, 0, n_reads * 8, s));
     HIP_TRY(hipMemsetAsync(ctx->b_rcnt.p, 0, n_reads * 4, s));
   } else {
-    KU_TRY(ku_launch_rle((const uint32_t *)ctx->b_taxa.p, ctx->db.k, (const uint64_t *)ctx->b_off.p,
+    KU_TRY(ku_launch_rle((const uint32_t *)ctx->b_taxa.p, ctx->m.db.k, (const uint64_t *)ctx->b_off.p,
                          (const uint32_t *)ctx->b_len.p, n_reads, ctx->b_runs.p, runs_cap, d_counter,
                          (uint64_t *)ctx->b_roff.p, (uint32_t *)ctx->b_rcnt.p, ctx->n_cu, s));
   }

@@ -207,7 +207,15 @@ struct Sb {
 extern "C" int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_taxid, const uint64_t *n_kmers,
                          const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads,
                          uint64_t n_nodes, char **out, size_t *out_len) {
-  if (!tax || !out || !out_len || (n_slots && (!slot_taxid || !n_kmers || !registers)) || (n_nodes && (!node_taxid || !n_reads))) {
+  return ku_report_multi(tax, counts_path ? &counts_path : nullptr, counts_path ? 1u : 0u, slot_taxid, n_kmers, registers,
+                         n_slots, node_taxid, n_reads, n_nodes, out, out_len);
+}
+
+extern "C" int ku_report_multi(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths,
+                               const uint32_t *slot_taxid, const uint64_t *n_kmers, const uint8_t *registers,
+                               uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes,
+                               char **out, size_t *out_len) {
+  if (!tax || !out || (n_paths && !counts_paths) || !out_len || (n_slots && (!slot_taxid || !n_kmers || !registers)) || (n_nodes && (!node_taxid || !n_reads))) {
     ku_set_error("ku_report: null argument");
     return KU_EINVAL;
   }
@@ -228,7 +236,9 @@ extern "C" int ku_report(const ku_tax *tax, const char *counts_path, const uint3
     gsize[it->second] += size;
     for (int64_t q = tax->parent_row(it->second); q >= 0; q = tax->parent_row((size_t)q)) gchild[q] += size;
   };
-  if (counts_path) {
+  for (uint32_t pi = 0; pi < n_paths; ++pi) {  // one counts file per database, in order (classify.cpp:263-285)
+    const char *counts_path = counts_paths[pi];
+    if (!counts_path) continue;
     FILE *f = fopen(counts_path, "r");
     if (!f) { ku_set_error(std::string("unable to open file ") + counts_path); return KU_ENOINPUT; }
     std::string data;

@@ -42,7 +42,10 @@
 // LAYOUT 0: sorted bins + binary search (the on-disk order); LAYOUT 1: hash table.
 // SHARDED: the context owns a strict sub-range of the minimizer bins, so the minimizer of
 // every k-mer is needed for the ownership test (always needed by LAYOUT 0 and MODE 2).
-template <int MODE, int LAYOUT, bool SHARDED>
+// PRIOR: a later database of a hierarchical run (classify.cpp:928-936): taxa[] holds the slots found in the earlier
+// databases; positions that already have one are not searched again, and the accounting (MODE 1, last database
+// only) books the k-mer under whichever slot it ends up with.
+template <int MODE, int LAYOUT, bool SHARDED, bool PRIOR>
 __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
                                                                const uint8_t *__restrict__ seqs,
                                                                uint64_t n_bytes, uint32_t *__restrict__ taxa,
@@ -130,6 +133,10 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         foreign[j] = false;
       }
     }
+
+    uint32_t prior[KU_ITEMS];  // PRIOR: slot from an earlier database (0 = not found yet)
+#pragma unroll
+    for (int j = 0; j < KU_ITEMS; ++j) prior[j] = (PRIOR && ok[j]) ? taxa[tile0 + (uint64_t)j * KU_THREADS + tid] : 0u;
 
     // ---- stage 3: minimizer = sliding-window minimum of the m-mer values; ownership; idx fetch
     uint32_t n_b[KU_ITEMS];          // bin size (LAYOUT 0 / MODE 2)
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         lp[j] = tab + ku_locus_line(ok[j] ? locus[j] : 0, db.n_lines) * KU_LINE_DWORDS;
         tag[j] = ku_table_tag(hh[j]);
         slot[j] = 0;
-        act[j] = ok[j] && !(ablate & 1u);
+        act[j] = ok[j] && !(ablate & 1u) && !(PRIOR && prior[j]);
       }
       // round trip 1: the 20-byte bucket headers of all items
 #pragma unroll
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         lo[j] = 0;
-        hi[j] = (ablate & 1u) ? 0 : n_b[j];
+        hi[j] = ((ablate & 1u) || (PRIOR && prior[j])) ? 0 : n_b[j];
         slot[j] = 0;
         if (DO_COUNTS) hh[j] = ku_fmix64(canon[j]);
       }
@@ -365,6 +372,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
 #pragma unroll
     for (int j = 0; j < KU_ITEMS; ++j) {
       uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
+      if (PRIOR && prior[j]) slot[j] = prior[j];
       if (DO_COUNTS && ok[j]) {
         if (!(ablate & 2u)) ku_hll_update(cnt.registers, slot[j], hh[j]);
         if (!(ablate & 4u)) ku_ct_add(s_ctk, s_ctc, &s_ctu, slot[j], 1, cnt.n_kmers);
@@ -397,19 +405,23 @@ static unsigned ku_lookup_grid(uint64_t n_bytes, int n_cu) {
 }
 
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
-                     uint32_t *d_taxa, bool do_counts, int n_cu, hipStream_t stream) {
+                     uint32_t *d_taxa, bool do_counts, bool prior, int n_cu, hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
   const dim3 grid(ku_lookup_grid(n_bytes, n_cu)), block(KU_THREADS);
   unsigned long long *ns = nullptr;
   const bool sharded = !(db.bin_lo == 0 && db.bin_hi == (1ull << (2 * db.nt)));
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
-#define KU_LAUNCH(M, L, S) hipLaunchKernelGGL((ku_lookup_kernel<M, L, S>), grid, block, 0, stream, db, cnt, d_seqs, n_bytes, d_taxa, ns, ablate)
-  if (db.table) {
-    if (do_counts) { if (sharded) KU_LAUNCH(1, 1, true); else KU_LAUNCH(1, 1, false); }
-    else { if (sharded) KU_LAUNCH(0, 1, true); else KU_LAUNCH(0, 1, false); }
+  if (prior && sharded) return KU_EUNSUP;
+#define KU_LAUNCH(M, L, S, P) hipLaunchKernelGGL((ku_lookup_kernel<M, L, S, P>), grid, block, 0, stream, db, cnt, d_seqs, n_bytes, d_taxa, ns, ablate)
+  if (prior) {
+    if (db.table) { if (do_counts) KU_LAUNCH(1, 1, false, true); else KU_LAUNCH(0, 1, false, true); }
+    else { if (do_counts) KU_LAUNCH(1, 0, true, true); else KU_LAUNCH(0, 0, true, true); }
+  } else if (db.table) {
+    if (do_counts) { if (sharded) KU_LAUNCH(1, 1, true, false); else KU_LAUNCH(1, 1, false, false); }
+    else { if (sharded) KU_LAUNCH(0, 1, true, false); else KU_LAUNCH(0, 1, false, false); }
   } else {
-    if (do_counts) KU_LAUNCH(1, 0, true); else KU_LAUNCH(0, 0, true);
+    if (do_counts) KU_LAUNCH(1, 0, true, false); else KU_LAUNCH(0, 0, true, false);
   }
 #undef KU_LAUNCH
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
@@ -418,7 +430,7 @@ int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d
 int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
                            int n_cu, hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
-  hipLaunchKernelGGL((ku_lookup_kernel<2, 0, true>), dim3(ku_lookup_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream,
+  hipLaunchKernelGGL((ku_lookup_kernel<2, 0, true, false>), dim3(ku_lookup_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream,
                      db, KuCountsDev{}, d_seqs, n_bytes, (uint32_t *)nullptr, d_stats, 0u);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

@@ -734,10 +734,11 @@ static void cmap_merge(ko_cmap *dst, const ko_cmap *src) {
 }
 
 /* one read; counts may be NULL (pure lookup) */
-static uint32_t classify_one(const ko_db *db, const ko_tax *tax, const char *seq, size_t len, int quick,
-                             uint32_t min_hits, uint32_t *taxa_out, uint8_t *ambig_out, size_t *n_out,
+#define KO_MAX_DBS 8
+static uint32_t classify_one(const ko_db *const *dbs, int n_dbs, const ko_tax *tax, const char *seq, size_t len,
+                             int quick, uint32_t min_hits, uint32_t *taxa_out, uint8_t *ambig_out, size_t *n_out,
                              uint32_t *hits_out, ko_cmap *counts, u32map *hit_counts) {
-  const int k = db->k;
+  const int k = dbs[0]->k; /* classify.cpp:913: KrakenDatabases[0]->get_k(), all k equal (:199-208) */
   size_t n = 0;
   uint32_t taxon = 0, hits = 0;
   u32map_clear(hit_counts);
@@ -745,7 +746,8 @@ static uint32_t classify_one(const ko_db *db, const ko_tax *tax, const char *seq
     const uint64_t kmer_mask = ~0ULL >> (64 - 2 * k);
     const uint32_t mini_mask = ~0U >> (32 - k);
     uint64_t kmer = 0; uint32_t ambig = 0;
-    ko_qstate st = {0, 1, 0}; /* classify.cpp:116 */
+    ko_qstate st[KO_MAX_DBS]; /* classify.cpp:116,911: one cached bin per database */
+    for (int d = 0; d < n_dbs; ++d) { st[d].bin = 0; st[d].min = 1; st[d].max = 0; }
     for (size_t i = 0; i < len; ++i) {
       kmer <<= 2; ambig <<= 1;
       switch (seq[i]) {
@@ -764,8 +766,10 @@ static uint32_t classify_one(const ko_db *db, const ko_tax *tax, const char *seq
       } else {
         uint64_t canon = ko_canonical(kmer, k);
         if (ambig_out) ambig_out[n] = 0;
-        int64_t pos = db_query_cached(db, canon, &st);
-        if (pos >= 0) taxon = db_val_at(db, pos);
+        for (int d = 0; d < n_dbs; ++d) { /* classify.cpp:928-936: the first database with the k-mer wins */
+          int64_t pos = db_query_cached(dbs[d], canon, &st[d]);
+          if (pos >= 0) { taxon = db_val_at(dbs[d], pos); break; }
+        }
         if (counts) { /* classify.cpp:939: also when taxon == 0 */
           ko_counts *c = cmap_get(counts, taxon);
           ++c->n_kmers;
@@ -802,7 +806,7 @@ uint32_t ko_classify_read(const ko_db *db, const ko_tax *tax, const char *seq, s
                           uint32_t min_hits, uint32_t *taxa_out, uint8_t *ambig_out, size_t *n_out,
                           uint32_t *hits_out) {
   u32map hc; u32map_init(&hc, 64);
-  uint32_t call = classify_one(db, tax, seq, len, quick, min_hits, taxa_out, ambig_out, n_out, hits_out,
+  uint32_t call = classify_one(&db, 1, tax, seq, len, quick, min_hits, taxa_out, ambig_out, n_out, hits_out,
                                NULL, &hc);
   u32map_free(&hc);
   return call;
@@ -824,7 +828,7 @@ size_t ko_hitlist_string(const uint32_t *taxa, const uint8_t *ambig, size_t n, c
 }
 
 struct ko_run {
-  const ko_db *db; const ko_tax *tax;
+  const ko_db *dbs[KO_MAX_DBS]; int n_dbs; const ko_tax *tax;
   uint64_t unit_nt; int quick; uint32_t min_hits; int threads;
   ko_cmap global;
   uint64_t total_sequences, total_classified;
@@ -835,10 +839,15 @@ struct ko_run {
 ko_run *ko_run_new(const ko_db *db, const ko_tax *tax, uint64_t work_unit_nt, int quick, uint32_t min_hits,
                    int threads) {
   ko_run *r = (ko_run *)calloc(1, sizeof(*r));
-  r->db = db; r->tax = tax; r->unit_nt = work_unit_nt ? work_unit_nt : 500000; /* classify.cpp:38 */
+  r->dbs[0] = db; r->n_dbs = 1; r->tax = tax; r->unit_nt = work_unit_nt ? work_unit_nt : 500000; /* classify.cpp:38 */
   r->quick = quick; r->min_hits = min_hits ? min_hits : 1; r->threads = threads > 0 ? threads : 1;
   cmap_init(&r->global);
   return r;
+}
+int ko_run_add_db(ko_run *r, const ko_db *db) { /* a further -d/-i pair, searched after the earlier ones */
+  if (r->n_dbs >= KO_MAX_DBS || db->k != r->dbs[0]->k) return -1;
+  r->dbs[r->n_dbs++] = db;
+  return 0;
 }
 void ko_run_free(ko_run *r) { if (!r) return; cmap_free(&r->global); free(r->order); free(r); }
 
@@ -871,7 +880,7 @@ void ko_run_classify(ko_run *r, const char *seqs, const uint64_t *off, const uin
       uint64_t ncls = 0;
       for (size_t j = ustart[u]; j < ustart[u + 1]; ++j) {
         size_t n = 0; uint32_t h = 0;
-        uint32_t call = classify_one(r->db, r->tax, seqs + off[j], len[j], r->quick, r->min_hits,
+        uint32_t call = classify_one(r->dbs, r->n_dbs, r->tax, seqs + off[j], len[j], r->quick, r->min_hits,
                                      taxa_flat ? taxa_flat + taxa_off[j] : NULL,
                                      ambig_flat ? ambig_flat + taxa_off[j] : NULL, &n, &h, &local, &hc);
         if (calls) calls[j] = call;
@@ -1034,8 +1043,12 @@ char *ko_run_report(const ko_run *r, const char *taxdb_path, const char *counts_
   /* taxdb.hpp:867-885 readGenomeSizes: "while(!eof) { in >> id >> size; set(id,size); }"
    * -> when the file ends with whitespace after the last number the failed
    * extraction leaves (id,size) unchanged and the LAST pair is applied twice. */
-  if (counts_path) {
-    FILE *f = fopen(counts_path, "r");
+  /* several databases: one counts file each, read in order (classify.cpp:263-285); here '\n'-separated */
+  char *paths = counts_path ? strdup(counts_path) : NULL;
+  for (char *one = paths; one && *one;) {
+    char *nl = strchr(one, '\n');
+    if (nl) *nl = 0;
+    FILE *f = fopen(one, "r");
     if (f) {
       fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
       char *buf = (char *)malloc((size_t)sz + 1);
@@ -1061,7 +1074,9 @@ char *ko_run_report(const ko_run *r, const char *taxdb_path, const char *counts_
       }
       free(buf);
     }
+    one = nl ? nl + 1 : NULL;
   }
+  free(paths);
   /* taxdb.hpp:928-973: every taxon with counts contributes to itself and all ancestors */
   for (size_t i = 0; i < r->global.n; ++i) {
     int64_t row = tax_row(t, r->global.taxids[i]);

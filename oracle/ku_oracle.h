@@ -93,6 +93,7 @@ typedef struct ko_run ko_run;
 /* work_unit_nt: classify.cpp:38 (500000). threads>1 uses OpenMP over work units. */
 ko_run *ko_run_new(const ko_db *db, const ko_tax *tax, uint64_t work_unit_nt, int quick,
                    uint32_t min_hits, int threads);
+int ko_run_add_db(ko_run *r, const ko_db *db); /* hierarchical multi-DB (classify.cpp:928-936); -1: k differs / too many */
 void ko_run_free(ko_run *r);
 /* Classify n_reads reads (read i = seqs[off[i] .. off[i]+len[i])) emulating
  * process_file's work-unit partition (classify.cpp:487-564).  Optional flat

@@ -71,6 +71,7 @@ def lib():
                                           u32p, u8p, C.POINTER(C.c_size_t), u32p]),
         "ko_hitlist_string": (C.c_size_t, [u32p, u8p, C.c_size_t, C.c_char_p]),
         "ko_run_new": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_int]),
+        "ko_run_add_db": (C.c_int, [C.c_void_p, C.c_void_p]),
         "ko_run_free": (None, [C.c_void_p]),
         "ko_run_classify": (None, [C.c_void_p, C.c_void_p, u64p, u32p, C.c_size_t, u32p, u32p, u8p, u64p, u32p,
                                    u32p]),
@@ -222,10 +223,14 @@ def pack_reads(seqs):
 class Run:
     """One classify run (per-read results + per-taxon counts + report)."""
 
-    def __init__(self, db: Db, tax: Tax, work_unit_nt=500000, quick=False, min_hits=1, threads=1):
+    def __init__(self, db: Db, tax: Tax, work_unit_nt=500000, quick=False, min_hits=1, threads=1, extra_dbs=()):
         self.db, self.tax = db, tax
         self.h = lib().ko_run_new(db.h, tax.h, work_unit_nt, int(quick), min_hits, threads)
         self.quick = quick
+        self.extra_dbs = list(extra_dbs)  # further -d/-i pairs, searched in order after `db`
+        for e in self.extra_dbs:
+            if lib().ko_run_add_db(self.h, e.h) != 0:
+                raise ValueError("databases must share k (at most 8)")
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

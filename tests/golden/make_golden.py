@@ -20,6 +20,7 @@ Fixtures:
   f2/   edge FASTA (short / N / empty / lower-case / multi-line) + outputs
   f4/   paired FASTQs -> read_merger.pl -> merged.fa + outputs
   f7/   legacy KRAKIDX (type 1) index variant of f1 + outputs
+  f8/   second database + reads for hierarchical multi-database runs (both orders, quick mode)
   kat.json  per-function known-answer vectors from ref_kat
 """
 import json
@@ -179,6 +180,39 @@ def make_f7(f1):
     return d
 
 
+def make_f8(f1, genomes):
+    """Second database for hierarchical runs (classify -d A -i A.idx -d B -i B.idx, classify.cpp:928-936): other
+    minimizer length, a new genome under genus 3, and a third of f1's species-4 k-mers re-labelled species 6 so
+    that the database order decides their taxon."""
+    d = os.path.join(HERE, "f8")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    rng = np.random.default_rng(23)
+    k1, v1, _, k, _, _ = synth.read_db(f1)
+    g_new = synth.procedural_genome(7, 55, 2500)
+    new = np.setdiff1d(np.unique(synth.canonical(synth.kmers_forward(g_new, K), K)), k1)
+    shared = k1[v1 == 4][::3]
+    kmers = np.concatenate([new, shared])
+    vals = np.concatenate([np.full(len(new), 3, np.uint32), np.full(len(shared), 6, np.uint32)])
+    perm = rng.permutation(len(kmers))
+    synth.write_jdb(os.path.join(d, "database.jdb"), kmers[perm], vals[perm], K)
+    run([os.path.join(REF, "db_sort"), "-n", "6", "-d", f"{d}/database.jdb", "-o", f"{d}/database.kdb",
+         "-i", f"{d}/database.idx"])
+    os.remove(os.path.join(d, "database.jdb"))
+    src_genomes = {4: genomes[4], 6: genomes[6], 3: g_new}
+    reads, src = synth.sample_reads(src_genomes, 300, 150, rng, frac_random=0.2)
+    synth.write_fastq(os.path.join(d, "reads.fq"), reads, [f"m{i}_t{t}" for i, t in enumerate(src)])
+    a = ["-d", f"{f1}/database.kdb", "-i", f"{f1}/database.idx"]
+    b = ["-d", f"{d}/database.kdb", "-i", f"{d}/database.idx"]
+    cl = [os.path.join(REF, "classify"), "-a", f"{f1}/taxDB"]
+    rd = [f"{d}/reads.fq"]
+    run(cl + a + b + ["-o", f"{d}/out.tsv", "-r", f"{d}/report.tsv"] + rd)          # writes f8's .counts too
+    run(cl + b + a + ["-o", f"{d}/out_swapped.tsv", "-r", f"{d}/report_swapped.tsv"] + rd)
+    run(cl + a + b + ["-q", "-m", "2", "-o", f"{d}/out_quick.tsv"] + rd)
+    assert open(f"{d}/out.tsv", "rb").read() != open(f"{d}/out_swapped.tsv", "rb").read()
+    return d
+
+
 class Kat:
     def __init__(self):
         self.p = subprocess.Popen([os.path.join(REF, "ref_kat")], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
@@ -321,7 +355,12 @@ def make_kat(f1):
 def main():
     if not os.path.exists(os.path.join(REF, "classify")):
         raise SystemExit("build the reference first: make -C oracle ref")
+    if sys.argv[1:] == ["f8"]:  # add the multi-database fixture without regenerating the others
+        g4 = synth.procedural_genome(7, 4, 3000)
+        make_f8(os.path.join(HERE, "f1"), {4: g4, 6: synth.procedural_genome(7, 6, 3000)})
+        return
     f1, genomes = make_f1()
+    make_f8(f1, genomes)
     make_f2(f1)
     make_f4(f1, genomes)
     make_f7(f1)

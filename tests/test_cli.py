@@ -35,7 +35,7 @@ def test_usage_and_exit_codes():
     r = run(["-d", f"{F1}/taxDB", "-i", f"{F1}/database.idx", "-a", f"{F1}/taxDB", "r.fq"])
     assert r.returncode == 65  # EX_DATAERR: not a JFLISTDN file
     assert run(DB + ["-I", "uid.map", "r.fq"]).returncode == 70
-    assert run(DB + ["-d", "second.kdb", "r.fq"]).returncode == 70
+    assert run(DB + ["-d", "second.kdb", "r.fq"]).returncode == 64  # a -d without its -i
 
 
 @pytest.mark.gpu
@@ -101,3 +101,35 @@ def test_fasta_paired_edge_and_read_files(tmp_path):
     want_c = "".join("\n".join(src[i:i + 4]) + "\n" for i in range(0, len(src) - 1, 4) if calls[src[i][1:]] == "C")
     want_u = "".join("\n".join(src[i:i + 4]) + "\n" for i in range(0, len(src) - 1, 4) if calls[src[i][1:]] == "U")
     assert c.read_text() == want_c and u.read_text() == want_u
+
+
+@pytest.mark.gpu
+def test_hierarchical_multi_db_run(tmp_path):
+    """-d A -i A.idx -d B -i B.idx (classify.cpp:163-177,928-936): both database orders against the reference's outputs"""
+    g = os.path.join(ROOT, "tests", "golden")
+    dirs = {}
+    for name in ("f1", "f8"):  # private copies: the CLI writes database.kdb.counts next to each database
+        d = tmp_path / name
+        d.mkdir()
+        for fn in ("database.kdb", "database.idx"):
+            (d / fn).write_bytes(open(f"{g}/{name}/{fn}", "rb").read())
+        dirs[name] = d
+    a = ["-d", f"{dirs['f1']}/database.kdb", "-i", f"{dirs['f1']}/database.idx"]
+    b = ["-d", f"{dirs['f8']}/database.kdb", "-i", f"{dirs['f8']}/database.idx"]
+    common = ["-a", f"{F1}/taxDB", f"{g}/f8/reads.fq"]
+    for first, second, tag in ((a, b, ""), (b, a, "_swapped")):
+        out, rep = tmp_path / f"out{tag}.tsv", tmp_path / f"rep{tag}.tsv"
+        r = run(first + second + ["-o", str(out), "-r", str(rep)] + common)
+        assert r.returncode == 0, r.stderr.decode()
+        assert out.read_bytes() == open(f"{g}/f8/out{tag}.tsv", "rb").read()
+        ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{g}/f8/report{tag}.tsv").read().strip().split("\n")}
+        got = rep.read_text().strip().split("\n")
+        assert len(got) == len(ref)
+        for ln in got:
+            f = ln.split("\t")
+            assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
+            if f[3] != "kmers":
+                assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
+    for name in ("f1", "f8"):
+        assert (dirs[name] / "database.kdb.counts").read_text() == open(f"{g}/{name}/database.kdb.counts").read()
+    assert run(a + b + ["-q", "-m", "2"] + common).stdout == open(f"{g}/f8/out_quick.tsv", "rb").read()

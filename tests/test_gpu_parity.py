@@ -301,6 +301,61 @@ def test_rle_long_reads_and_empty_batch(f1):
     ctx.reset_counts()
 
 
+@pytest.mark.parametrize("order,layout", [("", "hash"), ("_swapped", "hash"), ("", "sorted")])
+def test_f8_hierarchical_multi_db(golden, f1, monkeypatch, order, layout):
+    """classify -d A -d B (classify.cpp:928-936): one lookup pass per database, first hit wins, accounted once"""
+    if layout == "sorted":
+        monkeypatch.setenv("KU_LAYOUT", "sorted")
+    d8, d1 = os.path.join(golden, "f8"), f1["dir"]
+    dirs = [d1, d8] if order == "" else [d8, d1]
+    cdbs = [capi.Db(f"{x}/database.kdb", f"{x}/database.idx") for x in dirs]
+    odbs = [ko.Db(f"{x}/database.kdb", f"{x}/database.idx") for x in dirs]
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdbs[0])
+    ctx.add_db(cdbs[1])
+    with pytest.raises(capi.KuError):  # k differs (classify.cpp:199-208)
+        rng = np.random.default_rng(3)
+        other = random_db(rng, n_genomes=2, glen=300, k=25, nt=6)
+        raw = np.zeros((len(other["kmers"]), 7 + 4), dtype=np.uint8)
+        raw[:, :7] = other["kmers"].astype("<u8").view(np.uint8).reshape(-1, 8)[:, :7]
+        raw[:, 7:] = other["vals"].astype("<u4").view(np.uint8).reshape(-1, 4)
+        ctx.add_db(capi.Db(pairs=raw.reshape(-1), key_ct=len(other["kmers"]), k=25, offsets=other["offsets"], nt=6))
+    ctx.set_taxonomy(f1["ctax"])
+    with pytest.raises(capi.KuError):  # too late
+        ctx.add_db(cdbs[1])
+    ids, seqs = synth.read_seqfile(f"{d8}/reads.fq")
+    run, res, buf, off, lens, taxa = oracle_flat(odbs[0], f1["otax"], seqs, extra_dbs=odbs[1:])
+    gpu = ctx.classify_batch(buf, off, lens)
+    assert_same_classification(gpu, res, taxa, off, lens, K)
+    assert capi.format_kraken(buf, off, lens, ids, K, gpu["calls"], taxa=gpu["taxa"]) == open(f"{d8}/out{order}.tsv").read()
+    counts = ctx.counts()
+    assert_same_counts(counts, run)
+    # the run-length encoded output path goes through the same passes
+    ctx.reset_counts()
+    rle = ctx.classify_batch_rle(buf, off, lens)
+    assert capi.format_kraken_rle(buf, off, lens, ids, K, rle) == open(f"{d8}/out{order}.tsv").read()
+    assert_same_counts(ctx.counts(), run)
+    # one counts file per database, genome sizes add up (report identical to the dense-sketch oracle)
+    cpaths = [f"{x}/database.kdb.counts" for x in dirs]
+    for i, x in enumerate(dirs):
+        t, c = ctx.count_taxons(i)
+        assert "".join(f"{a}\t{b}\n" for a, b in zip(t.tolist(), c.tolist())) == open(f"{x}/database.kdb.counts").read()
+    ko.set_hll_sparse(False)
+    try:
+        run_d = ko.Run(odbs[0], f1["otax"], extra_dbs=odbs[1:])
+        run_d.classify(seqs)
+        want = run_d.report(f"{d1}/taxDB", "\n".join(cpaths))
+    finally:
+        ko.set_hll_sparse(True)
+    assert capi.report(f1["ctax"], counts, cpaths) == want
+    if order == "":
+        ctx.reset_counts()
+        runq, resq, *_ = oracle_flat(odbs[0], f1["otax"], seqs, quick=True, min_hits=2, extra_dbs=odbs[1:])
+        q = ctx.classify_batch(buf, off, lens, flags=capi.KU_F_QUICK, min_hits=2)
+        assert capi.format_kraken(buf, off, lens, ids, K, q["calls"], hits=q["hits"], flags=capi.KU_P_QUICK) == open(f"{d8}/out_quick.tsv").read()
+        assert_same_counts(ctx.counts(), runq)
+
+
 def test_revcomp_invariance_property(f1):
     """size-independent property: a read and its reverse complement get the same call and mirrored hit list"""
     ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
