@@ -150,6 +150,8 @@ int ku_ctx_reset_counts(ku_ctx *ctx);
 #define KU_F_QUICK 0x1u        /* -q : stop at min_hits hits (classify.cpp:943-944,962-963) */
 #define KU_F_NO_COUNTS 0x2u    /* do not touch HLL / n_kmers / n_reads (pure lookup) */
 #define KU_F_KEEP_SLOTS 0x4u   /* leave taxa[] as internal slot ids (multi-GPU reduce stage) */
+#define KU_F_MERGE_CHUNK 0x8u  /* ku_lookup_device: positions whose bin this shard does not own keep their value
+                                  (pass over one chunk of an out-of-core run; "non-zero wins", classify.cpp:445-452) */
 
 typedef struct ku_opts {
   uint32_t flags;
@@ -193,6 +195,31 @@ int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const
                           const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                           uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs);
 int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs);
+
+/* ---- out-of-core run: the database streamed through HBM chunk by chunk (classify -x SIZE; KrakenDB::prepare_chunking /
+ * load_chunk / is_minimizer_in_chunk krakendb.cpp:411-526, process_file_with_db_chunk classify.cpp:566-791).  The
+ * reference re-reads the input for every chunk and merges per-read taxa through temp files; here the read batches
+ * stay resident on the device and each chunk is one lookup pass over them:
+ *   ku_db_values(db) -> ku_ctx_load_db(ctx, db, chunk 0) -> ku_ctx_set_taxonomy(ctx, tax, values, n)
+ *   b_i = ku_batch_create(...) for every batch of reads
+ *   for every chunk c: ku_ctx_swap_shard(ctx, db, lo_c, hi_c) (c > 0); ku_batch_lookup(ctx, b_i, opts) for every i
+ *   ku_batch_finish(ctx, b_i, ...) + ku_fetch_runs; ku_batch_destroy(b_i)
+ * Every k-mer is searched and accounted (HLL, n_kmers; misses under taxon 0) by the one chunk that owns its
+ * minimizer bin, so the chunks must tile [0, 4^nt).  Results equal a run with the whole database resident. */
+/* ascending distinct non-zero taxids of the WHOLE database (host scan): the all_values of ku_ctx_set_taxonomy */
+int ku_db_values(const ku_db *db, uint32_t *out, uint64_t *n);
+/* replace the resident shard by bins [bin_lo, bin_hi) of `db`, keeping taxonomy, slot numbering and per-taxon state;
+ * the slot table given to ku_ctx_set_taxonomy must cover the new shard's values (KU_EINVAL otherwise) */
+int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi);
+typedef struct ku_batch ku_batch; /* reads + merged per-k-mer slots of one batch, resident on the context's device */
+int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
+                    uint64_t n_reads, ku_batch **out);
+/* one pass against the resident shard (opts->flags: KU_F_QUICK defers the accounting to ku_batch_finish) */
+int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts);
+/* after the last chunk: resolve_tree / quick call per read + run-length encoding; outputs as ku_classify_batch_rle */
+int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
+                    uint32_t *run_cnt, uint64_t *n_runs);
+void ku_batch_destroy(ku_batch *b);
 
 /* Same on device-resident buffers, asynchronous on `stream` (a hipStream_t
  * passed as void*; NULL = the context's own stream). */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("KU_LIB") or os.path.join(_HERE, "libkrakenuniq_amd.so
 
 KU_AMBIG = 0xFFFFFFFF
 KU_HLL_M = 4096
-KU_F_QUICK, KU_F_NO_COUNTS, KU_F_KEEP_SLOTS = 1, 2, 4
+KU_F_QUICK, KU_F_NO_COUNTS, KU_F_KEEP_SLOTS, KU_F_MERGE_CHUNK = 1, 2, 4, 8
 KU_P_ONLY_CLASSIFIED, KU_P_SEQUENCE, KU_P_QUICK = 1, 2, 4
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
@@ -60,6 +60,12 @@ SIGNATURES = {
     "ku_db_get_info": (C.c_int, [C.c_void_p, C.POINTER(DbInfo)]),
     "ku_db_shard_plan": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "ku_db_chunk_plan": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_uint32, u32p]),
+    "ku_db_values": (C.c_int, [C.c_void_p, u32p, u64p]),
+    "ku_ctx_swap_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "ku_batch_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ku_batch_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts)]),
+    "ku_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts), u32p, u32p, u64p, u32p, u64p]),
+    "ku_batch_destroy": (None, [C.c_void_p]),
     "ku_tax_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ku_tax_from_arrays": (C.c_int, [u32p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "ku_tax_close": (None, [C.c_void_p]),
@@ -174,6 +180,15 @@ class Db:
         _chk(lib().ku_db_chunk_plan(self.h, max_bytes, _p(b, u64p), cap, C.byref(n)), "ku_db_chunk_plan")
         return b[:n.value + 1]
 
+    def values(self):
+        """ascending distinct non-zero taxids of the whole database (host scan)"""
+        n = C.c_uint64()
+        _chk(lib().ku_db_values(self.h, None, C.byref(n)), "ku_db_values")
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        n2 = C.c_uint64(len(out))
+        _chk(lib().ku_db_values(self.h, _p(out, u32p), C.byref(n2)), "ku_db_values")
+        return out[:n2.value]
+
 
 class Tax:
     """Host taxonomy (ku_tax)."""
@@ -221,6 +236,13 @@ class Ctx:
         if bin_hi is None:
             bin_hi = db.info.n_bins
         _chk(lib().ku_ctx_load_db(self.h, db.h, bin_lo, bin_hi), "ku_ctx_load_db")
+
+    def swap_shard(self, db: Db, bin_lo, bin_hi):
+        """out-of-core run: make bins [bin_lo, bin_hi) the resident shard, keeping slots and per-taxon state"""
+        _chk(lib().ku_ctx_swap_shard(self.h, db.h, int(bin_lo), int(bin_hi)), "ku_ctx_swap_shard")
+
+    def batch(self, buf, off, lens):
+        return Batch(self, buf, off, lens)
 
     def add_db(self, db: Db):
         """a further database of a hierarchical run, searched after the ones already resident"""
@@ -341,6 +363,48 @@ class Ctx:
                                          C.byref(nn)), "ku_counts_device_ptrs")
         return {"registers": r.value, "register_bytes": nb.value, "n_kmers": k.value, "n_slots": ns.value,
                 "n_reads": n.value, "n_nodes": nn.value}
+
+
+class Batch:
+    """Reads of one batch resident on the device across the chunk passes of an out-of-core run (ku_batch)."""
+
+    def __init__(self, ctx, buf, off, lens):
+        arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
+        self.ctx, self.n = ctx, len(lens)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.h = C.c_void_p()
+        _chk(lib().ku_batch_create(ctx.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), self.n,
+                                   C.byref(self.h)), "ku_batch_create")
+
+    def lookup(self, flags=0, min_hits=1):
+        o = Opts(flags, min_hits, 0, 0)
+        _chk(lib().ku_batch_lookup(self.ctx.h, self.h, C.byref(o)), "ku_batch_lookup")
+
+    def finish(self, flags=0, min_hits=1):
+        n = self.n
+        calls = np.zeros(max(n, 1), dtype=np.uint32)
+        hits = np.zeros(max(n, 1), dtype=np.uint32)
+        roff = np.zeros(max(n, 1), dtype=np.uint64)
+        rcnt = np.zeros(max(n, 1), dtype=np.uint32)
+        total = C.c_uint64()
+        o = Opts(flags, min_hits, 0, 0)
+        _chk(lib().ku_batch_finish(self.ctx.h, self.h, C.byref(o), _p(calls, u32p), _p(hits, u32p), _p(roff, u64p),
+                                   _p(rcnt, u32p), C.byref(total)), "ku_batch_finish")
+        runs = np.zeros((max(total.value, 1), 2), dtype=np.uint32)
+        _chk(lib().ku_fetch_runs(self.ctx.h, runs.ctypes.data, total.value), "ku_fetch_runs")
+        return {"calls": calls[:n], "hits": hits[:n], "runs": runs[:total.value], "run_off": roff[:n], "run_cnt": rcnt[:n]}
+
+    def close(self):
+        if self.h:
+            lib().ku_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def hll_cardinality(registers, n_observed, p=12):

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -213,6 +214,7 @@ struct Batch {
   std::vector<uint32_t> len, calls, hits, run_cnt;
   bool fastq = false;
   uint64_t nt = 0;
+  ku_batch *dev = nullptr;    // -x runs: the batch stays on the device across the chunk passes
   void clear() {
     seqs_len = 0; nt = 0;
     ids.clear(); headers.clear(); quals.clear();
@@ -275,6 +277,7 @@ int main(int argc, char **argv) {
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
   uint64_t unit_nt = 64ull << 20;
+  uint64_t chunk_bytes = 0;  // -x SIZE: stream the database through HBM in chunks of at most SIZE bytes
   int fmt_threads = 4;  // -t: host threads that format the Kraken lines (the GPU replaces the OpenMP team)
   if (argc > 1 && strcmp(argv[1], "-h") == 0) usage(0);
   int opt;
@@ -310,7 +313,8 @@ int main(int argc, char **argv) {
       case 'M': populate = true; break;
       case 'x':
         populate = true;
-        if (parse_size(optarg) == 0) die(EX_USAGE, "can't parse preload size %s", optarg);
+        chunk_bytes = parse_size(optarg);
+        if (chunk_bytes == 0) die(EX_USAGE, "can't parse preload size %s", optarg);
         break;
       case 'I': die(EX_SOFTWARE, "UID mapping (-I) is not built into the MI355X classify (see DESIGN.md)");
       case 'n': break;
@@ -345,9 +349,55 @@ int main(int argc, char **argv) {
   ku_ctx *ctx = nullptr;
   const char *dev_env = getenv("KU_DEVICE");
   KU_CHECK(ku_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx));
-  KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
-  for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
-  KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
+  // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference; one chunk = everything resident as usual
+  std::vector<uint64_t> chunk_bounds;
+  if (chunk_bytes) {
+    chunk_bounds.resize(info.n_bins + 2 < (1u << 20) ? info.n_bins + 2 : (1u << 20));
+    uint32_t n_chunks = 0;
+    KU_CHECK(ku_db_chunk_plan(db, chunk_bytes, chunk_bounds.data(), (uint32_t)chunk_bounds.size() - 1, &n_chunks));
+    chunk_bounds.resize(n_chunks + 1);
+    chunk_bounds.back() = info.n_bins;  // the bins behind the last chunk hold no pairs
+    if (n_chunks <= 1) chunk_bounds.clear();
+  }
+  const bool chunked = !chunk_bounds.empty();
+  // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
+  auto counts_file_good = [](const std::string &name, bool say) {
+    bool good = false;
+    if (FILE *cf = fopen(name.c_str(), "r")) {
+      good = fgetc(cf) != EOF;
+      fclose(cf);
+      if (!good && say) fprintf(stderr, "Kmer counts file is empty - trying to regenerate ...\n");
+    }
+    return good;
+  };
+  const bool want_report = !report_out.empty() && report_out != "off";
+  const bool sum_chunk_counts = chunked && want_report && !counts_file_good(dbs[0] + ".counts", false);
+  std::map<uint32_t, uint64_t> chunk_counts;
+  auto add_chunk_counts = [&] {
+    if (!sum_chunk_counts) return;
+    uint64_t nc = 0;
+    KU_CHECK(ku_ctx_count_taxons(ctx, nullptr, nullptr, &nc));
+    std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
+    uint64_t cap = nc;
+    KU_CHECK(ku_ctx_count_taxons(ctx, ct.data(), cc.data(), &cap));
+    for (uint64_t i = 0; i < cap; ++i) chunk_counts[ct[i]] += cc[i];
+  };
+  if (chunked) {
+    if (db_handles.size() > 1) die(EX_SOFTWARE, "-x with several databases is not supported (the reference only searches the first one there)");
+    fprintf(stderr, "Streaming the database through the GPU in %zu chunks of at most %" PRIu64 " bytes\n", chunk_bounds.size() - 1, chunk_bytes);
+    uint64_t nv = 0;
+    KU_CHECK(ku_db_values(db, nullptr, &nv));
+    std::vector<uint32_t> values(nv + 1);
+    uint64_t cap = nv;
+    KU_CHECK(ku_db_values(db, values.data(), &cap));
+    KU_CHECK(ku_ctx_load_db(ctx, db, chunk_bounds[0], chunk_bounds[1]));
+    KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, values.data(), cap));
+    add_chunk_counts();
+  } else {
+    KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
+    for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
+    KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
+  }
 
   Sink s_kraken, s_cls, s_ucls;
   bool print_kraken = true;
@@ -383,7 +433,7 @@ int main(int argc, char **argv) {
       rd.open(argv[fi]);
       bool more = true;
       while (more) {
-        Batch *bt = free_q.pop();
+        Batch *bt = chunked ? new Batch() : free_q.pop();  // -x: every batch stays alive until the last chunk
         bt->clear();
         bt->fastq = rd.fastq;
         uint64_t nt = 0;
@@ -403,7 +453,10 @@ int main(int argc, char **argv) {
           nt += seq.size();
         }
         bt->nt = nt;
-        if (nt == 0) { free_q.push(bt); break; }  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
+        if (nt == 0) {  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
+          if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
+          break;
+        }
         parsed_q.push(bt);
       }
       rd.close();
@@ -459,10 +512,42 @@ int main(int argc, char **argv) {
       total_sequences += n;
       total_bases += bt->nt;
       fprintf(stderr, "\r Processed %llu sequences (%.2f%% classified)", total_sequences, total_classified * 100.0 / total_sequences);
-      free_q.push(bt);
+      if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
     }
   });
 
+  if (chunked) {
+    // out-of-core run (src/classify.cpp:566-791): chunk 0 is searched while the input is still being parsed; then
+    // one pass per further chunk over the batches resident on the device; then calls + hit lists per batch
+    std::vector<Batch *> all;
+    ku_opts opts = base_opts;
+    for (;;) {
+      Batch *bt = parsed_q.pop();
+      if (!bt) break;
+      KU_CHECK(ku_batch_create(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), bt->off.size(), &bt->dev));
+      KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
+      all.push_back(bt);
+    }
+    for (size_t c = 1; c + 1 < chunk_bounds.size(); ++c) {
+      fprintf(stderr, "\r Database chunk %zu of %zu", c + 1, chunk_bounds.size() - 1);
+      KU_CHECK(ku_ctx_swap_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]));
+      add_chunk_counts();
+      for (Batch *bt : all) KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
+    }
+    for (Batch *bt : all) {
+      const uint64_t n = bt->off.size();
+      bt->calls.assign(n, 0); bt->hits.assign(n, 0); bt->run_off.assign(n, 0); bt->run_cnt.assign(n, 0);
+      uint64_t n_runs = 0;
+      KU_CHECK(ku_batch_finish(ctx, bt->dev, &opts, bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
+      if (print_kraken && !quick) {
+        bt->reserve_runs(n_runs);
+        KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
+      }
+      ku_batch_destroy(bt->dev);
+      bt->dev = nullptr;
+      done_q.push(bt);
+    }
+  } else
   for (;;) {  // GPU stage
     Batch *bt = parsed_q.pop();
     if (!bt) break;
@@ -505,9 +590,14 @@ int main(int argc, char **argv) {
     for (size_t di = 0; di < dbs.size(); ++di) {
       const std::string cname = dbs[di] + ".counts";
       cnames.push_back(cname);
-      bool good = false;
-      if (FILE *cf = fopen(cname.c_str(), "r")) { good = fgetc(cf) != EOF; fclose(cf); if (!good) fprintf(stderr, "Kmer counts file is empty - trying to regenerate ...\n"); }
-      if (!good) {
+      const bool good = counts_file_good(cname, true);
+      if (!good && chunked) {
+        fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
+        FILE *cf = fopen(cname.c_str(), "w");
+        if (!cf) die(EX_OSERR, "can't write %s", cname.c_str());
+        for (const auto &kv : chunk_counts) fprintf(cf, "%u\t%" PRIu64 "\n", kv.first, kv.second);
+        fclose(cf);
+      } else if (!good) {
         fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
         uint64_t nc = 0;
         KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, nullptr, nullptr, &nc));

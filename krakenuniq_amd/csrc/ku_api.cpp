@@ -9,6 +9,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -221,6 +223,48 @@ extern "C" int ku_db_chunk_plan(const ku_db *db, uint64_t max_bytes, uint64_t *b
   }
   *n_chunks = n;
   return n <= cap ? KU_OK : fail(KU_EINVAL, "ku_db_chunk_plan: bounds array too small");
+}
+
+extern "C" int ku_db_values(const ku_db *db, uint32_t *out, uint64_t *n) {
+  if (!db || !n) return fail(KU_EINVAL, "ku_db_values: null argument");
+  // one bit per possible value, set by a team of scanning threads (the 4-byte value sits behind every key)
+  const uint64_t np = db->info.key_ct, ps = db->info.key_len + 4, kl = db->info.key_len;
+  std::vector<std::atomic<uint64_t>> bits(1ull << 26);
+  for (auto &w : bits) w.store(0, std::memory_order_relaxed);
+  unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (np < (1u << 20)) nthr = 1;
+  std::vector<std::thread> team;
+  for (unsigned t = 0; t < nthr; ++t)
+    team.emplace_back([&, t] {
+      const uint64_t lo = np * t / nthr, hi = np * (t + 1) / nthr;
+      uint32_t last = 0;
+      for (uint64_t i = lo; i < hi; ++i) {
+        uint32_t v;
+        memcpy(&v, db->pairs + i * ps + kl, 4);
+        if (v == last) continue;  // values come in long runs inside a bin
+        last = v;
+        std::atomic<uint64_t> &w = bits[v >> 6];
+        const uint64_t m = 1ull << (v & 63);
+        if (!(w.load(std::memory_order_relaxed) & m)) w.fetch_or(m, std::memory_order_relaxed);
+      }
+    });
+  for (auto &th : team) th.join();
+  uint64_t count = 0;
+  for (uint64_t wi = 0; wi < bits.size(); ++wi) {
+    uint64_t w = bits[wi].load(std::memory_order_relaxed);
+    if (wi == 0) w &= ~1ull;  // value 0 is "no taxon", never a slot
+    while (w) {
+      const uint32_t v = (uint32_t)(wi * 64 + (uint64_t)__builtin_ctzll(w));
+      w &= w - 1;
+      if (out) {
+        if (count >= *n) return fail(KU_EINVAL, "ku_db_values: output array too small");
+        out[count] = v;
+      }
+      ++count;
+    }
+  }
+  *n = count;
+  return KU_OK;
 }
 
 // ---------------------------------------------------------------------------- ku_tax
@@ -446,7 +490,7 @@ static void fill_db_dev(DbStore &d, uint64_t n_pairs, uint64_t pair_base, uint32
 }
 
 // host KrakenDB bins [bin_lo, bin_hi) -> device pairs (12-byte form) + offsets slice
-static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
+static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi, bool scan_values = true) {
   const uint64_t p0 = db->offsets[bin_lo], p1 = db->offsets[bin_hi], np = p1 - p0;
   const uint32_t kl = db->info.key_len, ps = kl + 4;
   HIP_TRY(hipMalloc((void **)&d.d_pairs, std::max<uint64_t>(np, 1) * 12));
@@ -467,7 +511,7 @@ static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_l
   d.offsets_owned = true;
   HIP_TRY(hipMemcpy(d.d_offsets, db->offsets + bin_lo, no * 8, hipMemcpyHostToDevice));
   fill_db_dev(d, np, p0, db->info.k, db->info.nt, db->info.idx_type, bin_lo, bin_hi);
-  return store_scan_values(ctx, d);
+  return scan_values ? store_scan_values(ctx, d) : KU_OK;
 }
 
 extern "C" int ku_ctx_load_db(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
@@ -728,7 +772,7 @@ extern "C" int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
   for (size_t i = 0; i < nd; ++i) {
     const DbStore &d = i ? ctx->extra[i - 1] : ctx->m;
     int st = ku_launch_lookup(d.db, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_taxa, counts && i + 1 == nd, i > 0,
-                              ctx->n_cu, s);
+                              (flags & KU_F_MERGE_CHUNK) != 0, ctx->n_cu, s);
     if (st != KU_OK) return fail(st, "lookup kernel launch failed");
   }
   return KU_OK;
@@ -832,6 +876,32 @@ extern "C" int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes
   return KU_OK;
 }
 
+// run-length encode d_taxa into ctx->b_runs and bring calls / hits / (run_off, run_cnt) / the run total to the host
+static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads,
+                         uint64_t runs_cap, bool quick, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
+                         uint32_t *run_cnt, uint64_t *n_runs) {
+  hipStream_t s = ctx->stream;
+  unsigned long long *d_counter = (unsigned long long *)(ctx->d_scalar + 2);
+  if (quick) {  // quick mode stops at the first hits: no per-k-mer codes, no runs
+    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_roff.p, 0, n_reads * 8, s));
+    HIP_TRY(hipMemsetAsync(ctx->b_rcnt.p, 0, n_reads * 4, s));
+  } else {
+    KU_TRY(ku_launch_rle(d_taxa, ctx->m.db.k, d_off, d_len, n_reads, ctx->b_runs.p, runs_cap, d_counter,
+                         (uint64_t *)ctx->b_roff.p, (uint32_t *)ctx->b_rcnt.p, ctx->n_cu, s));
+  }
+  unsigned long long total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(calls, ctx->b_calls.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  if (hits) HIP_TRY(hipMemcpyAsync(hits, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(run_off, ctx->b_roff.p, n_reads * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(run_cnt, ctx->b_rcnt.p, n_reads * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (total > runs_cap) return fail(KU_EHIP, "run-length encoder overflowed its bound");
+  *n_runs = ctx->n_runs = total;
+  return KU_OK;
+}
+
 extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
                                      const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                                      uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
@@ -859,26 +929,8 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
   KU_TRY(ku_classify_batch_device(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
                                   n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
                                   (uint32_t *)ctx->b_hits.p, s));
-  unsigned long long *d_counter = (unsigned long long *)(ctx->d_scalar + 2);
-  if (o.flags & KU_F_QUICK) {  // quick mode stops at the first hits: no per-k-mer codes, no runs
-    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
-    HIP_TRY(hipMemsetAsync(ctx->b_roff.p, 0, n_reads * 8, s));
-    HIP_TRY(hipMemsetAsync(ctx->b_rcnt.p, 0, n_reads * 4, s));
-  } else {
-    KU_TRY(ku_launch_rle((const uint32_t *)ctx->b_taxa.p, ctx->m.db.k, (const uint64_t *)ctx->b_off.p,
-                         (const uint32_t *)ctx->b_len.p, n_reads, ctx->b_runs.p, runs_cap, d_counter,
-                         (uint64_t *)ctx->b_roff.p, (uint32_t *)ctx->b_rcnt.p, ctx->n_cu, s));
-  }
-  unsigned long long total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(calls, ctx->b_calls.p, n_reads * 4, hipMemcpyDeviceToHost, s));
-  if (hits) HIP_TRY(hipMemcpyAsync(hits, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(run_off, ctx->b_roff.p, n_reads * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(run_cnt, ctx->b_rcnt.p, n_reads * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  if (total > runs_cap) return fail(KU_EHIP, "run-length encoder overflowed its bound");
-  *n_runs = ctx->n_runs = total;
-  return KU_OK;
+  return rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p, n_reads,
+                       runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits, run_off, run_cnt, n_runs);
 }
 
 extern "C" int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs) {
@@ -889,6 +941,99 @@ extern "C" int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs) {
   HIP_TRY(hipMemcpyAsync(runs, ctx->b_runs.p, n_runs * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return KU_OK;
+}
+
+// ---------------------------------------------------------------------------- out-of-core run
+extern "C" int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
+  KU_TRY(check_ready(ctx));
+  if (!db) return fail(KU_EINVAL, "ku_ctx_swap_shard: null argument");
+  if (bin_lo > bin_hi || bin_hi > db->info.n_bins) return fail(KU_EINVAL, "bin range out of bounds");
+  if (!ctx->extra.empty()) return fail(KU_EUNSUP, "chunked runs use one database (as the reference's: classify.cpp:639)");
+  if (db->info.k != ctx->m.db.k) return fail(KU_EINVAL, "ku_ctx_swap_shard: k differs from the resident shard's");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  store_free(ctx->m);
+  ctx->db_loaded = false;
+  KU_TRY(store_upload(ctx, ctx->m, db, bin_lo, bin_hi, /*scan_values=*/false));
+  int st = store_finalize(ctx, ctx->m);
+  if (st == KU_EDATA) return fail(KU_EINVAL, "ku_ctx_swap_shard: the slot table does not cover this shard's values "
+                                             "(pass ku_db_values() of the whole database to ku_ctx_set_taxonomy)");
+  KU_TRY(st);
+  ctx->db_loaded = true;
+  return KU_OK;
+}
+
+struct ku_batch {
+  ku_ctx *ctx = nullptr;
+  uint64_t n_bytes = 0, n_reads = 0;
+  uint32_t max_len = 0;
+  void *d_seqs = nullptr;
+  uint64_t *d_off = nullptr;
+  uint32_t *d_len = nullptr, *d_taxa = nullptr;
+};
+
+extern "C" void ku_batch_destroy(ku_batch *b) {
+  if (!b) return;
+  if (b->ctx) (void)hipSetDevice(b->ctx->device);
+  for (void *p : {b->d_seqs, (void *)b->d_off, (void *)b->d_len, (void *)b->d_taxa})
+    if (p) (void)hipFree(p);
+  delete b;
+}
+
+extern "C" int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                               const uint32_t *seq_len, uint64_t n_reads, ku_batch **out) {
+  if (!ctx || !out || (n_bytes && !seqs) || (n_reads && (!seq_off || !seq_len))) return fail(KU_EINVAL, "ku_batch_create: null argument");
+  *out = nullptr;
+  KU_TRY(ctx_activate(ctx));
+  uint32_t max_len = 0;
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    if (seq_off[i] + seq_len[i] > n_bytes) return fail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
+    max_len = std::max(max_len, seq_len[i]);
+  }
+  ku_batch *b = new ku_batch();
+  b->ctx = ctx; b->n_bytes = n_bytes; b->n_reads = n_reads; b->max_len = max_len;
+  hipStream_t s = ctx->stream;
+  bool ok = hipMalloc(&b->d_seqs, n_bytes + 16) == hipSuccess && hipMalloc((void **)&b->d_off, std::max<uint64_t>(n_reads, 1) * 8) == hipSuccess &&
+            hipMalloc((void **)&b->d_len, std::max<uint64_t>(n_reads, 1) * 4) == hipSuccess &&
+            hipMalloc((void **)&b->d_taxa, (n_bytes + 16) * 4) == hipSuccess;
+  if (!ok) { ku_batch_destroy(b); return fail(KU_ENOMEM, "device memory for a resident read batch"); }
+  ok = (!n_bytes || hipMemcpyAsync(b->d_seqs, seqs, n_bytes, hipMemcpyHostToDevice, s) == hipSuccess) &&
+       (!n_reads || (hipMemcpyAsync(b->d_off, seq_off, n_reads * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+                     hipMemcpyAsync(b->d_len, seq_len, n_reads * 4, hipMemcpyHostToDevice, s) == hipSuccess)) &&
+       hipMemsetAsync(b->d_taxa, 0, (n_bytes + 16) * 4, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  if (!ok) { ku_batch_destroy(b); return fail(KU_EHIP, "upload of a resident read batch failed"); }
+  *out = b;
+  return KU_OK;
+}
+
+extern "C" int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts) {
+  KU_TRY(check_ready(ctx));
+  if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_lookup: batch of another context");
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  o.flags |= KU_F_MERGE_CHUNK | KU_F_KEEP_SLOTS;
+  return ku_lookup_device(ctx, b->d_seqs, b->n_bytes, &o, b->d_taxa, nullptr);
+}
+
+extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, uint32_t *calls, uint32_t *hits,
+                               uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
+  KU_TRY(check_ready(ctx));
+  if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_finish: batch of another context");
+  if (!n_runs || (b->n_reads && (!calls || !run_off || !run_cnt))) return fail(KU_EINVAL, "ku_batch_finish: null buffer");
+  *n_runs = 0;
+  ctx->n_runs = 0;
+  const uint64_t n_reads = b->n_reads;
+  if (n_reads == 0) return KU_OK;
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  o.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
+  o.max_read_len = b->max_len;
+  const uint64_t runs_cap = b->n_bytes + 1;
+  if (ctx->b_calls.reserve(n_reads * 4) || ctx->b_hits.reserve(n_reads * 4) || ctx->b_runs.reserve(runs_cap * 8) ||
+      ctx->b_roff.reserve(n_reads * 8) || ctx->b_rcnt.reserve(n_reads * 4))
+    return fail(KU_ENOMEM, "device batch buffers");
+  hipStream_t s = ctx->stream;
+  KU_TRY(ku_resolve_device(ctx, b->d_seqs, b->d_off, b->d_len, n_reads, &o, (uint32_t *)ctx->b_calls.p, b->d_taxa,
+                           (uint32_t *)ctx->b_hits.p, s));
+  return rle_and_fetch(ctx, b->d_taxa, b->d_off, b->d_len, n_reads, runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits,
+                       run_off, run_cnt, n_runs);
 }
 
 extern "C" int ku_ctx_synchronize(ku_ctx *ctx) {

@@ -47,7 +47,7 @@ struct KuCountsDev {
 
 // launch wrappers implemented in ku_kernels.hip (all asynchronous on `stream`)
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
-                     uint32_t *d_taxa, bool do_counts, bool prior, int n_cu, hipStream_t stream);
+                     uint32_t *d_taxa, bool do_counts, bool prior, bool merge_chunk, int n_cu, hipStream_t stream);
 int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
                            int n_cu, hipStream_t stream);
 int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,

@@ -32,6 +32,7 @@
 #ifndef KU_ITEMS
 #define KU_ITEMS 3
 #endif
+#define KU_CTL_MERGE 16u                  // lookup kernel control bit: do not store positions another chunk owns
 #define KU_TILE (KU_THREADS * KU_ITEMS)   // k-mer start positions per block iteration
 #define KU_PACKW ((KU_TILE + 64) / 16)    // 16-base words staged per tile (covers TILE + 63 bases)
 
@@ -50,7 +51,9 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
                                                                const uint8_t *__restrict__ seqs,
                                                                uint64_t n_bytes, uint32_t *__restrict__ taxa,
                                                                unsigned long long *stats, uint32_t ablate) {
-  // `ablate` is a measurement knob (env KU_ABLATE, scripts/ablate_lookup.py): bit0 skip the table/bin probe,
+  // bit 4 of `ablate` (KU_CTL_MERGE) is a production flag: chunk pass of an out-of-core run -- positions owned by
+  // another chunk keep what that chunk's pass wrote ("non-zero wins" merge, classify.cpp:445-452).  The other
+  // bits are a measurement knob (env KU_ABLATE, scripts/ablate_lookup.py): bit0 skip the table/bin probe,
   // bit1 skip the HLL update, bit2 skip the n_kmers counter, bit3 skip the taxa store.  0 in production.
   constexpr bool DO_COUNTS = MODE == 1;
   constexpr bool NEED_MIN = true;  // every variant uses the LDS sliding-window minimizer (bin, and for LAYOUT 1 its position)
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         if (!(ablate & 2u)) ku_hll_update(cnt.registers, slot[j], hh[j]);
         if (!(ablate & 4u)) ku_ct_add(s_ctk, s_ctc, &s_ctu, slot[j], 1, cnt.n_kmers);
       }
-      if (pos < n_bytes && !(ablate & 8u)) {
+      if (pos < n_bytes && !(ablate & 8u) && !((ablate & KU_CTL_MERGE) && foreign[j])) {
         // ambiguous -> KU_AMBIG on every shard; not owned -> 0 (the owner's value wins the max-reduce)
         taxa[pos] = ok[j] ? slot[j] : (foreign[j] ? 0u : KU_AMBIG);
       }
@@ -405,13 +408,13 @@ static unsigned ku_lookup_grid(uint64_t n_bytes, int n_cu) {
 }
 
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
-                     uint32_t *d_taxa, bool do_counts, bool prior, int n_cu, hipStream_t stream) {
+                     uint32_t *d_taxa, bool do_counts, bool prior, bool merge_chunk, int n_cu, hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
   const dim3 grid(ku_lookup_grid(n_bytes, n_cu)), block(KU_THREADS);
   unsigned long long *ns = nullptr;
   const bool sharded = !(db.bin_lo == 0 && db.bin_hi == (1ull << (2 * db.nt)));
   const char *ab = getenv("KU_ABLATE");
-  const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
+  const uint32_t ablate = ((ab ? (uint32_t)atoi(ab) : 0u) & ~KU_CTL_MERGE) | (merge_chunk ? KU_CTL_MERGE : 0u);
   if (prior && sharded) return KU_EUNSUP;
 #define KU_LAUNCH(M, L, S, P) hipLaunchKernelGGL((ku_lookup_kernel<M, L, S, P>), grid, block, 0, stream, db, cnt, d_seqs, n_bytes, d_taxa, ns, ablate)
   if (prior) {

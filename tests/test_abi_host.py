@@ -105,6 +105,26 @@ def test_chunk_plan_matches_reference_rule(f1):
         f1["db"].chunk_plan(16)
 
 
+def test_db_values_host_scan(golden, f1):
+    """ku_db_values == the taxids of database.kdb.counts minus 0 (whole-database slot universe of a chunked run)"""
+    for name in ("f1", "f8"):
+        d = os.path.join(golden, name)
+        db = capi.Db(f"{d}/database.kdb", f"{d}/database.idx")
+        want = sorted(int(ln.split()[0]) for ln in open(f"{d}/database.kdb.counts") if ln.strip() and int(ln.split()[0]))
+        assert db.values().tolist() == want
+    # a larger wrapped database exercises the threaded scan
+    rng = np.random.default_rng(3)
+    n = 1 << 21
+    pairs = np.zeros((n, 3), dtype=np.uint32)
+    pairs[:, 0] = np.arange(n, dtype=np.uint32)
+    vals = rng.choice(np.array([0, 7, 9, 1000000001, 4294967295, 12345], dtype=np.uint64), n).astype(np.uint32)
+    pairs[:, 2] = vals
+    off = np.zeros(4 ** 3 + 1, dtype=np.uint64)
+    off[1:] = n
+    big = capi.Db(pairs=pairs.reshape(-1).view(np.uint8), key_ct=n, k=31, offsets=off, nt=3)
+    assert big.values().tolist() == [7, 9, 12345, 1000000001, 4294967295]
+
+
 def test_taxonomy_parent_map(f1):
     tax, otax = f1["tax"], ko.Tax(f"{f1['dir']}/taxDB")
     for t in (0, 1, 2, 3, 4, 5, 6, 777, 1000000001, 12345):

@@ -133,3 +133,35 @@ def test_hierarchical_multi_db_run(tmp_path):
     for name in ("f1", "f8"):
         assert (dirs[name] / "database.kdb.counts").read_text() == open(f"{g}/{name}/database.kdb.counts").read()
     assert run(a + b + ["-q", "-m", "2"] + common).stdout == open(f"{g}/f8/out_quick.tsv", "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", ["70K", "30K"])
+def test_out_of_core_chunked_run(tmp_path, size):
+    """-x SIZE: database streamed through HBM in chunks (src/classify.cpp:566-791) -> the reference's -x outputs;
+    the counts file is summed up over the chunks"""
+    d = tmp_path / "db"
+    d.mkdir()
+    for fn in ("database.kdb", "database.idx", "taxDB"):
+        (d / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
+    db = ["-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB"]
+    out, rep = tmp_path / "out.tsv", tmp_path / "rep.tsv"
+    r = run(db + ["-x", size, "-t", "2", "-u", "1", "-o", str(out), "-r", str(rep), f"{F1}/reads.fq"])
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"Streaming the database through the GPU in" in r.stderr
+    assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
+    assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
+    ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{F1}/report_chunk.tsv").read().strip().split("\n")}
+    got = rep.read_text().strip().split("\n")
+    assert len(got) == len(ref)
+    for ln in got:
+        f = ln.split("\t")
+        assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
+        if f[3] != "kmers":
+            assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
+    # identical to the run with everything resident, FASTA + second file included
+    g = os.path.join(ROOT, "tests", "golden")
+    r1 = run(db + ["-x", size, f"{g}/f2/edge.fa", f"{g}/f4/merged.fa"])
+    assert r1.stdout == open(f"{g}/f2/out.tsv", "rb").read() + open(f"{g}/f4/out.tsv", "rb").read()
+    # a budget smaller than the largest bin is a usage error, as in the reference
+    assert run(db + ["-x", "1K", f"{F1}/reads.fq"]).returncode != 0

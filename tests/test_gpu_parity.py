@@ -356,6 +356,51 @@ def test_f8_hierarchical_multi_db(golden, f1, monkeypatch, order, layout):
         assert_same_counts(ctx.counts(), runq)
 
 
+@pytest.mark.parametrize("budget,layout,quick", [(70 << 10, "hash", False), (30 << 10, "hash", False),
+                                                 (70 << 10, "sorted", False), (50 << 10, "hash", True)])
+def test_out_of_core_chunked_run(golden, f1, monkeypatch, budget, layout, quick):
+    """classify -x SIZE (krakendb.cpp:411-526, classify.cpp:566-791): the database streamed through HBM chunk by chunk
+    over device-resident read batches == the run with the whole database resident == the reference's -x output"""
+    if layout == "sorted":
+        monkeypatch.setenv("KU_LAYOUT", "sorted")
+    d = f1["dir"]
+    cdb = capi.Db(f"{d}/database.kdb", f"{d}/database.idx")
+    bounds = cdb.chunk_plan(budget).tolist()
+    bounds[-1] = cdb.info.n_bins  # the bins behind the last chunk hold no pairs
+    assert len(bounds) - 1 >= 2
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdb, bounds[0], bounds[1])
+    ctx.set_taxonomy(f1["ctax"], cdb.values())
+    ids, seqs = synth.read_seqfile(f"{d}/reads.fq")
+    parts = [(0, 400), (400, 401), (401, 1000)]  # several resident batches, one of a single read
+    packed = [ko.pack_reads(seqs[a:b]) for a, b in parts]
+    batches = [ctx.batch(*p) for p in packed]
+    flags = capi.KU_F_QUICK if quick else 0
+    for c in range(len(bounds) - 1):
+        if c:
+            ctx.swap_shard(cdb, bounds[c], bounds[c + 1])
+        for b in batches:
+            b.lookup(flags=flags, min_hits=2)
+    text = ""
+    calls = []
+    for (a, e), p, b in zip(parts, packed, batches):
+        res = b.finish(flags=flags, min_hits=2)
+        calls.append(res["calls"])
+        text += capi.format_kraken_rle(p[0], p[1], p[2], ids[a:e], K, res, flags=capi.KU_P_QUICK if quick else 0)
+        b.close()
+    run, res, *_ = oracle_flat(f1["odb"], f1["otax"], seqs, quick=quick, min_hits=2)
+    assert np.array_equal(np.concatenate(calls), res["calls"])
+    assert text == open(f"{d}/out_quick.tsv" if quick else f"{d}/out_chunk.tsv").read()
+    assert_same_counts(ctx.counts(), run)
+    # a slot table that does not cover the next shard is refused
+    d8 = os.path.join(golden, "f8")
+    ctx2 = capi.Ctx(0)
+    ctx2.load_db(capi.Db(f"{d8}/database.kdb", f"{d8}/database.idx"))
+    ctx2.set_taxonomy(f1["ctax"])  # slots for taxids 3 and 6 only
+    with pytest.raises(capi.KuError):
+        ctx2.swap_shard(cdb, bounds[0], bounds[1])
+
+
 def test_revcomp_invariance_property(f1):
     """size-independent property: a read and its reverse complement get the same call and mirrored hit list"""
     ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
