@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/krakenuniq_amd.h"
+#include "ku_seqio.h"
 
 static void die(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3), noreturn));
 static void die(int code, const char *fmt, ...) {
@@ -48,6 +49,16 @@ static void die(int code, const char *fmt, ...) {
   va_end(ap);
   exit(code);
 }
+void ku_seqio::fatal(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "classify: ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  exit(code);
+}
+
 static int exit_code_of(int st) {
   switch (st) {
     case KU_EINVAL: return EX_USAGE;
@@ -84,6 +95,7 @@ static void usage(int code) {  // text of src/classify.cpp:1164-1189
           "  -M               Preload database files\n"
           "  -x size          Preload database files using x amount of RAM (e.g. 10G)\n"
           "  -s               Print read sequence in Kraken output\n"
+          "  -P               (extension) input files are mate pairs: merged on the fly as read_merger.pl does\n"
           "  -h               Print this message\n\n"
           "Kraken output is to standard output by default.\n");
   exit(code);
@@ -130,128 +142,8 @@ struct Sink {
   }
 };
 
-// ---- FASTA/FASTQ reader with the record semantics of src/seqreader.cpp:26-133 (gz transparently via zlib)
-struct Reader {
-  gzFile g = nullptr;
-  bool fastq = false, valid = true;
-  std::string pending;  // FASTA look-ahead header line
-  bool have_pending = false;
-  std::vector<char> buf;
-  size_t pos = 0, len = 0;
-  bool eof = false;
-  void open(const char *path) {
-    g = gzopen(path, "rb");
-    if (!g) die(EX_NOINPUT, "can't open %s", path);
-    gzbuffer(g, 1 << 20);
-    buf.resize(1 << 22);
-    int c = peek();
-    fastq = c == '@';  // determine_input_file_type (src/classify.cpp:377-388)
-  }
-  bool fill() {
-    if (eof) return false;
-    int n = gzread(g, buf.data(), (unsigned)buf.size());
-    if (n <= 0) { eof = true; len = pos = 0; return false; }
-    len = (size_t)n; pos = 0;
-    return true;
-  }
-  int peek() { if (pos >= len && !fill()) return -1; return (unsigned char)buf[pos]; }
-  bool getline(std::string &line) {  // without the '\n'; false at EOF with nothing read
-    line.clear();
-    bool any = false;
-    for (;;) {
-      if (pos >= len && !fill()) return any;
-      any = true;
-      const char *s = buf.data() + pos;
-      const char *nl = (const char *)memchr(s, '\n', len - pos);
-      if (nl) { line.append(s, nl - s); pos += (nl - s) + 1; return true; }
-      line.append(s, len - pos);
-      pos = len;
-    }
-  }
-  // returns false when the stream is exhausted / malformed (reader->is_valid() == false)
-  bool next(std::string &header, std::string &seq, std::string &quals) {
-    header.clear(); seq.clear(); quals.clear();
-    std::string line;
-    if (fastq) {
-      if (!valid || !getline(line) || line.empty()) { valid = false; return false; }
-      if (line[0] != '@') {
-        if (line[0] != '\r') fprintf(stderr, "classify: malformed fastq file - sequence header (%s)\n", line.c_str());
-        valid = false; return false;
-      }
-      header = line.substr(1);
-      getline(seq);
-      if (!getline(line) || line.empty() || line[0] != '+') {
-        if (line.empty() || line[0] != '\r') fprintf(stderr, "classify: malformed fastq file - quality header (%s)\n", line.c_str());
-        valid = false; return false;
-      }
-      getline(quals);
-      return true;
-    }
-    if (have_pending) { line = pending; have_pending = false; }
-    else if (!getline(line)) { valid = false; return false; }
-    if (line.empty() || line[0] != '>') {
-      fprintf(stderr, "classify: malformed fasta file - expected header char > not found\n");
-      valid = false; return false;
-    }
-    header = line.substr(1);
-    while (getline(line)) {
-      if (!line.empty() && line[0] == '>') { pending = line; have_pending = true; break; }
-      seq += line;
-    }
-    return true;
-  }
-  void close() { if (g) gzclose(g); g = nullptr; }
-};
-
-// ---- a batch of reads travelling through the pipeline; the two big arrays live in pinned host memory
-struct Batch {
-  char *seqs = nullptr;       // reads, each followed by '\n'
-  size_t seqs_len = 0, seqs_cap = 0;
-  ku_run *runs = nullptr;     // run-length encoded per-k-mer codes (ku_classify_batch_rle)
-  size_t runs_cap = 0;
-  std::string ids, headers, quals;
-  std::vector<uint64_t> off, idoff, hoff, qoff, run_off;
-  std::vector<uint32_t> len, calls, hits, run_cnt;
-  bool fastq = false;
-  uint64_t nt = 0;
-  ku_batch *dev = nullptr;    // -x runs: the batch stays on the device across the chunk passes
-  void clear() {
-    seqs_len = 0; nt = 0;
-    ids.clear(); headers.clear(); quals.clear();
-    off.clear(); idoff.clear(); hoff.clear(); qoff.clear(); len.clear();
-  }
-  void append_seq(const std::string &sq) {
-    const size_t need = seqs_len + sq.size() + 1;
-    if (need > seqs_cap) {
-      size_t ncap = seqs_cap ? seqs_cap : (size_t)1 << 24;
-      while (ncap < need) ncap *= 2;
-      void *np = nullptr;
-      if (ku_host_alloc(ncap, &np) != KU_OK) die(EX_OSERR, "out of host memory");
-      if (seqs_len) memcpy(np, seqs, seqs_len);
-      if (seqs) ku_host_free(seqs);
-      seqs = (char *)np;
-      seqs_cap = ncap;
-    }
-    memcpy(seqs + seqs_len, sq.data(), sq.size());
-    seqs_len += sq.size();
-    seqs[seqs_len++] = '\n';
-  }
-  void reserve_runs(size_t n) {
-    if (n <= runs_cap) return;
-    if (runs) ku_host_free(runs);
-    size_t ncap = runs_cap ? runs_cap : (size_t)1 << 20;
-    while (ncap < n) ncap *= 2;
-    void *np = nullptr;
-    if (ku_host_alloc(ncap * sizeof(ku_run), &np) != KU_OK) die(EX_OSERR, "out of host memory");
-    runs = (ku_run *)np;
-    runs_cap = ncap;
-  }
-  void release() {
-    if (seqs) ku_host_free(seqs);
-    if (runs) ku_host_free(runs);
-    seqs = nullptr; runs = nullptr;
-  }
-};
+using ku_seqio::Batch;
+using ku_seqio::Reader;
 
 struct Queue {  // unbounded MPSC-ish queue; the number of Batch objects bounds what is in flight
   std::mutex m;
@@ -267,6 +159,11 @@ struct Queue {  // unbounded MPSC-ish queue; the number of Batch objects bounds 
   }
 };
 
+static double now_s() {
+  timeval t;
+  gettimeofday(&t, nullptr);
+  return (double)t.tv_sec + (double)t.tv_usec / 1e6;
+}
 static double seconds_between(const timeval &a, const timeval &b) {
   return (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_usec - a.tv_usec) / 1e6;
 }
@@ -274,6 +171,7 @@ static double seconds_between(const timeval &a, const timeval &b) {
 int main(int argc, char **argv) {
   std::vector<std::string> dbs, idxs;
   std::string kraken_out, report_out, taxdb, cls_out, ucls_out;
+  bool paired = false, warned_pairs = false;
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
   uint64_t unit_nt = 64ull << 20;
@@ -281,7 +179,7 @@ int main(int argc, char **argv) {
   int fmt_threads = 4;  // -t: host threads that format the Kraken lines (the GPU replaces the OpenMP team)
   if (argc > 1 && strcmp(argv[1], "-h") == 0) usage(0);
   int opt;
-  while ((opt = getopt(argc, argv, "d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:")) != -1) {
+  while ((opt = getopt(argc, argv, "d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:P")) != -1) {
     long long sig;
     switch (opt) {
       case 'd': dbs.push_back(optarg); break;
@@ -318,6 +216,7 @@ int main(int argc, char **argv) {
         break;
       case 'I': die(EX_SOFTWARE, "UID mapping (-I) is not built into the MI355X classify (see DESIGN.md)");
       case 'n': break;
+      case 'P': paired = true; break;  // extension: the input files are mate pairs, merged on the fly (scripts/read_merger.pl)
       default: usage(EX_USAGE);
     }
   }
@@ -326,6 +225,7 @@ int main(int argc, char **argv) {
   if (dbs.size() != idxs.size()) die(EX_USAGE, "every -d needs its -i (%zu databases, %zu indexes)", dbs.size(), idxs.size());
   if (dbs.size() > 8) die(EX_SOFTWARE, "at most 8 databases");
   if (optind == argc && !populate) fprintf(stderr, "No sequence data files specified\n");
+  if (paired && (argc - optind) % 2) die(EX_USAGE, "-P needs the input files in pairs (mate 1, mate 2)");
   if (taxdb.empty()) { fprintf(stderr, "TaxDB argument is required!\n"); return 1; }  // src/classify.cpp:221-222
 
   // hierarchical run: the databases are searched in command-line order (src/classify.cpp:163-177,928-936)
@@ -425,41 +325,71 @@ int main(int argc, char **argv) {
   Queue free_q, parsed_q, done_q;
   for (auto &bt : pool) free_q.push(&bt);
   const bool keep_records = print_cls || print_ucls;
+  double busy_reader = 0, busy_gpu = 0, busy_writer = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
 
   std::thread reader([&] {
-    std::string header, seq, quals;
-    for (int fi = optind; fi < argc; ++fi) {
-      Reader rd;
+    std::string header, quals, header2;
+    auto add_record_meta = [&](Batch *bt, const std::string &hdr, size_t id_lo, size_t id_hi, const std::string &q) {
+      bt->idoff.push_back(bt->ids.size());
+      bt->ids.append(hdr, id_lo, id_hi - id_lo);
+      bt->ids.push_back('\0');
+      if (keep_records) {
+        bt->hoff.push_back(bt->headers.size()); bt->headers += hdr; bt->headers.push_back('\0');
+        bt->qoff.push_back(bt->quals.size()); bt->quals += q; bt->quals.push_back('\0');
+      }
+    };
+    for (int fi = optind; fi < argc; fi += paired ? 2 : 1) {
+      Reader rd, rd2;
       rd.open(argv[fi]);
+      if (paired) rd2.open(argv[fi + 1]);
       bool more = true;
       while (more) {
         Batch *bt = chunked ? new Batch() : free_q.pop();  // -x: every batch stays alive until the last chunk
+        const double t_parse = now_s();
         bt->clear();
-        bt->fastq = rd.fastq;
-        uint64_t nt = 0;
-        while (nt < unit_nt) {
-          if (!rd.next(header, seq, quals)) { more = false; break; }
-          bt->off.push_back(bt->seqs_len);
-          bt->len.push_back((uint32_t)seq.size());
-          bt->append_seq(seq);  // + '\n' separator required by the C ABI (any non-ACGT byte)
-          size_t e = header.find_first_of(" \t\r\v\f");  // id = header up to first whitespace (src/seqreader.cpp:57-58)
-          bt->idoff.push_back(bt->ids.size());
-          bt->ids.append(header, 0, e == std::string::npos ? header.size() : e);
-          bt->ids.push_back('\0');
-          if (keep_records) {
-            bt->hoff.push_back(bt->headers.size()); bt->headers += header; bt->headers.push_back('\0');
-            bt->qoff.push_back(bt->quals.size()); bt->quals += quals; bt->quals.push_back('\0');
+        bt->fastq = paired ? false : rd.fastq;  // mate pairs travel as merged FASTA records (read_merger.pl:187-197)
+        while (bt->nt < unit_nt) {
+          size_t n1 = 0, n2 = 0, lo, hi;
+          bt->begin_read();
+          if (!paired) {
+            if (!ku_seqio::next_record(rd, *bt, &header, keep_records ? &quals : nullptr, &n1)) { bt->off.pop_back(); more = false; break; }
+            bt->end_read();
+            ku_seqio::split_id(header.data(), header.size(), lo, hi);
+            add_record_meta(bt, header, lo, hi, quals);
+            continue;
           }
-          nt += seq.size();
+          // mate pairs: id of mate 1 without its /1 suffix, seq1 + "N" + seq2 (read_merger.pl:102-117,182,187-191);
+          // when one file runs out the other's remaining reads go through unpaired, with the script's warning
+          const bool got1 = ku_seqio::next_record(rd, *bt, &header, nullptr, &n1);
+          if (got1) {
+            const size_t mark = bt->seqs_len;
+            bt->append("N", 1);
+            if (!ku_seqio::next_record(rd2, *bt, &header2, nullptr, &n2)) {
+              if (!warned_pairs) fprintf(stderr, "classify: mismatched sequence counts - file 1 has more reads\n\n  Outputting the further reads unpaired\n");
+              warned_pairs = true;
+              bt->seqs_len = mark;  // drop the joining N
+            }
+          } else if (ku_seqio::next_record(rd2, *bt, &header, nullptr, &n2)) {
+            if (!warned_pairs) fprintf(stderr, "classify: mismatched sequence counts - file 2 has more reads\n\n  Outputting the further reads unpaired\n");
+            warned_pairs = true;
+          } else { bt->off.pop_back(); more = false; break; }
+          bt->end_read();
+          ku_seqio::split_id(header.data(), header.size(), lo, hi);
+          hi = lo + ku_seqio::strip_mate_suffix(header.data() + lo, hi - lo);
+          header.erase(hi);  // -C/-U records carry the merged id only
+          header.erase(0, lo);
+          quals.clear();
+          add_record_meta(bt, header, 0, header.size(), quals);
         }
-        bt->nt = nt;
-        if (nt == 0) {  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
+        busy_reader += now_s() - t_parse;
+        if (bt->nt == 0) {  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
           if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
           break;
         }
         parsed_q.push(bt);
       }
       rd.close();
+      rd2.close();
     }
     parsed_q.push(nullptr);
   });
@@ -470,6 +400,7 @@ int main(int argc, char **argv) {
       Batch *bt = done_q.pop();
       if (!bt) break;
       const uint64_t n = bt->off.size();
+      const double t_write = now_s();
       if (print_kraken) {
         // format disjoint read ranges in parallel, write them in order
         std::vector<std::thread> helpers;
@@ -508,6 +439,7 @@ int main(int argc, char **argv) {
           sk.write(rec.data(), rec.size());
         }
       }
+      busy_writer += now_s() - t_write;
       for (uint64_t i = 0; i < n; ++i) total_classified += bt->calls[i] != 0;
       total_sequences += n;
       total_bases += bt->nt;
@@ -552,6 +484,7 @@ int main(int argc, char **argv) {
     Batch *bt = parsed_q.pop();
     if (!bt) break;
     const uint64_t n = bt->off.size();
+    const double t_gpu = now_s();
     bt->calls.assign(n, 0);
     bt->hits.assign(n, 0);
     bt->run_off.assign(n, 0);
@@ -564,6 +497,7 @@ int main(int argc, char **argv) {
       bt->reserve_runs(n_runs);
       KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
     }
+    busy_gpu += now_s() - t_gpu;
     done_q.push(bt);
   }
   done_q.push(nullptr);
@@ -581,6 +515,8 @@ int main(int argc, char **argv) {
             (total_sequences - total_classified) * 100.0 / total_sequences);
   }
   s_kraken.close(); s_cls.close(); s_ucls.close();
+  if (getenv("KU_CLI_TIMES"))
+    fprintf(stderr, "stage busy seconds: reader %.3f, device %.3f, writer %.3f\n", busy_reader, busy_gpu, busy_writer);
 
   if (!report_out.empty() && report_out != "off") {
     gettimeofday(&tv1, nullptr);

@@ -1,0 +1,211 @@
+// Host-side sequence input of the classify executable: FASTA/FASTQ(+gz) records parsed straight into the pinned
+// read batch the C ABI takes (no per-record std::string round trips), with the record semantics of the reference's
+// readers (src/seqreader.cpp:26-133) and, for mate pairs, of scripts/read_merger.pl:100-197.
+#pragma once
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/krakenuniq_amd.h"
+
+namespace ku_seqio {
+
+[[noreturn]] void fatal(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));  // provided by the program
+
+// ---- a batch of reads travelling through the pipeline; the big arrays live in pinned host memory
+struct Batch {
+  char *seqs = nullptr;       // reads, each followed by '\n' (the separator the C ABI asks for)
+  size_t seqs_len = 0, seqs_cap = 0;
+  ku_run *runs = nullptr;     // run-length encoded per-k-mer codes (ku_classify_batch_rle)
+  size_t runs_cap = 0;
+  std::string ids, headers, quals;
+  std::vector<uint64_t> off, idoff, hoff, qoff, run_off;
+  std::vector<uint32_t> len, calls, hits, run_cnt;
+  bool fastq = false;
+  uint64_t nt = 0;
+  ku_batch *dev = nullptr;    // -x runs: the batch stays on the device across the chunk passes
+  void clear() {
+    seqs_len = 0; nt = 0;
+    ids.clear(); headers.clear(); quals.clear();
+    off.clear(); idoff.clear(); hoff.clear(); qoff.clear(); len.clear();
+  }
+  void reserve_seq(size_t extra) {
+    const size_t need = seqs_len + extra + 1;
+    if (need <= seqs_cap) return;
+    size_t ncap = seqs_cap ? seqs_cap : (size_t)1 << 24;
+    while (ncap < need) ncap *= 2;
+    void *np = nullptr;
+    if (ku_host_alloc(ncap, &np) != KU_OK) fatal(71, "out of host memory");
+    if (seqs_len) memcpy(np, seqs, seqs_len);
+    if (seqs) ku_host_free(seqs);
+    seqs = (char *)np;
+    seqs_cap = ncap;
+  }
+  // a read is built from one or more pieces (FASTA lines, mate 1 + 'N' + mate 2) and closed with end_read()
+  void begin_read() { off.push_back(seqs_len); }
+  void append(const char *p, size_t n) {
+    reserve_seq(n);
+    memcpy(seqs + seqs_len, p, n);
+    seqs_len += n;
+  }
+  void end_read() {
+    const uint64_t l = seqs_len - off.back();
+    len.push_back((uint32_t)l);
+    nt += l;
+    reserve_seq(0);
+    seqs[seqs_len++] = '\n';
+  }
+  void reserve_runs(size_t n) {
+    if (n <= runs_cap) return;
+    if (runs) ku_host_free(runs);
+    size_t ncap = runs_cap ? runs_cap : (size_t)1 << 20;
+    while (ncap < n) ncap *= 2;
+    void *np = nullptr;
+    if (ku_host_alloc(ncap * sizeof(ku_run), &np) != KU_OK) fatal(71, "out of host memory");
+    runs = (ku_run *)np;
+    runs_cap = ncap;
+  }
+  void release() {
+    if (seqs) ku_host_free(seqs);
+    if (runs) ku_host_free(runs);
+    seqs = nullptr; runs = nullptr;
+    seqs_cap = runs_cap = 0;
+  }
+};
+
+// ---- FASTA/FASTQ reader (gz transparently via zlib).  Lines are handed out as ranges of one large buffer.
+struct Reader {
+  gzFile g = nullptr;
+  int fd = -1;  // plain (uncompressed) files are read with read(2): one copy less than through zlib
+  bool fastq = false, valid = true, eof = false;
+  std::vector<char> buf;
+  size_t pos = 0, len = 0;  // unconsumed bytes: buf[pos, len)
+  void open(const char *path) {
+    g = gzopen(path, "rb");
+    if (!g) fatal(66, "can't open %s", path);
+    gzbuffer(g, 1 << 20);
+    fd = -1;
+    if (gzdirect(g)) {  // not gzip data: bypass zlib
+      fd = ::open(path, O_RDONLY);
+      if (fd >= 0) { gzclose(g); g = nullptr; }
+    }
+    buf.resize((size_t)1 << 24);
+    pos = len = 0;
+    valid = true; eof = false;
+    more();
+    fastq = len > 0 && buf[0] == '@';  // determine_input_file_type (src/classify.cpp:377-388)
+  }
+  void close() {
+    if (g) gzclose(g);
+    if (fd >= 0) ::close(fd);
+    g = nullptr; fd = -1;
+  }
+  // append file data behind the unconsumed bytes (which move to the front); false at end of file
+  bool more() {
+    if (eof) return false;
+    if (pos > 0) {
+      if (len > pos) memmove(buf.data(), buf.data() + pos, len - pos);
+      len -= pos;
+      pos = 0;
+    }
+    if (len == buf.size()) buf.resize(buf.size() * 2);
+    const size_t room = buf.size() - len;
+    const size_t want = room < ((size_t)1 << 30) ? room : ((size_t)1 << 30);
+    long n = fd >= 0 ? (long)::read(fd, buf.data() + len, want) : (long)gzread(g, buf.data() + len, (unsigned)want);
+    if (n <= 0) { eof = true; return false; }
+    len += (size_t)n;
+    return true;
+  }
+  // line starting `from` bytes behind pos: [lo, hi) without the '\n', `next` = start of the following line (all
+  // relative to pos, so they survive more()).  false when the file ends before `from` (std::getline's failure).
+  bool line_at(size_t from, size_t &hi, size_t &next) {
+    for (;;) {
+      const size_t avail = len - pos > from ? len - pos - from : 0;
+      const char *b = buf.data() + pos + from;
+      const char *nl = avail ? (const char *)memchr(b, '\n', avail) : nullptr;
+      if (nl) { hi = from + (size_t)(nl - b); next = hi + 1; return true; }
+      if (!more()) {
+        const size_t rest = len - pos > from ? len - pos - from : 0;
+        if (rest == 0) return false;
+        hi = from + rest; next = hi;
+        return true;
+      }
+    }
+  }
+  const char *at(size_t rel) const { return buf.data() + pos + rel; }
+};
+
+// id = first whitespace-delimited token of the header line ("istringstream >> id", src/seqreader.cpp:56-58,114-116)
+inline void split_id(const char *h, size_t n, size_t &lo, size_t &hi) {
+  auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+  lo = 0;
+  while (lo < n && ws(h[lo])) ++lo;
+  hi = lo;
+  while (hi < n && !ws(h[hi])) ++hi;
+}
+
+// One record of `rd`: sequence pieces appended to the read currently open in `bt`; header (without '>'/'@') and
+// quality line to `header` / `quals` when wanted.  false when the stream is exhausted or malformed
+// (reader->is_valid() == false); a malformed record ends the stream with the reference's warning.
+inline bool next_record(Reader &rd, Batch &bt, std::string *header, std::string *quals, size_t *seq_bytes) {
+  size_t h_hi, h_next;
+  *seq_bytes = 0;
+  if (rd.fastq) {  // FastqReader::next_sequence (src/seqreader.cpp:96-133)
+    if (!rd.valid || !rd.line_at(0, h_hi, h_next) || h_hi == 0) { rd.valid = false; return false; }
+    if (*rd.at(0) != '@') {
+      if (*rd.at(0) != '\r') fprintf(stderr, "classify: malformed fastq file - sequence header (%.*s)\n", (int)h_hi, rd.at(0));
+      rd.valid = false;
+      return false;
+    }
+    size_t s_hi = h_next, s_next = h_next, p_hi = h_next, p_next = h_next, q_hi, q_next;
+    const bool has_seq = rd.line_at(h_next, s_hi, s_next);
+    const bool has_plus = has_seq && rd.line_at(s_next, p_hi, p_next);
+    if (!has_plus || p_hi == s_next || *rd.at(s_next) != '+') {
+      if (has_plus && p_hi > s_next && *rd.at(s_next) != '\r')
+        fprintf(stderr, "classify: malformed fastq file - quality header (%.*s)\n", (int)(p_hi - s_next), rd.at(s_next));
+      else if (!has_plus || p_hi == s_next)
+        fprintf(stderr, "classify: malformed fastq file - quality header ()\n");
+      rd.valid = false;
+      return false;
+    }
+    const bool has_q = rd.line_at(p_next, q_hi, q_next);
+    if (!has_q) { q_hi = p_next; q_next = p_next; }
+    if (header) header->assign(rd.at(1), h_hi - 1);
+    bt.append(rd.at(h_next), s_hi - h_next);
+    *seq_bytes = s_hi - h_next;
+    if (quals) quals->assign(rd.at(p_next), q_hi - p_next);
+    rd.pos += q_next;
+    return true;
+  }
+  // FastaReader::next_sequence (src/seqreader.cpp:34-80)
+  if (!rd.valid || !rd.line_at(0, h_hi, h_next)) { rd.valid = false; return false; }
+  if (h_hi == 0 || *rd.at(0) != '>') {
+    fprintf(stderr, "classify: malformed fasta file - expected header char > not found\n");
+    rd.valid = false;
+    return false;
+  }
+  if (header) header->assign(rd.at(1), h_hi - 1);
+  rd.pos += h_next;
+  size_t l_hi, l_next;
+  while (rd.line_at(0, l_hi, l_next)) {
+    if (l_hi > 0 && *rd.at(0) == '>') break;  // next record: not consumed
+    bt.append(rd.at(0), l_hi);
+    *seq_bytes += l_hi;
+    rd.pos += l_next;
+  }
+  return true;
+}
+
+// read_merger.pl:182 "$id =~ s/[\/_.][12]$//"
+inline size_t strip_mate_suffix(const char *id, size_t n) {
+  if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && (id[n - 2] == '/' || id[n - 2] == '_' || id[n - 2] == '.')) return n - 2;
+  return n;
+}
+
+}  // namespace ku_seqio

@@ -96,8 +96,9 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
     }
     uint32_t v[ITEMS];  // slot of every k-mer (0 = miss or ambiguous)
     bool amb_k[ITEMS];  // ambiguous k-mer (reported as KU_AMBIG)
+    uint64_t hh[ITEMS]; // fmix64(canonical k-mer): bucket tag and HLL index / rank
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { v[j] = 0; amb_k[j] = false; }
+    for (int j = 0; j < ITEMS; ++j) { v[j] = 0; amb_k[j] = false; hh[j] = 0; }
 
     if (n > 0) {
       // ---- stage 1: ASCII -> 2-bit codes + ambiguity bits, 16 bases per lane, wave-private LDS
@@ -198,7 +199,6 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
       }
       const uint32_t *lp[ITEMS];
       uint32_t tag[ITEMS], cand[ITEMS];
-      uint64_t hh[ITEMS];
       bool act[ITEMS], ovf[ITEMS];
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
@@ -291,19 +291,12 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
         }
       }
 
-      // ---- stage 5: ReadCounts::add_kmer for every unambiguous k-mer, misses included (classify.cpp:939)
-      if (DO_COUNTS) {
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-          if (ok[j]) {
-            if (!(ablate & 2u)) ku_hll_update(cnt.registers, v[j], hh[j]);
-            if (!(ablate & 4u)) ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], v[j], 1, cnt.n_kmers);
-          }
-      }
     }
 
     // ---- resolve_tree (krakenutil.cpp:149-200) from registers
     uint32_t call_node = 0;
+    bool uni = false;        // at most one distinct hit taxon in the read (the common case)
+    uint32_t uni_slot = 0;   // that taxon's slot (0 = no hit at all)
     if (!(ablate & 32u)) {
       uint32_t mine = 0;
 #pragma unroll
@@ -316,6 +309,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
       for (int j = 0; j < ITEMS; ++j) diff |= (v[j] != 0 && v[j] != first);
       if (!__any(diff)) {
         call_node = first ? tax.slot_node[first] : 0u;  // at most one distinct hit taxon
+        uni = true;
+        uni_slot = first;
       } else {
         // hit_counts in the wave's LDS table
         if (lane == 0) misc[2] = 0;
@@ -395,7 +390,29 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
       }
     }
 
+    // ---- ReadCounts::add_kmer for every unambiguous k-mer, misses included (classify.cpp:939): HLL register per
+    // k-mer; n_kmers per read when the read met one taxon at most (two counter updates instead of one per lane)
+    if (DO_COUNTS && n > 0) {
+      uint32_t n_hit = 0, n_miss = 0;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const bool okc = j * 64 + lane < n && !amb_k[j];
+        if (okc && !(ablate & 2u)) ku_hll_update(cnt.registers, v[j], hh[j]);
+        if (uni) {
+          n_hit += (uint32_t)__popcll(__ballot(okc && v[j] != 0));
+          n_miss += (uint32_t)__popcll(__ballot(okc && v[j] == 0));
+        } else if (okc && !(ablate & 4u)) {
+          ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], v[j], 1, cnt.n_kmers);
+        }
+      }
+      if (uni && lane == 0 && !(ablate & 4u)) {
+        if (n_hit) ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], uni_slot, n_hit, cnt.n_kmers);
+        if (n_miss) ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], 0u, n_miss, cnt.n_kmers);
+      }
+    }
+
     // ---- outputs
+    const uint32_t uni_code = uni && uni_slot ? (keep_slots ? uni_slot : tax.slot_taxid[uni_slot]) : 0u;
     if (lane == 0) {
       calls[r] = tax.node_taxid[call_node];
       if (hits_out) hits_out[r] = 0;
@@ -404,7 +421,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t p = j * 64 + lane;
-      if (p < n && !(ablate & 8u)) taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (keep_slots ? v[j] : tax.slot_taxid[v[j]]) : 0u);
+      if (p < n && !(ablate & 8u))
+        taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (uni ? uni_code : (keep_slots ? v[j] : tax.slot_taxid[v[j]])) : 0u);
     }
     ks_wave_sync();  // the next read reuses the wave's LDS arrays
   }

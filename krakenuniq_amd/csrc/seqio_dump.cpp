@@ -1,0 +1,78 @@
+// Test / measurement aid for the classify executable's input stage (ku_seqio.h): parses FASTA/FASTQ(+gz) files
+// exactly as the reader thread does and prints "id<TAB>sequence" per read, or with -n only the parsing rate.
+// Host-only: does not link the GPU library (pinned allocation is replaced by malloc here), classifies nothing.
+#include <sys/time.h>
+
+#include <cstdarg>
+#include <cstdlib>
+
+#include "ku_seqio.h"
+
+extern "C" int ku_host_alloc(size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? KU_OK : KU_ENOMEM; }
+extern "C" void ku_host_free(void *p) { free(p); }
+
+void ku_seqio::fatal(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  exit(code);
+}
+
+int main(int argc, char **argv) {
+  bool paired = false, quiet = false;
+  int a = 1;
+  for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
+    if (argv[a][1] == 'P') paired = true;
+    else if (argv[a][1] == 'n') quiet = true;
+  }
+  timeval t0, t1;
+  gettimeofday(&t0, nullptr);
+  uint64_t n_reads = 0, n_bytes = 0;
+  std::string header, header2;
+  for (; a < argc; a += paired ? 2 : 1) {
+    ku_seqio::Reader rd, rd2;
+    rd.open(argv[a]);
+    if (paired) {
+      if (a + 1 >= argc) ku_seqio::fatal(64, "-P needs the files in pairs");
+      rd2.open(argv[a + 1]);
+    }
+    ku_seqio::Batch bt;
+    for (bool more = true; more;) {
+      bt.clear();
+      while (bt.nt < (64u << 20)) {
+        size_t n1, n2, lo, hi;
+        bt.begin_read();
+        bool got = ku_seqio::next_record(rd, bt, &header, nullptr, &n1);
+        if (paired) {
+          if (got) {
+            const size_t mark = bt.seqs_len;
+            bt.append("N", 1);
+            if (!ku_seqio::next_record(rd2, bt, &header2, nullptr, &n2)) bt.seqs_len = mark;
+          } else got = ku_seqio::next_record(rd2, bt, &header, nullptr, &n2);
+        }
+        if (!got) { bt.off.pop_back(); more = false; break; }
+        bt.end_read();
+        ku_seqio::split_id(header.data(), header.size(), lo, hi);
+        if (paired) hi = lo + ku_seqio::strip_mate_suffix(header.data() + lo, hi - lo);
+        ++n_reads;
+        if (!quiet) {
+          fwrite(header.data() + lo, 1, hi - lo, stdout);
+          fputc('\t', stdout);
+          fwrite(bt.seqs + bt.off.back(), 1, bt.len.back(), stdout);
+          fputc('\n', stdout);
+        }
+      }
+      n_bytes += bt.nt;
+      if (bt.nt == 0) break;
+    }
+    bt.release();
+    rd.close();
+    rd2.close();
+  }
+  gettimeofday(&t1, nullptr);
+  const double s = (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_usec - t0.tv_usec) / 1e6;
+  fprintf(stderr, "%llu reads, %.1f Mbp in %.3f s: %.2f M reads/s\n", (unsigned long long)n_reads, n_bytes / 1e6, s, n_reads / s / 1e6);
+  return 0;
+}

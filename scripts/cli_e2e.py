@@ -15,7 +15,7 @@ db = f"{ROOT}/tests/golden/f1"
 for out in ("/dev/shm/ku_out.tsv", "off"):
     t = time.time()
     r = subprocess.run([f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB",
-                        "-t", thr, "-o", out, path], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
-    line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l]
-    print(f"-o {out}: wall {time.time() - t:.2f}s rc={r.returncode}", line[-1] if line else r.stderr.decode()[-300:])
+                        "-t", thr, "-o", out, path], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, env=dict(os.environ, KU_CLI_TIMES="1"))
+    line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l or "stage busy" in l]
+    print(f"-o {out}: wall {time.time() - t:.2f}s rc={r.returncode}", " | ".join(line) if line else r.stderr.decode()[-300:])
 os.remove(path)

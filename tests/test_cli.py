@@ -165,3 +165,20 @@ def test_out_of_core_chunked_run(tmp_path, size):
     assert r1.stdout == open(f"{g}/f2/out.tsv", "rb").read() + open(f"{g}/f4/out.tsv", "rb").read()
     # a budget smaller than the largest bin is a usage error, as in the reference
     assert run(db + ["-x", "1K", f"{F1}/reads.fq"]).returncode != 0
+
+
+@pytest.mark.gpu
+def test_mate_pairs_merged_on_the_fly(tmp_path):
+    """-P r_1.fq r_2.fq == read_merger.pl | classify (scripts/krakenuniq:230-238): the reference's f4 outputs"""
+    g = os.path.join(ROOT, "tests", "golden")
+    r = run(DB + ["-P", f"{g}/f4/r_1.fq", f"{g}/f4/r_2.fq"])
+    assert r.returncode == 0 and r.stdout == open(f"{g}/f4/out.tsv", "rb").read()
+    # classified / unclassified records are the merged FASTA records classify would have seen
+    c, u = tmp_path / "c.fa", tmp_path / "u.fa"
+    assert run(DB + ["-P", "-o", "off", "-C", str(c), "-U", str(u), f"{g}/f4/r_1.fq", f"{g}/f4/r_2.fq"]).returncode == 0
+    calls = {ln.split("\t")[1]: ln[0] for ln in open(f"{g}/f4/out.tsv").read().strip().split("\n")}
+    merged = open(f"{g}/f4/merged.fa").read().split("\n")
+    recs = [(merged[i][1:], merged[i + 1]) for i in range(0, len(merged) - 1, 2)]
+    assert c.read_text() == "".join(f">{i}\n{s}\n" for i, s in recs if calls[i] == "C")
+    assert u.read_text() == "".join(f">{i}\n{s}\n" for i, s in recs if calls[i] == "U")
+    assert run(DB + ["-P", f"{g}/f4/r_1.fq"]).returncode == 64

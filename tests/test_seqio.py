@@ -1,0 +1,78 @@
+"""Input stage of the classify executable (krakenuniq_amd/csrc/ku_seqio.h) through the parser-only aid
+bin/seqio_dump: record semantics of src/seqreader.cpp:26-133 and of scripts/read_merger.pl (mate pairs)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+
+from krakenuniq_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "krakenuniq_amd", "bin", "seqio_dump")
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def dump(args, **kw):
+    r = subprocess.run([DUMP] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, **kw)
+    assert r.returncode == 0, r.stderr.decode()
+    recs = [ln.split(b"\t") for ln in r.stdout.split(b"\n")[:-1]]
+    return [a.decode() for a, _ in recs], [b for _, b in recs], r.stderr.decode()
+
+
+def test_fixture_files_parse_like_the_python_reader(tmp_path):
+    assert os.path.exists(DUMP), "build with make -C krakenuniq_amd/csrc"
+    for fn in ("f1/reads.fq", "f2/edge.fa", "f4/merged.fa", "f8/reads.fq"):
+        ids, seqs = synth.read_seqfile(os.path.join(G, fn))
+        got_ids, got_seqs, _ = dump([os.path.join(G, fn)])
+        assert got_ids == ids and got_seqs == seqs, fn
+    # gz input, two files in one run
+    gz = tmp_path / "r.fq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(open(f"{G}/f1/reads.fq", "rb").read())
+    a, b, _ = dump([str(gz), f"{G}/f2/edge.fa"])
+    i1, s1 = synth.read_seqfile(f"{G}/f1/reads.fq")
+    i2, s2 = synth.read_seqfile(f"{G}/f2/edge.fa")
+    assert a == i1 + i2 and b == s1 + s2
+
+
+def test_mate_pairs_merge_like_read_merger(tmp_path):
+    """-P: id without /1, seq1 + N + seq2 == the reference's read_merger.pl output committed as f4/merged.fa"""
+    ids, seqs = synth.read_seqfile(f"{G}/f4/merged.fa")
+    got_ids, got_seqs, _ = dump(["-P", f"{G}/f4/r_1.fq", f"{G}/f4/r_2.fq"])
+    assert got_ids == ids and got_seqs == seqs
+    # unequal counts: the longer file's tail goes through unpaired (read_merger.pl:104-126)
+    r1 = open(f"{G}/f4/r_1.fq").read().split("\n")
+    short = tmp_path / "short_2.fq"
+    short.write_text("\n".join(open(f"{G}/f4/r_2.fq").read().split("\n")[:4 * 150]) + "\n")
+    a, b, _ = dump(["-P", f"{G}/f4/r_1.fq", str(short)])
+    assert len(a) == 200 and b[:150] == seqs[:150]
+    assert b[150:] == [x.encode() for x in r1[1::4][150:200]]
+
+
+def test_record_edge_cases(tmp_path):
+    p = tmp_path / "x.fa"
+    # multi-line FASTA, blank line inside a record, description after the id, no trailing newline, CRLF kept as is
+    p.write_bytes(b">a desc one\nACGT\nAC\n\nGT\n>b\n>c\tdesc\nTTTT")
+    ids, seqs, _ = dump([str(p)])
+    assert ids == ["a", "b", "c"] and seqs == [b"ACGTACGT", b"", b"TTTT"]
+    q = tmp_path / "x.fq"
+    q.write_bytes(b"@r1 d\nACGT\n+\nIIII\n@r2\nAC\n+r2\nII\n\n@never\nAA\n+\nII\n")
+    ids, seqs, _ = dump([str(q)])
+    assert ids == ["r1", "r2"] and seqs == [b"ACGT", b"AC"]  # an empty line ends a FASTQ stream (seqreader.cpp:103-106)
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r1\nACGT\n+\nIIII\n@r2\nACGT\nIIII\n")
+    ids, seqs, err = dump([str(bad)])
+    assert ids == ["r1"] and "malformed fastq file - quality header (IIII)" in err
+    # a record longer than the reader's 16 MiB buffer
+    big = tmp_path / "big.fa"
+    rng = np.random.default_rng(1)
+    s = synth.codes_to_ascii(rng.integers(0, 4, 40_000_000, dtype=np.uint8))
+    with open(big, "wb") as f:
+        f.write(b">big\n")
+        for i in range(0, len(s), 80):
+            f.write(s[i:i + 80] + b"\n")
+        f.write(b">tail\nACGT\n")
+    r = subprocess.run([DUMP, str(big)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    lines = r.stdout.split(b"\n")
+    assert lines[0] == b"big\t" + s and lines[1] == b"tail\tACGT"
