@@ -115,6 +115,21 @@ struct __attribute__((packed, aligned(4))) KuPair {  // the on-disk record (krak
   uint32_t key_lo, key_hi, slot;
 };
 
+// Four ASCII bases in one dword (first base in the low byte) -> 8 bits of 2-bit codes (first base in bits 7..6) and
+// 4 ambiguity bits (first base in bit 3): the SWAR form of four ku_pack_byte calls.  The per-byte fields are
+// gathered with one multiply each (disjoint partial products, no carries).
+__device__ __forceinline__ void ku_pack_dword(uint32_t d, uint32_t &codes8, uint32_t &amb4) {
+  const uint32_t c = d & 0xDFDFDFDFu;                              // fold case
+  const uint32_t x = ((c >> 1) ^ (c >> 2)) & 0x03030303u;          // A=0 C=1 G=2 T=3 per byte
+  codes8 = (x * 0x40100401u) >> 24;
+  const uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u, b01 = b0 & b1;
+  // the letter each code stands for: 'A' + {0, 2, 6, 19}; any other byte differs from it
+  const uint32_t expect = 0x41414141u + (b0 << 1) + (b1 << 2) + (b1 << 1) + (b01 << 3) + (b01 << 1) + b01;
+  const uint32_t diff = c ^ expect;
+  const uint32_t nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
+  amb4 = (((nz >> 7) * 0x08040201u) >> 24) & 0xFu;
+}
+
 // ASCII -> (2-bit code, valid): A/a=0 C/c=1 G/g=2 T/t=3 (krakenutil.cpp:252-263)
 __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &word, uint32_t &amb) {
   uint32_t c = b & 0xDFu;

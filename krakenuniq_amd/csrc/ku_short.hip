@@ -49,8 +49,13 @@ __device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32
   ks_wave_sync();
 }
 
+// waves per SIMD the variant is compiled for: 2 k-mers per lane fit 96 VGPRs (5 waves), 3 per lane need 128 (4 waves)
+#ifndef KS_OCC2
+#define KS_OCC2 5
+#endif
+#define KS_OCC(ITEMS) ((ITEMS) == 2 ? KS_OCC2 : 4)
 template <int ITEMS, bool DO_COUNTS>
-__global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
+__global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_short_kernel(
     KuDbDev db, KuTaxDev tax, KuCountsDev cnt, const uint8_t *__restrict__ seqs, uint64_t n_bytes,
     const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, uint64_t n_reads,
     uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t *__restrict__ hits_out, uint32_t keep_slots,
@@ -101,33 +106,38 @@ __global__ __launch_bounds__(64 * KS_WAVES, 4) void ku_classify_short_kernel(
     for (int j = 0; j < ITEMS; ++j) { v[j] = 0; amb_k[j] = false; hh[j] = 0; }
 
     if (n > 0) {
-      // ---- stage 1: ASCII -> 2-bit codes + ambiguity bits, 16 bases per lane, wave-private LDS
-      static_assert(G::NWORDS <= 64, "one packing pass");
-      if (lane < (uint32_t)G::NWORDS) {
-        const uint32_t wi = lane, b0 = 16 * wi;
-        uint32_t word = 0, ab = 0xFFFFu;
+      // ---- stage 1: ASCII -> 2-bit codes + ambiguity bits in wave-private LDS: four bases per lane (one dword,
+      // SWAR), the four lanes of a quad OR their bytes into one 16-base word
+#pragma unroll
+      for (uint32_t pl = lane; pl < (uint32_t)((G::NWORDS * 4 + 63) / 64) * 64; pl += 64) {
+        const uint32_t b0 = 4 * pl;  // first base of this lane
+        uint32_t c8 = 0, a4 = 0xFu;
         if (b0 < len) {
-          ab = 0;
           const uint64_t a = off + b0;
           const uint64_t a0 = a & ~3ull;
-          if (a0 + 20 <= n_bytes) {  // 5 aligned dwords cover the 16 bytes at any alignment
+          uint32_t d;
+          if (a0 + 8 <= n_bytes) {  // two aligned dwords cover the four bytes at any alignment
             const uint32_t *q = reinterpret_cast<const uint32_t *>(seqs + a0);
-            const uint32_t sh = (uint32_t)(a & 3ull) * 8;
-            const uint32_t d[5] = {q[0], q[1], q[2], q[3], q[4]};
-#pragma unroll
-            for (uint32_t x = 0; x < 4; ++x) {
-              uint32_t dw = sh ? ((d[x] >> sh) | (d[x + 1] << (32 - sh))) : d[x];
-#pragma unroll
-              for (uint32_t j = 0; j < 4; ++j) ku_pack_byte((dw >> (8 * j)) & 0xffu, 4 * x + j, word, ab);
-            }
+            d = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3ull));
           } else {
-            for (uint32_t j = 0; j < 16; ++j) ku_pack_byte(a + j < n_bytes ? seqs[a + j] : (uint32_t)'N', j, word, ab);
+            d = 0;
+            for (uint32_t j = 0; j < 4; ++j) d |= (a + j < n_bytes ? (uint32_t)seqs[a + j] : (uint32_t)'N') << (8 * j);
           }
-          const uint32_t valid = len - b0;  // bases of this word that belong to the read
-          if (valid < 16) ab |= (1u << (16 - valid)) - 1u;
+          ku_pack_dword(d, c8, a4);
+          const uint32_t valid = len - b0;  // bases of this dword that belong to the read
+          if (valid < 4) a4 |= (1u << (4 - valid)) - 1u;
         }
-        codes[wi] = word;
-        amb16[wi ^ 1u] = (uint16_t)ab;
+        const uint32_t q4 = pl & 3u;
+        uint32_t word = c8 << (24 - 8 * q4), ab = a4 << (12 - 4 * q4);
+        word |= (uint32_t)__shfl_xor((int)word, 1);
+        ab |= (uint32_t)__shfl_xor((int)ab, 1);
+        word |= (uint32_t)__shfl_xor((int)word, 2);
+        ab |= (uint32_t)__shfl_xor((int)ab, 2);
+        const uint32_t wi = pl >> 2;
+        if (q4 == 0 && wi < (uint32_t)G::NWORDS) {
+          codes[wi] = word;
+          amb16[wi ^ 1u] = (uint16_t)ab;
+        }
       }
       ks_wave_sync();
 
@@ -447,7 +457,11 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
   const uint32_t keep = (flags & KU_F_KEEP_SLOTS) ? 1u : 0u;
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
-  const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * 8;
+  // persistent grid: two rounds of the blocks a CU holds at once (KS_OCC blocks of KS_WAVES = 4 waves per CU)
+  const int items = max_kmers <= 128 ? 2 : 3;
+  const char *oe = getenv("KU_SHORT_BLOCKS_PER_CU");
+  const uint64_t per_cu = oe ? (uint64_t)atoi(oe) : 2ull * KS_OCC(items);
+  const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * per_cu;
   const dim3 grid((unsigned)(want < cap ? want : cap)), block(64 * KS_WAVES);
 #define KS_LAUNCH(I, C)                                                                                              \
   hipLaunchKernelGGL((ku_classify_short_kernel<I, C>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes, d_seq_off, \
