@@ -71,7 +71,6 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   const uint32_t k = db.k, m = db.nt;
   const uint32_t w = k - m + 1;  // m-mers per k-mer (krakendb.cpp:208)
   const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
-  const bool aligned = (((uintptr_t)seqs) & 15u) == 0;
   // LAYOUT 1 with nt <= 13 keeps the m-mer values pre-shifted by 5 bits in LDS (ku_window_argmin)
   const uint32_t mm_shift = (LAYOUT == 1 && MODE != 2 && m <= 13) ? 5u : 0u;
   const uint32_t mm_bias = mm_shift ? 1u : 0u;  // value + 1: the field never underflows when an offset is subtracted
@@ -83,27 +82,35 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     const uint64_t tile0 = tile * KU_TILE;
     __syncthreads();  // previous iteration's LDS readers are done
     if (DO_COUNTS) ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, cnt.n_kmers);
-    // ---- stage 1: ASCII -> packed 2-bit codes + ambiguity bits (16 bases per lane)
-    if (tid < KU_PACKW + 4) {
-      uint64_t b0 = tile0 + 16ull * tid;
-      uint32_t word = 0, amb = 0;
-      if (tid >= KU_PACKW || b0 >= n_bytes) {
-        amb = 0xFFFFu;
-      } else if (aligned && b0 + 16 <= n_bytes) {
-        uint4 v = *reinterpret_cast<const uint4 *>(seqs + b0);
-        uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q)
-#pragma unroll
-          for (uint32_t j = 0; j < 4; ++j) ku_pack_byte((d[q] >> (8 * j)) & 0xffu, 4 * q + j, word, amb);
-      } else {
-        for (uint32_t j = 0; j < 16; ++j) {
-          uint32_t b = (b0 + j < n_bytes) ? seqs[b0 + j] : (uint32_t)'N';
-          ku_pack_byte(b, j, word, amb);
+    // ---- stage 1: ASCII -> packed 2-bit codes + ambiguity bits: four bases per thread (one dword, SWAR), the four
+    // lanes of a quad OR their bytes into one 16-base word
+    static_assert(4 * (KU_PACKW + 4) <= KU_THREADS, "one packing pass");
+    if (tid < 4 * (KU_PACKW + 4)) {
+      const uint32_t wi = tid >> 2, q4 = tid & 3u;
+      const uint64_t b0 = tile0 + 4ull * tid;
+      uint32_t c8 = 0, a4 = 0xFu;
+      if (wi < KU_PACKW && b0 < n_bytes) {
+        const uint8_t *src = seqs + b0;
+        const uintptr_t mis = (uintptr_t)src & 3u;
+        uint32_t d;
+        if (b0 + 8 - mis <= n_bytes) {  // two aligned dwords cover the four bytes at any alignment
+          const uint32_t *q = reinterpret_cast<const uint32_t *>(src - mis);
+          d = mis ? __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)mis) : q[0];
+        } else {
+          d = 0;
+          for (uint32_t j = 0; j < 4; ++j) d |= (b0 + j < n_bytes ? (uint32_t)src[j] : (uint32_t)'N') << (8 * j);
         }
+        ku_pack_dword(d, c8, a4);
       }
-      s_codes[tid] = word;
-      s_amb16[tid ^ 1u] = (uint16_t)amb;  // even word -> high half (little-endian uint16 view)
+      uint32_t word = c8 << (24 - 8 * q4), amb = a4 << (12 - 4 * q4);
+      word |= (uint32_t)__shfl_xor((int)word, 1);
+      amb |= (uint32_t)__shfl_xor((int)amb, 1);
+      word |= (uint32_t)__shfl_xor((int)word, 2);
+      amb |= (uint32_t)__shfl_xor((int)amb, 2);
+      if (q4 == 0) {
+        s_codes[wi] = word;
+        s_amb16[wi ^ 1u] = (uint16_t)amb;  // even word -> high half (little-endian uint16 view)
+      }
     }
     __syncthreads();
 
