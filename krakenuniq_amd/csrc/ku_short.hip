@@ -49,9 +49,10 @@ __device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32
   ks_wave_sync();
 }
 
-// waves per SIMD the variant is compiled for: 2 k-mers per lane fit 96 VGPRs (5 waves), 3 per lane need 128 (4 waves)
+// waves per SIMD the variant is compiled for: 2 k-mers per lane fit 80 VGPRs (6 waves, 8 B of scratch; LDS allows 6
+// blocks per CU), 3 per lane need 128 (4 waves)
 #ifndef KS_OCC2
-#define KS_OCC2 5
+#define KS_OCC2 6
 #endif
 #define KS_OCC(ITEMS) ((ITEMS) == 2 ? KS_OCC2 : 4)
 template <int ITEMS, bool DO_COUNTS>
@@ -74,7 +75,10 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   __shared__ uint32_t s_rk[KS_WAVES][1 << G::RCT_LOG2], s_rc[KS_WAVES][1 << G::RCT_LOG2];
   __shared__ uint32_t s_misc[KS_WAVES][4];      // [0] n_kmers table fill, [1] n_reads table fill, [2] list length, [3] bcast
 
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  // the wave index is uniform: telling the compiler so moves the per-read metadata (r, len, off, n) and the wave's LDS
+  // base addresses to scalar registers and scalar loads
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint32_t *codes = s_codes[wv], *amb = s_amb[wv], *mmv = s_mm[wv];
   uint32_t *t_key = s_tkey[wv], *t_cnt = s_tcnt[wv];
   uint16_t *t_list = s_tlist[wv];
