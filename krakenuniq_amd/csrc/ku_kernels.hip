@@ -26,11 +26,15 @@
 #include "ku_device.h"
 
 #define KU_THREADS 256
+// One k-mer position per lane and 8 waves per SIMD (64 VGPRs): measured best on MI355X once the kernel became
+// instruction-issue bound -- (items, waves, lookup ms per 5 M pairs 2x150): (3, 4) 26.7, (2, 5) 23.6, (1, 7) 22.2,
+// (1, 8) 21.3.  More resident waves hide the LDS / ALU latencies of the scan stages better than more probes in
+// flight per lane hide HBM latency.
 #ifndef KU_MIN_WAVES
-#define KU_MIN_WAVES 4  // waves per SIMD the lookup kernel is compiled for (<= 128 VGPRs)
+#define KU_MIN_WAVES 8  // waves per SIMD the lookup kernel is compiled for
 #endif
 #ifndef KU_ITEMS
-#define KU_ITEMS 3
+#define KU_ITEMS 1
 #endif
 #define KU_CTL_MERGE 16u                  // lookup kernel control bit: do not store positions another chunk owns
 #define KU_TILE (KU_THREADS * KU_ITEMS)   // k-mer start positions per block iteration
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
 
 static unsigned ku_lookup_grid(uint64_t n_bytes, int n_cu) {
   uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
-  uint64_t max_blocks = (uint64_t)n_cu * 8;
+  uint64_t max_blocks = (uint64_t)n_cu * 2 * KU_MIN_WAVES;  // two rounds of the blocks a CU holds at once
   return (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
 }
 
