@@ -825,7 +825,7 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
   const uint32_t flags = opts ? opts->flags : 0;
   // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
   const uint32_t short_max = (getenv("KU_NO_FUSED") || !ctx->extra.empty()) ? 0 : ku_short_max_kmers(ctx->m.db);
-  if (short_max && !(flags & KU_F_QUICK) && n_reads) {
+  if (short_max && !(flags & (KU_F_QUICK | KU_F_KEEP_SLOTS)) && n_reads) {
     if (!d_seqs || !d_seq_off || !d_seq_len || !d_calls || !d_taxa) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     uint32_t max_len = opts ? opts->max_read_len : 0;

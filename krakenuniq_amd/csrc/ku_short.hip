@@ -17,6 +17,11 @@
 #include "ku_device.h"
 
 #define KS_WAVES 4  // reads in flight per 256-thread block
+#ifdef KU_ABLATION
+#define KS_ABL(bit) ((ablate & (bit)) != 0)
+#else
+#define KS_ABL(bit) false
+#endif
 
 template <int ITEMS> struct KsGeom {
   static constexpr int MAXN = 64 * ITEMS;                      // k-mers per read
@@ -55,13 +60,17 @@ __device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32
 #define KS_OCC2 6
 #endif
 #define KS_OCC(ITEMS) ((ITEMS) == 2 ? KS_OCC2 : 4)
-template <int ITEMS, bool DO_COUNTS>
+// KK / MM: compile-time k-mer and minimizer lengths of the common database geometries (0 = read them from `db`):
+// every shift count and the window length become literals instead of loop-invariant scalars that the register
+// allocator has to park in VGPR lanes and read back in the read loop.
+template <int ITEMS, bool DO_COUNTS, int KK, int MM>
 __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_short_kernel(
     KuDbDev db, KuTaxDev tax, KuCountsDev cnt, const uint8_t *__restrict__ seqs, uint64_t n_bytes,
     const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, uint64_t n_reads,
-    uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t *__restrict__ hits_out, uint32_t keep_slots,
-    uint32_t ablate) {
-  // `ablate`: measurement knob (env KU_ABLATE): 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
+    uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t ablate) {
+  // KS_ABL(bit): measurement knob, compiled in only with -DKU_ABLATION (then env KU_ABLATE selects the bits; the
+  // production build has no trace of it -- the flag checks cost scalar registers and branches in the read loop):
+  // 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
   // 32 skip resolve (call 0), 64 skip locus/minimizer stage (bucket 0).  0 in production.
   using G = KsGeom<ITEMS>;
   constexpr uint32_t TCAP = 1u << G::TCAP_LOG2;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   uint16_t *t_list = s_tlist[wv];
   uint16_t *amb16 = reinterpret_cast<uint16_t *>(amb);
   uint32_t *misc = s_misc[wv];
-  const uint32_t k = db.k, m = db.nt, w = k - m + 1;
+  const uint32_t k = KK ? (uint32_t)KK : db.k, m = KK ? (uint32_t)MM : db.nt, w = k - m + 1;
   const bool packed_ok = m <= 13;  // (value + 1) << 5 | offset fits 32 bits
   const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
 
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       ks_wave_sync();
 
       // ---- stage 2: k-mers, ambiguity, canonical form, m-mer values
-      uint64_t canon[ITEMS], canon_rc[ITEMS];
+      uint64_t canon[ITEMS];
       bool is_fwd[ITEMS], ok[ITEMS];
 #pragma unroll
       for (int j = 0; j <= ITEMS; ++j) {
@@ -164,7 +173,6 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
           const uint64_t rc = ku_revcomp64(fwd, k);
           is_fwd[j] = fwd <= rc;
           canon[j] = is_fwd[j] ? fwd : rc;
-          canon_rc[j] = is_fwd[j] ? rc : fwd;
           const uint32_t ai = p >> 5, as = p & 31u;
           const uint64_t a = (((uint64_t)amb[ai] << 32) | amb[ai + 1]) << as;
           amb_k[j] = p < n && (a >> (64 - k)) != 0;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 
       // ---- stage 3: minimizer + its first position in the canonical k-mer's frame -> locus key (ku_locus_key)
       uint32_t mn[ITEMS], aoff[ITEMS];
-      if (ablate & 64u) {
+      if (KS_ABL(64u)) {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) { mn[j] = 0; aoff[j] = 0; }
       } else if (packed_ok) {
@@ -224,21 +232,23 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
         const uint32_t rcm = ku_revcomp32(mmf, m);
         const bool plus = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
-        const uint64_t cp = plus ? canon[j] : canon_rc[j];
         const uint32_t ap = plus ? a : w - 1 - a;
         const uint32_t left = ap, right = w - 1 - ap;
         const bool use_r = right >= left;
         const uint32_t side = use_r ? right : left;
         const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
         const uint32_t end = use_r ? ap + m + flen : ap;
-        const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
+        // bases [end - flen, end) of the strand on which the minimizer m-mer is canonical; on the other strand they
+        // are the reverse complement of bases [k - end, k - end + flen) of the canonical k-mer (no second 64-bit copy)
+        const uint32_t seg = (uint32_t)(canon[j] >> (2 * (plus ? k - end : end - flen))) & ((1u << (2 * flen)) - 1u);
+        const uint32_t flank = flen ? (plus ? seg : ku_revcomp32(seg, flen)) : 0u;
         const uint64_t locus = ((uint64_t)mn[j] << 32) | ((uint64_t)flank << 12) | (flen << 8) |
                                ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
         hh[j] = ku_fmix64(canon[j]);
         lp[j] = tab + ku_locus_line(ok[j] ? locus : 0, db.n_lines) * KU_LINE_DWORDS;
         tag[j] = ku_table_tag(hh[j]);
-        act[j] = ok[j] && !(ablate & 1u);
-        if (ablate & 64u) lp[j] = tab;
+        act[j] = ok[j] && !KS_ABL(1u);
+        if (KS_ABL(64u)) lp[j] = tab;
       }
 
       // ---- stage 4: bucket probe (header round trip, entry in the same line, lockstep tail)
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     uint32_t call_node = 0;
     bool uni = false;        // at most one distinct hit taxon in the read (the common case)
     uint32_t uni_slot = 0;   // that taxon's slot (0 = no hit at all)
-    if (!(ablate & 32u)) {
+    if (!KS_ABL(32u)) {
       uint32_t mine = 0;
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j)
@@ -411,32 +421,31 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
         const bool okc = j * 64 + lane < n && !amb_k[j];
-        if (okc && !(ablate & 2u)) ku_hll_update(cnt.registers, v[j], hh[j]);
+        if (okc && !KS_ABL(2u)) ku_hll_update(cnt.registers, v[j], hh[j]);
         if (uni) {
           n_hit += (uint32_t)__popcll(__ballot(okc && v[j] != 0));
           n_miss += (uint32_t)__popcll(__ballot(okc && v[j] == 0));
-        } else if (okc && !(ablate & 4u)) {
+        } else if (okc && !KS_ABL(4u)) {
           ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], v[j], 1, cnt.n_kmers);
         }
       }
-      if (uni && lane == 0 && !(ablate & 4u)) {
+      if (uni && lane == 0 && !KS_ABL(4u)) {
         if (n_hit) ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], uni_slot, n_hit, cnt.n_kmers);
         if (n_miss) ku_ct_add<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], 0u, n_miss, cnt.n_kmers);
       }
     }
 
     // ---- outputs
-    const uint32_t uni_code = uni && uni_slot ? (keep_slots ? uni_slot : tax.slot_taxid[uni_slot]) : 0u;
+    const uint32_t uni_code = uni && uni_slot ? tax.slot_taxid[uni_slot] : 0u;
     if (lane == 0) {
       calls[r] = tax.node_taxid[call_node];
-      if (hits_out) hits_out[r] = 0;
       if (DO_COUNTS) ku_ct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], call_node, 1, cnt.n_reads);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t p = j * 64 + lane;
-      if (p < n && !(ablate & 8u))
-        taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (uni ? uni_code : (keep_slots ? v[j] : tax.slot_taxid[v[j]])) : 0u);
+      if (p < n && !KS_ABL(8u))
+        taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (uni ? uni_code : tax.slot_taxid[v[j]]) : 0u);
     }
     ks_wave_sync();  // the next read reuses the wave's LDS arrays
   }
@@ -458,7 +467,8 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
                              int n_cu, hipStream_t stream) {
   if (n_reads == 0) return KU_OK;
   const bool counts = !(flags & KU_F_NO_COUNTS);
-  const uint32_t keep = (flags & KU_F_KEEP_SLOTS) ? 1u : 0u;
+  if (flags & KU_F_KEEP_SLOTS) return KU_EINVAL;  // slot ids are for the sharded path, which does not come here
+  if (d_hits && hipMemsetAsync(d_hits, 0, n_reads * 4, stream) != hipSuccess) return KU_EHIP;  // "Q:n" is quick mode only
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
   // persistent grid: two rounds of the blocks a CU holds at once (KS_OCC blocks of KS_WAVES = 4 waves per CU)
@@ -467,12 +477,23 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
   const uint64_t per_cu = oe ? (uint64_t)atoi(oe) : 2ull * KS_OCC(items);
   const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * per_cu;
   const dim3 grid((unsigned)(want < cap ? want : cap)), block(64 * KS_WAVES);
-#define KS_LAUNCH(I, C)                                                                                              \
-  hipLaunchKernelGGL((ku_classify_short_kernel<I, C>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes, d_seq_off, \
-                     d_seq_len, n_reads, d_calls, d_taxa, d_hits, keep, ablate)
-  if (max_kmers <= 128) { if (counts) KS_LAUNCH(2, true); else KS_LAUNCH(2, false); }
-  else if (max_kmers <= 192) { if (counts) KS_LAUNCH(3, true); else KS_LAUNCH(3, false); }
-  else return KU_EINVAL;
+#define KS_LAUNCH(I, C, K, M)                                                                                       \
+  hipLaunchKernelGGL((ku_classify_short_kernel<I, C, K, M>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes,  \
+                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate)
+  // specialised geometries (accounting runs only): k = 31 with nt = 13 (MiniKraken-size databases) or 15 (standard)
+  const int geo = !counts || db.k != 31 ? 0 : (db.nt == 13 ? 13 : (db.nt == 15 ? 15 : 0));
+  if (max_kmers > 192) return KU_EINVAL;
+  if (max_kmers <= 128) {
+    if (!counts) KS_LAUNCH(2, false, 0, 0);
+    else if (geo == 13) KS_LAUNCH(2, true, 31, 13);
+    else if (geo == 15) KS_LAUNCH(2, true, 31, 15);
+    else KS_LAUNCH(2, true, 0, 0);
+  } else {
+    if (!counts) KS_LAUNCH(3, false, 0, 0);
+    else if (geo == 13) KS_LAUNCH(3, true, 31, 13);
+    else if (geo == 15) KS_LAUNCH(3, true, 31, 15);
+    else KS_LAUNCH(3, true, 0, 0);
+  }
 #undef KS_LAUNCH
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
