@@ -340,8 +340,8 @@ int main(int argc, char **argv) {
     };
     for (int fi = optind; fi < argc; fi += paired ? 2 : 1) {
       Reader rd, rd2;
-      rd.open(argv[fi]);
-      if (paired) rd2.open(argv[fi + 1]);
+      rd.open(argv[fi], /*prefetch=*/true);
+      if (paired) rd2.open(argv[fi + 1], /*prefetch=*/true);
       bool more = true;
       while (more) {
         Batch *bt = chunked ? new Batch() : free_q.pop();  // -x: every batch stays alive until the last chunk

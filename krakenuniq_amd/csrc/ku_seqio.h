@@ -6,10 +6,15 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/krakenuniq_amd.h"
@@ -79,14 +84,34 @@ struct Batch {
   }
 };
 
-// ---- FASTA/FASTQ reader (gz transparently via zlib).  Lines are handed out as ranges of one large buffer.
+// ---- FASTA/FASTQ reader (gz transparently via zlib).  Lines are handed out as ranges of one large buffer.  With
+// prefetch on, a producer thread per file does the read(2) / inflate into a small ring of blocks, so decompression
+// overlaps with parsing and the two files of a mate pair are inflated concurrently.
 struct Reader {
   gzFile g = nullptr;
   int fd = -1;  // plain (uncompressed) files are read with read(2): one copy less than through zlib
   bool fastq = false, valid = true, eof = false;
   std::vector<char> buf;
   size_t pos = 0, len = 0;  // unconsumed bytes: buf[pos, len)
-  void open(const char *path) {
+  // producer side (prefetch)
+  static constexpr size_t BLOCK = (size_t)4 << 20;
+  struct Block { std::vector<char> data; size_t n = 0; };
+  std::thread producer;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Block *> ready, spare;
+  std::vector<Block> blocks;
+  bool produced_all = false, stop = false;
+
+  Reader() = default;
+  Reader(const Reader &) = delete;
+  Reader &operator=(const Reader &) = delete;
+  ~Reader() { close(); }
+
+  long raw_read(char *dst, size_t want) {
+    return fd >= 0 ? (long)::read(fd, dst, want) : (long)gzread(g, dst, (unsigned)want);
+  }
+  void open(const char *path, bool prefetch = false) {
     g = gzopen(path, "rb");
     if (!g) fatal(66, "can't open %s", path);
     gzbuffer(g, 1 << 20);
@@ -98,10 +123,39 @@ struct Reader {
     buf.resize((size_t)1 << 24);
     pos = len = 0;
     valid = true; eof = false;
+    produced_all = stop = false;
+    if (prefetch) {
+      blocks.resize(4);
+      for (Block &b : blocks) { b.data.resize(BLOCK); spare.push_back(&b); }
+      producer = std::thread([this] {
+        for (;;) {
+          Block *b;
+          {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return stop || !spare.empty(); });
+            if (stop) return;
+            b = spare.front();
+            spare.pop_front();
+          }
+          long n = raw_read(b->data.data(), BLOCK);
+          std::lock_guard<std::mutex> l(mu);
+          if (n <= 0) { spare.push_back(b); produced_all = true; cv.notify_all(); return; }
+          b->n = (size_t)n;
+          ready.push_back(b);
+          cv.notify_all();
+        }
+      });
+    }
     more();
     fastq = len > 0 && buf[0] == '@';  // determine_input_file_type (src/classify.cpp:377-388)
   }
   void close() {
+    if (producer.joinable()) {
+      { std::lock_guard<std::mutex> l(mu); stop = true; }
+      cv.notify_all();
+      producer.join();
+    }
+    ready.clear(); spare.clear(); blocks.clear();
     if (g) gzclose(g);
     if (fd >= 0) ::close(fd);
     g = nullptr; fd = -1;
@@ -114,10 +168,25 @@ struct Reader {
       len -= pos;
       pos = 0;
     }
+    if (producer.joinable()) {
+      Block *b = nullptr;
+      {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return !ready.empty() || produced_all; });
+        if (!ready.empty()) { b = ready.front(); ready.pop_front(); }
+      }
+      if (!b) { eof = true; return false; }
+      if (len + b->n > buf.size()) buf.resize(std::max(buf.size() * 2, len + b->n));
+      memcpy(buf.data() + len, b->data.data(), b->n);
+      len += b->n;
+      { std::lock_guard<std::mutex> l(mu); spare.push_back(b); }
+      cv.notify_all();
+      return true;
+    }
     if (len == buf.size()) buf.resize(buf.size() * 2);
     const size_t room = buf.size() - len;
     const size_t want = room < ((size_t)1 << 30) ? room : ((size_t)1 << 30);
-    long n = fd >= 0 ? (long)::read(fd, buf.data() + len, want) : (long)gzread(g, buf.data() + len, (unsigned)want);
+    long n = raw_read(buf.data() + len, want);
     if (n <= 0) { eof = true; return false; }
     len += (size_t)n;
     return true;

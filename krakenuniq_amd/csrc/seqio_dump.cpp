@@ -21,11 +21,12 @@ void ku_seqio::fatal(int code, const char *fmt, ...) {
 }
 
 int main(int argc, char **argv) {
-  bool paired = false, quiet = false;
+  bool paired = false, quiet = false, prefetch = false;
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
     if (argv[a][1] == 'P') paired = true;
     else if (argv[a][1] == 'n') quiet = true;
+    else if (argv[a][1] == 'T') prefetch = true;  // producer thread per file, as the classify executable runs
   }
   timeval t0, t1;
   gettimeofday(&t0, nullptr);
@@ -33,10 +34,10 @@ int main(int argc, char **argv) {
   std::string header, header2;
   for (; a < argc; a += paired ? 2 : 1) {
     ku_seqio::Reader rd, rd2;
-    rd.open(argv[a]);
+    rd.open(argv[a], prefetch);
     if (paired) {
       if (a + 1 >= argc) ku_seqio::fatal(64, "-P needs the files in pairs");
-      rd2.open(argv[a + 1]);
+      rd2.open(argv[a + 1], prefetch);
     }
     ku_seqio::Batch bt;
     for (bool more = true; more;) {
