@@ -216,7 +216,8 @@ int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint6
                     uint64_t n_reads, ku_batch **out);
 /* one pass against the resident shard (opts->flags: KU_F_QUICK defers the accounting to ku_batch_finish) */
 int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts);
-/* after the last chunk: resolve_tree / quick call per read + run-length encoding; outputs as ku_classify_batch_rle */
+/* after the last chunk, once per batch (KU_ESTATE afterwards): resolve_tree / quick call per read + run-length
+ * encoding; outputs as ku_classify_batch_rle */
 int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
                     uint32_t *run_cnt, uint64_t *n_runs);
 void ku_batch_destroy(ku_batch *b);

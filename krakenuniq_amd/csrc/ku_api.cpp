@@ -966,6 +966,7 @@ struct ku_batch {
   ku_ctx *ctx = nullptr;
   uint64_t n_bytes = 0, n_reads = 0;
   uint32_t max_len = 0;
+  bool finished = false;  // ku_batch_finish translated the slots to taxids in place: no further passes
   void *d_seqs = nullptr;
   uint64_t *d_off = nullptr;
   uint32_t *d_len = nullptr, *d_taxa = nullptr;
@@ -1008,6 +1009,7 @@ extern "C" int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, 
 extern "C" int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts) {
   KU_TRY(check_ready(ctx));
   if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_lookup: batch of another context");
+  if (b->finished) return fail(KU_ESTATE, "ku_batch_lookup: the batch was already finished");
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   o.flags |= KU_F_MERGE_CHUNK | KU_F_KEEP_SLOTS;
   return ku_lookup_device(ctx, b->d_seqs, b->n_bytes, &o, b->d_taxa, nullptr);
@@ -1018,6 +1020,7 @@ extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, ui
   KU_TRY(check_ready(ctx));
   if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_finish: batch of another context");
   if (!n_runs || (b->n_reads && (!calls || !run_off || !run_cnt))) return fail(KU_EINVAL, "ku_batch_finish: null buffer");
+  if (b->finished) return fail(KU_ESTATE, "ku_batch_finish: the batch was already finished");
   *n_runs = 0;
   ctx->n_runs = 0;
   const uint64_t n_reads = b->n_reads;
@@ -1032,6 +1035,7 @@ extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, ui
   hipStream_t s = ctx->stream;
   KU_TRY(ku_resolve_device(ctx, b->d_seqs, b->d_off, b->d_len, n_reads, &o, (uint32_t *)ctx->b_calls.p, b->d_taxa,
                            (uint32_t *)ctx->b_hits.p, s));
+  b->finished = true;
   return rle_and_fetch(ctx, b->d_taxa, b->d_off, b->d_len, n_reads, runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits,
                        run_off, run_cnt, n_runs);
 }

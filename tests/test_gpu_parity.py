@@ -387,6 +387,8 @@ def test_out_of_core_chunked_run(golden, f1, monkeypatch, budget, layout, quick)
         res = b.finish(flags=flags, min_hits=2)
         calls.append(res["calls"])
         text += capi.format_kraken_rle(p[0], p[1], p[2], ids[a:e], K, res, flags=capi.KU_P_QUICK if quick else 0)
+        with pytest.raises(capi.KuError):  # a finished batch takes no further passes
+            b.lookup()
         b.close()
     run, res, *_ = oracle_flat(f1["odb"], f1["otax"], seqs, quick=quick, min_hits=2)
     assert np.array_equal(np.concatenate(calls), res["calls"])
