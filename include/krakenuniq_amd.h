@@ -81,6 +81,15 @@ int ku_db_shard_plan(const ku_db *db, uint32_t n_shards, uint64_t *bin_bounds);
 int ku_db_chunk_plan(const ku_db *db, uint64_t max_bytes, uint64_t *bin_bounds, uint32_t cap,
                      uint32_t *n_chunks);
 
+/* ------------------------------------------------------------------ database construction (offline)
+ * db_sort on the GPU (src/db_sort.cpp:34-128 + KrakenDB::make_index, src/krakendb.cpp:118-148): reads a
+ * Jellyfish-format k-mer list (JFLISTDN header, unsorted key/value records), orders the records by (minimizer bin
+ * key, k-mer) and writes database.kdb (header copied verbatim, sorted records) and database.idx ("KRAKIX2", nt,
+ * 4^nt + 1 offsets) -- byte for byte what the reference writes.  zero_vals = db_sort -z.  nt in [1, 15].  The whole
+ * list has to fit the device (about 45 bytes of HBM per record at the peak). */
+int ku_db_sort_files(int device, const char *in_path, const char *out_kdb_path, const char *out_idx_path, uint32_t nt,
+                     int zero_vals);
+
 /* ------------------------------------------------------------------ taxonomy
  * Host taxonomy: taxDB text -> entries + Parent_map
  * (taxdb.hpp:563-605 readTaxonomyIndex_, :411-433 createPointers, :383-398 getParentMap). */

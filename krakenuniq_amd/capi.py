@@ -61,6 +61,7 @@ SIGNATURES = {
     "ku_db_shard_plan": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "ku_db_chunk_plan": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_uint32, u32p]),
     "ku_db_values": (C.c_int, [C.c_void_p, u32p, u64p]),
+    "ku_db_sort_files": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
     "ku_ctx_swap_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ku_batch_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "ku_batch_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts)]),
@@ -405,6 +406,12 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def db_sort_files(in_path, out_kdb, out_idx, nt, zero_vals=False, device=0):
+    """db_sort on the GPU: Jellyfish-format list -> database.kdb + database.idx"""
+    _chk(lib().ku_db_sort_files(device, in_path.encode(), out_kdb.encode(), out_idx.encode(), nt, int(zero_vals)),
+         "ku_db_sort_files")
 
 
 def hll_cardinality(registers, n_observed, p=12):

@@ -239,15 +239,15 @@ def write_db(dirname: str, kmers: np.ndarray, vals: np.ndarray, offsets: np.ndar
         f.write(offsets.astype("<u8").tobytes())
 
 
-def read_db(dirname: str):
+def read_db(dirname: str, kdb: str = "database.kdb", idx: str = "database.idx"):
     """Parse database.kdb/.idx back into (kmers, vals, offsets, k, nt, idx_type)."""
-    raw = np.fromfile(os.path.join(dirname, "database.kdb"), dtype=np.uint8)
+    raw = np.fromfile(os.path.join(dirname, kdb), dtype=np.uint8)
     assert raw[:8].tobytes() == b"JFLISTDN"
     key_bits = int.from_bytes(raw[8:16].tobytes(), "little")
     key_ct = int.from_bytes(raw[48:56].tobytes(), "little")
     hdr = 72 + 2 * (4 + 8 * key_bits)
     pairs = raw[hdr:hdr + 12 * key_ct].view(PAIR_DT)
-    idx = np.fromfile(os.path.join(dirname, "database.idx"), dtype=np.uint8)
+    idx = np.fromfile(os.path.join(dirname, idx), dtype=np.uint8)
     magic = idx[:7].tobytes()
     nt = int(idx[7])
     offsets = idx[8:].view("<u8")
