@@ -232,7 +232,9 @@ int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, uint32_t *cal
 void ku_batch_destroy(ku_batch *b);
 
 /* Same on device-resident buffers, asynchronous on `stream` (a hipStream_t
- * passed as void*; NULL = the context's own stream). */
+ * passed as void*; NULL = the context's own, non-blocking stream).  The caller orders the work: whatever produced
+ * the input buffers must have completed (or be ordered before `stream`), and the outputs are ready after
+ * ku_ctx_synchronize / a synchronisation of `stream`. */
 int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
                              const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
                              uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream);
