@@ -155,6 +155,22 @@ int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *taxids, uin
 /* zero HLL registers / n_kmers / n_reads (start of a run) */
 int ku_ctx_reset_counts(ku_ctx *ctx);
 
+/* ---- set_lcas on the GPU (src/set_lcas.cpp:429-476, the database build step after db_sort): every k-mer of a library
+ * sequence that the database holds gets  value = lca(Parent_map, taxid of the sequence, value)  (krakenutil.cpp:90-118).
+ * ku_setlcas_open uploads the database in its on-disk order and the taxonomy; ku_setlcas_add folds one sequence
+ * (ASCII, any case; k-mers with other letters are skipped) and blocks until done; ku_setlcas_finish returns the
+ * value of every pair in database order (and how many sequence k-mers the database did not hold: an error for
+ * set_lcas without -x).  KU_SL_RESET = -R (the sequences' k-mers are set to 0 instead), KU_SL_FORCE_CONTAMINANT = -T
+ * (a k-mer of a 'synthetic construct' / 'artificial sequences' sequence, taxids 32630 / 81077, keeps that taxid: the
+ * first such sequence in call order wins, values that already are one of the two stay). */
+#define KU_SL_RESET 0x1u
+#define KU_SL_FORCE_CONTAMINANT 0x2u
+typedef struct ku_setlcas ku_setlcas;
+int ku_setlcas_open(int device, const ku_db *db, const ku_tax *tax, uint32_t flags, ku_setlcas **out);
+int ku_setlcas_add(ku_setlcas *s, const char *seq, uint64_t len, uint32_t taxid);
+int ku_setlcas_finish(ku_setlcas *s, uint32_t *values_out, uint64_t *n_missing);
+void ku_setlcas_close(ku_setlcas *s);
+
 /* ------------------------------------------------------------------ classification */
 #define KU_F_QUICK 0x1u        /* -q : stop at min_hits hits (classify.cpp:943-944,962-963) */
 #define KU_F_NO_COUNTS 0x2u    /* do not touch HLL / n_kmers / n_reads (pure lookup) */

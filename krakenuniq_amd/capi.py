@@ -61,6 +61,10 @@ SIGNATURES = {
     "ku_db_shard_plan": (C.c_int, [C.c_void_p, C.c_uint32, u64p]),
     "ku_db_chunk_plan": (C.c_int, [C.c_void_p, C.c_uint64, u64p, C.c_uint32, u32p]),
     "ku_db_values": (C.c_int, [C.c_void_p, u32p, u64p]),
+    "ku_setlcas_open": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "ku_setlcas_add": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32]),
+    "ku_setlcas_finish": (C.c_int, [C.c_void_p, u32p, u64p]),
+    "ku_setlcas_close": (None, [C.c_void_p]),
     "ku_db_sort_files": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
     "ku_ctx_swap_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "ku_batch_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -399,6 +403,39 @@ class Batch:
     def close(self):
         if self.h:
             lib().ku_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+KU_SL_RESET, KU_SL_FORCE_CONTAMINANT = 1, 2
+
+
+class SetLcas:
+    """set_lcas on the GPU (ku_setlcas_*): fold library sequences into the database values."""
+
+    def __init__(self, db: Db, tax: Tax, flags=0, device=0):
+        self.h = C.c_void_p()
+        self.n = db.info.key_ct
+        _chk(lib().ku_setlcas_open(device, db.h, tax.h, flags, C.byref(self.h)), "ku_setlcas_open")
+        self._keep = (db, tax)
+
+    def add(self, seq: bytes, taxid: int):
+        _chk(lib().ku_setlcas_add(self.h, seq, len(seq), taxid), "ku_setlcas_add")
+
+    def finish(self):
+        vals = np.zeros(max(self.n, 1), dtype=np.uint32)
+        miss = C.c_uint64()
+        _chk(lib().ku_setlcas_finish(self.h, _p(vals, u32p), C.byref(miss)), "ku_setlcas_finish")
+        return vals[:self.n], miss.value
+
+    def close(self):
+        if self.h:
+            lib().ku_setlcas_close(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -225,6 +225,13 @@ extern "C" int ku_db_chunk_plan(const ku_db *db, uint64_t max_bytes, uint64_t *b
   return n <= cap ? KU_OK : fail(KU_EINVAL, "ku_db_chunk_plan: bounds array too small");
 }
 
+int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets) {
+  if (!db || !pairs || !offsets) return KU_EINVAL;
+  *pairs = db->pairs;
+  *offsets = db->offsets;
+  return KU_OK;
+}
+
 extern "C" int ku_db_values(const ku_db *db, uint32_t *out, uint64_t *n) {
   if (!db || !n) return fail(KU_EINVAL, "ku_db_values: null argument");
   // one bit per possible value, set by a team of scanning threads (the 4-byte value sits behind every key)

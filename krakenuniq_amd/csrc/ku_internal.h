@@ -45,6 +45,10 @@ struct KuCountsDev {
   unsigned long long *n_reads;        // n_nodes
 };
 
+// host-side view of an opened database for the other translation units (ku_api.cpp owns the struct)
+struct ku_db;
+int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets);
+
 // launch wrappers implemented in ku_kernels.hip (all asynchronous on `stream`)
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
                      uint32_t *d_taxa, bool do_counts, bool prior, bool merge_chunk, int n_cu, hipStream_t stream);

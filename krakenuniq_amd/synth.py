@@ -60,6 +60,15 @@ def codes_to_ascii(codes: np.ndarray) -> bytes:
     return _ASCII[codes].tobytes()
 
 
+def ascii_to_codes(seq: bytes) -> np.ndarray:
+    """inverse of codes_to_ascii for upper-case ACGT text"""
+    lut = np.full(256, 255, dtype=np.uint8)
+    lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+    codes = lut[np.frombuffer(seq, dtype=np.uint8)]
+    assert not (codes == 255).any(), "ACGT only"
+    return codes
+
+
 def revcomp_codes(codes: np.ndarray) -> np.ndarray:
     return (3 - codes[::-1]).astype(np.uint8)
 

@@ -20,6 +20,7 @@ Fixtures:
   f2/   edge FASTA (short / N / empty / lower-case / multi-line) + outputs
   f4/   paired FASTQs -> read_merger.pl -> merged.fa + outputs
   f7/   legacy KRAKIDX (type 1) index variant of f1 + outputs
+  f9/   set_lcas: library FASTA + seqid map -> the reference's database.kdb / counts
   f8/   second database + reads for hierarchical multi-database runs (both orders, quick mode)
   kat.json  per-function known-answer vectors from ref_kat
 """
@@ -213,6 +214,47 @@ def make_f8(f1, genomes):
     return d
 
 
+def make_f9(f1, genomes):
+    """set_lcas (the database build step behind db_sort): f1's k-mers with zeroed values + a small library -> the
+    reference's set_lcas output.  The library exercises the ID forms of src/set_lcas.cpp:263-300: plain ID, ID with a
+    .N version suffix, kraken:taxid| header, lower case / N bases, an unmapped ID (skipped), a taxid missing from
+    taxDB (skipped), an empty record, and a sequence whose k-mers the database does not hold (-x)."""
+    d = os.path.join(HERE, "f9")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    kmers, vals, off, k, nt, _ = synth.read_db(f1)
+    synth.write_db(d, kmers, np.zeros_like(vals), off, k, nt)
+    os.rename(f"{d}/database.kdb", f"{d}/database0.kdb")
+    os.remove(f"{d}/database.idx")
+    a = synth.codes_to_ascii
+    g4, g5, g6, gp = a(genomes[4]), a(genomes[5]), a(genomes[6]), a(genomes[1000000001])
+    recs = [
+        (b"seqA first genome", g4[:1500].lower() + g4[1500:]),
+        (b"seqB.1 versioned id", g5),
+        (b"kraken:taxid|6|seqC taxid in the header", g6[:1000] + b"N" + g6[1001:]),
+        (b"seqP plasmid", gp),
+        (b"unmapped no taxid for this one", g4[:200]),
+        (b"seqX taxid 999 is not in taxDB", g5[:200]),
+        (b"seqE empty record", b""),
+        (b"seqN novel sequence, not in the database", a(synth.procedural_genome(7, 4242, 300))),
+    ]
+    with open(f"{d}/library.fa", "wb") as f:
+        for h, s in recs:
+            f.write(b">" + h + b"\n")
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + b"\n")
+    with open(f"{d}/seqid2taxid.map", "w") as f:
+        f.write("seqA\t4\nseqB\t5\nseqP\t1000000001\nseqX\t999\nseqE\t4\nseqN\t5\nseqA\t6\n")
+    run([os.path.join(REF, "set_lcas"), "-M", "-x", "-d", f"{d}/database0.kdb", "-o", f"{d}/database.kdb",
+         "-i", f"{f1}/database.idx", "-b", f"{f1}/taxDB", "-m", f"{d}/seqid2taxid.map", "-F", f"{d}/library.fa",
+         "-c", f"{d}/database.kdb.counts"])
+    os.remove(f"{d}/database0.kdb")  # == f1's database.kdb with zeroed values (rebuilt by the test)
+    # the genomes are f1's: the LCAs must be f1's values wherever f1's value came from the genomes
+    k9, v9, *_ = synth.read_db(d, idx=os.path.join(f1, "database.idx"))
+    assert np.array_equal(k9, kmers)
+    return d
+
+
 class Kat:
     def __init__(self):
         self.p = subprocess.Popen([os.path.join(REF, "ref_kat")], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
@@ -355,12 +397,21 @@ def make_kat(f1):
 def main():
     if not os.path.exists(os.path.join(REF, "classify")):
         raise SystemExit("build the reference first: make -C oracle ref")
+    if sys.argv[1:] == ["f9"]:  # add the set_lcas fixture without regenerating the others
+        rng = np.random.default_rng(7)
+        g4 = synth.procedural_genome(7, 4, 3000)
+        g5 = synth.mutate(g4, 0.03, rng)
+        g6 = synth.procedural_genome(7, 6, 3000)
+        gp = np.concatenate([g6[2000:2300], synth.procedural_genome(7, 99, 300)])
+        make_f9(os.path.join(HERE, "f1"), {4: g4, 5: g5, 6: g6, 1000000001: gp})
+        return
     if sys.argv[1:] == ["f8"]:  # add the multi-database fixture without regenerating the others
         g4 = synth.procedural_genome(7, 4, 3000)
         make_f8(os.path.join(HERE, "f1"), {4: g4, 6: synth.procedural_genome(7, 6, 3000)})
         return
     f1, genomes = make_f1()
     make_f8(f1, genomes)
+    make_f9(f1, genomes)
     make_f2(f1)
     make_f4(f1, genomes)
     make_f7(f1)
