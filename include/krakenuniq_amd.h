@@ -152,6 +152,14 @@ int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_t *all_valu
 int ku_ctx_count_taxons(ku_ctx *ctx, uint32_t *taxids, uint64_t *counts, uint64_t *n);
 /* Same for the db_index-th database of a hierarchical run (0 = the first one); one .counts file per database. */
 int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *taxids, uint64_t *counts, uint64_t *n);
+/* Exact distinct k-mer counting next to the sketches (classifyExact): one device-wide set of canonical k-mers with
+ * 2^capacity_log2 cells (8 bytes each; keep the number of distinct k-mers of the run below ~70 % of that), filled by
+ * ku_classify_batch / _rle / _device (plain mode only: KU_EUNSUP with quick mode, slot output, count-less runs, the
+ * two-stage device API and resident batches).  Call after ku_ctx_set_taxonomy; ku_ctx_reset_counts empties the set.
+ * ku_counts_export_exact returns the distinct count per slot (same order as ku_counts_export's slot_taxid), or
+ * KU_ENOMEM when the set overflowed. */
+int ku_ctx_enable_exact(ku_ctx *ctx, uint32_t capacity_log2);
+int ku_counts_export_exact(ku_ctx *ctx, uint64_t *unique_kmers);
 /* zero HLL registers / n_kmers / n_reads (start of a run) */
 int ku_ctx_reset_counts(ku_ctx *ctx);
 
@@ -329,6 +337,12 @@ int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_t
  * (readGenomeSizes once per database, classify.cpp:263-285; taxdb.hpp:850-885). */
 int ku_report_multi(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
                     const uint64_t *n_kmers, const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid,
+                    const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
+/* classifyExact's report (classify built with EXACT_COUNTING, classify.cpp:46-53): `kmers` is the exact number of
+ * distinct k-mers (ku_counts_export_exact) instead of the HyperLogLog estimate; a clade's count is the sum over its
+ * members (a k-mer has one database value, the members' sets are disjoint). */
+int ku_report_exact(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
+                    const uint64_t *n_kmers, const uint64_t *unique_kmers, uint64_t n_slots, const uint32_t *node_taxid,
                     const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
 void ku_free(void *p);
 /* Page-locked host memory for batch buffers (fast, truly asynchronous H2D / D2H in ku_classify_batch). */

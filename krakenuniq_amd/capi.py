@@ -88,6 +88,8 @@ SIGNATURES = {
     "ku_ctx_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
     "ku_ctx_count_taxons_db": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p, u64p]),
     "ku_ctx_reset_counts": (C.c_int, [C.c_void_p]),
+    "ku_ctx_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "ku_counts_export_exact": (C.c_int, [C.c_void_p, u64p]),
     "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
                                     u32p, u32p, u32p]),
     "ku_classify_batch_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p, u32p,
@@ -113,6 +115,8 @@ SIGNATURES = {
     "ku_report": (C.c_int, [C.c_void_p, C.c_char_p, u32p, u64p, u8p, C.c_uint64, u32p, u64p, C.c_uint64,
                             C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_report_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u8p, C.c_uint64, u32p, u64p,
+                                  C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_report_exact": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u64p, C.c_uint64, u32p, u64p,
                                   C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_free": (None, [C.c_void_p]),
     "ku_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -288,6 +292,16 @@ class Ctx:
         n2 = C.c_uint64(len(t))
         _chk(lib().ku_ctx_count_taxons_db(self.h, db_index, _p(t, u32p), _p(c, u64p), C.byref(n2)), "ku_ctx_count_taxons_db")
         return t[:n2.value], c[:n2.value]
+
+    def enable_exact(self, capacity_log2=20):
+        _chk(lib().ku_ctx_enable_exact(self.h, capacity_log2), "ku_ctx_enable_exact")
+
+    def exact_counts(self):
+        d = CountsDims()
+        _chk(lib().ku_counts_dims_get(self.h, C.byref(d)), "ku_counts_dims_get")
+        out = np.zeros(d.n_slots, dtype=np.uint64)
+        _chk(lib().ku_counts_export_exact(self.h, _p(out, u64p)), "ku_counts_export_exact")
+        return out
 
     def reset_counts(self):
         _chk(lib().ku_ctx_reset_counts(self.h), "ku_ctx_reset_counts")
@@ -491,6 +505,20 @@ def format_kraken_rle(buf, off, lens, ids, k, res, flags=0):
                                     _p(np.ascontiguousarray(res["run_cnt"], dtype=np.uint32), u32p),
                                     _p(np.ascontiguousarray(res["hits"], dtype=np.uint32), u32p), flags,
                                     C.byref(out), C.byref(n)), "ku_format_kraken_rle")
+    s = C.string_at(out, n.value).decode()
+    lib().ku_free(out)
+    return s
+
+
+def report_exact(tax: Tax, counts: dict, unique, counts_paths):
+    """classifyExact's report: `unique` = Ctx.exact_counts(), counts_paths = list of database.kdb.counts files"""
+    out, n = C.c_void_p(), C.c_size_t()
+    paths = (C.c_char_p * len(counts_paths))(*[p.encode() for p in counts_paths])
+    unique = np.ascontiguousarray(unique, dtype=np.uint64)
+    _chk(lib().ku_report_exact(tax.h, paths, len(counts_paths), _p(counts["slot_taxid"], u32p), _p(counts["n_kmers"], u64p),
+                               _p(unique, u64p), len(counts["slot_taxid"]), _p(counts["node_taxid"], u32p),
+                               _p(counts["n_reads"], u64p), len(counts["node_taxid"]), C.byref(out), C.byref(n)),
+         "ku_report_exact")
     s = C.string_at(out, n.value).decode()
     lib().ku_free(out)
     return s

@@ -224,6 +224,11 @@ int main(int argc, char **argv) {
   if (idxs.empty()) { fprintf(stderr, "Missing mandatory option -i\n"); usage(EX_USAGE); }
   if (dbs.size() != idxs.size()) die(EX_USAGE, "every -d needs its -i (%zu databases, %zu indexes)", dbs.size(), idxs.size());
   if (dbs.size() > 8) die(EX_SOFTWARE, "at most 8 databases");
+  // installed as `classifyExact` (the reference's EXACT_COUNTING build, src/classify.cpp:46-53) the report counts
+  // distinct k-mers exactly instead of estimating them
+  const char *base = strrchr(argv[0], '/');
+  const bool exact = strcmp(base ? base + 1 : argv[0], "classifyExact") == 0 || getenv("KU_EXACT") != nullptr;
+  if (exact && quick) die(EX_SOFTWARE, "exact counting with quick mode is not built into the MI355X classifyExact");
   if (optind == argc && !populate) fprintf(stderr, "No sequence data files specified\n");
   if (paired && (argc - optind) % 2) die(EX_USAGE, "-P needs the input files in pairs (mate 1, mate 2)");
   if (taxdb.empty()) { fprintf(stderr, "TaxDB argument is required!\n"); return 1; }  // src/classify.cpp:221-222
@@ -260,6 +265,7 @@ int main(int argc, char **argv) {
     if (n_chunks <= 1) chunk_bounds.clear();
   }
   const bool chunked = !chunk_bounds.empty();
+  if (chunked && exact) die(EX_SOFTWARE, "exact counting with -x chunks is not built into the MI355X classifyExact");
   // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
   auto counts_file_good = [](const std::string &name, bool say) {
     bool good = false;
@@ -297,6 +303,10 @@ int main(int argc, char **argv) {
     KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
     for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
     KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
+  }
+  if (exact) {  // 2^30 cells = 8 GiB hold ~750 M distinct k-mers; KU_EXACT_LOG2 sizes it for larger runs
+    const char *e = getenv("KU_EXACT_LOG2");
+    KU_CHECK(ku_ctx_enable_exact(ctx, e ? (uint32_t)atoi(e) : 30u));
   }
 
   Sink s_kraken, s_cls, s_ucls;
@@ -555,6 +565,12 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> regs(d.n_slots * (size_t)KU_HLL_M);
     KU_CHECK(ku_counts_export(ctx, st.data(), nk.data(), regs.data(), ntx.data(), nr.data()));
     char *text = nullptr; size_t tn = 0;
+    if (exact) {
+      std::vector<uint64_t> uniq(d.n_slots);
+      KU_CHECK(ku_counts_export_exact(ctx, uniq.data()));
+      KU_CHECK(ku_report_exact(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), uniq.data(), d.n_slots,
+                               ntx.data(), nr.data(), d.n_nodes, &text, &tn));
+    } else
     KU_CHECK(ku_report_multi(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), regs.data(), d.n_slots, ntx.data(),
                              nr.data(), d.n_nodes, &text, &tn));
     if (tn == 0) fprintf(stderr, "total number of reads is zero - not creating a report!\n");

@@ -382,6 +382,9 @@ struct ku_ctx {
   DevBuf b_seqs, b_off, b_len, b_calls, b_taxa, b_hits, b_ws, b_runs, b_roff, b_rcnt;
   uint32_t *d_scalar = nullptr;
   uint64_t n_runs = 0;  // runs of the last ku_classify_batch_rle, still in b_runs
+  // exact distinct counting (classifyExact): one global set of canonical k-mers + first-insertion counters per slot
+  unsigned long long *d_exact_set = nullptr, *d_exact_unique = nullptr;
+  uint64_t exact_mask = 0;
 };
 
 static int ctx_activate(ku_ctx *ctx) {
@@ -434,6 +437,10 @@ static void ctx_free_tax(ku_ctx *ctx) {
   if (ctx->cnt.registers) (void)hipFree(ctx->cnt.registers);
   if (ctx->cnt.n_kmers) (void)hipFree(ctx->cnt.n_kmers);
   if (ctx->cnt.n_reads) (void)hipFree(ctx->cnt.n_reads);
+  if (ctx->d_exact_set) (void)hipFree(ctx->d_exact_set);
+  if (ctx->d_exact_unique) (void)hipFree(ctx->d_exact_unique);
+  ctx->d_exact_set = ctx->d_exact_unique = nullptr;
+  ctx->exact_mask = 0;
   ctx->cnt = KuCountsDev{};
   ctx->tax_set = false;
 }
@@ -719,7 +726,43 @@ extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
   HIP_TRY(hipMemsetAsync(ctx->cnt.registers, 0, (size_t)ctx->tax.n_slots * KU_HLL_M, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->cnt.n_kmers, 0, (size_t)ctx->tax.n_slots * 8, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->cnt.n_reads, 0, (size_t)ctx->tax.n_nodes * 8, ctx->stream));
+  if (ctx->d_exact_set) {
+    HIP_TRY(hipMemsetAsync(ctx->d_exact_set, 0, (ctx->exact_mask + 1) * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_exact_unique, 0, (size_t)ctx->tax.n_slots * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_scalar + 6, 0, 4, ctx->stream));
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return KU_OK;
+}
+
+static int check_ready(ku_ctx *ctx);
+
+extern "C" int ku_ctx_enable_exact(ku_ctx *ctx, uint32_t capacity_log2) {
+  KU_TRY(check_ready(ctx));
+  if (capacity_log2 < 10 || capacity_log2 > 36) return fail(KU_EINVAL, "ku_ctx_enable_exact: capacity_log2 out of range (10..36)");
+  if (ctx->d_exact_set) { (void)hipFree(ctx->d_exact_set); ctx->d_exact_set = nullptr; }
+  if (ctx->d_exact_unique) { (void)hipFree(ctx->d_exact_unique); ctx->d_exact_unique = nullptr; }
+  ctx->exact_mask = 0;
+  const uint64_t cells = 1ull << capacity_log2;
+  if (hipMalloc((void **)&ctx->d_exact_set, cells * 8) != hipSuccess) { ctx->d_exact_set = nullptr; return fail(KU_ENOMEM, "device memory for the exact k-mer set"); }
+  if (hipMalloc((void **)&ctx->d_exact_unique, (size_t)ctx->tax.n_slots * 8) != hipSuccess) {
+    (void)hipFree(ctx->d_exact_set);
+    ctx->d_exact_set = ctx->d_exact_unique = nullptr;
+    return fail(KU_ENOMEM, "device memory for the exact counters");
+  }
+  ctx->exact_mask = cells - 1;
+  return ku_ctx_reset_counts(ctx);
+}
+
+extern "C" int ku_counts_export_exact(ku_ctx *ctx, uint64_t *unique_kmers) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->d_exact_set) return fail(KU_ESTATE, "exact counting is not enabled (ku_ctx_enable_exact)");
+  if (!unique_kmers) return fail(KU_EINVAL, "ku_counts_export_exact: null buffer");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  uint32_t overflow = 0;
+  HIP_TRY(hipMemcpy(&overflow, ctx->d_scalar + 6, 4, hipMemcpyDeviceToHost));
+  if (overflow) return fail(KU_ENOMEM, "the exact k-mer set is full: enable it with a larger capacity");
+  HIP_TRY(hipMemcpy(unique_kmers, ctx->d_exact_unique, (size_t)ctx->tax.n_slots * 8, hipMemcpyDeviceToHost));
   return KU_OK;
 }
 
@@ -831,7 +874,10 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
   KU_TRY(check_ready(ctx));
   const uint32_t flags = opts ? opts->flags : 0;
   // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
-  const uint32_t short_max = (getenv("KU_NO_FUSED") || !ctx->extra.empty()) ? 0 : ku_short_max_kmers(ctx->m.db);
+  const bool exact = ctx->d_exact_set != nullptr;
+  if (exact && (flags & (KU_F_QUICK | KU_F_KEEP_SLOTS | KU_F_NO_COUNTS)))
+    return fail(KU_EUNSUP, "exact counting goes with the plain classification only (no quick mode / slot output / count-less runs)");
+  const uint32_t short_max = (getenv("KU_NO_FUSED") || !ctx->extra.empty() || exact) ? 0 : ku_short_max_kmers(ctx->m.db);
   if (short_max && !(flags & (KU_F_QUICK | KU_F_KEEP_SLOTS)) && n_reads) {
     if (!d_seqs || !d_seq_off || !d_seq_len || !d_calls || !d_taxa) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -853,6 +899,13 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
     return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, &o, d_calls, d_taxa, d_hits, stream);
   }
   KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, opts, d_taxa, stream));
+  if (exact) {  // between the stages: d_taxa holds slot ids
+    if (n_reads && (!d_seqs || !d_seq_off || !d_seq_len || !d_taxa)) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
+    int st = ku_launch_exact(ctx->m.db.k, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, d_taxa, ctx->d_exact_set,
+                             ctx->exact_mask, ctx->d_exact_unique, ctx->d_scalar + 6, ctx->n_cu,
+                             stream ? (hipStream_t)stream : ctx->stream);
+    if (st != KU_OK) return fail(st, "exact counting kernel launch failed");
+  }
   return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, opts, d_calls, d_taxa, d_hits, stream);
 }
 
@@ -1017,6 +1070,7 @@ extern "C" int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts) {
   KU_TRY(check_ready(ctx));
   if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_lookup: batch of another context");
   if (b->finished) return fail(KU_ESTATE, "ku_batch_lookup: the batch was already finished");
+  if (ctx->d_exact_set) return fail(KU_EUNSUP, "exact counting is not available for resident batches");
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   o.flags |= KU_F_MERGE_CHUNK | KU_F_KEEP_SLOTS;
   return ku_lookup_device(ctx, b->d_seqs, b->n_bytes, &o, b->d_taxa, nullptr);

@@ -187,7 +187,7 @@ extern "C" void ku_free(void *p) { free(p); }
 // ---------------------------------------------------------------------------- report
 namespace {
 struct Clade {
-  uint64_t reads = 0, kmers = 0;
+  uint64_t reads = 0, kmers = 0, uniq = 0;
   std::vector<uint8_t> regs;  // dense p=12 registers of the merged sketch (empty until first k-mer source)
   bool present = false;
 };
@@ -211,20 +211,45 @@ extern "C" int ku_report(const ku_tax *tax, const char *counts_path, const uint3
                          n_slots, node_taxid, n_reads, n_nodes, out, out_len);
 }
 
+static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
+                       const uint64_t *n_kmers, const uint8_t *registers, const uint64_t *unique, uint64_t n_slots,
+                       const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
+
 extern "C" int ku_report_multi(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths,
                                const uint32_t *slot_taxid, const uint64_t *n_kmers, const uint8_t *registers,
                                uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes,
                                char **out, size_t *out_len) {
-  if (!tax || !out || (n_paths && !counts_paths) || !out_len || (n_slots && (!slot_taxid || !n_kmers || !registers)) || (n_nodes && (!node_taxid || !n_reads))) {
+  if (n_slots && !registers) { ku_set_error("ku_report: null argument"); return KU_EINVAL; }
+  return report_impl(tax, counts_paths, n_paths, slot_taxid, n_kmers, registers, nullptr, n_slots, node_taxid, n_reads, n_nodes, out, out_len);
+}
+
+extern "C" int ku_report_exact(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths,
+                               const uint32_t *slot_taxid, const uint64_t *n_kmers, const uint64_t *unique_kmers,
+                               uint64_t n_slots, const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes,
+                               char **out, size_t *out_len) {
+  if (n_slots && !unique_kmers) { ku_set_error("ku_report_exact: null argument"); return KU_EINVAL; }
+  return report_impl(tax, counts_paths, n_paths, slot_taxid, n_kmers, nullptr, unique_kmers, n_slots, node_taxid, n_reads, n_nodes, out, out_len);
+}
+
+static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
+                       const uint64_t *n_kmers, const uint8_t *registers, const uint64_t *unique, uint64_t n_slots,
+                       const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len) {
+  if (!tax || !out || (n_paths && !counts_paths) || !out_len || (n_slots && (!slot_taxid || !n_kmers || (!registers && !unique))) || (n_nodes && (!node_taxid || !n_reads))) {
     ku_set_error("ku_report: null argument");
     return KU_EINVAL;
   }
   const size_t nt = tax->ids.size();
   // taxon_counts: taxid -> (n_reads, n_kmers, sketch); an entry exists when either count is non-zero
-  struct TaxCount { uint64_t reads = 0, kmers = 0; const uint8_t *regs = nullptr; };
+  // (exact mode, classifyExact: the sketch is a set of k-mers; a k-mer has one database value, so the sets of
+  // different taxa are disjoint and a clade's distinct count is the sum of its members')
+  struct TaxCount { uint64_t reads = 0, kmers = 0, uniq = 0; const uint8_t *regs = nullptr; };
   std::unordered_map<uint32_t, TaxCount> tc;
   for (uint64_t s = 0; s < n_slots; ++s)
-    if (n_kmers[s]) { auto &e = tc[slot_taxid[s]]; e.kmers = n_kmers[s]; e.regs = registers + s * KU_HLL_M; }
+    if (n_kmers[s]) {
+      auto &e = tc[slot_taxid[s]];
+      e.kmers = n_kmers[s];
+      if (unique) e.uniq = unique[s]; else e.regs = registers + s * KU_HLL_M;
+    }
   for (uint64_t i = 0; i < n_nodes; ++i)
     if (n_reads[i]) tc[node_taxid[i]].reads = n_reads[i];
   // genome sizes: readGenomeSizes (taxdb.hpp:867-885).  "while(!eof){in >> id >> size; set(id,size);}" applies
@@ -271,6 +296,7 @@ extern "C" int ku_report_multi(const ku_tax *tax, const char *const *counts_path
       c.present = true;
       c.reads += kv.second.reads;
       c.kmers += kv.second.kmers;
+      c.uniq += kv.second.uniq;
       if (kv.second.regs) {
         if (c.regs.empty()) c.regs.assign(kv.second.regs, kv.second.regs + KU_HLL_M);
         else for (int i = 0; i < KU_HLL_M; ++i) c.regs[i] = std::max(c.regs[i], kv.second.regs[i]);
@@ -297,7 +323,7 @@ extern "C" int ku_report_multi(const ku_tax *tax, const char *const *counts_path
       const Clade &c = clade[fr.row];
       if (!c.present || c.reads == 0) continue;
       const uint8_t *regs = c.regs.empty() ? zero_regs.data() : c.regs.data();
-      const uint64_t uniq = ku_hll_cardinality(regs, KU_HLL_P, c.kmers);
+      const uint64_t uniq = unique ? c.uniq : ku_hll_cardinality(regs, KU_HLL_P, c.kmers);
       volatile double gs = double(gsize[fr.row] + gchild[fr.row]);
       volatile double kc = double(c.kmers), un = double(uniq);
       auto ti = tc.find(tax->ids[fr.row]);

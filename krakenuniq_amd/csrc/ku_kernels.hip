@@ -786,6 +786,50 @@ __device__ __forceinline__ uint64_t ku_canon_from_ascii(const uint8_t *p, uint32
   return fwd < rc ? fwd : rc;
 }
 
+// Exact distinct k-mer counting (classifyExact = classify built with EXACT_COUNTING, classify.cpp:46-53: the per-taxon
+// container is a hash set of k-mers instead of a HyperLogLog sketch).  A canonical k-mer has exactly one database
+// value, so one global open-addressing set of k-mers + a "first insertion" counter per slot is the same thing as one
+// set per taxon.  Runs between the lookup and the resolve stage (taxa[] still holds slot ids), one wave per read.
+__global__ __launch_bounds__(64) void ku_exact_kernel(uint32_t k, const uint8_t *__restrict__ seqs,
+                                                      const uint64_t *__restrict__ seq_off,
+                                                      const uint32_t *__restrict__ seq_len, uint64_t n_reads,
+                                                      const uint32_t *__restrict__ taxa, unsigned long long *set,
+                                                      uint64_t mask, unsigned long long *unique, uint32_t *overflow) {
+  const uint32_t tid = threadIdx.x;
+  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t off = seq_off[r];
+    for (uint32_t i = tid; i < n; i += 64) {
+      const uint32_t s = taxa[off + i];
+      if (s == KU_AMBIG) continue;
+      const uint64_t canon = ku_canon_from_ascii(seqs + off + i, k);
+      const unsigned long long key = canon + 1;  // 0 marks an empty cell
+      uint64_t h = ku_fmix64(canon) & mask;
+      bool done = false;
+      for (uint32_t probe = 0; probe < 4096 && !done; ++probe) {
+        unsigned long long cur = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+          cur = atomicCAS(&set[h], 0ull, key);
+          if (cur == 0) { atomicAdd(&unique[s], 1ull); done = true; }
+        }
+        if (cur == key) done = true;
+        h = (h + 1) & mask;
+      }
+      if (!done) atomicExch(overflow, 1u);
+    }
+  }
+}
+int ku_launch_exact(uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
+                    const uint32_t *d_taxa, unsigned long long *d_set, uint64_t mask, unsigned long long *d_unique,
+                    uint32_t *d_overflow, int n_cu, hipStream_t stream) {
+  if (n_reads == 0) return KU_OK;
+  const uint64_t cap = (uint64_t)n_cu * 32;
+  hipLaunchKernelGGL(ku_exact_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, k, d_seqs,
+                     d_seq_off, d_seq_len, n_reads, d_taxa, d_set, mask, d_unique, d_overflow);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
 // Quick mode (classify.cpp:943-944,962-963): stop at the min_hits-th hit, call =
 // its taxon; only the k-mers scanned up to and including that one are counted.
 __global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev cnt, uint32_t k,

@@ -182,3 +182,21 @@ def test_mate_pairs_merged_on_the_fly(tmp_path):
     assert c.read_text() == "".join(f">{i}\n{s}\n" for i, s in recs if calls[i] == "C")
     assert u.read_text() == "".join(f">{i}\n{s}\n" for i, s in recs if calls[i] == "U")
     assert run(DB + ["-P", f"{g}/f4/r_1.fq"]).returncode == 64
+
+
+@pytest.mark.gpu
+def test_classify_exact_binary(tmp_path):
+    """bin/classifyExact: same Kraken output, report with exact distinct k-mer counts == the reference's classifyExact"""
+    exact = os.path.join(ROOT, "krakenuniq_amd", "bin", "classifyExact")
+    d = tmp_path / "db"
+    d.mkdir()
+    for fn in ("database.kdb", "database.idx", "taxDB", "database.kdb.counts"):
+        (d / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
+    out, rep = tmp_path / "out.tsv", tmp_path / "rep.tsv"
+    r = subprocess.run([exact, "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB", "-o", str(out),
+                        "-r", str(rep), f"{F1}/reads.fq"], stderr=subprocess.PIPE, env=dict(os.environ, KU_EXACT_LOG2="18"))
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+    assert rows(rep.read_text()) == rows(open(f"{F1}/report_exact.tsv").read())
+    assert subprocess.run([exact, "-q", "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB",
+                           f"{F1}/reads.fq"], stderr=subprocess.PIPE).returncode == 70

@@ -403,6 +403,36 @@ def test_out_of_core_chunked_run(golden, f1, monkeypatch, budget, layout, quick)
         ctx2.swap_shard(cdb, bounds[0], bounds[1])
 
 
+def test_exact_counting_reproduces_classify_exact(golden, f1):
+    """classifyExact (EXACT_COUNTING build, classify.cpp:46-53): distinct k-mers counted exactly -> the reference's
+    report_exact.tsv row for row; the sketches are filled as usual next to it"""
+    d = f1["dir"]
+    ids, seqs = synth.read_seqfile(f"{d}/reads.fq")
+    run, res, buf, off, lens, taxa = oracle_flat(f1["odb"], f1["otax"], seqs)
+    ctx, _, _ = make_ctx(d)
+    ctx.enable_exact(16)
+    half = 500
+    for a, b in ((0, half), (half, 1000)):  # the set persists across batches
+        p = ko.pack_reads(seqs[a:b])
+        gpu = ctx.classify_batch(*p)
+        assert np.array_equal(gpu["calls"], res["calls"][a:b])
+    counts = ctx.counts()
+    assert_same_counts(counts, run)
+    uniq = ctx.exact_counts()
+    got = capi.report_exact(f1["ctax"], counts, uniq, [f"{d}/database.kdb.counts"])
+    assert rows(got) == rows(open(f"{d}/report_exact.tsv").read())
+    assert (uniq <= counts["n_kmers"]).all() and uniq.sum() > 50000
+    with pytest.raises(capi.KuError):  # plain mode only
+        ctx.classify_batch(*ko.pack_reads(seqs[:10]), flags=capi.KU_F_QUICK)
+    ctx.reset_counts()
+    assert not ctx.exact_counts().any()
+    # a set that is too small is reported, not silently wrong
+    ctx.enable_exact(10)
+    ctx.classify_batch(*ko.pack_reads(seqs))
+    with pytest.raises(capi.KuError):
+        ctx.exact_counts()
+
+
 def test_revcomp_invariance_property(f1):
     """size-independent property: a read and its reverse complement get the same call and mirrored hit list"""
     ids, seqs = synth.read_seqfile(f"{f1['dir']}/reads.fq")
