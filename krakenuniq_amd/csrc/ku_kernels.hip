@@ -626,7 +626,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     const uint64_t off = seq_off[r];
     ku_ct_maybe_flush<RCT>(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
     if (tid == 0) s_n_list = 0;
-    uint32_t call_node = 0;
+    uint32_t call_node = 0, uni_taxid = 0;
     bool resolved = false;
     // MODE 0 keeps the read's codes in registers (<= 6 per lane) and short-cuts the common case of at most
     // one distinct hit taxon: resolve_tree() then returns that taxon (or 0) without any tree walk.
@@ -648,7 +648,9 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
       for (int c = 0; c < NV; ++c) diff |= (v[c] != 0 && v[c] != first);
       if (!__any(diff)) {
         resolved = true;
+        // the two table reads depend on `first` only: issued together (one round trip instead of a chain)
         call_node = first ? tax.slot_node[first] : 0u;
+        uni_taxid = first ? tax.slot_taxid[first] : 0u;
       }
     }
     if (!resolved) {
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     }
     }  // !resolved
     if (tid == 0) {
-      calls[r] = tax.node_taxid[call_node];
+      calls[r] = (MODE == 0 && resolved) ? uni_taxid : tax.node_taxid[call_node];
       if (hits_out) hits_out[r] = 0;
       if (do_counts) ku_ct_add<RCT>(s_ctk, s_ctc, &s_ctu, call_node, 1, cnt.n_reads);  // incrementReadCount (classify.cpp:968)
     }
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
           uint32_t i = c * 64 + tid;
-          if (i < n && v[c] != 0) taxa[off + i] = tax.slot_taxid[v[c]];
+          if (i < n && v[c] != 0) taxa[off + i] = resolved ? uni_taxid : tax.slot_taxid[v[c]];  // one taxon: no gather
         }
       } else {
         for (uint32_t i = tid; i < n; i += GROUP) {
@@ -934,7 +936,8 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
                        n_reads, flags, min_hits ? min_hits : 1u, d_calls, d_taxa, d_hits);
     return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
   }
-  {  // MODE 0: every read with n <= 384 (incl. reads shorter than k)
+  {  // MODE 0: every read with n <= 384 (incl. reads shorter than k).  24 one-wave blocks per CU all fit at once
+     // (6 KB of LDS each); 32 would run as 26 + a straggling 6 and measured slower
     uint64_t mb = (uint64_t)n_cu * 24;
     unsigned grid = (unsigned)(n_reads < mb ? n_reads : mb);
     size_t lds = (2u << KuResolveCfg<0>::CAP_LOG2) * 4 + KuResolveCfg<0>::MAX_N * 2 + 64;
