@@ -16,12 +16,16 @@
 //   -p N                                accepted and ignored exactly like the reference
 //   -I file                             UID mapping: not built here -> exit 70 with a message
 // Extension: env KU_DEVICE selects the GPU (default 0).
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <sysexits.h>
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cinttypes>
 #include <cstdarg>
@@ -330,25 +334,101 @@ int main(int argc, char **argv) {
   // Three-stage host pipeline: reader thread (FASTA/FASTQ(+gz) -> pinned batch) | this thread
   // (ku_classify_batch_rle: H2D, kernels, run-length encoding, D2H) | writer thread (Kraken lines formatted by `fmt_threads` helpers,
   // files written in input order).  Batches circulate through two bounded queues.
-  const int n_batches = 3;
+  // a team of parser threads for plain-text inputs (-t, at most 8): every member owns one batch while it parses
+  const int parse_team = paired ? 1 : (fmt_threads < 8 ? fmt_threads : 8);
+  const int n_batches = 3 + (parse_team > 1 ? parse_team : 0);
   std::vector<Batch> pool(n_batches);
   Queue free_q, parsed_q, done_q;
   for (auto &bt : pool) free_q.push(&bt);
   const bool keep_records = print_cls || print_ucls;
   double busy_reader = 0, busy_gpu = 0, busy_writer = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
 
+  // Plain (uncompressed) regular files: the file is mapped, cut into record-aligned regions of about one work unit
+  // and parsed by `parse_team` threads, each into its own batch; the batches go on in file order.  A member takes a
+  // batch BEFORE it takes a region number, so the lowest outstanding region always owns one and the team cannot
+  // starve itself.  false: not a plain regular file -> the sequential reader below handles it.
+  auto parse_plain_file_in_regions = [&](const char *path) -> bool {
+    {
+      gzFile g = gzopen(path, "rb");
+      if (!g) die(EX_NOINPUT, "can't open %s", path);
+      const bool direct = gzdirect(g) != 0;
+      gzclose(g);
+      if (!direct) return false;
+    }
+    int fd = ::open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { if (fd >= 0) ::close(fd); return false; }
+    const size_t n = (size_t)st.st_size;
+    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (map == MAP_FAILED) return false;
+    const char *data = (const char *)map;
+    const bool fastq = data[0] == '@';  // determine_input_file_type (src/classify.cpp:377-388)
+    const double t_parse = now_s();
+    // a quarter of a work unit per region: the team's batches are pinned memory, smaller ones are quicker to set up
+    // and keep the three stages busier.  FASTQ text is ~2.2 bytes per base (header, '+', qualities), FASTA ~1.05
+    const size_t region_bytes = std::max<size_t>((size_t)1 << 20, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next_cut = 0, next_region = 0, next_out = 0;
+    bool stop = false;  // the stream ended inside a region: nothing behind it counts
+    std::map<size_t, std::pair<Batch *, bool>> ready;
+    auto member = [&] {
+      for (;;) {
+        Batch *bt = chunked ? new Batch() : free_q.pop();
+        size_t lo, hi, idx;
+        {
+          std::lock_guard<std::mutex> l(mu);
+          if (stop || next_cut >= n) { if (chunked) { bt->release(); delete bt; } else free_q.push(bt); return; }
+          lo = next_cut;
+          hi = ku_seqio::find_record_start(data, n, lo + region_bytes, fastq);
+          next_cut = hi;
+          idx = next_region++;
+        }
+        bt->clear();
+        bt->fastq = fastq;
+        bt->reserve_seq(fastq ? (hi - lo) / 2 + 4096 : hi - lo);  // one allocation: the sequences are at most that long
+        const bool whole = ku_seqio::parse_region(data + lo, hi - lo, fastq, *bt, keep_records);
+        std::lock_guard<std::mutex> l(mu);
+        ready[idx] = {bt, whole};
+        cv.notify_all();
+      }
+    };
+    std::vector<std::thread> team;
+    for (int t = 0; t < parse_team; ++t) team.emplace_back(member);
+    for (;;) {  // forward the batches in file order
+      std::unique_lock<std::mutex> l(mu);
+      cv.wait(l, [&] { return ready.count(next_out) || (next_cut >= n && next_out == next_region) || (stop && next_out == next_region); });
+      auto it = ready.find(next_out);
+      if (it == ready.end()) break;  // every region handed out and forwarded
+      Batch *bt = it->second.first;
+      const bool whole = it->second.second;
+      ready.erase(it);
+      ++next_out;
+      const bool ends = !whole || bt->nt == 0;  // malformed record, or a unit without nucleotides (src/classify.cpp:522-523)
+      if (ends) stop = true;
+      l.unlock();
+      if (bt->nt == 0) { if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
+      else parsed_q.push(bt);
+      if (ends) break;
+    }
+    for (auto &t : team) t.join();
+    {  // batches parsed behind the end of the stream are dropped
+      std::lock_guard<std::mutex> l(mu);
+      for (auto &kv : ready) { Batch *bt = kv.second.first; if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
+    }
+    munmap(map, n);
+    busy_reader += now_s() - t_parse;
+    return true;
+  };
+
   std::thread reader([&] {
     std::string header, quals, header2;
     auto add_record_meta = [&](Batch *bt, const std::string &hdr, size_t id_lo, size_t id_hi, const std::string &q) {
-      bt->idoff.push_back(bt->ids.size());
-      bt->ids.append(hdr, id_lo, id_hi - id_lo);
-      bt->ids.push_back('\0');
-      if (keep_records) {
-        bt->hoff.push_back(bt->headers.size()); bt->headers += hdr; bt->headers.push_back('\0');
-        bt->qoff.push_back(bt->quals.size()); bt->quals += q; bt->quals.push_back('\0');
-      }
+      bt->add_meta(hdr, id_lo, id_hi, q, keep_records);
     };
     for (int fi = optind; fi < argc; fi += paired ? 2 : 1) {
+      if (parse_team > 1 && parse_plain_file_in_regions(argv[fi])) continue;  // plain text: the parser team took it
       Reader rd, rd2;
       rd.open(argv[fi], /*prefetch=*/true);
       if (paired) rd2.open(argv[fi + 1], /*prefetch=*/true);

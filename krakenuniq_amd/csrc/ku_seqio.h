@@ -66,6 +66,16 @@ struct Batch {
     reserve_seq(0);
     seqs[seqs_len++] = '\n';
   }
+  // id (a slice of the header line) and, for -C/-U, the whole header and the quality line of the read just closed
+  void add_meta(const std::string &hdr, size_t id_lo, size_t id_hi, const std::string &q, bool keep_records) {
+    idoff.push_back(ids.size());
+    ids.append(hdr, id_lo, id_hi - id_lo);
+    ids.push_back('\0');
+    if (keep_records) {
+      hoff.push_back(headers.size()); headers += hdr; headers.push_back('\0');
+      qoff.push_back(quals.size()); quals += q; quals.push_back('\0');
+    }
+  }
   void reserve_runs(size_t n) {
     if (n <= runs_cap) return;
     if (runs) ku_host_free(runs);
@@ -92,6 +102,7 @@ struct Reader {
   int fd = -1;  // plain (uncompressed) files are read with read(2): one copy less than through zlib
   bool fastq = false, valid = true, eof = false;
   std::vector<char> buf;
+  const char *mem = nullptr;  // memory mode: parse [mem, mem + len) in place (a record-aligned region of a mapped file)
   size_t pos = 0, len = 0;  // unconsumed bytes: buf[pos, len)
   // producer side (prefetch)
   static constexpr size_t BLOCK = (size_t)4 << 20;
@@ -149,7 +160,15 @@ struct Reader {
     more();
     fastq = len > 0 && buf[0] == '@';  // determine_input_file_type (src/classify.cpp:377-388)
   }
+  // parse a region that already sits in memory (no file behind it)
+  void open_memory(const char *p, size_t n, bool is_fastq) {
+    mem = p;
+    pos = 0; len = n;
+    valid = true; eof = true;
+    fastq = is_fastq;
+  }
   void close() {
+    mem = nullptr;
     if (producer.joinable()) {
       { std::lock_guard<std::mutex> l(mu); stop = true; }
       cv.notify_all();
@@ -196,7 +215,7 @@ struct Reader {
   bool line_at(size_t from, size_t &hi, size_t &next) {
     for (;;) {
       const size_t avail = len - pos > from ? len - pos - from : 0;
-      const char *b = buf.data() + pos + from;
+      const char *b = (mem ? mem : buf.data()) + pos + from;
       const char *nl = avail ? (const char *)memchr(b, '\n', avail) : nullptr;
       if (nl) { hi = from + (size_t)(nl - b); next = hi + 1; return true; }
       if (!more()) {
@@ -207,7 +226,7 @@ struct Reader {
       }
     }
   }
-  const char *at(size_t rel) const { return buf.data() + pos + rel; }
+  const char *at(size_t rel) const { return (mem ? mem : buf.data()) + pos + rel; }
 };
 
 // id = first whitespace-delimited token of the header line ("istringstream >> id", src/seqreader.cpp:56-58,114-116)
@@ -269,6 +288,47 @@ inline bool next_record(Reader &rd, Batch &bt, std::string *header, std::string 
     rd.pos += l_next;
   }
   return true;
+}
+
+// First record start at or behind offset x of a file image [data, data + n) whose offset 0 starts a record; n when
+// there is none.  FASTA: a line starting with '>'.  FASTQ (4-line records as the reference reads them): a line
+// starting with '@' whose second successor starts with '+' -- a quality line may start with '@' too, but then the
+// second line behind it is a sequence line, which never starts with '+'.
+inline size_t find_record_start(const char *data, size_t n, size_t x, bool fastq) {
+  if (x == 0) return 0;
+  if (x >= n) return n;
+  const char *nl = (const char *)memchr(data + x - 1, '\n', n - (x - 1));  // x itself starts a line if data[x-1] == '\n'
+  size_t p = nl ? (size_t)(nl - data) + 1 : n;
+  while (p < n) {
+    if (!fastq) {
+      if (data[p] == '>') return p;
+    } else if (data[p] == '@') {
+      const char *l1 = (const char *)memchr(data + p, '\n', n - p);
+      const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', n - (size_t)(l1 + 1 - data)) : nullptr;
+      if (!l2 || (size_t)(l2 + 1 - data) >= n) return p;  // the tail of the file: let the parser judge it
+      if (l2[1] == '+') return p;
+    }
+    const char *e = (const char *)memchr(data + p, '\n', n - p);
+    p = e ? (size_t)(e - data) + 1 : n;
+  }
+  return n;
+}
+
+// Every record of the record-aligned region [data, data + n) of a plain-text file into `bt`.  false when the stream
+// ends inside the region (malformed record / empty FASTQ line: the reference stops reading there).
+inline bool parse_region(const char *data, size_t n, bool fastq, Batch &bt, bool keep_records) {
+  Reader rd;
+  rd.open_memory(data, n, fastq);
+  std::string header, quals;
+  size_t nb, lo, hi;
+  for (;;) {
+    bt.begin_read();
+    if (!next_record(rd, bt, &header, keep_records ? &quals : nullptr, &nb)) { bt.off.pop_back(); break; }
+    bt.end_read();
+    split_id(header.data(), header.size(), lo, hi);
+    bt.add_meta(header, lo, hi, quals, keep_records);
+  }
+  return rd.pos == rd.len;
 }
 
 // read_merger.pl:182 "$id =~ s/[\/_.][12]$//"

@@ -1,7 +1,14 @@
 // Test / measurement aid for the classify executable's input stage (ku_seqio.h): parses FASTA/FASTQ(+gz) files
 // exactly as the reader thread does and prints "id<TAB>sequence" per read, or with -n only the parsing rate.
+// -j N parses N record-aligned regions of each (plain) file independently, as the executable's parser team does.
 // Host-only: does not link the GPU library (pinned allocation is replaced by malloc here), classifies nothing.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/time.h>
+#include <unistd.h>
+
+#include <thread>
 
 #include <cstdarg>
 #include <cstdlib>
@@ -22,16 +29,52 @@ void ku_seqio::fatal(int code, const char *fmt, ...) {
 
 int main(int argc, char **argv) {
   bool paired = false, quiet = false, prefetch = false;
+  int regions = 0;
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
     if (argv[a][1] == 'P') paired = true;
     else if (argv[a][1] == 'n') quiet = true;
-    else if (argv[a][1] == 'T') prefetch = true;  // producer thread per file, as the classify executable runs
+    else if (argv[a][1] == 'T') prefetch = true;
+    else if (argv[a][1] == 'j' && a + 1 < argc) regions = atoi(argv[++a]);  // producer thread per file, as the classify executable runs
   }
   timeval t0, t1;
   gettimeofday(&t0, nullptr);
   uint64_t n_reads = 0, n_bytes = 0;
   std::string header, header2;
+  for (; regions > 0 && a < argc; ++a) {  // region-parallel parse of plain files
+    int fd = ::open(argv[a], O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) ku_seqio::fatal(66, "can't open %s", argv[a]);
+    const size_t n = (size_t)st.st_size;
+    const char *data = n ? (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+    ::close(fd);
+    const bool fastq = n && data[0] == '@';
+    std::vector<size_t> cut{0};
+    for (int r = 1; r < regions; ++r) cut.push_back(ku_seqio::find_record_start(data, n, std::max(cut.back(), n * r / regions), fastq));
+    cut.push_back(n);
+    std::vector<ku_seqio::Batch> bts(regions);
+    std::vector<char> ok(regions, 1);
+    std::vector<std::thread> team;
+    for (int r = 0; r < regions; ++r)
+      team.emplace_back([&, r] { ok[r] = ku_seqio::parse_region(data + cut[r], cut[r + 1] - cut[r], fastq, bts[r], false); });
+    for (auto &t : team) t.join();
+    for (int r = 0; r < regions; ++r) {
+      ku_seqio::Batch &bt = bts[r];
+      for (size_t i = 0; i < bt.off.size(); ++i) {
+        ++n_reads;
+        n_bytes += bt.len[i];
+        if (!quiet) {
+          fputs(bt.ids.c_str() + bt.idoff[i], stdout);
+          fputc('\t', stdout);
+          fwrite(bt.seqs + bt.off[i], 1, bt.len[i], stdout);
+          fputc('\n', stdout);
+        }
+      }
+      bt.release();
+      if (!ok[r]) break;  // the stream ended inside this region
+    }
+    if (n) munmap((void *)data, n);
+  }
   for (; a < argc; a += paired ? 2 : 1) {
     ku_seqio::Reader rd, rd2;
     rd.open(argv[a], prefetch);

@@ -76,3 +76,27 @@ def test_record_edge_cases(tmp_path):
     r = subprocess.run([DUMP, str(big)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     lines = r.stdout.split(b"\n")
     assert lines[0] == b"big\t" + s and lines[1] == b"tail\tACGT"
+
+
+def test_region_parallel_parse_equals_sequential(tmp_path):
+    """-j N: N record-aligned regions parsed independently (find_record_start + parse_region) == one sequential pass,
+    with quality lines that start with '@' or '+', and the stream still ends at the first malformed record"""
+    rng = np.random.default_rng(4)
+    recs = []
+    for i in range(3000):
+        L = int(rng.integers(1, 200))
+        seq = synth.codes_to_ascii(rng.integers(0, 4, L, dtype=np.uint8))
+        q = bytes(rng.choice(np.frombuffer(b"@+I5#", dtype=np.uint8), L).tolist())
+        recs.append(b"@r%d x\n" % i + seq + b"\n+\n" + q + b"\n")
+    fq = tmp_path / "tricky.fq"
+    fq.write_bytes(b"".join(recs))
+    want = dump([str(fq)])[:2]
+    for j in (1, 2, 5, 16, 64):
+        assert dump(["-j", str(j), str(fq)])[:2] == want, j
+    for fn in ("f1/reads.fq", "f2/edge.fa", "f4/merged.fa"):
+        assert dump(["-j", "6", os.path.join(G, fn)])[:2] == dump([os.path.join(G, fn)])[:2], fn
+    # an empty line after record 1500 ends the stream in both modes
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"".join(recs[:1500]) + b"\n" + b"".join(recs[1500:]))
+    assert dump(["-j", "8", str(bad)])[:2] == dump([str(bad)])[:2]
+    assert len(dump([str(bad)])[0]) == 1500
