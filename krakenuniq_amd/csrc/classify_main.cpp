@@ -485,7 +485,8 @@ int main(int argc, char **argv) {
   });
 
   std::thread writer([&] {
-    std::vector<std::string> parts(fmt_threads);
+    std::vector<char *> parts(fmt_threads, nullptr);  // formatted Kraken lines of the helpers' read ranges
+    std::vector<size_t> part_len(fmt_threads, 0);
     for (;;) {
       Batch *bt = done_q.pop();
       if (!bt) break;
@@ -498,20 +499,23 @@ int main(int argc, char **argv) {
         for (int t = 0; t < fmt_threads; ++t) {
           helpers.emplace_back([&, t] {
             const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
-            parts[t].clear();
+            parts[t] = nullptr;
+            part_len[t] = 0;
             if (hi <= lo) return;
-            char *text = nullptr; size_t tn = 0;
             status[t] = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
                                              bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
                                              bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
-                                             pflags, &text, &tn);
-            if (status[t] == KU_OK) { parts[t].assign(text, tn); ku_free(text); }
+                                             pflags, &parts[t], &part_len[t]);
           });
         }
         for (auto &h : helpers) h.join();
         for (int t = 0; t < fmt_threads; ++t) {
           if (status[t] != KU_OK) die(exit_code_of(status[t]), "%s", ku_strerror(status[t]));
-          s_kraken.write(parts[t].data(), parts[t].size());
+          if (parts[t]) {
+            s_kraken.write(parts[t], part_len[t]);
+            ku_free(parts[t]);
+            parts[t] = nullptr;
+          }
         }
       }
       if (keep_records) {  // print_sequence (src/classify.cpp:794-805)
