@@ -43,6 +43,14 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(capi.KuError) as e:
         capi.Ctx(0)
     assert e.value.status == -5  # KU_EHIP
+    # the database build steps are device code too: no host stand-in
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f1")
+    with pytest.raises(capi.KuError) as e:
+        capi.db_sort_files(f"{d}/database.kdb", "/tmp/ku_never.kdb", "/tmp/ku_never.idx", 7)
+    assert e.value.status == -5 and not os.path.exists("/tmp/ku_never.kdb")
+    with pytest.raises(capi.KuError) as e:
+        capi.SetLcas(capi.Db(f"{d}/database.kdb", f"{d}/database.idx"), capi.Tax(f"{d}/taxDB"))
+    assert e.value.status == -5
 
 
 def test_db_open_and_errors(f1, tmp_path):
