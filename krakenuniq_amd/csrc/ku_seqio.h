@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -35,6 +36,13 @@ struct Batch {
   bool fastq = false;
   uint64_t nt = 0;
   ku_batch *dev = nullptr;    // -x runs: the batch stays on the device across the chunk passes
+  bool pinned = true;         // page-locked buffers for the copies to the device; false: plain host memory
+  void *alloc_bytes(size_t n) {
+    void *p = nullptr;
+    if (pinned ? ku_host_alloc(n, &p) != KU_OK : (p = malloc(n)) == nullptr) fatal(71, "out of host memory");
+    return p;
+  }
+  void free_bytes(void *p) { if (pinned) ku_host_free(p); else free(p); }
   void clear() {
     seqs_len = 0; nt = 0;
     ids.clear(); headers.clear(); quals.clear();
@@ -45,10 +53,9 @@ struct Batch {
     if (need <= seqs_cap) return;
     size_t ncap = seqs_cap ? seqs_cap : (size_t)1 << 24;
     while (ncap < need) ncap *= 2;
-    void *np = nullptr;
-    if (ku_host_alloc(ncap, &np) != KU_OK) fatal(71, "out of host memory");
+    void *np = alloc_bytes(ncap);
     if (seqs_len) memcpy(np, seqs, seqs_len);
-    if (seqs) ku_host_free(seqs);
+    if (seqs) free_bytes(seqs);
     seqs = (char *)np;
     seqs_cap = ncap;
   }
@@ -78,17 +85,15 @@ struct Batch {
   }
   void reserve_runs(size_t n) {
     if (n <= runs_cap) return;
-    if (runs) ku_host_free(runs);
+    if (runs) free_bytes(runs);
     size_t ncap = runs_cap ? runs_cap : (size_t)1 << 20;
     while (ncap < n) ncap *= 2;
-    void *np = nullptr;
-    if (ku_host_alloc(ncap * sizeof(ku_run), &np) != KU_OK) fatal(71, "out of host memory");
-    runs = (ku_run *)np;
+    runs = (ku_run *)alloc_bytes(ncap * sizeof(ku_run));
     runs_cap = ncap;
   }
   void release() {
-    if (seqs) ku_host_free(seqs);
-    if (runs) ku_host_free(runs);
+    if (seqs) free_bytes(seqs);
+    if (runs) free_bytes(runs);
     seqs = nullptr; runs = nullptr;
     seqs_cap = runs_cap = 0;
   }

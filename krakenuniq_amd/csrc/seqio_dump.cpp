@@ -15,8 +15,9 @@
 
 #include "ku_seqio.h"
 
-extern "C" int ku_host_alloc(size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? KU_OK : KU_ENOMEM; }
-extern "C" void ku_host_free(void *p) { free(p); }
+// the batches of this tool are plain host memory (Batch::pinned = false); these are never called
+extern "C" int ku_host_alloc(size_t, void **out) { *out = nullptr; return KU_ENOMEM; }
+extern "C" void ku_host_free(void *) {}
 
 void ku_seqio::fatal(int code, const char *fmt, ...) {
   va_list ap;
@@ -53,6 +54,7 @@ int main(int argc, char **argv) {
     for (int r = 1; r < regions; ++r) cut.push_back(ku_seqio::find_record_start(data, n, std::max(cut.back(), n * r / regions), fastq));
     cut.push_back(n);
     std::vector<ku_seqio::Batch> bts(regions);
+    for (auto &b : bts) b.pinned = false;
     std::vector<char> ok(regions, 1);
     std::vector<std::thread> team;
     for (int r = 0; r < regions; ++r)
@@ -83,6 +85,7 @@ int main(int argc, char **argv) {
       rd2.open(argv[a + 1], prefetch);
     }
     ku_seqio::Batch bt;
+    bt.pinned = false;
     for (bool more = true; more;) {
       bt.clear();
       while (bt.nt < (64u << 20)) {

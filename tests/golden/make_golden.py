@@ -248,6 +248,19 @@ def make_f9(f1, genomes):
     run([os.path.join(REF, "set_lcas"), "-M", "-x", "-d", f"{d}/database0.kdb", "-o", f"{d}/database.kdb",
          "-i", f"{f1}/database.idx", "-b", f"{f1}/taxDB", "-m", f"{d}/seqid2taxid.map", "-F", f"{d}/library.fa",
          "-c", f"{d}/database.kdb.counts"])
+    # -a -A: new taxids for assemblies (third map column) and sequences; rewrites taxDB, prints the new map
+    with open(f"{d}/seqid2taxid_aA.map", "w") as f:
+        f.write("seqA\t4\tassembly one\nseqB\t5\tassembly one\nseqP\t1000000001\nseqX\t999\tasm x\nseqE\t4\n"
+                "seqN\t5\tassembly two\nseqA\t6\tdup\n")
+    for tag, flags in (("a", ["-a"]), ("A", ["-A"]), ("aA", ["-a", "-A"])):
+        shutil.copy(f"{f1}/taxDB", f"{d}/taxDB_{tag}")
+        r = run([os.path.join(REF, "set_lcas"), "-M", "-x", "-d", f"{d}/database0.kdb", "-o", f"{d}/tmp.kdb",
+                 "-i", f"{f1}/database.idx", "-b", f"{d}/taxDB_{tag}", "-m", f"{d}/seqid2taxid_aA.map",
+                 "-F", f"{d}/library.fa", "-c", f"{d}/counts_{tag}"] + flags)
+        open(f"{d}/map_{tag}.out", "wb").write(r.stdout)
+        raw = np.fromfile(f"{d}/tmp.kdb", dtype=np.uint8)
+        raw[-12 * len(kmers):].view(synth.PAIR_DT)["val"].astype("<u4").tofile(f"{d}/values_{tag}.u32")
+        os.remove(f"{d}/tmp.kdb")
     os.remove(f"{d}/database0.kdb")  # == f1's database.kdb with zeroed values (rebuilt by the test)
     # the genomes are f1's: the LCAs must be f1's values wherever f1's value came from the genomes
     k9, v9, *_ = synth.read_db(d, idx=os.path.join(f1, "database.idx"))

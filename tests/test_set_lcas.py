@@ -20,8 +20,23 @@ def test_cli_usage_without_gpu():
     r = subprocess.run([BIN], stderr=subprocess.PIPE)
     assert r.returncode == 64 and b"Usage: set_lcas" in r.stderr
     assert subprocess.run([BIN, "-d", "a", "-i", "b", "-b", "c"], stderr=subprocess.PIPE).returncode == 64  # no -f / -F -m
-    assert subprocess.run([BIN, "-a", "-d", "a", "-i", "b", "-b", "c", "-F", "x", "-m", "y"], stderr=subprocess.PIPE).returncode == 70
+    assert subprocess.run([BIN, "-I", "uid.map", "-d", "a", "-i", "b", "-b", "c", "-F", "x", "-m", "y"], stderr=subprocess.PIPE).returncode == 70
     assert subprocess.run([BIN, "-h"], stderr=subprocess.PIPE).returncode == 0
+
+
+@pytest.mark.parametrize("tag,flags", [("a", ["-a"]), ("A", ["-A"]), ("aA", ["-a", "-A"])])
+def test_new_taxids_map_and_taxdb_host_logic(tmp_path, tag, flags):
+    """-a / -A (src/set_lcas.cpp:169-237,321-330): new taxids for sequences / assemblies, printed map and rewritten
+    taxDB byte-identical to the reference's -- host logic, checked here through the KU_SETLCAS_DRY hook (no device)"""
+    (tmp_path / "taxDB").write_bytes(open(f"{G}/f1/taxDB", "rb").read())
+    r = subprocess.run([BIN, "-x", "-d", "unused.kdb", "-i", "unused.idx", "-b", str(tmp_path / "taxDB"),
+                        "-m", f"{G}/f9/seqid2taxid_aA.map", "-F", f"{G}/f9/library.fa"] + flags,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_SETLCAS_DRY="1"))
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == open(f"{G}/f9/map_{tag}.out", "rb").read()
+    assert (tmp_path / "taxDB").read_bytes() == open(f"{G}/f9/taxDB_{tag}", "rb").read()
+    if "-A" in flags:
+        assert b"parent taxon 999 not in database" in r.stderr
 
 
 def _zeroed_db(tmp_path):
@@ -115,3 +130,21 @@ def test_contaminants_and_preset_values_against_the_sequential_model(tmp_path, f
     with pytest.raises(capi.KuError):
         sl.add(seqs[0][0], 424242)  # neither in the taxonomy nor a database value
     sl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,flags", [("a", ["-a"]), ("A", ["-A"]), ("aA", ["-a", "-A"])])
+def test_new_taxids_end_to_end(tmp_path, tag, flags):
+    """-a / -A through the device: the values of every k-mer, the counts file, the new taxDB and the printed map equal
+    the reference's"""
+    _zeroed_db(tmp_path)
+    (tmp_path / "taxDB").write_bytes(open(f"{G}/f1/taxDB", "rb").read())
+    r = subprocess.run([BIN, "-M", "-x", "-d", str(tmp_path / "database.kdb"), "-o", str(tmp_path / "out.kdb"),
+                        "-i", str(tmp_path / "database.idx"), "-b", str(tmp_path / "taxDB"), "-m", f"{G}/f9/seqid2taxid_aA.map",
+                        "-F", f"{G}/f9/library.fa", "-c", str(tmp_path / "counts")] + flags, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    _, got, *_ = synth.read_db(str(tmp_path), kdb="out.kdb")
+    assert np.array_equal(got, np.fromfile(f"{G}/f9/values_{tag}.u32", dtype="<u4"))
+    assert (tmp_path / "counts").read_text() == open(f"{G}/f9/counts_{tag}").read()
+    assert r.stdout == open(f"{G}/f9/map_{tag}.out", "rb").read()
+    assert (tmp_path / "taxDB").read_bytes() == open(f"{G}/f9/taxDB_{tag}", "rb").read()
