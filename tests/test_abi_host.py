@@ -237,6 +237,38 @@ def test_format_kraken_rle_reproduces_reference_output(golden, f1, fixture, read
         assert capi.format_kraken_rle(buf, off, lens, ids, 31, q, flags=capi.KU_P_QUICK) == open(f"{d}/out_quick.tsv").read()
 
 
+def test_format_kraken_rle_equals_raw_on_random_codes():
+    """randomised: any code sequence (taxids incl. > 2^31, 0, KU_AMBIG, runs crossing word sizes) formats the same from
+    raw codes and from runs; -c / -s / quick flags included; both agree with the oracle's hitlist_string"""
+    rng = np.random.default_rng(12)
+    k = 31
+    seqs, codes = [], []
+    alphabet = np.array([0, 0, 5, 5, 77, 4000000000, capi.KU_AMBIG, 1, 1000000001], dtype=np.uint64)
+    for i in range(400):
+        L = int(rng.integers(0, 400)) if i % 7 else int(rng.integers(0, 31))
+        seqs.append(synth.codes_to_ascii(rng.integers(0, 4, L, dtype=np.uint8)))
+        n = max(L - k + 1, 0)
+        run_lens = rng.geometric(0.2, size=n + 1)
+        c = np.repeat(rng.choice(alphabet, size=n + 1), run_lens)[:n].astype(np.uint32)
+        codes.append(c)
+    buf, off, lens = ko.pack_reads(seqs)
+    taxa = np.zeros(len(buf), dtype=np.uint32)
+    for o, c in zip(off.tolist(), codes):
+        taxa[o:o + len(c)] = c
+    calls = rng.choice(np.array([0, 5, 4000000000], dtype=np.uint64), size=len(seqs)).astype(np.uint32)
+    hits = rng.integers(0, 9, len(seqs)).astype(np.uint32)
+    ids = [f"read{i}" for i in range(len(seqs))]
+    rle = dict(_rle(taxa, off, lens, calls, shuffle=True), hits=hits)
+    for flags in (0, capi.KU_P_ONLY_CLASSIFIED, capi.KU_P_SEQUENCE, capi.KU_P_QUICK, capi.KU_P_SEQUENCE | capi.KU_P_ONLY_CLASSIFIED):
+        a = capi.format_kraken(buf, off, lens, ids, k, calls, taxa=taxa, hits=hits, flags=flags)
+        assert a == capi.format_kraken_rle(buf, off, lens, ids, k, rle, flags=flags), flags
+    lines = capi.format_kraken(buf, off, lens, ids, k, calls, taxa=taxa).split("\n")
+    for i in (0, 5, 123, 399):
+        c = codes[i]
+        want = ko.hitlist(np.where(c == capi.KU_AMBIG, 0, c).astype(np.uint32), (c == capi.KU_AMBIG).astype(np.uint8))
+        assert lines[i].split("\t")[4] == want and capi.hitlist_string(c) == want
+
+
 def _counts_from_oracle(run):
     """Oracle per-taxon state -> the arrays ku_counts_export would deliver (dense registers)."""
     c = run.counts()
