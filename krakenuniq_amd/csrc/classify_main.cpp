@@ -348,6 +348,8 @@ int main(int argc, char **argv) {
   // batch BEFORE it takes a region number, so the lowest outstanding region always owns one and the team cannot
   // starve itself.  false: not a plain regular file -> the sequential reader below handles it.
   auto parse_plain_file_in_regions = [&](const char *path) -> bool {
+    struct stat st;
+    if (::stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) return false;  // pipes: one sequential reader
     {
       gzFile g = gzopen(path, "rb");
       if (!g) die(EX_NOINPUT, "can't open %s", path);
@@ -356,8 +358,7 @@ int main(int argc, char **argv) {
       if (!direct) return false;
     }
     int fd = ::open(path, O_RDONLY);
-    struct stat st;
-    if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { if (fd >= 0) ::close(fd); return false; }
+    if (fd < 0) return false;
     const size_t n = (size_t)st.st_size;
     void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);

@@ -3,6 +3,7 @@
 // readers (src/seqreader.cpp:26-133) and, for mate pairs, of scripts/read_merger.pl:100-197.
 #pragma once
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -132,8 +133,9 @@ struct Reader {
     if (!g) fatal(66, "can't open %s", path);
     gzbuffer(g, 1 << 20);
     fd = -1;
-    if (gzdirect(g)) {  // not gzip data: bypass zlib
-      fd = ::open(path, O_RDONLY);
+    struct stat st;
+    if (::stat(path, &st) == 0 && S_ISREG(st.st_mode) && gzdirect(g)) {  // a regular file without gzip data: bypass zlib
+      fd = ::open(path, O_RDONLY);  // (a pipe such as <(cat library/*.fna) must stay with the one reader that opened it)
       if (fd >= 0) { gzclose(g); g = nullptr; }
     }
     buf.resize((size_t)1 << 24);

@@ -100,3 +100,16 @@ def test_region_parallel_parse_equals_sequential(tmp_path):
     bad.write_bytes(b"".join(recs[:1500]) + b"\n" + b"".join(recs[1500:]))
     assert dump(["-j", "8", str(bad)])[:2] == dump([str(bad)])[:2]
     assert len(dump([str(bad)])[0]) == 1500
+
+
+def test_pipes_are_read_through_one_handle(tmp_path):
+    """inputs such as <(cat library/*.fna) (scripts/build_db.sh:272) are pipes: nothing may be lost between the format
+    probe and the parser, with and without the producer thread"""
+    ids, seqs = synth.read_seqfile(f"{G}/f1/reads.fq")
+    for flags in ([], ["-T"]):
+        r = subprocess.run(["bash", "-c", f"{DUMP} {' '.join(flags)} <(cat {G}/f1/reads.fq) <(gzip -c {G}/f4/merged.fa)"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        recs = [ln.split(b"\t") for ln in r.stdout.split(b"\n")[:-1]]
+        i4, s4 = synth.read_seqfile(f"{G}/f4/merged.fa")
+        assert [a.decode() for a, _ in recs] == ids + i4 and [b for _, b in recs] == seqs + s4
