@@ -200,3 +200,13 @@ def test_classify_exact_binary(tmp_path):
     assert rows(rep.read_text()) == rows(open(f"{F1}/report_exact.tsv").read())
     assert subprocess.run([exact, "-q", "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB",
                            f"{F1}/reads.fq"], stderr=subprocess.PIPE).returncode == 70
+
+
+@pytest.mark.gpu
+def test_pipe_inputs(tmp_path):
+    """classify <(cat reads.fq) and a gzip stream through a pipe (the wrapper and build_db.sh hand over such paths)"""
+    cmd = f"{BIN} {' '.join(DB)} -t 4 <(cat {F1}/reads.fq) <(gzip -c {F1}/reads.fq)"
+    r = subprocess.run(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    want = open(f"{F1}/out.tsv", "rb").read()
+    assert r.stdout == want + want
