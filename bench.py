@@ -6,8 +6,10 @@
 Workload at N = 1 (BASELINE.json configs[1]): ~8 GB MiniKraken-style database (k = 31,
 minimizer nt = 13, ~0.62 G pairs, ~2000 taxa) built directly in HBM by
 krakenuniq_amd/synth_torch.py, 10 M synthetic 150 bp reads resident in HBM.  One "step"
-= one pass of the whole hot path over the 10 M-read batch:
-    ku_lookup_device  (scan, canonical k-mer, minimizer, idx fetch, in-bin search, HLL + n_kmers)
+= one pass of the whole hot path over the 10 M-read batch: ku_classify_batch_device, i.e. for reads of up to 222 bp
+the fused wave-per-read kernel (scan, canonical k-mer, minimizer, bucket probe, HLL + n_kmers, hit counts,
+resolve_tree / LCA, n_reads, per-k-mer taxids); for longer reads, --paired and --mode sharded the two stages
+    ku_lookup_device  (scan, canonical k-mer, minimizer, probe / in-bin search, HLL + n_kmers)
     ku_resolve_device (hit counts, resolve_tree / LCA, n_reads, slot -> taxid)
 N > 1 (default --mode replicas, weak scaling): every rank holds the database and classifies
 its own 10 M reads; the per-taxon state is merged with RCCL inside every step (registers MAX,
@@ -15,8 +17,8 @@ counters SUM).  --mode sharded keeps 1/N of the minimizer bins per rank, scans t
 on every rank, merges per-k-mer slots with all_reduce(MAX) and resolves 1/N of the reads per
 rank (the 300 GB layout of configs[2]).
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (lookup kernel,
-algorithmic bytes / HIP-event time vs 8 TB/s) and `cpu_baseline` (the compiled reference's
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (the dominant kernel: the fused kernel, or the
+lookup kernel of the two-stage path; algorithmic bytes / HIP-event time vs 8 TB/s) and `cpu_baseline` (the compiled reference's
 `classify` -- or the C oracle if the binary is absent -- on the host cores, bounded sample).
 """
 import argparse
