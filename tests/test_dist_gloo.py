@@ -98,6 +98,42 @@ def test_sharded_merge_world2():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
+def _replica_worker(rank, ws, port, ret):
+    """replicas mode: every rank classifies its own reads; reduce_state (registers MAX, counters SUM) must give the
+    per-taxon state of one run over all reads (taxon_counts[t] += local[t], classify.cpp:541-544)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        ids, seqs = synth.read_seqfile(f"{GOLDEN}/reads.fq")
+        seqs = seqs[:400]
+        odb, otax = ko.Db(f"{GOLDEN}/database.kdb", f"{GOLDEN}/database.idx"), ko.Tax(f"{GOLDEN}/taxDB")
+        whole = ko.Run(odb, otax)
+        whole.classify(seqs)
+        want = whole.counts()
+        taxids = sorted(want)  # same universe on every rank
+        mine = ko.Run(odb, otax)
+        mine.classify(seqs[rank::ws])  # interleaved shares
+        c = mine.counts()
+        regs = np.stack([c[t]["sketch"].registers() if t in c else np.zeros(4096, np.uint8) for t in taxids])
+        nk = np.array([c[t]["n_kmers"] if t in c else 0 for t in taxids], dtype=np.int64)
+        nr = np.array([c[t]["n_reads"] if t in c else 0 for t in taxids], dtype=np.int64)
+        R, Kc, Nr = kdist.reduce_state(torch.from_numpy(regs), torch.from_numpy(nk), torch.from_numpy(nr))
+        for i, t in enumerate(taxids):
+            assert int(Kc[i]) == want[t]["n_kmers"] and int(Nr[i]) == want[t]["n_reads"]
+            assert (R[i].numpy() == want[t]["sketch"].registers()).all()
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_state_merge_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_replica_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
 def test_read_slice_and_bounds():
     for n, ws in ((10, 3), (0, 2), (7, 8), (1000, 4)):
         cover = []
