@@ -541,7 +541,8 @@ int ku_launch_count_table(const void *d_table, uint64_t n_lines, unsigned long l
 // score array).
 template <int MODE> struct KuResolveCfg;
 template <> struct KuResolveCfg<0> { static constexpr int GROUP = 64, CAP_LOG2 = 9, MAX_N = 384; };
-template <> struct KuResolveCfg<1> { static constexpr int GROUP = 256, CAP_LOG2 = 14, MAX_N = 12288; };
+// (the 16384-cell table fills most of a CU's LDS, so one block per CU: 1024 threads keep its 4 SIMDs at 4 waves each)
+template <> struct KuResolveCfg<1> { static constexpr int GROUP = 1024, CAP_LOG2 = 14, MAX_N = 12288; };
 template <> struct KuResolveCfg<2> { static constexpr int GROUP = 256, CAP_LOG2 = 0, MAX_N = 0x7fffffff; };
 
 template <int GROUP> __device__ __forceinline__ uint32_t ku_group_max(uint32_t v, uint32_t *s_red) {
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
   using Cfg = KuResolveCfg<MODE>;
   constexpr int GROUP = Cfg::GROUP;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  __shared__ uint32_t s_red[4];
+  __shared__ uint32_t s_red[16];  // one word per wave of the group
   __shared__ uint32_t s_n_list;
   __shared__ uint32_t s_bcast;
   constexpr int RCT = 7;  // n_reads counter table: 128 entries keep the block's LDS at ~6 KB (occupancy)
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     const uint64_t off = seq_off[r];
     ku_ct_maybe_flush<RCT>(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
     if (tid == 0) s_n_list = 0;
+    __syncthreads();  // the list is appended to by whichever lane claims a table cell
     uint32_t call_node = 0, uni_taxid = 0;
     bool resolved = false;
     // MODE 0 keeps the read's codes in registers (<= 6 per lane) and short-cuts the common case of at most
@@ -655,16 +657,20 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     }
     if (!resolved) {
     // ---- hit_counts[taxon]++ (classify.cpp:941-942)
-    auto table_insert = [&](uint32_t s) {
+    auto table_insert = [&](uint32_t s, uint32_t count) {
       uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
       for (;;) {
         uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == 0) {
           uint32_t old = atomicCAS(&t_key[h], 0u, s + 1);
+          if (old == 0) {  // first sight of this taxon in the read: it gets a place in the list of distinct taxa
+            const uint32_t e = atomicAdd(&s_n_list, 1u);
+            if (MODE == 2) t_list[e] = h; else t_list16[e] = (uint16_t)h;
+          }
           cur = old == 0 ? s + 1 : old;
         }
         if (cur == s + 1) {
-          atomicAdd(&t_cnt[h], 1u);
+          atomicAdd(&t_cnt[h], count);
           break;
         }
         h = (h + 1) & (cap - 1);
@@ -673,22 +679,27 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
     if (MODE == 0) {
 #pragma unroll
       for (int c = 0; c < NV; ++c)
-        if (v[c] != 0) table_insert(v[c]);
+        if (v[c] != 0) table_insert(v[c], 1u);
     } else {
-      for (uint32_t i = tid; i < n; i += GROUP) {
-        uint32_t s = taxa[off + i];
-        if (s != 0 && s != KU_AMBIG) table_insert(s);
+      // long reads: neighbouring k-mers mostly carry the same slot, so a wave first groups its 64 codes (one
+      // ballot per distinct slot) and a single lane books the whole group -- instead of 64 atomics on one LDS word
+      for (uint32_t base = 0; base < n; base += GROUP) {
+        const uint32_t i = base + tid;
+        const uint32_t s = i < n ? taxa[off + i] : 0u;
+        const bool active = s != 0 && s != KU_AMBIG;
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t ls = (uint32_t)__shfl((int)s, leader);
+          const unsigned long long same = __ballot(active && s == ls);
+          if ((int)(tid & 63u) == leader) table_insert(ls, (uint32_t)__popcll(same));
+          todo &= ~same;
+        }
       }
     }
     __syncthreads();
-    // ---- compact the occupied entries so that every distinct taxon gets its own lane
-    for (uint32_t i = tid; i < cap; i += GROUP) {
-      if (t_key[i]) {
-        uint32_t e = atomicAdd(&s_n_list, 1u);
-        if (MODE == 2) t_list[e] = i; else t_list16[e] = (uint16_t)i;
-      }
-    }
-    __syncthreads();
+    // every distinct taxon of the read is in the list now (appended by the lane that claimed its table cell -- no
+    // scan over the table, which for the 16384-cell table of 10 kbp reads cost as much as the lookups)
     const uint32_t n_list = s_n_list;
     if (n_list > 0) {
       // ---- score(t) = sum of hit counts on t's root path (krakenutil.cpp:157-177)
@@ -954,7 +965,7 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL(ku_resolve_kernel<1>, dim3(grid), dim3(256), lds, stream, tax, cnt, k, d_seq_off, d_seq_len,
+    hipLaunchKernelGGL(ku_resolve_kernel<1>, dim3(grid), dim3(KuResolveCfg<1>::GROUP), lds, stream, tax, cnt, k, d_seq_off, d_seq_len,
                        n_reads, (uint32_t)KuResolveCfg<0>::MAX_N + 1, flags, d_calls, d_taxa, d_hits,
                        (uint32_t *)nullptr, 0u);
   }
