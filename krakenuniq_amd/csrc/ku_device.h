@@ -184,32 +184,91 @@ __device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32
 #ifndef KU_OFFCLASS
 #define KU_OFFCLASS 4  // offsets per locus class: 4 measured best (3: 25.7, 4: 25.3, 5: 26.8, 8: 28.1 ms at load 0.3)
 #endif
-__device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint64_t c_rc, uint32_t k, uint32_t m, uint32_t xor_mask,
-                                                 uint32_t &bin) {
-  const uint32_t w = k - m + 1;
-  const uint32_t mask = (1u << (2 * m)) - 1u;  // m <= 15
-  uint32_t best = 0xFFFFFFFFu, a = 0;
-  bool plus = true;
-  for (uint32_t j = 0; j < w; ++j) {  // j = offset of the m-mer from the left (most significant) end of c
-    uint32_t mm = (uint32_t)(c >> (2 * (k - m - j))) & mask;
-    uint32_t rcmm = ku_revcomp32(mm, m);
-    uint32_t v = (mm < rcmm ? mm : rcmm) ^ xor_mask;
-    bool lt = v < best;
-    best = lt ? v : best;
-    a = lt ? j : a;
-    plus = lt ? (mm <= rcmm) : plus;
+
+// ---- the anchor of a k-mer: WHICH m-mer occurrence its bucket is derived from.
+// Every m-mer position j of the canonical k-mer (j = offset from its left / most significant end) has the value
+// v_j = scrambled canonical m-mer -- the terms KrakenDB::bin_key minimises (krakendb.cpp:200-215); the minimizer bin
+// is min_j v_j.  The anchor is the FIRST j (canonical frame) that minimises the 26-bit order key
+//     key_j = v_j >> ku_key_shift(m)            (= v_j itself for m <= 13)
+// 26 bits because key, window offset (5 bits: w = k - m + 1 <= 31) and the strand bit of the occurrence then fit one
+// dword, which makes the sliding-window argmin a log-step min of packed dwords for every minimizer length up to
+// 15.  With a unique minimal key the anchor is the minimizer occurrence itself (key_a < key_j  =>  v_a < v_j).  The rule is a
+// pure function of the canonical k-mer, so table build and lookup agree by construction.
+__device__ __forceinline__ uint32_t ku_key_shift(uint32_t m) { return m > 13 ? 2 * m - 26 : 0; }
+// packed window element: key << 6 | offset << 1 | strand bit (1: the read-strand m-mer is <= its reverse complement)
+#define KU_PK_KEYSHIFT 6
+__device__ __forceinline__ uint32_t ku_pk_make(uint32_t value, uint32_t key_shift, bool fwd_le) {
+  return ((value >> key_shift) << KU_PK_KEYSHIFT) | (uint32_t)fwd_le;
+}
+// One doubling step: `own` covers the positions [p, p + s), `nb` the block [p + s, p + 2s) as stored (offsets relative
+// to p + s).  Ties between DIFFERENT positions with equal keys are reported through `tie`: the packed minimum then
+// holds the smallest read position, which is the canonical-frame rule only for k-mers whose read strand is the canonical
+// one -- callers fall back to the exact scan (ku_anchor_exact) when any lane saw a tie.
+__device__ __forceinline__ uint32_t ku_pk_combine(uint32_t own, uint32_t nb, uint32_t s, bool &tie) {
+  nb += s << 1;
+  tie |= (own ^ nb) < (1u << KU_PK_KEYSHIFT);
+  return min(own, nb);
+}
+// last step of a window that is not a power of two: the two blocks overlap, the same element may win in both
+__device__ __forceinline__ uint32_t ku_pk_combine_overlap(uint32_t own, uint32_t nb, uint32_t s, bool &tie) {
+  nb += s << 1;
+  tie |= ((own ^ nb) - 2u) < (1u << KU_PK_KEYSHIFT) - 2u;  // equal keys, different offsets
+  return min(own, nb);
+}
+// Exact anchor by a sequential scan in the canonical k-mer's frame over the raw values raw[0 .. w) of the k-mer's
+// m-mer positions in READ order (is_fwd: the read strand is the canonical one).  Returns the minimal key, sets a =
+// its first canonical-frame offset and bin = the minimizer (min raw value).
+__device__ __forceinline__ uint32_t ku_anchor_exact(const uint32_t *raw, uint32_t w, uint32_t key_shift, bool is_fwd,
+                                                    uint32_t &a, uint32_t &bin) {
+  const int32_t j0 = is_fwd ? 0 : (int32_t)w - 1, dj = is_fwd ? 1 : -1;
+  uint32_t best = 0xFFFFFFFFu, mn = 0xFFFFFFFFu;
+  a = 0;
+  for (uint32_t t = 0; t < w; ++t) {
+    const uint32_t vv = raw[j0 + dj * (int32_t)t], kk = vv >> key_shift;
+    const bool lt = kk < best;
+    best = lt ? kk : best;
+    a = lt ? t : a;
+    mn = min(mn, vv);
   }
-  bin = best;
-  const uint64_t cp = plus ? c : c_rc;            // strand on which the minimizer occurrence is canonical
-  const uint32_t ap = plus ? a : w - 1 - a;       // its offset on that strand
+  bin = mn;
+  return best;
+}
+// Locus key from the anchor: (key, the KU_FLANK bases next to the anchor occurrence on the longer side, offset class),
+// all taken on the strand where the anchor m-mer is canonical (plus: that is the canonical k-mer's own strand).
+__device__ __forceinline__ uint64_t ku_locus_assemble(uint64_t canon, uint32_t key, uint32_t a, bool plus, uint32_t k,
+                                                      uint32_t m) {
+  const uint32_t w = k - m + 1;
+  const uint32_t ap = plus ? a : w - 1 - a;  // offset of the occurrence on that strand
   const uint32_t left = ap, right = w - 1 - ap;
   const bool use_r = right >= left;
   const uint32_t side = use_r ? right : left;
   const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
-  // right flank = offsets [ap+m, ap+m+flen), left flank = [ap-flen, ap)
-  const uint32_t end = use_r ? ap + m + flen : ap;  // one past the flank's last base
-  const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
-  return ((uint64_t)best << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
+  // right flank = offsets [ap+m, ap+m+flen), left flank = [ap-flen, ap); one past the flank's last base:
+  const uint32_t end = use_r ? ap + m + flen : ap;
+  // bases [end - flen, end) of that strand; on the other strand they are the reverse complement of bases
+  // [k - end, k - end + flen) of the canonical k-mer (no second 64-bit copy of the k-mer needed)
+  const uint32_t seg = (uint32_t)(canon >> (2 * (plus ? k - end : end - flen))) & ((1u << (2 * flen)) - 1u);
+  const uint32_t flank = flen ? (plus ? seg : ku_revcomp32(seg, flen)) : 0u;
+  return ((uint64_t)key << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
+}
+// table build: locus key of a stored canonical k-mer c (+ its minimizer bin)
+__device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint32_t k, uint32_t m, uint32_t xor_mask, uint32_t &bin) {
+  const uint32_t w = k - m + 1, sh = ku_key_shift(m);
+  const uint32_t mask = (1u << (2 * m)) - 1u;  // m <= 15
+  uint32_t best = 0xFFFFFFFFu, mn = 0xFFFFFFFFu, a = 0;
+  bool plus = true;
+  for (uint32_t j = 0; j < w; ++j) {  // j = offset of the m-mer from the left (most significant) end of c
+    const uint32_t mm = (uint32_t)(c >> (2 * (k - m - j))) & mask;
+    const uint32_t rcmm = ku_revcomp32(mm, m);
+    const uint32_t v = (mm < rcmm ? mm : rcmm) ^ xor_mask, kk = v >> sh;
+    const bool lt = kk < best;
+    best = lt ? kk : best;
+    a = lt ? j : a;
+    plus = lt ? (mm <= rcmm) : plus;
+    mn = min(mn, v);
+  }
+  bin = mn;
+  return ku_locus_assemble(c, best, a, plus, k, m);
 }
 __device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lines) {
   // 32-bit mixing (v_mul_lo/hi_u32 are quarter-rate on CDNA; 64-bit multiplies cost four of them each);
@@ -219,32 +278,6 @@ __device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lin
   g *= 0x2C1B3C6Du;
   g ^= g >> 13;
   return __umulhi(g, (uint32_t)n_lines);
-}
-
-// Sliding-window minimum with the position of the minimum, for N windows at once (independent chains ->
-// the LDS reads pipeline).  s_mm holds the m-mer values PRE-SHIFTED by 5 bits (low 5 bits zero, values <= 27
-// bits, i.e. minimizer length <= 13) and biased by +1.  Every lane reads its window forward (conflict-free across lanes) and
-// minimises  s_mm[t] + sgn * t  in one v_mad_i32_i24 + v_min_u32 per element:
-//   sgn = +1: ties resolve to the smallest t (first minimum), result = value + t
-//   sgn = -1: ties resolve to the largest t (last minimum),   result = value - t   (a borrow from the value
-//             field keeps the order: value1 < value2  =>  value1 - t1 < value2 - t2 because values are 32 apart)
-// W > 0: compile-time window length (fully unrolled), W == 0: run-time length w.
-template <int W, int N>
-__device__ __forceinline__ void ku_window_argmin(const uint32_t *s_mm, const uint32_t (&base)[N],
-                                                 const int32_t (&sgn)[N], uint32_t w, uint32_t (&out)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) out[j] = 0xFFFFFFFFu;
-  if (W > 0) {
-#pragma unroll
-    for (int t = 0; t < W; ++t)
-#pragma unroll
-      for (int j = 0; j < N; ++j) out[j] = min(out[j], s_mm[base[j] + t] + (uint32_t)(sgn[j] * t));
-  } else {
-    for (uint32_t t = 0; t < w; ++t)
-#pragma unroll
-      for (int j = 0; j < N; ++j)
-        out[j] = min(out[j], s_mm[base[j] + t] + (uint32_t)(sgn[j] * (int32_t)t));
-  }
 }
 
 // lca() in node space (krakenutil.cpp:90-118).  Nodes are ranks of taxids in a

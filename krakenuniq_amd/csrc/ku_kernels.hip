@@ -66,7 +66,13 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   // funnel shift over three consecutive words.
   __shared__ uint32_t s_codes[KU_PACKW + 4];
   __shared__ uint32_t s_amb[(KU_PACKW + 4) / 2 + 2];       // 32 bases per word, MSB first
-  __shared__ uint32_t s_mm[NEED_MIN ? KU_TILE + 64 : 1];   // scrambled canonical m-mer per start position
+  __shared__ uint32_t s_mm[NEED_MIN ? KU_TILE + 64 : 1];   // scrambled canonical m-mer per start position (raw value)
+  // hash layout: packed window elements (key, offset, strand bit; ku_device.h) of the anchor search, two buffers so
+  // that a doubling step reads one and writes the other (one barrier per step)
+  constexpr bool PK = LAYOUT == 1 && MODE != 2;
+  __shared__ uint32_t s_pa[PK ? KU_TILE + 64 : 1];
+  __shared__ uint32_t s_pb[PK ? KU_TILE + 64 : 1];
+  __shared__ uint32_t s_tie;
   __shared__ uint32_t s_ctk[KU_CT_CAP];
   __shared__ uint32_t s_ctc[KU_CT_CAP];
   __shared__ uint32_t s_ctu;
@@ -75,11 +81,14 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   const uint32_t k = db.k, m = db.nt;
   const uint32_t w = k - m + 1;  // m-mers per k-mer (krakendb.cpp:208)
   const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
-  // LAYOUT 1 with nt <= 13 keeps the m-mer values pre-shifted by 5 bits in LDS (ku_window_argmin)
-  const uint32_t mm_shift = (LAYOUT == 1 && MODE != 2 && m <= 13) ? 5u : 0u;
-  const uint32_t mm_bias = mm_shift ? 1u : 0u;  // value + 1: the field never underflows when an offset is subtracted
+  const uint32_t key_shift = ku_key_shift(m);
+  const uint32_t n_pos = KU_TILE + w - 1;  // m-mer positions a tile needs
   uint16_t *s_amb16 = reinterpret_cast<uint16_t *>(s_amb);
 
+  if (PK) {  // unique sentinels behind the last position: the widest doubling step reads 16 elements ahead
+    if (tid < 16) s_pa[n_pos + tid] = s_pb[n_pos + tid] = (0x03FFFFFFu - tid) << KU_PK_KEYSHIFT;
+    if (tid == 0) s_tie = 0;
+  }
   if (DO_COUNTS) ku_ct_clear(s_ctk, s_ctc, &s_ctu);
 
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -119,27 +128,35 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     __syncthreads();
 
     // ---- stage 2: forward k-mer, ambiguity, canonical form (+ m-mer value) per position
-    uint64_t canon[KU_ITEMS], canon_rc[KU_ITEMS];
+    uint64_t canon[KU_ITEMS];
     bool is_fwd[KU_ITEMS];   // the read-strand k-mer is the canonical one
     bool ok[KU_ITEMS];       // k-mer is unambiguous, inside the buffer and (after stage 3) owned by this shard
     bool foreign[KU_ITEMS];  // unambiguous but its bin belongs to another shard
+    uint32_t pk[KU_ITEMS + 1];  // packed window element of the position, then of growing blocks starting there
+    bool tie = false;
 #pragma unroll
     for (int j = 0; j <= KU_ITEMS; ++j) {
       uint32_t p = j * KU_THREADS + tid;
-      if (j == KU_ITEMS && (!NEED_MIN || p >= KU_TILE + w - 1)) break;
+      pk[j] = 0;
+      if (j == KU_ITEMS && (!NEED_MIN || p >= n_pos)) break;
       uint32_t wi = p >> 4, sh = (p & 15u) * 2;
       uint64_t hi = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
       uint64_t x = sh ? ((hi << sh) | (uint64_t)(s_codes[wi + 2] >> (32 - sh))) : hi;  // 32 bases from p
       if (NEED_MIN) {  // m-mer starting at p, canonical, scrambled (krakendb.cpp:209)
         uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
         uint32_t mrc = ku_revcomp32(mm, m);
-        s_mm[p] = (((mm < mrc ? mm : mrc) ^ db.xor_mask) + mm_bias) << mm_shift;
+        const uint32_t val = (mm < mrc ? mm : mrc) ^ db.xor_mask;
+        s_mm[p] = val;
+        if (PK) {
+          pk[j] = ku_pk_make(val, key_shift, mm <= mrc);
+          s_pa[p] = pk[j];
+          if ((m & 1u) == 0) tie |= mm == mrc;  // palindromic m-mer: its strand bit is not enough
+        }
       }
       if (j < KU_ITEMS) {
         uint64_t fwd = x >> (64 - 2 * k);
         uint64_t rc = ku_revcomp64(fwd, k);
         canon[j] = fwd <= rc ? fwd : rc;
-        canon_rc[j] = fwd <= rc ? rc : fwd;
         is_fwd[j] = fwd <= rc;
         uint32_t ai = p >> 5, as = p & 31u;
         uint64_t a = (((uint64_t)s_amb[ai] << 32) | s_amb[ai + 1]) << as;
@@ -158,28 +175,62 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     uint64_t locus[KU_ITEMS];        // locus key (LAYOUT 1), see ku_locus_key()
     if (NEED_MIN) {
       __syncthreads();
-      uint32_t packed[KU_ITEMS];  // (minimum << 5) | first offset, canonical k-mer frame (LAYOUT 1, m <= 13)
-      if (LAYOUT == 1 && MODE != 2 && m <= 13) {
-        uint32_t base[KU_ITEMS], r[KU_ITEMS];
-        int32_t sgn[KU_ITEMS];
+      uint32_t key[KU_ITEMS], aoff[KU_ITEMS], bin_v[KU_ITEMS];
+      bool plus[KU_ITEMS];
+      if (PK) {
+        // anchor search (ku_device.h): block minima of 2, 4, 8, 16 positions by doubling, then one overlapping step
+        // for the window length -- five packed dword minima per position for any minimizer length
+        uint32_t *src = s_pa, *dst = s_pb;
+        uint32_t blk = 1;
+        for (uint32_t st = 1; 2 * st <= w; st <<= 1) {
+#pragma unroll
+          for (int j = 0; j <= KU_ITEMS; ++j) {
+            const uint32_t p = j * KU_THREADS + tid;
+            if (p < n_pos) {
+              pk[j] = ku_pk_combine(pk[j], src[p + st], st, tie);
+              dst[p] = pk[j];
+            }
+          }
+          __syncthreads();
+          uint32_t *t = src; src = dst; dst = t;
+          blk = 2 * st;
+        }
+        if (w > blk) {
+#pragma unroll
+          for (int j = 0; j < KU_ITEMS; ++j) {
+            const uint32_t p = j * KU_THREADS + tid;
+            pk[j] = ku_pk_combine_overlap(pk[j], src[p + (w - blk)], w - blk, tie);
+          }
+        }
+        if (tie) s_tie = 1;
+        __syncthreads();
+        const bool exact = s_tie != 0;  // block-uniform
 #pragma unroll
         for (int j = 0; j < KU_ITEMS; ++j) {
-          base[j] = j * KU_THREADS + tid;
-          sgn[j] = is_fwd[j] ? 1 : -1;
+          const uint32_t p = j * KU_THREADS + tid;
+          if (!exact) {
+            const uint32_t t = (pk[j] >> 1) & 31u;  // read-order offset of the first minimal key
+            key[j] = pk[j] >> KU_PK_KEYSHIFT;
+            aoff[j] = is_fwd[j] ? t : w - 1 - t;
+            plus[j] = ((pk[j] & 1u) != 0) == is_fwd[j];
+            // a unique minimal key is the minimizer occurrence: its raw value is the bin
+            bin_v[j] = (SHARDED && key_shift) ? s_mm[p + t] : key[j];
+          } else if (ok[j]) {
+            // rare (low-complexity sequence): scan the raw values in the canonical k-mer's frame
+            key[j] = ku_anchor_exact(s_mm + p, w, key_shift, is_fwd[j], aoff[j], bin_v[j]);
+            const uint32_t q = p + (is_fwd[j] ? aoff[j] : w - 1 - aoff[j]);
+            const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
+            const uint64_t two = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
+            const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
+            const uint32_t rcm = ku_revcomp32(mmf, m);
+            plus[j] = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
+          } else {
+            key[j] = 0; aoff[j] = 0; plus[j] = true; bin_v[j] = 0;
+          }
         }
-        switch (w) {  // block-uniform; the common geometries get fully unrolled windows
-          case 19: ku_window_argmin<19, KU_ITEMS>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 13
-          case 20: ku_window_argmin<20, KU_ITEMS>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 12
-          case 25: ku_window_argmin<25, KU_ITEMS>(s_mm, base, sgn, w, r); break;  // k = 31, nt = 7
-          default: ku_window_argmin<0, KU_ITEMS>(s_mm, base, sgn, w, r); break;
-        }
-        // offset in the canonical k-mer's frame: read offset t when the read strand is canonical, else w-1-t
-        // (the first minimum there is the LAST one in read order)
-#pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
-          uint32_t t = is_fwd[j] ? (r[j] & 31u) : ((0u - r[j]) & 31u);
-          uint32_t val = (is_fwd[j] ? (r[j] >> 5) : ((r[j] + 31u) >> 5)) - 1u;  // undo the +1 bias
-          packed[j] = (val << 5) | (is_fwd[j] ? t : w - 1 - t);
+        if (exact) {
+          __syncthreads();  // every thread has read the flag
+          if (tid == 0) s_tie = 0;
         }
       }
 #pragma unroll
@@ -188,45 +239,14 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         n_b[j] = 0;
         if (ok[j]) {
           uint32_t mn = 0xFFFFFFFFu;
-          if (LAYOUT == 1 && MODE != 2) {
-            // minimum AND its first position in the canonical k-mer's frame (offset t from the left end of the
-            // canonical k-mer = read offset t for a forward-canonical k-mer, w-1-t otherwise) -- must agree with
-            // ku_locus_key(), which the table build evaluates on the stored canonical k-mer
-            const int32_t j0 = is_fwd[j] ? 0 : (int32_t)w - 1, dj = is_fwd[j] ? 1 : -1;
-            uint32_t a = 0;
-            if (m <= 13) {  // (value << 5 | offset) fits 32 bits: one min per m-mer, done above for all items
-              a = packed[j] & 31u;
-              mn = packed[j] >> 5;
-            } else {
-              for (uint32_t t = 0; t < w; ++t) {
-                uint32_t vv = s_mm[p + j0 + dj * (int32_t)t];
-                bool lt = vv < mn;
-                mn = lt ? vv : mn;
-                a = lt ? t : a;
-              }
-            }
-            // orientation of the minimizer occurrence: forward read m-mer at read offset jr
-            const uint32_t jr = is_fwd[j] ? a : w - 1 - a, q = p + jr;
-            const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
-            const uint64_t two = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
-            const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
-            const uint32_t rcm = ku_revcomp32(mmf, m);
-            const bool plus = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
-            const uint64_t cp = plus ? canon[j] : canon_rc[j];
-            const uint32_t ap = plus ? a : w - 1 - a;
-            const uint32_t left = ap, right = w - 1 - ap;
-            const bool use_r = right >= left;
-            const uint32_t side = use_r ? right : left;
-            const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
-            const uint32_t end = use_r ? ap + m + flen : ap;
-            const uint32_t flank = flen ? (uint32_t)(cp >> (2 * (k - end))) & ((1u << (2 * flen)) - 1u) : 0u;
-            locus[j] = ((uint64_t)mn << 32) | ((uint64_t)flank << 12) | (flen << 8) | ((side / KU_OFFCLASS) << 1) |
-                       (uint32_t)use_r;
+          if (PK) {
+            locus[j] = ku_locus_assemble(canon[j], key[j], aoff[j], plus[j], k, m);
+            mn = bin_v[j];
           } else {
             for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
           }
           uint64_t bin = mn;
-          if (bin >= db.bin_lo && bin < db.bin_hi) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
+          if (!SHARDED || (bin >= db.bin_lo && bin < db.bin_hi)) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
             if (LAYOUT == 0 || MODE == 2) {
               const uint64_t *o = db.offsets + (bin - db.bin_lo);
               uint64_t lo = o[0], hi = o[1];
@@ -457,7 +477,7 @@ __global__ void ku_build_table_kernel(const uint32_t *__restrict__ pairs, uint64
     const uint64_t key = ((uint64_t)khi << 32) | klo;
     const uint32_t tag = ku_table_tag(ku_fmix64(key));
     uint32_t bin;
-    uint64_t line = ku_locus_line(ku_locus_key(key, ku_revcomp64(key, k), k, m, xor_mask, bin), n_lines);
+    uint64_t line = ku_locus_line(ku_locus_key(key, k, m, xor_mask, bin), n_lines);
     for (uint32_t hops = 0;; ++hops) {
       uint32_t *lp = table + line * KU_LINE_DWORDS;
       // claim the next free entry of the bucket: count lives in the low half of dword 0

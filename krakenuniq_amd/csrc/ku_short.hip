@@ -17,6 +17,7 @@
 #include "ku_device.h"
 
 #define KS_WAVES 4  // reads in flight per 256-thread block
+#define KS_PAD 16   // sentinel elements behind a read's last m-mer (the widest doubling step reads 16 positions ahead)
 #ifdef KU_ABLATION
 #define KS_ABL(bit) ((ablate & (bit)) != 0)
 #else
@@ -25,9 +26,11 @@
 
 template <int ITEMS> struct KsGeom {
   static constexpr int MAXN = 64 * ITEMS;                      // k-mers per read
-  static constexpr int NWORDS = (MAXN + 31 + 15) / 16 + 3;     // 16-base code words (+ funnel slack)
+  static constexpr int NWORDS = (MAXN + 31 + 15) / 16 + 3;     // 16-base code words stage 1 fills (+ funnel slack)
+  static constexpr int NCODES = (MAXN + 64) / 16 + 4;          // words allocated: lanes behind the read's end read junk here
   static constexpr int NAMB = (NWORDS + 1) / 2 + 2;            // 32-base ambiguity words
-  static constexpr int NMM = MAXN + 64;                        // m-mer values
+  static constexpr int NMM = MAXN + 64 + 32;                   // packed window elements: 64 * (ITEMS + 1) positions + the
+                                                               // widest step (16) ahead; the last one is the dump slot
   static constexpr int TCAP_LOG2 = ITEMS <= 2 ? 8 : (ITEMS <= 4 ? 9 : 10);  // resolve table >= 2 * MAXN
   static constexpr int KCT_LOG2 = 8;                           // n_kmers counter table (per wave)
   static constexpr int RCT_LOG2 = 6;                           // n_reads counter table (per wave)
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   // 32 skip resolve (call 0), 64 skip locus/minimizer stage (bucket 0).  0 in production.
   using G = KsGeom<ITEMS>;
   constexpr uint32_t TCAP = 1u << G::TCAP_LOG2;
-  __shared__ uint32_t s_codes[KS_WAVES][G::NWORDS];
+  __shared__ uint32_t s_codes[KS_WAVES][G::NCODES];
   __shared__ uint32_t s_amb[KS_WAVES][G::NAMB];
   __shared__ uint32_t s_mm[KS_WAVES][G::NMM];
   __shared__ uint32_t s_tkey[KS_WAVES][TCAP];   // resolve table: slot + 1
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   uint16_t *amb16 = reinterpret_cast<uint16_t *>(amb);
   uint32_t *misc = s_misc[wv];
   const uint32_t k = KK ? (uint32_t)KK : db.k, m = KK ? (uint32_t)MM : db.nt, w = k - m + 1;
-  const bool packed_ok = m <= 13;  // (value + 1) << 5 | offset fits 32 bits
+  const uint32_t key_shift = ku_key_shift(m);
   const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
 
   for (uint32_t i = lane; i < TCAP; i += 64) { t_key[i] = 0; t_cnt[i] = 0; }
@@ -154,20 +157,29 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       }
       ks_wave_sync();
 
-      // ---- stage 2: k-mers, ambiguity, canonical form, m-mer values
+      // ---- stage 2: k-mers, ambiguity, canonical form; one packed window element (key, offset 0, strand bit) per
+      // m-mer position in the wave's LDS array.  P = n + w - 1 positions carry an m-mer that belongs to a k-mer of this
+      // read; the KS_PAD elements behind them are unique sentinels (the doubling steps below never read stale data)
+      // and lanes whose position lies behind P compute on junk and store to a dump slot: no branch in the hot path.
+      const uint32_t P = n + w - 1;
       uint64_t canon[ITEMS];
       bool is_fwd[ITEMS], ok[ITEMS];
+      uint32_t pk[ITEMS + 1], wr[ITEMS + 1];
+      uint32_t tacc = 0xFFFFFFFFu;  // min over the steps of (own ^ neighbour) - 2: < 62 <=> equal keys at two positions
+      bool tie = false;             // ... somewhere in the read -> exact scan below
+      if (lane < KS_PAD) mmv[P + lane] = (0x03FFFFFFu - lane) << KU_PK_KEYSHIFT;
 #pragma unroll
       for (int j = 0; j <= ITEMS; ++j) {
         const uint32_t p = j * 64 + lane;
-        if (j == ITEMS && p >= n + w - 1) break;
+        wr[j] = p < P ? p : (uint32_t)G::NMM - 1u;
         const uint32_t wi = p >> 4, sh = (p & 15u) * 2;
         const uint64_t hi = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
         const uint64_t x = sh ? ((hi << sh) | (uint64_t)(codes[wi + 2] >> (32 - sh))) : hi;
         const uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
         const uint32_t mrc = ku_revcomp32(mm, m);
-        const uint32_t val = (mm < mrc ? mm : mrc) ^ db.xor_mask;
-        mmv[p] = packed_ok ? (val + 1u) << 5 : val;
+        pk[j] = ku_pk_make((mm < mrc ? mm : mrc) ^ db.xor_mask, key_shift, mm <= mrc);
+        if ((m & 1u) == 0) tie |= p < P && mm == mrc;  // palindromic m-mer: its strand bit is not enough
+        mmv[wr[j]] = pk[j];
         if (j < ITEMS) {
           const uint64_t fwd = x >> (64 - 2 * k);
           const uint64_t rc = ku_revcomp64(fwd, k);
@@ -181,42 +193,84 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       }
       ks_wave_sync();
 
-      // ---- stage 3: minimizer + its first position in the canonical k-mer's frame -> locus key (ku_locus_key)
-      uint32_t mn[ITEMS], aoff[ITEMS];
+      // ---- stage 3: anchor = sliding-window minimum of the packed elements (ku_device.h): log2(w) doubling steps
+      // through the wave's own LDS array (block minima of 2, 4, 8, 16 positions), then one overlapping step for the
+      // window length itself -- five dword minima per k-mer where a scan needs w
+      uint32_t key[ITEMS], aoff[ITEMS];
+      bool plus[ITEMS];
       if (KS_ABL(64u)) {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { mn[j] = 0; aoff[j] = 0; }
-      } else if (packed_ok) {
-        uint32_t base[ITEMS], rr[ITEMS];
-        int32_t sgn[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { base[j] = j * 64 + lane; sgn[j] = is_fwd[j] ? 1 : -1; }
-        switch (w) {
-          case 19: ku_window_argmin<19, ITEMS>(mmv, base, sgn, w, rr); break;
-          case 20: ku_window_argmin<20, ITEMS>(mmv, base, sgn, w, rr); break;
-          case 25: ku_window_argmin<25, ITEMS>(mmv, base, sgn, w, rr); break;
-          default: ku_window_argmin<0, ITEMS>(mmv, base, sgn, w, rr); break;
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-          const uint32_t t = is_fwd[j] ? (rr[j] & 31u) : ((0u - rr[j]) & 31u);
-          mn[j] = (is_fwd[j] ? (rr[j] >> 5) : ((rr[j] + 31u) >> 5)) - 1u;
-          aoff[j] = is_fwd[j] ? t : w - 1 - t;
-        }
+        for (int j = 0; j < ITEMS; ++j) { key[j] = 0; aoff[j] = 0; plus[j] = true; }
       } else {
+        uint32_t blk = 1;
+        uint32_t tj[ITEMS + 1];
+#pragma unroll
+        for (int j = 0; j <= ITEMS; ++j) tj[j] = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t sft = 0; sft < 5; ++sft) {
+          const uint32_t st = 1u << sft;
+          if (2 * st > w) break;
+          uint32_t nb[ITEMS + 1];
+#pragma unroll
+          for (int j = 0; j <= ITEMS; ++j) nb[j] = mmv[j * 64 + lane + st] + (st << 1);
+          ks_wave_sync();  // every read of this step before any write (in-place update)
+#pragma unroll
+          for (int j = 0; j <= ITEMS; ++j) {
+            tj[j] = min(tj[j], (pk[j] ^ nb[j]) - 2u);
+            pk[j] = min(pk[j], nb[j]);
+            mmv[wr[j]] = pk[j];
+          }
+          ks_wave_sync();
+          blk = 2 * st;
+        }
+        if (w > blk) {
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t nbj = mmv[j * 64 + lane + (w - blk)] + ((w - blk) << 1);
+            tj[j] = min(tj[j], (pk[j] ^ nbj) - 2u);  // the two blocks overlap: the same element in both is no tie
+            pk[j] = min(pk[j], nbj);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j <= ITEMS; ++j) tacc = min(tacc, j * 64 + lane < P ? tj[j] : 0xFFFFFFFFu);
+        tie |= tacc < (1u << KU_PK_KEYSHIFT) - 2u;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-          const uint32_t p = j * 64 + lane;
-          const int32_t j0 = is_fwd[j] ? 0 : (int32_t)w - 1, dj = is_fwd[j] ? 1 : -1;
-          mn[j] = 0xFFFFFFFFu;
-          aoff[j] = 0;
-          if (ok[j])
-            for (uint32_t t = 0; t < w; ++t) {
-              const uint32_t vv = mmv[p + j0 + dj * (int32_t)t];
-              const bool lt = vv < mn[j];
-              mn[j] = lt ? vv : mn[j];
-              aoff[j] = lt ? t : aoff[j];
+          const uint32_t t = (pk[j] >> 1) & 31u;  // read-order offset of the first minimal key
+          key[j] = pk[j] >> KU_PK_KEYSHIFT;
+          aoff[j] = is_fwd[j] ? t : w - 1 - t;
+          plus[j] = ((pk[j] & 1u) != 0) == is_fwd[j];
+        }
+        if (__any(tie)) {
+          // rare (low-complexity sequence): the raw values go back into the array and every lane scans its window in
+          // the canonical k-mer's frame
+          ks_wave_sync();
+#pragma unroll
+          for (int j = 0; j <= ITEMS; ++j) {
+            const uint32_t p = j * 64 + lane;
+            if (p < P) {
+              const uint32_t wi = p >> 4, sh = (p & 15u) * 2;
+              const uint64_t two = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
+              const uint32_t mm = (uint32_t)((two << sh) >> (64 - 2 * m));
+              const uint32_t mrc = ku_revcomp32(mm, m);
+              mmv[p] = (mm < mrc ? mm : mrc) ^ db.xor_mask;
             }
+          }
+          ks_wave_sync();
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t p = j * 64 + lane;
+            if (ok[j]) {
+              uint32_t bin;
+              key[j] = ku_anchor_exact(mmv + p, w, key_shift, is_fwd[j], aoff[j], bin);
+              const uint32_t q = p + (is_fwd[j] ? aoff[j] : w - 1 - aoff[j]);
+              const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
+              const uint64_t two = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
+              const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
+              const uint32_t rcm = ku_revcomp32(mmf, m);
+              plus[j] = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
+            }
+          }
         }
       }
       const uint32_t *lp[ITEMS];
@@ -224,26 +278,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       bool act[ITEMS], ovf[ITEMS];
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t p = j * 64 + lane;
-        const uint32_t a = aoff[j];
-        const uint32_t jr = is_fwd[j] ? a : w - 1 - a, q = (ok[j] ? p : 0) + jr;
-        const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
-        const uint64_t two = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
-        const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
-        const uint32_t rcm = ku_revcomp32(mmf, m);
-        const bool plus = is_fwd[j] ? (mmf <= rcm) : (rcm <= mmf);
-        const uint32_t ap = plus ? a : w - 1 - a;
-        const uint32_t left = ap, right = w - 1 - ap;
-        const bool use_r = right >= left;
-        const uint32_t side = use_r ? right : left;
-        const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
-        const uint32_t end = use_r ? ap + m + flen : ap;
-        // bases [end - flen, end) of the strand on which the minimizer m-mer is canonical; on the other strand they
-        // are the reverse complement of bases [k - end, k - end + flen) of the canonical k-mer (no second 64-bit copy)
-        const uint32_t seg = (uint32_t)(canon[j] >> (2 * (plus ? k - end : end - flen))) & ((1u << (2 * flen)) - 1u);
-        const uint32_t flank = flen ? (plus ? seg : ku_revcomp32(seg, flen)) : 0u;
-        const uint64_t locus = ((uint64_t)mn[j] << 32) | ((uint64_t)flank << 12) | (flen << 8) |
-                               ((side / KU_OFFCLASS) << 1) | (uint32_t)use_r;
+        const uint64_t locus = ku_locus_assemble(canon[j], key[j], aoff[j], plus[j], k, m);
         hh[j] = ku_fmix64(canon[j]);
         lp[j] = tab + ku_locus_line(ok[j] ? locus : 0, db.n_lines) * KU_LINE_DWORDS;
         tag[j] = ku_table_tag(hh[j]);
