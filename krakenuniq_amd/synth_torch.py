@@ -112,19 +112,57 @@ class BenchDb:
                 km, sp = km[keep], sp[keep]
             parts_k.append(km)
             parts_v.append(sp)
-        km = torch.cat(parts_k)
-        sp = torch.cat(parts_v)
+        # torch sorts / scans stop at 2^31 elements: large builds (the 36 GB shard of the 300 GB layout is 3 G pairs) go
+        # through buckets of the k-mer space (dedup + LCA per bucket) and ranges of the bin space (bin order per range);
+        # with one bucket and one range this is the plain  sort by k-mer -> dedup -> stable sort by bin
+        total = sum(int(t.numel()) for t in parts_k)
+        n_buckets = 1 if total < (1 << 30) else 16
+        dedup = []
+        for bkt in range(n_buckets):
+            if n_buckets == 1:
+                kb, vb = torch.cat(parts_k), torch.cat(parts_v)
+            else:
+                sel = [(t >> (2 * k - 4)) == bkt for t in parts_k]
+                kb = torch.cat([t[m] for t, m in zip(parts_k, sel)])
+                vb = torch.cat([t[m] for t, m in zip(parts_v, sel)])
+                del sel
+            dedup.append(self._dedup_lca(kb, vb))
+            del kb, vb
         del parts_k, parts_v
-        km, vals = self._dedup_lca(km, sp)
-        del sp
-        b = bin_key(km, k, nt)
-        order = torch.sort(b, stable=True).indices  # k-mers are ascending already -> (bin, kmer) order
-        km, vals, b = km[order], vals[order], b[order]
-        del order
-        counts = torch.bincount(b - self.bin_lo, minlength=self.bin_hi - self.bin_lo)
-        self.offsets = torch.zeros(self.bin_hi - self.bin_lo + 1, dtype=torch.int64, device=device)
-        torch.cumsum(counts, 0, out=self.offsets[1:])
-        del b, counts
+        n_unique = sum(int(t[0].numel()) for t in dedup)
+        n_ranges = 1 if n_unique < (1 << 30) else -(-n_unique // (1 << 28))
+        span = self.bin_hi - self.bin_lo
+        bounds = [self.bin_lo + span * r // n_ranges for r in range(n_ranges + 1)]
+        by_range = [[] for _ in range(n_ranges)]
+        for kb, vb in dedup:
+            b = bin_key(kb, k, nt)
+            if n_ranges == 1:
+                by_range[0].append((kb, vb, b))
+            else:
+                for r in range(n_ranges):
+                    m = (b >= bounds[r]) & (b < bounds[r + 1])
+                    by_range[r].append((kb[m], vb[m], b[m]))
+            del b
+        del dedup
+        self.offsets = torch.zeros(span + 1, dtype=torch.int64, device=device)
+        out_k, out_v, base = [], [], 0
+        for r in range(n_ranges):
+            kr = torch.cat([t[0] for t in by_range[r]])
+            vr = torch.cat([t[1] for t in by_range[r]])
+            br = torch.cat([t[2] for t in by_range[r]])
+            by_range[r] = None
+            order = torch.sort(br, stable=True).indices  # k-mers are ascending already -> (bin, kmer) order
+            out_k.append(kr[order])
+            out_v.append(vr[order])
+            counts = torch.bincount(br - bounds[r], minlength=bounds[r + 1] - bounds[r])
+            seg = self.offsets[bounds[r] - self.bin_lo + 1:bounds[r + 1] - self.bin_lo + 1]
+            torch.cumsum(counts, 0, out=seg)
+            seg += base
+            base += int(kr.numel())
+            del kr, vr, br, order, counts
+        km = out_k[0] if n_ranges == 1 else torch.cat(out_k)
+        vals = out_v[0] if n_ranges == 1 else torch.cat(out_v)
+        del out_k, out_v
         self.n_pairs = km.numel()
         pairs = torch.empty((self.n_pairs, 3), dtype=torch.int32, device=device)
         pairs[:, 0] = ((km << 32) >> 32).to(torch.int32)  # low dword, sign-extended so the cast is exact
