@@ -302,6 +302,74 @@ int ku_counts_export(ku_ctx *ctx, uint32_t *slot_taxid, uint64_t *n_kmers, uint8
 int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_register_bytes,
                           uint64_t **d_n_kmers, uint64_t *n_slots, uint64_t **d_n_reads, uint64_t *n_nodes);
 
+/* ------------------------------------------------------------------ several GPUs
+ * The database split into contiguous minimizer-bin ranges, one per GPU, all resident at the same time.  The reference
+ * has this partitioning only in time (--preload-size chunk mode): ownership KrakenDB::prepare_chunking / upper_bound /
+ * is_minimizer_in_chunk (krakendb.cpp:430-526), per-chunk lookup classify_sequence_with_db_chunk (classify.cpp:1014-1056),
+ * "non-zero wins" merge (classify.cpp:445-452), final resolve pass (classify.cpp:676-785).  Here, per batch:
+ *   broadcast of the read batch from rank 0 -> ku_lookup_device(KU_F_KEEP_SLOTS) on every rank (each searches and
+ *   accounts -- HLL, n_kmers, misses under taxon 0 -- only the k-mers whose bin it owns) -> max-reduce of the per-k-mer
+ *   slots, scattered over the read dimension (rank r receives the merged slots of its slice of the reads) ->
+ *   ku_resolve_device + run-length encoding of that slice on rank r;
+ * at the end of the run ku_mgpu_reduce_state merges the per-taxon state (registers MAX, n_kmers / n_reads SUM).
+ * A ku_mgpu drives `n_local` ranks of a `world` of ranks from this process, one host thread per rank:
+ *   - one process, all ranks (first_rank = 0, n_local = world, id = NULL): what the classify executable does for
+ *     KU_DEVICES=0,1,...; the collectives are RCCL (ncclBroadcast, grouped ncclReduce = reduce-scatter with read-aligned
+ *     slices, ncclAllReduce) over xGMI when the devices are distinct, and device-to-device copies + merge kernels when
+ *     a device is listed more than once (several ranks on one GPU: tests, 1-GPU boxes; RCCL allows one rank per device);
+ *   - one process per GPU (n_local = 1, the launcher hands every process the id rank 0 made with ku_mgpu_unique_id):
+ *     RCCL through ncclCommInitRank; bench.py under torch.distributed.run.
+ * KU_MGPU_REPLICAS: every rank holds the whole database instead and classifies its own reads; only the per-taxon
+ * state is merged.  Collective calls (create, load / set_taxonomy, every batch, reduce_state) must be made by every
+ * process of the world in the same order. */
+typedef struct ku_mgpu ku_mgpu;
+#define KU_MGPU_ID_BYTES 128
+#define KU_MGPU_REPLICAS 0x1u
+#define KU_MGPU_NO_RCCL 0x2u /* single-process groups: use the copy + merge-kernel exchange even between distinct devices */
+int ku_mgpu_unique_id(uint8_t *id /* [KU_MGPU_ID_BYTES] */);
+int ku_mgpu_create(const int *devices, uint32_t n_local, uint32_t first_rank, uint32_t world, const uint8_t *id,
+                   uint32_t flags, ku_mgpu **out);
+void ku_mgpu_destroy(ku_mgpu *m);
+/* the context of local rank i (0 <= i < n_local): adopt a device-resident shard, export counts, ... */
+ku_ctx *ku_mgpu_ctx(ku_mgpu *m, uint32_t local_index);
+/* 1 when the ranks exchange through RCCL, 0 for the same-process copy + merge exchange */
+int ku_mgpu_uses_rccl(const ku_mgpu *m);
+/* shard plan (ku_db_shard_plan over the world) + upload of every local rank's range + taxonomy with the slot table of
+ * the whole database (the ranks' distinct values are all-gathered); KU_MGPU_REPLICAS: the whole database everywhere */
+int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax);
+/* the same last step alone, after the local shards were adopted through ku_mgpu_ctx() + ku_ctx_adopt_db */
+int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax);
+/* One batch on host buffers, arguments and results as ku_classify_batch_rle (+ ku_mgpu_fetch_runs for the runs).
+ * Single-process groups only.  Sharded: broadcast / lookup / reduce-scatter / resolve as above; replicas: the reads are
+ * cut into `world` slices, rank r classifies slice r. */
+int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                               const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                               uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs);
+int ku_mgpu_fetch_runs(ku_mgpu *m, ku_run *runs, uint64_t n_runs);
+/* One sharded batch on device buffers, asynchronous on each local rank's stream (measurement path; multi-process
+ * capable).  Per local rank: d_seqs / d_seq_off / d_seq_len hold the batch on rank 0 and receive it elsewhere
+ * (n_bytes + 16, n_reads * 8, n_reads * 4 bytes), d_taxa (4 * (n_bytes + 16) bytes) and d_calls (4 * n_reads) are
+ * outputs: rank r leaves the calls and per-k-mer taxids of the reads [read_bounds[r], read_bounds[r+1]) in place
+ * (same indices as an unsharded run).  pos_bounds[r] = seq_off[read_bounds[r]] (pos_bounds[world] = n_bytes): the
+ * slice of the per-k-mer array rank r receives.  stream = NULL: the context's own. */
+typedef struct ku_mgpu_dev_batch {
+  void *d_seqs;
+  uint64_t *d_seq_off;
+  uint32_t *d_seq_len;
+  uint32_t *d_calls;
+  uint32_t *d_taxa;
+  void *stream;
+} ku_mgpu_dev_batch;
+int ku_mgpu_step_device(ku_mgpu *m, const ku_mgpu_dev_batch *local /* [n_local] */, uint64_t n_bytes, uint64_t n_reads,
+                        const uint64_t *read_bounds /* [world + 1] */, const uint64_t *pos_bounds /* [world + 1] */,
+                        const ku_opts *opts);
+/* merge the per-taxon state over all ranks in place (every rank ends up with the whole run's state): HLL registers
+ * MAX, n_kmers and n_reads SUM -- taxon_counts[t] += local[t] (classify.cpp:541-544) across GPUs.  Call once, at the
+ * end of the run (a second call would add the sums again); streams[i] = NULL: the context's own stream. */
+int ku_mgpu_reduce_state(ku_mgpu *m, void *const *streams /* [n_local] or NULL */);
+/* database.kdb.counts over all local shards (ku_ctx_count_taxons summed; single-process groups) */
+int ku_mgpu_count_taxons(ku_mgpu *m, uint32_t *taxids, uint64_t *counts, uint64_t *n);
+
 /* ------------------------------------------------------------------ host-side helpers
  * (double arithmetic / text; the reference does these on the host too) */
 /* Ertl improved estimator on dense registers, clipped to n_observed

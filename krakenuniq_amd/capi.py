@@ -47,6 +47,11 @@ class CountsDims(C.Structure):
     _fields_ = [("n_slots", C.c_uint64), ("n_nodes", C.c_uint64)]
 
 
+class DevBatch(C.Structure):  # ku_mgpu_dev_batch
+    _fields_ = [("d_seqs", C.c_void_p), ("d_seq_off", C.c_void_p), ("d_seq_len", C.c_void_p), ("d_calls", C.c_void_p),
+                ("d_taxa", C.c_void_p), ("stream", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/krakenuniq_amd.h one to one
 SIGNATURES = {
     "ku_strerror": (C.c_char_p, [C.c_int]),
@@ -118,6 +123,20 @@ SIGNATURES = {
                                   C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_report_exact": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u64p, C.c_uint64, u32p, u64p,
                                   C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_mgpu_unique_id": (C.c_int, [u8p]),
+    "ku_mgpu_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint32,
+                                 C.POINTER(C.c_void_p)]),
+    "ku_mgpu_destroy": (None, [C.c_void_p]),
+    "ku_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "ku_mgpu_uses_rccl": (C.c_int, [C.c_void_p]),
+    "ku_mgpu_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ku_mgpu_set_taxonomy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ku_mgpu_classify_batch_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p,
+                                             u32p, u64p, u32p, u64p]),
+    "ku_mgpu_fetch_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ku_mgpu_step_device": (C.c_int, [C.c_void_p, C.POINTER(DevBatch), C.c_uint64, C.c_uint64, u64p, u64p, C.POINTER(Opts)]),
+    "ku_mgpu_reduce_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ku_mgpu_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
     "ku_free": (None, [C.c_void_p]),
     "ku_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ku_host_free": (None, [C.c_void_p]),
@@ -229,15 +248,19 @@ class Tax:
 class Ctx:
     """Per-GPU context (ku_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, borrowed=None):
+        self._keep = []
+        self._borrowed = borrowed is not None
+        if borrowed is not None:  # a context owned by a multi-GPU group (ku_mgpu_ctx)
+            self.h = C.c_void_p(borrowed)
+            return
         self.h = C.c_void_p()
         _chk(lib().ku_ctx_create(device, C.byref(self.h)), "ku_ctx_create")
-        self._keep = []
 
     def close(self):
-        if getattr(self, "h", None) and _lib is not None:
+        if getattr(self, "h", None) and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.ku_ctx_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     __del__ = close
 
@@ -382,6 +405,97 @@ class Ctx:
                                          C.byref(nn)), "ku_counts_device_ptrs")
         return {"registers": r.value, "register_bytes": nb.value, "n_kmers": k.value, "n_slots": ns.value,
                 "n_reads": n.value, "n_nodes": nn.value}
+
+
+KU_MGPU_REPLICAS, KU_MGPU_NO_RCCL = 1, 2
+
+
+def mgpu_unique_id():
+    """the RCCL id rank 0 makes and the launcher hands to every process (ku_mgpu_unique_id)"""
+    buf = np.zeros(128, dtype=np.uint8)
+    _chk(lib().ku_mgpu_unique_id(_p(buf, u8p)), "ku_mgpu_unique_id")
+    return buf
+
+
+class Mgpu:
+    """Several GPUs driven through the C++ multi-GPU driver (ku_mgpu): n_local ranks of `world` from this process."""
+
+    def __init__(self, devices, first_rank=0, world=None, unique_id=None, flags=0):
+        devices = list(devices)
+        self.n_local = len(devices)
+        self.world = self.n_local if world is None else world
+        self.first_rank = first_rank
+        arr = (C.c_int * self.n_local)(*devices)
+        idb = np.ascontiguousarray(unique_id, dtype=np.uint8) if unique_id is not None else None
+        self.h = C.c_void_p()
+        _chk(lib().ku_mgpu_create(arr, self.n_local, first_rank, self.world, _p(idb, u8p), flags, C.byref(self.h)),
+             "ku_mgpu_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ku_mgpu_destroy(self.h)
+        self.h = C.c_void_p()
+
+    __del__ = close
+
+    def ctx(self, i=0):
+        return Ctx(borrowed=lib().ku_mgpu_ctx(self.h, i))
+
+    def uses_rccl(self):
+        return bool(lib().ku_mgpu_uses_rccl(self.h))
+
+    def load(self, db: Db, tax: Tax):
+        self._keep += [db, tax]
+        _chk(lib().ku_mgpu_load(self.h, db.h, tax.h), "ku_mgpu_load")
+
+    def set_taxonomy(self, tax: Tax):
+        self._keep.append(tax)
+        _chk(lib().ku_mgpu_set_taxonomy(self.h, tax.h), "ku_mgpu_set_taxonomy")
+
+    def classify_batch_rle(self, buf, off, lens, flags=0, min_hits=1):
+        arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        calls = np.zeros(max(n, 1), dtype=np.uint32)
+        hits = np.zeros(max(n, 1), dtype=np.uint32)
+        roff = np.zeros(max(n, 1), dtype=np.uint64)
+        rcnt = np.zeros(max(n, 1), dtype=np.uint32)
+        o = Opts(flags, min_hits, 0, 0)
+        total = C.c_uint64()
+        _chk(lib().ku_mgpu_classify_batch_rle(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n,
+                                              C.byref(o), _p(calls, u32p), _p(hits, u32p), _p(roff, u64p), _p(rcnt, u32p),
+                                              C.byref(total)), "ku_mgpu_classify_batch_rle")
+        runs = np.zeros((max(total.value, 1), 2), dtype=np.uint32)
+        _chk(lib().ku_mgpu_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_mgpu_fetch_runs")
+        return {"calls": calls[:n], "hits": hits[:n], "runs": runs[:total.value], "run_off": roff[:n], "run_cnt": rcnt[:n]}
+
+    def step_device(self, batches, n_bytes, n_reads, read_bounds, pos_bounds, flags=0, min_hits=1, max_read_len=0):
+        """batches: one dict per local rank with the device pointers d_seqs, d_seq_off, d_seq_len, d_calls, d_taxa, stream"""
+        arr = (DevBatch * self.n_local)()
+        for i, b in enumerate(batches):
+            arr[i] = DevBatch(b["d_seqs"], b["d_seq_off"], b["d_seq_len"], b["d_calls"], b["d_taxa"], b.get("stream"))
+        rb = np.ascontiguousarray(read_bounds, dtype=np.uint64)
+        pb = np.ascontiguousarray(pos_bounds, dtype=np.uint64)
+        o = Opts(flags, min_hits, max_read_len, 0)
+        _chk(lib().ku_mgpu_step_device(self.h, arr, n_bytes, n_reads, _p(rb, u64p), _p(pb, u64p), C.byref(o)),
+             "ku_mgpu_step_device")
+
+    def reduce_state(self, streams=None):
+        arr = None
+        if streams is not None:
+            arr = (C.c_void_p * self.n_local)(*streams)
+        _chk(lib().ku_mgpu_reduce_state(self.h, arr), "ku_mgpu_reduce_state")
+
+    def count_taxons(self):
+        n = C.c_uint64()
+        _chk(lib().ku_mgpu_count_taxons(self.h, None, None, C.byref(n)), "ku_mgpu_count_taxons")
+        t = np.zeros(max(n.value, 1), dtype=np.uint32)
+        c = np.zeros(max(n.value, 1), dtype=np.uint64)
+        n2 = C.c_uint64(len(t))
+        _chk(lib().ku_mgpu_count_taxons(self.h, _p(t, u32p), _p(c, u64p), C.byref(n2)), "ku_mgpu_count_taxons")
+        return t[:n2.value], c[:n2.value]
 
 
 class Batch:

@@ -4,18 +4,24 @@
 // classification path in this program.
 //
 // Honoured getopt string (src/classify.cpp:1074): d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:
-//   -d kdb  -i idx  -a taxDB            as the reference (one database; a second -d/-i is KU_EUNSUP)
+//   -d kdb  -i idx  -a taxDB            as the reference; several -d/-i pairs = hierarchical run, searched in order
+//                                       (src/classify.cpp:163-177,928-936)
 //   -o file|off|-                       Kraken output ("-" and "off" both disable it, src/classify.cpp:234-235)
 //   -r file|off                         report, opened in APPEND mode like the reference (:286)
 //   -C/-U file                          classified / unclassified reads;  -c only classified lines;  -s print sequence
 //   -q -m N                             quick mode
-//   -t N                                host threads formatting the output (must be > 0; default 4); the GPU replaces
-//                                       the OpenMP classification team
+//   -t N                                host threads parsing the input and formatting the output (0 < N <= processors,
+//                                       src/classify.cpp:1085-1088; default 4); the GPU replaces the OpenMP classification team
 //   -u N                                accepted (must be > 0); sets the ingest batch size in nt (default 64 Mi, at least 1 Mi)
-//   -M, -x SIZE                         accepted: the database is always resident in HBM (SIZE is parsed and checked)
+//   -M                                  accepted: the database is always preloaded (into HBM)
+//   -x SIZE                             the database is streamed through HBM in minimizer-range chunks of at most SIZE
+//                                       bytes (src/krakendb.cpp:463-522) when that yields more than one chunk
 //   -p N                                accepted and ignored exactly like the reference
 //   -I file                             UID mapping: not built here -> exit 70 with a message
-// Extension: env KU_DEVICE selects the GPU (default 0).
+// Extensions: -P (mate pairs merged on the fly); env KU_DEVICE selects the GPU (default 0); env KU_DEVICES=0,1,...
+// runs on several GPUs through the multi-GPU driver (ku_mgpu: database sharded by minimizer range, read batches
+// broadcast, per-k-mer slots reduce-scattered, per-taxon state reduced at the end; KU_MGPU_MODE=replicas keeps the
+// whole database on every GPU and splits the reads instead).
 #include <fcntl.h>
 #include <getopt.h>
 #include <sys/mman.h>
@@ -191,6 +197,10 @@ int main(int argc, char **argv) {
       case 't':
         sig = atoll(optarg);
         if (sig <= 0) die(EX_USAGE, "can't use nonpositive thread count");
+        {  // src/classify.cpp:1085-1088 (omp_get_num_procs there)
+          const long procs = sysconf(_SC_NPROCESSORS_ONLN);
+          if (procs > 0 && sig > procs) die(EX_USAGE, "thread count exceeds number of processors");
+        }
         fmt_threads = (int)(sig > 64 ? 64 : sig);
         break;
       case 'p': break;  // HLL_PRECISION only selects report columns in the reference; the sketch is p = 12
@@ -256,8 +266,31 @@ int main(int argc, char **argv) {
   ku_tax *tax = nullptr;
   KU_CHECK(ku_tax_open(taxdb.c_str(), &tax));
   ku_ctx *ctx = nullptr;
-  const char *dev_env = getenv("KU_DEVICE");
-  KU_CHECK(ku_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx));
+  ku_mgpu *mg = nullptr;  // KU_DEVICES=0,1,...: several GPUs through the multi-GPU driver
+  std::vector<int> devices;
+  if (const char *dl = getenv("KU_DEVICES")) {
+    for (const char *p = dl; *p;) {
+      char *end = nullptr;
+      const long d = strtol(p, &end, 10);
+      if (end == p || d < 0) die(EX_USAGE, "can't parse KU_DEVICES=%s", dl);
+      devices.push_back((int)d);
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') die(EX_USAGE, "can't parse KU_DEVICES=%s", dl);
+    }
+  }
+  if (devices.size() > 1) {
+    if (db_handles.size() > 1) die(EX_SOFTWARE, "KU_DEVICES with several databases is not supported");
+    if (chunk_bytes) die(EX_SOFTWARE, "KU_DEVICES with -x is not supported: the shards are resident on the GPUs");
+    const char *mode = getenv("KU_MGPU_MODE");
+    const uint32_t mflags = (mode && strcmp(mode, "replicas") == 0) ? KU_MGPU_REPLICAS : 0u;
+    KU_CHECK(ku_mgpu_create(devices.data(), (uint32_t)devices.size(), 0, (uint32_t)devices.size(), nullptr, mflags, &mg));
+    fprintf(stderr, "Running on %zu GPU ranks (%s, %s exchange)\n", devices.size(), mflags ? "replicas" : "database sharded by minimizer range",
+            ku_mgpu_uses_rccl(mg) ? "RCCL" : "same-process");
+    ctx = ku_mgpu_ctx(mg, 0);
+  } else {
+    const char *dev_env = getenv("KU_DEVICE");
+    KU_CHECK(ku_ctx_create(devices.size() == 1 ? devices[0] : (dev_env ? atoi(dev_env) : 0), &ctx));
+  }
   // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference; one chunk = everything resident as usual
   std::vector<uint64_t> chunk_bounds;
   if (chunk_bytes) {
@@ -269,6 +302,7 @@ int main(int argc, char **argv) {
     if (n_chunks <= 1) chunk_bounds.clear();
   }
   const bool chunked = !chunk_bounds.empty();
+  if (mg && exact) die(EX_SOFTWARE, "exact counting on several GPUs is not built into the MI355X classifyExact");
   if (chunked && exact) die(EX_SOFTWARE, "exact counting with -x chunks is not built into the MI355X classifyExact");
   // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
   auto counts_file_good = [](const std::string &name, bool say) {
@@ -303,6 +337,8 @@ int main(int argc, char **argv) {
     KU_CHECK(ku_ctx_load_db(ctx, db, chunk_bounds[0], chunk_bounds[1]));
     KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, values.data(), cap));
     add_chunk_counts();
+  } else if (mg) {
+    KU_CHECK(ku_mgpu_load(mg, db, tax));
   } else {
     KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
     for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
@@ -586,11 +622,16 @@ int main(int argc, char **argv) {
     bt->run_cnt.assign(n, 0);
     ku_opts opts = base_opts;
     uint64_t n_runs = 0;
-    KU_CHECK(ku_classify_batch_rle(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
-                                   bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
+    if (mg)
+      KU_CHECK(ku_mgpu_classify_batch_rle(mg, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
+                                          bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
+    else
+      KU_CHECK(ku_classify_batch_rle(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
+                                     bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
     if (print_kraken && !quick) {  // the runs only feed the Kraken lines
       bt->reserve_runs(n_runs);
-      KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
+      if (mg) KU_CHECK(ku_mgpu_fetch_runs(mg, bt->runs, n_runs));
+      else KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
     }
     busy_gpu += now_s() - t_gpu;
     done_q.push(bt);
@@ -631,10 +672,12 @@ int main(int argc, char **argv) {
       } else if (!good) {
         fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
         uint64_t nc = 0;
-        KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, nullptr, nullptr, &nc));
+        if (mg) KU_CHECK(ku_mgpu_count_taxons(mg, nullptr, nullptr, &nc));
+        else KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, nullptr, nullptr, &nc));
         std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
         uint64_t cap = nc;
-        KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, ct.data(), cc.data(), &cap));
+        if (mg) KU_CHECK(ku_mgpu_count_taxons(mg, ct.data(), cc.data(), &cap));
+        else KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, ct.data(), cc.data(), &cap));
         FILE *cf = fopen(cname.c_str(), "w");
         if (!cf) die(EX_OSERR, "can't write %s", cname.c_str());
         for (uint64_t i = 0; i < cap; ++i) fprintf(cf, "%u\t%" PRIu64 "\n", ct[i], cc[i]);
@@ -643,6 +686,7 @@ int main(int argc, char **argv) {
     }
     std::vector<const char *> cpaths;
     for (const std::string &c : cnames) cpaths.push_back(c.c_str());
+    if (mg) KU_CHECK(ku_mgpu_reduce_state(mg, nullptr));  // every rank's registers / counters into rank 0's context
     ku_counts_dims d;
     KU_CHECK(ku_counts_dims_get(ctx, &d));
     std::vector<uint32_t> st(d.n_slots), ntx(d.n_nodes);
@@ -668,7 +712,8 @@ int main(int argc, char **argv) {
     fprintf(stderr, "Report finished in %.3f seconds.\n", seconds_between(tv1, tv2));
   }
   fprintf(stderr, "Finishing up ...\n");
-  ku_ctx_destroy(ctx);
+  if (mg) ku_mgpu_destroy(mg);
+  else ku_ctx_destroy(ctx);
   ku_tax_close(tax);
   for (ku_db *h : db_handles) ku_db_close(h);
   return 0;

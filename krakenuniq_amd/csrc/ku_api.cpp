@@ -388,6 +388,11 @@ struct ku_ctx {
   uint64_t exact_mask = 0;
 };
 
+hipStream_t ku_ctx_stream_of(ku_ctx *ctx) { return ctx->stream; }
+int ku_ctx_device_of(const ku_ctx *ctx) { return ctx->device; }
+int ku_ctx_cus_of(const ku_ctx *ctx) { return ctx->n_cu; }
+uint32_t ku_ctx_k_of(const ku_ctx *ctx) { return ctx->m.db.k; }
+
 static int ctx_activate(ku_ctx *ctx) {
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(KU_EHIP, "hipSetDevice failed");
   return KU_OK;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/krakenuniq_amd.h"
 
 // Device view of the resident DB shard.  Pairs keep the reference's on-disk
@@ -49,6 +51,14 @@ struct KuCountsDev {
 struct ku_db;
 int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets);
 
+// context internals the multi-GPU driver (ku_mgpu.cpp) needs
+struct ku_ctx;
+hipStream_t ku_ctx_stream_of(ku_ctx *ctx);
+int ku_ctx_device_of(const ku_ctx *ctx);
+int ku_ctx_cus_of(const ku_ctx *ctx);
+uint32_t ku_ctx_k_of(const ku_ctx *ctx);
+void ku_set_error(const std::string &s);
+
 // launch wrappers implemented in ku_kernels.hip (all asynchronous on `stream`)
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
                      uint32_t *d_taxa, bool do_counts, bool prior, bool merge_chunk, int n_cu, hipStream_t stream);
@@ -73,6 +83,10 @@ int ku_launch_rle(const uint32_t *d_taxa, uint32_t k, const uint64_t *d_seq_off,
                   uint64_t n_reads, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter, uint64_t *d_run_off,
                   uint32_t *d_run_cnt, int n_cu, hipStream_t stream);
 int ku_launch_max_len(const uint32_t *d_seq_len, uint64_t n_reads, uint32_t *d_out, hipStream_t stream);
+// element-wise merges of the multi-GPU driver's same-process exchange: dst = max(dst, src) / dst += src
+int ku_launch_merge_max_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream);
+int ku_launch_merge_max_u8(uint8_t *dst, const uint8_t *src, uint64_t n, hipStream_t stream);
+int ku_launch_merge_add_u64(unsigned long long *dst, const unsigned long long *src, uint64_t n, hipStream_t stream);
 // DB preparation
 int ku_launch_repack(const uint8_t *d_raw, uint64_t n_pairs, uint32_t key_len, uint32_t *d_pairs,
                      hipStream_t stream);

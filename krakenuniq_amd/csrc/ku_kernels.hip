@@ -1084,6 +1084,40 @@ int ku_launch_max_len(const uint32_t *d_seq_len, uint64_t n_reads, uint32_t *d_o
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
+// element-wise merges (multi-GPU driver, same-process exchange): "non-zero wins" on per-k-mer slots (classify.cpp:445-452)
+// is a max because exactly one shard is non-zero and KU_AMBIG is the same on all; HLL registers merge by max, counters add
+__global__ void ku_merge_max_u32_kernel(uint32_t *dst, const uint32_t *__restrict__ src, uint64_t n) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = max(dst[i], src[i]);
+}
+__global__ void ku_merge_max_u8_kernel(uint8_t *dst, const uint8_t *__restrict__ src, uint64_t n) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = dst[i] > src[i] ? dst[i] : src[i];
+}
+__global__ void ku_merge_add_u64_kernel(unsigned long long *dst, const unsigned long long *__restrict__ src, uint64_t n) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] += src[i];
+}
+static unsigned ku_merge_grid(uint64_t n) {
+  uint64_t nb = (n + 255) / 256;
+  return (unsigned)(nb < 8192 ? (nb ? nb : 1) : 8192);
+}
+int ku_launch_merge_max_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream) {
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_merge_max_u32_kernel, dim3(ku_merge_grid(n)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_merge_max_u8(uint8_t *dst, const uint8_t *src, uint64_t n, hipStream_t stream) {
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_merge_max_u8_kernel, dim3(ku_merge_grid(n)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_merge_add_u64(unsigned long long *dst, const unsigned long long *src, uint64_t n, hipStream_t stream) {
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_merge_add_u64_kernel, dim3(ku_merge_grid(n)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
 // on-disk pairs with key_len < 8 (k < 29) -> the fixed 12-byte record the kernels use
 __global__ void ku_repack_kernel(const uint8_t *__restrict__ raw, uint64_t n, uint32_t key_len,
                                  uint32_t *__restrict__ out) {

@@ -1,0 +1,673 @@
+// ku_mgpu.cpp -- the classify hot path over several GPUs: host C++ over the C ABI + RCCL (include/krakenuniq_amd.h,
+// "several GPUs").  One host thread per rank; the database is sharded by minimizer-bin range (the reference's
+// --preload-size partitioning, krakendb.cpp:430-526, laid out in space instead of in time), read batches are broadcast,
+// per-k-mer slots are max-reduced ("non-zero wins", classify.cpp:445-452) and scattered over the read dimension, every
+// rank resolves its slice (classify.cpp:676-785), the per-taxon state is reduced at the end of the run.
+//
+// Two exchange back ends behind one small interface (Comm):
+//   RCCL      ncclBroadcast / grouped ncclReduce (a reduce-scatter whose slices end on read boundaries) / ncclAllReduce /
+//             ncclAllGather on the rank's stream.  librccl is bound with dlopen at the first use, so single-GPU users
+//             of the library never load it and a process that already holds an RCCL (PyTorch ships one) shares it.
+//   same-process copies + merge kernels, host barriers between the ranks' threads: ranks that share a device (RCCL
+//             admits one rank per device) -- the form the 1-GPU test box can run -- or KU_MGPU_NO_RCCL.
+#include <dlfcn.h>
+#include <pthread.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ku_internal.h"
+
+static int mfail(int code, const std::string &msg) {
+  ku_set_error(msg);
+  return code;
+}
+#define M_HIP(expr)                                                                                          \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess)                                                                                    \
+      return mfail(e_ == hipErrorOutOfMemory ? KU_ENOMEM : KU_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define M_TRY(expr)             \
+  do {                          \
+    int s_ = (expr);            \
+    if (s_ != KU_OK) return s_; \
+  } while (0)
+
+// ---------------------------------------------------------------------------- RCCL, bound at run time
+namespace {
+struct Rccl {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+pthread_once_t g_rccl_once = PTHREAD_ONCE_INIT;
+std::string g_rccl_err;
+
+void rccl_load() {
+  for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+    g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.h) break;
+  }
+  if (!g_rccl.h) {
+    g_rccl_err = std::string("cannot load librccl: ") + dlerror();
+    return;
+  }
+#define KU_SYM(field, sym)                                                     \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.h, sym)); \
+  if (!g_rccl.field) g_rccl_err = std::string("librccl lacks ") + sym;
+  KU_SYM(GetUniqueId, "ncclGetUniqueId")
+  KU_SYM(CommInitRank, "ncclCommInitRank")
+  KU_SYM(CommInitAll, "ncclCommInitAll")
+  KU_SYM(CommDestroy, "ncclCommDestroy")
+  KU_SYM(Broadcast, "ncclBroadcast")
+  KU_SYM(Reduce, "ncclReduce")
+  KU_SYM(AllReduce, "ncclAllReduce")
+  KU_SYM(AllGather, "ncclAllGather")
+  KU_SYM(GroupStart, "ncclGroupStart")
+  KU_SYM(GroupEnd, "ncclGroupEnd")
+  KU_SYM(GetErrorString, "ncclGetErrorString")
+#undef KU_SYM
+}
+int rccl_ready() {
+  pthread_once(&g_rccl_once, rccl_load);
+  if (!g_rccl_err.empty()) return mfail(KU_EHIP, g_rccl_err);
+  return KU_OK;
+}
+#define M_NCCL(expr)                                                                                     \
+  do {                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess) return mfail(KU_EHIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+struct DBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return KU_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      p = nullptr;
+      return mfail(KU_ENOMEM, "device memory for a multi-GPU batch buffer");
+    }
+    cap = want;
+    return KU_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// state the ranks of one process share for the same-process exchange
+struct Shared {
+  pthread_barrier_t bar;
+  bool bar_init = false;
+  std::vector<const void *> ptr_a, ptr_b, ptr_c;  // published per local rank
+  std::vector<std::vector<uint32_t>> vals;
+  std::vector<int> dev;
+  std::atomic<int> failed{0};
+};
+}  // namespace
+
+struct ku_mgpu {
+  uint32_t world = 0, first_rank = 0, n_local = 0, flags = 0;
+  bool use_rccl = false;
+  struct Rank {
+    uint32_t rank = 0, local = 0;
+    int device = 0;
+    ku_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    DBuf seqs, off, len, taxa, calls, hits, runs, roff, rcnt, scratch, small;
+    uint64_t n_runs = 0;   // runs of the last host batch still in `runs`
+    uint64_t run_base = 0; // where they start in the caller's array
+  };
+  std::vector<Rank> ranks;
+  Shared sh;
+  bool loaded = false, tax_set = false;
+};
+
+namespace {
+void barrier(ku_mgpu *m) {
+  if (m->n_local > 1) pthread_barrier_wait(&m->sh.bar);
+}
+
+// run fn(rank) on one host thread per local rank (inline for a single rank); the first failing status wins
+int run_all(ku_mgpu *m, const std::function<int(ku_mgpu::Rank &)> &fn) {
+  std::vector<int> st(m->n_local, KU_OK);
+  std::vector<std::string> msg(m->n_local);
+  auto body = [&](uint32_t i) {
+    ku_mgpu::Rank &r = m->ranks[i];
+    if (hipSetDevice(r.device) != hipSuccess) {
+      st[i] = KU_EHIP;
+      msg[i] = "hipSetDevice failed";
+      m->sh.failed.store(1);
+      return;
+    }
+    st[i] = fn(r);
+    if (st[i] != KU_OK) {
+      msg[i] = ku_last_error();
+      m->sh.failed.store(1);
+    }
+  };
+  m->sh.failed.store(0);
+  if (m->n_local == 1) {
+    body(0);
+  } else {
+    std::vector<std::thread> team;
+    for (uint32_t i = 0; i < m->n_local; ++i) team.emplace_back(body, i);
+    for (auto &t : team) t.join();
+  }
+  for (uint32_t i = 0; i < m->n_local; ++i)
+    if (st[i] != KU_OK) return mfail(st[i], "rank " + std::to_string(m->ranks[i].rank) + ": " + msg[i]);
+  return KU_OK;
+}
+
+// ---- the exchange primitives.  Same-process variants always pass every barrier, whatever the local status, so that
+// a failing rank cannot leave the others waiting; the status is checked behind the last barrier.
+int copy_from_peer(ku_mgpu *m, ku_mgpu::Rank &r, void *dst, const void *src, size_t bytes, hipStream_t s) {
+  (void)m;
+  (void)r;
+  if (bytes == 0) return KU_OK;
+  M_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
+  return KU_OK;
+}
+
+// same-process exchange: a rank that already failed says so before the first barrier, everybody leaves with an error
+// behind the last one
+void gate_in(ku_mgpu *m, int st) {
+  if (st != KU_OK) m->sh.failed.store(1);
+}
+int gate_out(ku_mgpu *m, int st) {
+  if (st == KU_OK && m->sh.failed.load()) return mfail(KU_ESTATE, "another rank of the group failed");
+  return st;
+}
+bool comm_noop(const ku_mgpu *m) { return m->world == 1 && !m->use_rccl; }
+
+int comm_broadcast(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *buf, size_t bytes, hipStream_t s) {
+  if (comm_noop(m) || bytes == 0) return st;
+  if (m->use_rccl) {
+    if (st != KU_OK) return st;
+    M_NCCL(g_rccl.Broadcast(buf, buf, bytes, ncclUint8, 0, r.comm, s));
+    return KU_OK;
+  }
+  if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "stream synchronisation failed");
+  m->sh.ptr_a[r.local] = buf;
+  gate_in(m, st);
+  barrier(m);
+  if (st == KU_OK && !m->sh.failed.load() && r.local != 0) {
+    st = copy_from_peer(m, r, buf, m->sh.ptr_a[0], bytes, s);
+    if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "broadcast copy failed");
+  }
+  gate_in(m, st);
+  barrier(m);
+  return gate_out(m, st);
+}
+
+// in place: afterwards rank r holds max over all ranks of taxa[pos[r] .. pos[r+1])
+int comm_reduce_slices_max(ku_mgpu *m, ku_mgpu::Rank &r, int st, uint32_t *taxa, const uint64_t *pos, hipStream_t s) {
+  if (comm_noop(m)) return st;
+  if (m->use_rccl) {
+    if (st != KU_OK) return st;
+    M_NCCL(g_rccl.GroupStart());
+    for (uint32_t q = 0; q < m->world; ++q) {
+      const uint64_t n = pos[q + 1] - pos[q];
+      if (n == 0) continue;
+      ncclResult_t e = g_rccl.Reduce(taxa + pos[q], taxa + pos[q], n, ncclUint32, ncclMax, (int)q, r.comm, s);
+      if (e != ncclSuccess) {
+        (void)g_rccl.GroupEnd();
+        return mfail(KU_EHIP, std::string("ncclReduce: ") + g_rccl.GetErrorString(e));
+      }
+    }
+    M_NCCL(g_rccl.GroupEnd());
+    return KU_OK;
+  }
+  if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "lookup failed");
+  m->sh.ptr_a[r.local] = taxa;
+  gate_in(m, st);
+  barrier(m);
+  const uint64_t lo = pos[r.rank], n = pos[r.rank + 1] - lo;
+  if (!m->sh.failed.load()) {
+    for (uint32_t q = 0; q < m->n_local && st == KU_OK && n; ++q) {
+      if (q == r.local) continue;
+      const uint32_t *src = (const uint32_t *)m->sh.ptr_a[q] + lo;
+      if (m->sh.dev[q] != r.device) {  // stage the peer's slice on this device first
+        st = r.scratch.reserve(n * 4);
+        if (st == KU_OK) st = copy_from_peer(m, r, r.scratch.p, src, n * 4, s);
+        src = (const uint32_t *)r.scratch.p;
+      }
+      if (st == KU_OK) st = ku_launch_merge_max_u32(taxa + lo, src, n, s);
+    }
+    if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "slot merge failed");
+  }
+  gate_in(m, st);
+  barrier(m);  // the peers may overwrite their arrays again
+  return gate_out(m, st);
+}
+
+int comm_allreduce_state(ku_mgpu *m, ku_mgpu::Rank &r, hipStream_t s) {
+  if (comm_noop(m)) return KU_OK;
+  uint8_t *regs = nullptr;
+  uint64_t n_regs = 0, n_slots = 0, n_nodes = 0, *nk = nullptr, *nr = nullptr;
+  int st = ku_counts_device_ptrs(r.ctx, &regs, &n_regs, &nk, &n_slots, &nr, &n_nodes);
+  if (m->use_rccl) {
+    if (st != KU_OK) return st;
+    M_NCCL(g_rccl.GroupStart());
+    ncclResult_t e1 = g_rccl.AllReduce(regs, regs, n_regs, ncclUint8, ncclMax, r.comm, s);
+    ncclResult_t e2 = g_rccl.AllReduce(nk, nk, n_slots, ncclUint64, ncclSum, r.comm, s);
+    ncclResult_t e3 = g_rccl.AllReduce(nr, nr, n_nodes, ncclUint64, ncclSum, r.comm, s);
+    M_NCCL(g_rccl.GroupEnd());
+    if (e1 != ncclSuccess || e2 != ncclSuccess || e3 != ncclSuccess) return mfail(KU_EHIP, "ncclAllReduce of the per-taxon state failed");
+    return KU_OK;
+  }
+  if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "stream synchronisation failed");
+  m->sh.ptr_a[r.local] = regs;
+  m->sh.ptr_b[r.local] = nk;
+  m->sh.ptr_c[r.local] = nr;
+  gate_in(m, st);
+  barrier(m);
+  if (r.local == 0 && !m->sh.failed.load()) {  // fold everybody into the first rank ...
+    for (uint32_t q = 1; q < m->n_local && st == KU_OK; ++q) {
+      const void *a = m->sh.ptr_a[q], *b = m->sh.ptr_b[q], *c = m->sh.ptr_c[q];
+      if (m->sh.dev[q] != r.device) {
+        st = r.scratch.reserve(n_regs + (n_slots + n_nodes) * 8);
+        uint8_t *sp = (uint8_t *)r.scratch.p;
+        if (st == KU_OK) st = copy_from_peer(m, r, sp, a, n_regs, s);
+        if (st == KU_OK) st = copy_from_peer(m, r, sp + n_regs, b, n_slots * 8, s);
+        if (st == KU_OK) st = copy_from_peer(m, r, sp + n_regs + n_slots * 8, c, n_nodes * 8, s);
+        a = sp;
+        b = sp + n_regs;
+        c = sp + n_regs + n_slots * 8;
+      }
+      if (st == KU_OK) st = ku_launch_merge_max_u8(regs, (const uint8_t *)a, n_regs, s);
+      if (st == KU_OK) st = ku_launch_merge_add_u64((unsigned long long *)nk, (const unsigned long long *)b, n_slots, s);
+      if (st == KU_OK) st = ku_launch_merge_add_u64((unsigned long long *)nr, (const unsigned long long *)c, n_nodes, s);
+      if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "state merge failed");
+    }
+  }
+  gate_in(m, st);
+  barrier(m);
+  if (r.local != 0 && st == KU_OK && !m->sh.failed.load()) {  // ... and hand the result back
+    st = copy_from_peer(m, r, regs, m->sh.ptr_a[0], n_regs, s);
+    if (st == KU_OK) st = copy_from_peer(m, r, nk, m->sh.ptr_b[0], n_slots * 8, s);
+    if (st == KU_OK) st = copy_from_peer(m, r, nr, m->sh.ptr_c[0], n_nodes * 8, s);
+    if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "state copy failed");
+  }
+  gate_in(m, st);
+  barrier(m);
+  return gate_out(m, st);
+}
+
+// union of every rank's ascending value list
+int comm_allgather_values(ku_mgpu *m, ku_mgpu::Rank &r, int st, const std::vector<uint32_t> &mine, std::vector<uint32_t> &all) {
+  all = mine;
+  if (comm_noop(m)) return st;
+  if (m->use_rccl) {
+    if (st != KU_OK) return st;
+    hipStream_t s = ku_ctx_stream_of(r.ctx);
+    M_TRY(r.small.reserve(8ull * m->world + 8));
+    unsigned long long mine_n = mine.size();
+    unsigned long long *d_n = (unsigned long long *)r.small.p;
+    M_HIP(hipMemcpyAsync(d_n + m->world, &mine_n, 8, hipMemcpyHostToDevice, s));
+    M_NCCL(g_rccl.AllGather(d_n + m->world, d_n, 1, ncclUint64, r.comm, s));
+    std::vector<unsigned long long> counts(m->world);
+    M_HIP(hipMemcpyAsync(counts.data(), d_n, 8ull * m->world, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    const uint64_t mx = std::max<uint64_t>(1, *std::max_element(counts.begin(), counts.end()));
+    M_TRY(r.scratch.reserve(4 * mx * (m->world + 1)));
+    uint32_t *d_all = (uint32_t *)r.scratch.p, *d_mine = d_all + mx * m->world;
+    M_HIP(hipMemsetAsync(d_mine, 0, 4 * mx, s));
+    if (!mine.empty()) M_HIP(hipMemcpyAsync(d_mine, mine.data(), 4 * mine.size(), hipMemcpyHostToDevice, s));
+    M_NCCL(g_rccl.AllGather(d_mine, d_all, mx, ncclUint32, r.comm, s));
+    std::vector<uint32_t> buf(mx * m->world);
+    M_HIP(hipMemcpyAsync(buf.data(), d_all, 4 * mx * m->world, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    all.clear();
+    for (uint32_t q = 0; q < m->world; ++q) all.insert(all.end(), buf.begin() + q * mx, buf.begin() + q * mx + counts[q]);
+  } else {
+    m->sh.vals[r.local] = mine;
+    gate_in(m, st);
+    barrier(m);
+    all.clear();
+    for (uint32_t q = 0; q < m->n_local; ++q) all.insert(all.end(), m->sh.vals[q].begin(), m->sh.vals[q].end());
+    barrier(m);
+    st = gate_out(m, st);
+  }
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  return st;
+}
+
+bool single_process(const ku_mgpu *m) { return m->first_rank == 0 && m->n_local == m->world; }
+}  // namespace
+
+// ---------------------------------------------------------------------------- life cycle
+extern "C" int ku_mgpu_unique_id(uint8_t *id) {
+  if (!id) return mfail(KU_EINVAL, "ku_mgpu_unique_id: null argument");
+  M_TRY(rccl_ready());
+  static_assert(sizeof(ncclUniqueId) == KU_MGPU_ID_BYTES, "RCCL unique id size");
+  ncclUniqueId u;
+  M_NCCL(g_rccl.GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return KU_OK;
+}
+
+extern "C" void ku_mgpu_destroy(ku_mgpu *m) {
+  if (!m) return;
+  for (auto &r : m->ranks) {
+    (void)hipSetDevice(r.device);
+    if (r.ctx) (void)ku_ctx_synchronize(r.ctx);
+    if (r.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r.comm);
+    for (DBuf *b : {&r.seqs, &r.off, &r.len, &r.taxa, &r.calls, &r.hits, &r.runs, &r.roff, &r.rcnt, &r.scratch, &r.small}) b->release();
+    if (r.ctx) ku_ctx_destroy(r.ctx);
+  }
+  if (m->sh.bar_init) pthread_barrier_destroy(&m->sh.bar);
+  delete m;
+}
+
+extern "C" int ku_mgpu_create(const int *devices, uint32_t n_local, uint32_t first_rank, uint32_t world, const uint8_t *id,
+                              uint32_t flags, ku_mgpu **out) {
+  if (!out || !devices || n_local == 0 || world == 0 || first_rank + n_local > world)
+    return mfail(KU_EINVAL, "ku_mgpu_create: bad rank layout");
+  *out = nullptr;
+  const bool all_here = first_rank == 0 && n_local == world;
+  if (!all_here && !id) return mfail(KU_EINVAL, "ku_mgpu_create: a world that spans processes needs the unique id of rank 0");
+  if (!all_here && n_local != 1) return mfail(KU_EUNSUP, "ku_mgpu_create: one rank per process, or all ranks in one process");
+  ku_mgpu *m = new ku_mgpu();
+  m->world = world;
+  m->first_rank = first_rank;
+  m->n_local = n_local;
+  m->flags = flags;
+  m->ranks.resize(n_local);
+  m->sh.ptr_a.assign(n_local, nullptr);
+  m->sh.ptr_b.assign(n_local, nullptr);
+  m->sh.ptr_c.assign(n_local, nullptr);
+  m->sh.vals.resize(n_local);
+  m->sh.dev.assign(devices, devices + n_local);
+  std::set<int> distinct(devices, devices + n_local);
+  // KU_MGPU_FORCE_RCCL=1 takes the RCCL calls even for a world of one rank (a way to exercise them on a 1-GPU box)
+  m->use_rccl = (world > 1 || getenv("KU_MGPU_FORCE_RCCL")) &&
+                (!all_here || (distinct.size() == n_local && !(flags & KU_MGPU_NO_RCCL) && !getenv("KU_MGPU_NO_RCCL")));
+  if (n_local > 1) {
+    if (pthread_barrier_init(&m->sh.bar, nullptr, n_local) != 0) { delete m; return mfail(KU_ENOMEM, "pthread_barrier_init"); }
+    m->sh.bar_init = true;
+  }
+  for (uint32_t i = 0; i < n_local; ++i) {
+    auto &r = m->ranks[i];
+    r.rank = first_rank + i;
+    r.local = i;
+    r.device = devices[i];
+    int st = ku_ctx_create(devices[i], &r.ctx);
+    if (st != KU_OK) { ku_mgpu_destroy(m); return st; }
+  }
+  if (m->use_rccl) {
+    int st = rccl_ready();
+    if (st != KU_OK) { ku_mgpu_destroy(m); return st; }
+    if (all_here && !(id && n_local == 1)) {
+      std::vector<ncclComm_t> comms(n_local);
+      ncclResult_t e = g_rccl.CommInitAll(comms.data(), (int)n_local, devices);
+      if (e != ncclSuccess) { ku_mgpu_destroy(m); return mfail(KU_EHIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e)); }
+      for (uint32_t i = 0; i < n_local; ++i) m->ranks[i].comm = comms[i];
+    } else {
+      ncclUniqueId u;
+      memcpy(&u, id, sizeof u);
+      if (hipSetDevice(devices[0]) != hipSuccess) { ku_mgpu_destroy(m); return mfail(KU_EHIP, "hipSetDevice failed"); }
+      ncclResult_t e = g_rccl.CommInitRank(&m->ranks[0].comm, (int)world, u, (int)first_rank);
+      if (e != ncclSuccess) { ku_mgpu_destroy(m); return mfail(KU_EHIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(e)); }
+    }
+  }
+  *out = m;
+  return KU_OK;
+}
+
+extern "C" ku_ctx *ku_mgpu_ctx(ku_mgpu *m, uint32_t local_index) {
+  return (m && local_index < m->n_local) ? m->ranks[local_index].ctx : nullptr;
+}
+extern "C" int ku_mgpu_uses_rccl(const ku_mgpu *m) { return m && m->use_rccl ? 1 : 0; }
+
+extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
+  if (!m || !tax) return mfail(KU_EINVAL, "ku_mgpu_set_taxonomy: null argument");
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    uint64_t n = 0;
+    int st = ku_ctx_db_values(r.ctx, nullptr, &n);
+    std::vector<uint32_t> mine(st == KU_OK ? n : 0), all;
+    if (st == KU_OK && n) st = ku_ctx_db_values(r.ctx, mine.data(), &n);
+    st = comm_allgather_values(m, r, st, mine, all);
+    if (st != KU_OK) return st;
+    return ku_ctx_set_taxonomy(r.ctx, tax, all.data(), all.size());
+  }));
+  m->tax_set = true;
+  return KU_OK;
+}
+
+extern "C" int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax) {
+  if (!m || !db || !tax) return mfail(KU_EINVAL, "ku_mgpu_load: null argument");
+  ku_db_info info;
+  M_TRY(ku_db_get_info(db, &info));
+  std::vector<uint64_t> bounds(m->world + 1);
+  M_TRY(ku_db_shard_plan(db, m->world, bounds.data()));
+  const bool replicas = (m->flags & KU_MGPU_REPLICAS) != 0;
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    return replicas ? ku_ctx_load_db(r.ctx, db, 0, info.n_bins) : ku_ctx_load_db(r.ctx, db, bounds[r.rank], bounds[r.rank + 1]);
+  }));
+  m->loaded = true;
+  return ku_mgpu_set_taxonomy(m, tax);
+}
+
+// ---------------------------------------------------------------------------- one batch
+namespace {
+// the sharded batch on one rank, everything on stream s: broadcast, lookup of the owned k-mers, slot merge, resolve
+int rank_step_sharded(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_t *d_off, uint32_t *d_len, uint32_t *d_calls,
+                      uint32_t *d_taxa, uint32_t *d_hits, uint64_t n_bytes, uint64_t n_reads, const uint64_t *rb,
+                      const uint64_t *pos, const ku_opts &opts, hipStream_t s) {
+  st = comm_broadcast(m, r, st, d_seqs, n_bytes, s);
+  st = comm_broadcast(m, r, st, d_off, n_reads * 8, s);
+  st = comm_broadcast(m, r, st, d_len, n_reads * 4, s);
+  ku_opts lo = opts;
+  lo.flags = (opts.flags & ~KU_F_MERGE_CHUNK) | KU_F_KEEP_SLOTS;
+  if (st == KU_OK) st = ku_lookup_device(r.ctx, d_seqs, n_bytes, &lo, d_taxa, s);
+  st = comm_reduce_slices_max(m, r, st, d_taxa, pos, s);
+  if (st != KU_OK) return st;
+  const uint64_t r0 = rb[r.rank], nr = rb[r.rank + 1] - r0;
+  ku_opts ro = opts;
+  ro.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
+  if (nr == 0) return KU_OK;
+  return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
+}
+}  // namespace
+
+extern "C" int ku_mgpu_step_device(ku_mgpu *m, const ku_mgpu_dev_batch *local, uint64_t n_bytes, uint64_t n_reads,
+                                   const uint64_t *read_bounds, const uint64_t *pos_bounds, const ku_opts *opts) {
+  if (!m || !local || !read_bounds || !pos_bounds) return mfail(KU_EINVAL, "ku_mgpu_step_device: null argument");
+  if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_step_device: load the database and the taxonomy first");
+  if (m->flags & KU_MGPU_REPLICAS) return mfail(KU_EINVAL, "ku_mgpu_step_device is the sharded step; replicas classify through their own contexts");
+  const ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  return run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    const ku_mgpu_dev_batch &b = local[r.local];
+    if (n_bytes && (!b.d_seqs || !b.d_taxa)) return mfail(KU_EINVAL, "ku_mgpu_step_device: null buffer");
+    hipStream_t s = b.stream ? (hipStream_t)b.stream : ku_ctx_stream_of(r.ctx);
+    return rank_step_sharded(m, r, KU_OK, b.d_seqs, b.d_seq_off, b.d_seq_len, b.d_calls, b.d_taxa, nullptr, n_bytes, n_reads,
+                             read_bounds, pos_bounds, o, s);
+  });
+}
+
+extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                                          const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                                          uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
+  if (!m || !n_runs || (n_bytes && !seqs) || (n_reads && (!seq_off || !seq_len || !calls || !run_off || !run_cnt)))
+    return mfail(KU_EINVAL, "ku_mgpu_classify_batch_rle: null argument");
+  if (!single_process(m)) return mfail(KU_EUNSUP, "host batches go through a single-process group");
+  if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_classify_batch_rle: load the database and the taxonomy first");
+  *n_runs = 0;
+  for (auto &r : m->ranks) r.n_runs = r.run_base = 0;
+  if (n_reads == 0) return KU_OK;
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  o.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
+  uint32_t max_len = 0;
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    if (seq_off[i] + seq_len[i] > n_bytes) return mfail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
+    if (i && seq_off[i] < seq_off[i - 1]) return mfail(KU_EINVAL, "ku_mgpu_classify_batch_rle: reads must be in buffer order");
+    max_len = std::max(max_len, seq_len[i]);
+  }
+  o.max_read_len = max_len;
+  const bool replicas = (m->flags & KU_MGPU_REPLICAS) != 0, quick = (o.flags & KU_F_QUICK) != 0;
+  // slices of the read dimension, balanced by bytes and cut at read boundaries
+  const uint32_t W = m->world;
+  std::vector<uint64_t> rb(W + 1), pos(W + 1);
+  rb[0] = 0;
+  for (uint32_t q = 1; q < W; ++q) {
+    const uint64_t target = n_bytes / W * q;
+    rb[q] = std::max<uint64_t>(rb[q - 1], (uint64_t)(std::lower_bound(seq_off, seq_off + n_reads, target) - seq_off));
+  }
+  rb[W] = n_reads;
+  for (uint32_t q = 0; q < W; ++q) pos[q] = rb[q] < n_reads ? seq_off[rb[q]] : n_bytes;
+  pos[0] = 0;
+  pos[W] = n_bytes;
+  std::vector<uint64_t> totals(W, 0);
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    hipStream_t s = ku_ctx_stream_of(r.ctx);
+    const uint64_t r0 = rb[r.rank], nr = rb[r.rank + 1] - r0;
+    // what this rank keeps resident: the whole batch (sharded: every rank scans everything) or its slice (replicas)
+    const uint64_t b0 = replicas ? pos[r.rank] : 0, nb = replicas ? pos[r.rank + 1] - b0 : n_bytes;
+    const uint64_t nq = replicas ? nr : n_reads;
+    const uint64_t runs_cap = (replicas ? nb : pos[r.rank + 1] - pos[r.rank]) + 1;
+    int st = KU_OK;
+    if (r.seqs.reserve(nb + 16) || r.off.reserve(nq * 8 + 8) || r.len.reserve(nq * 4 + 4) || r.calls.reserve(nq * 4 + 4) ||
+        r.taxa.reserve((nb + 16) * 4) || r.hits.reserve(nq * 4 + 4) || r.runs.reserve(runs_cap * 8) ||
+        r.roff.reserve(nq * 8 + 8) || r.rcnt.reserve(nq * 4 + 4) || r.small.reserve(64))
+      st = mfail(KU_ENOMEM, "device memory for the batch");
+    uint32_t *d_calls = (uint32_t *)r.calls.p, *d_hits = (uint32_t *)r.hits.p, *d_taxa = (uint32_t *)r.taxa.p;
+    uint64_t *d_off = (uint64_t *)r.off.p;
+    uint32_t *d_len = (uint32_t *)r.len.p;
+    if (replicas) {
+      // slice offsets are relative to the slice's first byte
+      std::vector<uint64_t> rel(nr);
+      for (uint64_t i = 0; i < nr; ++i) rel[i] = seq_off[r0 + i] - b0;
+      if (st == KU_OK && nr) {
+        M_HIP(hipMemcpyAsync(r.seqs.p, seqs + b0, nb, hipMemcpyHostToDevice, s));
+        M_HIP(hipMemcpyAsync(d_off, rel.data(), nr * 8, hipMemcpyHostToDevice, s));
+        M_HIP(hipMemcpyAsync(d_len, seq_len + r0, nr * 4, hipMemcpyHostToDevice, s));
+        M_HIP(hipStreamSynchronize(s));  // `rel` goes out of scope
+        st = ku_classify_batch_device(r.ctx, r.seqs.p, nb, d_off, d_len, nr, &o, d_calls, d_taxa, d_hits, s);
+      }
+    } else {
+      if (st == KU_OK && r.rank == 0 &&
+          (hipMemcpyAsync(r.seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s) != hipSuccess ||
+           hipMemcpyAsync(d_off, seq_off, n_reads * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+           hipMemcpyAsync(d_len, seq_len, n_reads * 4, hipMemcpyHostToDevice, s) != hipSuccess))
+        st = mfail(KU_EHIP, "upload of the batch failed");
+      st = rank_step_sharded(m, r, st, r.seqs.p, d_off, d_len, d_calls, d_taxa, d_hits, n_bytes, n_reads, rb.data(),
+                             pos.data(), o, s);
+    }
+    if (st != KU_OK) return st;
+    if (nr == 0) return KU_OK;
+    // run-length encoding of this rank's reads; (run_off, run_cnt) index the rank's own run array
+    const uint64_t lq = replicas ? 0 : r0;  // index of the slice's first read in this rank's arrays
+    unsigned long long *d_counter = (unsigned long long *)r.small.p;
+    if (quick) {
+      M_HIP(hipMemsetAsync(d_counter, 0, 8, s));
+      M_HIP(hipMemsetAsync((uint64_t *)r.roff.p + lq, 0, nr * 8, s));
+      M_HIP(hipMemsetAsync((uint32_t *)r.rcnt.p + lq, 0, nr * 4, s));
+    } else {
+      M_TRY(ku_launch_rle(d_taxa, ku_ctx_k_of(r.ctx), d_off + lq, d_len + lq, nr, r.runs.p, runs_cap, d_counter,
+                          (uint64_t *)r.roff.p + lq, (uint32_t *)r.rcnt.p + lq, ku_ctx_cus_of(r.ctx), s));
+    }
+    unsigned long long total = 0;
+    M_HIP(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
+    M_HIP(hipMemcpyAsync(calls + r0, d_calls + lq, nr * 4, hipMemcpyDeviceToHost, s));
+    if (hits) M_HIP(hipMemcpyAsync(hits + r0, d_hits + lq, nr * 4, hipMemcpyDeviceToHost, s));
+    M_HIP(hipMemcpyAsync(run_off + r0, (uint64_t *)r.roff.p + lq, nr * 8, hipMemcpyDeviceToHost, s));
+    M_HIP(hipMemcpyAsync(run_cnt + r0, (uint32_t *)r.rcnt.p + lq, nr * 4, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    if (total > runs_cap) return mfail(KU_EHIP, "run-length encoder overflowed its bound");
+    totals[r.rank] = total;
+    return KU_OK;
+  }));
+  // one run array for the caller: rank r's runs follow those of the ranks before it
+  uint64_t base = 0;
+  for (uint32_t q = 0; q < W; ++q) {
+    m->ranks[q].run_base = base;
+    m->ranks[q].n_runs = totals[q];
+    if (base)
+      for (uint64_t i = rb[q]; i < rb[q + 1]; ++i) run_off[i] += base;
+    base += totals[q];
+  }
+  *n_runs = base;
+  return KU_OK;
+}
+
+extern "C" int ku_mgpu_fetch_runs(ku_mgpu *m, ku_run *runs, uint64_t n_runs) {
+  if (!m) return mfail(KU_EINVAL, "ku_mgpu_fetch_runs: null argument");
+  uint64_t total = 0;
+  for (auto &r : m->ranks) total += r.n_runs;
+  if (n_runs > total) return mfail(KU_EINVAL, "ku_mgpu_fetch_runs: the last batch holds " + std::to_string(total) + " runs");
+  if (n_runs == 0) return KU_OK;
+  if (!runs) return mfail(KU_EINVAL, "ku_mgpu_fetch_runs: null buffer");
+  return run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    if (r.run_base >= n_runs || r.n_runs == 0) return KU_OK;
+    const uint64_t n = std::min(r.n_runs, n_runs - r.run_base);
+    hipStream_t s = ku_ctx_stream_of(r.ctx);
+    M_HIP(hipMemcpyAsync(runs + r.run_base, r.runs.p, n * 8, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    return KU_OK;
+  });
+}
+
+extern "C" int ku_mgpu_reduce_state(ku_mgpu *m, void *const *streams) {
+  if (!m) return mfail(KU_EINVAL, "ku_mgpu_reduce_state: null argument");
+  if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_reduce_state: no taxonomy set");
+  return run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    hipStream_t s = (streams && streams[r.local]) ? (hipStream_t)streams[r.local] : ku_ctx_stream_of(r.ctx);
+    return comm_allreduce_state(m, r, s);
+  });
+}
+
+extern "C" int ku_mgpu_count_taxons(ku_mgpu *m, uint32_t *taxids, uint64_t *counts, uint64_t *n) {
+  if (!m || !n) return mfail(KU_EINVAL, "ku_mgpu_count_taxons: null argument");
+  if (!single_process(m)) return mfail(KU_EUNSUP, "ku_mgpu_count_taxons: single-process groups only");
+  std::vector<std::pair<uint32_t, uint64_t>> acc;
+  const uint32_t n_src = (m->flags & KU_MGPU_REPLICAS) ? 1 : m->n_local;
+  for (uint32_t i = 0; i < n_src; ++i) {
+    uint64_t c = 0;
+    M_TRY(ku_ctx_count_taxons(m->ranks[i].ctx, nullptr, nullptr, &c));
+    std::vector<uint32_t> t(c + 1);
+    std::vector<uint64_t> v(c + 1);
+    uint64_t cap = c;
+    M_TRY(ku_ctx_count_taxons(m->ranks[i].ctx, t.data(), v.data(), &cap));
+    for (uint64_t j = 0; j < cap; ++j) acc.emplace_back(t[j], v[j]);
+  }
+  std::sort(acc.begin(), acc.end());
+  std::vector<std::pair<uint32_t, uint64_t>> out;
+  for (auto &kv : acc) {
+    if (!out.empty() && out.back().first == kv.first) out.back().second += kv.second;
+    else out.push_back(kv);
+  }
+  if (taxids && counts) {
+    if (*n < out.size()) return mfail(KU_EINVAL, "output arrays too small");
+    for (size_t j = 0; j < out.size(); ++j) { taxids[j] = out[j].first; counts[j] = out[j].second; }
+  }
+  *n = out.size();
+  return KU_OK;
+}

@@ -1,0 +1,190 @@
+"""-m gpu: the C++ multi-GPU driver (ku_mgpu, krakenuniq_amd/csrc/ku_mgpu.cpp) through the C ABI.
+
+A 1-GPU box runs several ranks on its one device (same-process exchange: device copies + merge kernels); boxes with
+more devices also take the RCCL exchange.  Every variant has to reproduce the single-context results: the reference's
+Kraken output byte for byte, and -- after ku_mgpu_reduce_state -- the per-taxon state (HLL registers, n_kmers,
+n_reads) bit for bit, i.e. k-mers are accounted exactly once (by the rank that owns their minimizer bin, misses under
+taxon 0 included)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from krakenuniq_amd import capi, synth, synth_torch
+from oracle import ku_oracle as ko
+import gpu_common as gc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F1 = os.path.join(ROOT, "tests", "golden", "f1")
+BIN = os.path.join(ROOT, "krakenuniq_amd", "bin", "classify")
+K = 31
+
+
+def device_lists():
+    n = capi.lib().ku_device_count()
+    out = [[0, 0], [0, 0, 0]]
+    if n >= 2:
+        out.append(list(range(min(n, 4))))
+    return out
+
+
+@pytest.fixture(scope="module")
+def f1():
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    rle = ctx.classify_batch_rle(buf, off, lens)
+    want_counts = ctx.counts()
+    return {"ids": ids, "seqs": seqs, "buf": buf, "off": off, "lens": lens, "counts": want_counts, "cdb": cdb,
+            "ctax": ctax, "text": open(f"{F1}/out.tsv").read()}
+
+
+def same_counts(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ("slot_taxid", "n_kmers", "registers", "node_taxid", "n_reads"))
+
+
+@pytest.mark.parametrize("devices", device_lists())
+@pytest.mark.parametrize("flags", [0, capi.KU_MGPU_REPLICAS])
+def test_group_reproduces_reference_output_and_state(f1, devices, flags):
+    mg = capi.Mgpu(devices, flags=flags)
+    mg.load(f1["cdb"], f1["ctax"])
+    # two batches: the state accumulates in the ranks' contexts across batches
+    n = len(f1["lens"])
+    h = n // 3
+    cut = int(f1["off"][h])
+    a = mg.classify_batch_rle(f1["buf"][:cut], f1["off"][:h], f1["lens"][:h])
+    b = mg.classify_batch_rle(f1["buf"][cut:], f1["off"][h:] - cut, f1["lens"][h:])
+    text = capi.format_kraken_rle(f1["buf"][:cut], f1["off"][:h], f1["lens"][:h], f1["ids"][:h], K, a)
+    text += capi.format_kraken_rle(f1["buf"][cut:], f1["off"][h:] - cut, f1["lens"][h:], f1["ids"][h:], K, b)
+    assert text == f1["text"]
+    mg.reduce_state()
+    for i in range(len(devices)):  # every rank ends up with the whole run's state
+        assert same_counts(mg.ctx(i).counts(), f1["counts"]), i
+    if not flags:
+        t, c = mg.count_taxons()
+        want = dict(tuple(map(int, ln.split("\t"))) for ln in open(f"{F1}/database.kdb.counts").read().split("\n") if ln)
+        assert dict(zip(t.tolist(), c.tolist())) == want
+    mg.close()
+
+
+@pytest.mark.parametrize("devices", device_lists()[:2])
+def test_group_quick_mode(f1, devices):
+    mg = capi.Mgpu(devices)
+    mg.load(f1["cdb"], f1["ctax"])
+    q = mg.classify_batch_rle(f1["buf"], f1["off"], f1["lens"], flags=capi.KU_F_QUICK, min_hits=2)
+    assert capi.format_kraken_rle(f1["buf"], f1["off"], f1["lens"], f1["ids"], K, q, flags=capi.KU_P_QUICK) == \
+        open(f"{F1}/out_quick.tsv").read()
+    mg.reduce_state()
+    ctx, _, _ = gc.make_ctx(F1)
+    ctx.classify_batch_rle(f1["buf"], f1["off"], f1["lens"], flags=capi.KU_F_QUICK, min_hits=2)
+    assert same_counts(mg.ctx(0).counts(), ctx.counts())
+    mg.close()
+
+
+def test_group_of_one_rank_through_rccl(f1, monkeypatch):
+    """the RCCL calls themselves (broadcast, grouped reduce, all-reduce, all-gather) on a world of one rank"""
+    monkeypatch.setenv("KU_MGPU_FORCE_RCCL", "1")
+    for uid in (None, capi.mgpu_unique_id()):  # ncclCommInitAll and ncclCommInitRank
+        mg = capi.Mgpu([0], unique_id=uid)
+        assert mg.uses_rccl()
+        mg.load(f1["cdb"], f1["ctax"])
+        rle = mg.classify_batch_rle(f1["buf"], f1["off"], f1["lens"])
+        assert capi.format_kraken_rle(f1["buf"], f1["off"], f1["lens"], f1["ids"], K, rle) == f1["text"]
+        mg.reduce_state()
+        assert same_counts(mg.ctx(0).counts(), f1["counts"])
+        mg.close()
+
+
+def test_empty_and_tiny_batches(f1):
+    mg = capi.Mgpu([0, 0, 0, 0])
+    mg.load(f1["cdb"], f1["ctax"])
+    e = mg.classify_batch_rle(b"", np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    assert len(e["calls"]) == 0 and len(e["runs"]) == 0
+    # fewer reads than ranks: some slices are empty
+    cut = int(f1["off"][2])
+    r = mg.classify_batch_rle(f1["buf"][:cut], f1["off"][:2], f1["lens"][:2])
+    assert capi.format_kraken_rle(f1["buf"][:cut], f1["off"][:2], f1["lens"][:2], f1["ids"][:2], K, r) == \
+        "".join(f1["text"].splitlines(True)[:2])
+    mg.close()
+
+
+def test_cli_with_several_ranks(tmp_path):
+    db = tmp_path / "db"
+    db.mkdir()
+    for fn in ("database.kdb", "database.idx", "taxDB"):
+        (db / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
+    args = ["-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB", "-t", "4"]
+    outs = {}
+    for name, env in (("one", {}), ("sharded", {"KU_DEVICES": "0,0,0"}),
+                      ("replicas", {"KU_DEVICES": "0,0", "KU_MGPU_MODE": "replicas"})):
+        out, rep = tmp_path / f"{name}.tsv", tmp_path / f"{name}.report"
+        r = subprocess.run([BIN] + args + ["-o", str(out), "-r", str(rep), f"{F1}/reads.fq"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr.decode()
+        if name != "one":
+            assert b"GPU ranks" in r.stderr
+        outs[name] = (out.read_bytes(), rep.read_text())
+        (db / "database.kdb.counts").unlink()  # regenerated by every run: the group sums it over the shards
+    assert outs["one"][0] == open(f"{F1}/out.tsv", "rb").read()
+    for name in ("sharded", "replicas"):
+        assert outs[name] == outs["one"], name
+
+
+def test_device_step_matches_single_context():
+    """ku_mgpu_step_device (the bench path) with three ranks on one device: shards adopted from device memory, batch
+    broadcast from rank 0, slices resolved per rank == one context holding the whole database"""
+    import torch
+    dev = torch.device("cuda:0")
+    NT, L, N, W = 11, 150, 300_000, 3
+    db = synth_torch.BenchDb(dev, n_species=100, genome_len=60_000, k=K, nt=NT, seed=3)
+    ids, par = db.tax.arrays()
+    ctax = capi.Tax(ids=ids, parents=par)
+    seqs, off, lens, _ = db.sample_reads(N, L, seed=5)
+    seqs = seqs.reshape(-1)
+    nb = seqs.numel()
+    # reference: one context
+    ctx = capi.Ctx(0)
+    ctx.adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), K, NT, 2, keep=db)
+    ctx.set_taxonomy(ctax)
+    taxa1 = torch.zeros(nb, dtype=torch.int32, device=dev)
+    calls1 = torch.zeros(N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.classify_batch_device(seqs.data_ptr(), nb, off.data_ptr(), lens.data_ptr(), N, calls1.data_ptr(), taxa1.data_ptr(),
+                              max_read_len=L)
+    ctx.synchronize()
+    want = ctx.counts()
+    # group: shard bounds at pair-count quantiles
+    offs = db.offsets
+    bounds = [0] + [int(torch.searchsorted(offs, offs[-1] * q // W).item()) for q in range(1, W)] + [4 ** NT]
+    mg = capi.Mgpu([0] * W)
+    shards, bufs = [], []
+    for r in range(W):
+        sh = synth_torch.BenchDb(dev, n_species=100, genome_len=60_000, k=K, nt=NT, seed=3, bin_lo=bounds[r], bin_hi=bounds[r + 1])
+        mg.ctx(r).adopt_db(sh.pairs.data_ptr(), sh.n_pairs, sh.offsets.data_ptr(), K, NT, 2, bounds[r], bounds[r + 1])
+        shards.append(sh)
+    mg.set_taxonomy(ctax)
+    stride = L + 1
+    rb = [N * r // W for r in range(W + 1)]
+    pb = [x * stride for x in rb]
+    for r in range(W):
+        b = {"seqs": seqs if r == 0 else torch.zeros(nb + 16, dtype=torch.uint8, device=dev),
+             "off": off if r == 0 else torch.zeros(N, dtype=torch.int64, device=dev),
+             "len": lens if r == 0 else torch.zeros(N, dtype=torch.int32, device=dev),
+             "calls": torch.zeros(N, dtype=torch.int32, device=dev), "taxa": torch.zeros(nb + 16, dtype=torch.int32, device=dev)}
+        bufs.append(b)
+    torch.cuda.synchronize()
+    mg.step_device([{"d_seqs": b["seqs"].data_ptr(), "d_seq_off": b["off"].data_ptr(), "d_seq_len": b["len"].data_ptr(),
+                     "d_calls": b["calls"].data_ptr(), "d_taxa": b["taxa"].data_ptr()} for b in bufs],
+                   nb, N, rb, pb, max_read_len=L)
+    for r in range(W):
+        mg.ctx(r).synchronize()
+    nk = L - K + 1
+    for r in range(W):
+        lo, hi = rb[r], rb[r + 1]
+        assert torch.equal(bufs[r]["calls"][lo:hi], calls1[lo:hi])
+        assert torch.equal(bufs[r]["taxa"][:nb].view(N, stride)[lo:hi, :nk], taxa1.view(N, stride)[lo:hi, :nk])
+    mg.reduce_state()
+    assert same_counts(mg.ctx(1).counts(), want)
+    mg.close()
