@@ -3,23 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-Workload at N = 1 (BASELINE.json configs[1]): ~8 GB MiniKraken-style database (k = 31,
-minimizer nt = 13, ~0.62 G pairs, ~2000 taxa) built directly in HBM by
-krakenuniq_amd/synth_torch.py, 10 M synthetic 150 bp reads resident in HBM.  One "step"
-= one pass of the whole hot path over the 10 M-read batch: ku_classify_batch_device, i.e. for reads of up to 222 bp
-the fused wave-per-read kernel (scan, canonical k-mer, minimizer, bucket probe, HLL + n_kmers, hit counts,
-resolve_tree / LCA, n_reads, per-k-mer taxids); for longer reads, --paired and --mode sharded the two stages
-    ku_lookup_device  (scan, canonical k-mer, minimizer, probe / in-bin search, HLL + n_kmers)
-    ku_resolve_device (hit counts, resolve_tree / LCA, n_reads, slot -> taxid)
-N > 1 (default --mode replicas, weak scaling): every rank holds the database and classifies
-its own 10 M reads; the per-taxon state is merged with RCCL inside every step (registers MAX,
-counters SUM).  --mode sharded keeps 1/N of the minimizer bins per rank, scans the same batch
-on every rank, merges per-k-mer slots with all_reduce(MAX) and resolves 1/N of the reads per
-rank (the 300 GB layout of configs[2]).
+Workload at N = 1 (BASELINE.json configs[1]): ~8 GB MiniKraken-style database (k = 31, minimizer nt = 13, ~0.61 G
+pairs, 2000 species) built directly in HBM by krakenuniq_amd/synth_torch.py; FOUR distinct batches of 10 M synthetic
+150 bp reads resident in HBM.  One "step" = one pass of the whole hot path over one 10 M-read batch
+(ku_classify_batch_device): for reads of up to 222 bp the fused wave-per-read kernel (scan, canonical k-mer, anchor /
+minimizer, bucket probe, HLL + n_kmers, hit counts, resolve_tree / LCA, n_reads, per-k-mer taxids); for longer reads
+and --paired the two stages ku_lookup_device + ku_resolve_device.  The steps rotate through the batches and the
+per-taxon state is zeroed at the start of every rotation (inside the timed region), so each rotation is a fresh 40 M-read
+run: HyperLogLog registers start empty and their compare-and-swap updates are part of what is timed.
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (the dominant kernel: the fused kernel, or the
-lookup kernel of the two-stage path; algorithmic bytes / HIP-event time vs 8 TB/s) and `cpu_baseline` (the compiled reference's
-`classify` -- or the C oracle if the binary is absent -- on the host cores, bounded sample).
+N > 1 goes through the product's C++ multi-GPU driver (ku_mgpu, RCCL), one process per GPU:
+  --mode replicas (default, weak scaling): every rank holds the database and classifies its own batches; the per-taxon
+      state is all-reduced once at the end of the run, inside the timed region (registers MAX, counters SUM);
+  --mode sharded (strong scaling, the 300 GB layout of configs[2]): rank r holds the minimizer bins of its range; each
+      step broadcasts the batch from rank 0, looks up the owned k-mers, reduce-scatters the per-k-mer slots over the read
+      dimension and resolves 1/N of the reads per rank (ku_mgpu_step_device).
+  A default N > 1 run also times a few sharded steps afterwards and reports them under "sharded".
+
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel; `frac` = `frac_model` =
+SURVEY 8(d) algorithmic bytes / HIP-event time / 8 TB/s, `frac_hw` = counter-measured HBM bytes of profiles/ for this
+very kernel source / time / 8 TB/s), `cpu_baseline` (the compiled reference's classify on the host cores over a bounded
+sample, with a parity check of that sample) and, at N = 1, `device_pipeline` (pinned host buffers -> H2D -> kernels ->
+run-length encoding -> D2H through ku_classify_batch_rle) and `e2e` (the classify executable on a FASTQ file in
+/dev/shm against the same database, its own timing window).
 """
 import argparse
 import json
@@ -44,9 +50,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s per GPU
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--batches", type=int, default=4, help="distinct read batches the steps rotate through")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--species", type=int, default=2000)
     ap.add_argument("--genome-len", type=int, default=310_000)
@@ -55,6 +62,7 @@ def parse():
     ap.add_argument("--paired", action="store_true", help="configs[3]-style reads: mate1 + 'N' + mate2 (2 x read-len + 1)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the device-pipeline / end-to-end / sharded legs")
     return ap.parse_args()
 
 
@@ -70,116 +78,12 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(db, ctx, d_seqs, read_len, n_sample, calls_gpu, taxa_gpu, threads):
-    """Time the reference's classify (oracle/_ref, travels as a binary) on the host cores over a
-    bounded sample of the same reads against the same database, and check the GPU results
-    against its output on that sample.  Falls back to the C oracle ("port") if the binary is absent."""
-    from krakenuniq_amd import capi
-    cores = threads
-    stride = read_len + 1
-    host = d_seqs[:n_sample * stride].cpu().numpy()
-    ids = [f"r{i}" for i in range(n_sample)]
-    tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 14e9 else None
-    tmp = tempfile.mkdtemp(prefix="ku_bench_", dir=tmp_root)
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "classify")
-    out = {"cores": cores, "unit": "Mreads/s"}
-    try:
-        off = np.arange(n_sample, dtype=np.uint64) * stride
-        lens = np.full(n_sample, read_len, dtype=np.uint32)
-        want_text = capi.format_kraken(host, off, lens, ids, db.k, calls_gpu[:n_sample], taxa=taxa_gpu[:n_sample * stride])
-        if os.path.exists(ref_bin):
-            # the resident pairs hold slot ids after ku_ctx_set_taxonomy: translate back to taxids for the files
-            db.write_files(tmp, slot_taxid=torch.from_numpy(ctx.counts()["slot_taxid"].astype(np.int64)).to(db.device))
-            with open(os.path.join(tmp, "sample.fa"), "wb") as f:
-                rows = host.reshape(n_sample, stride)
-                for i in range(n_sample):
-                    f.write(b">r%d\n" % i)
-                    f.write(rows[i].tobytes())
-            cmd = [ref_bin, "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB",
-                   "-t", str(cores), "-M", "-o", f"{tmp}/out.tsv", f"{tmp}/sample.fa"]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            err = r.stderr.decode(errors="replace")
-            m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
-            if r.returncode != 0 or not m:
-                raise RuntimeError("reference classify failed: " + err[-400:])
-            secs = float(m.group(3))  # the reference's own timing window (classify.cpp:248-258)
-            out.update(kind="reference", value=n_sample / secs / 1e6,
-                       sample=f"{n_sample} of the batch's reads, oracle/_ref/classify -t {cores} -M, "
-                              f"its report_stats window {secs:.3f}s")
-            got = sorted(open(f"{tmp}/out.tsv").read().split("\n"))
-            out["parity_vs_reference_on_sample"] = got == sorted(want_text.split("\n"))
-        else:
-            from oracle import ku_oracle as ko
-            st = torch.from_numpy(ctx.counts()["slot_taxid"].astype(np.int64)).to(db.device)
-            raw = db.pairs.clone()
-            raw[:, 2] = ((st[raw[:, 2].to(torch.int64)] << 32) >> 32).to(torch.int32)
-            pairs = raw.cpu().numpy().view(np.uint8).reshape(-1)
-            offs = db.offsets.cpu().numpy().astype(np.uint64)
-            ids_t, par_t = db.tax.arrays()
-            odb = ko.Db(pairs=pairs, key_ct=db.n_pairs, k=db.k, offsets=offs, nt=db.nt)
-            run = ko.Run(odb, ko.Tax(ids=ids_t, parents=par_t), threads=cores)
-            t0 = time.time()
-            res = run.classify_packed(host, off, lens, want_taxa=False)
-            secs = time.time() - t0
-            out.update(kind="port", value=n_sample / secs / 1e6,
-                       sample=f"{n_sample} of the batch's reads, oracle/libku_oracle.so OpenMP x{cores}, {secs:.3f}s")
-            out["parity_vs_reference_on_sample"] = bool((res["calls"] == calls_gpu[:n_sample]).all())
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    return out
-
-
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws != a.gpus and ws > 1:
-        a.gpus = ws
-    # debugging aid for 1-GPU boxes: KU_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and KU_BENCH_BACKEND=gloo
-    # replaces RCCL, so the N > 1 code path can be exercised without N GPUs (numbers are then meaningless)
-    if os.environ.get("KU_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("KU_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if ws > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    from krakenuniq_amd import capi, dist as kdist, synth_torch
-
-    k = 31
-    sharded = a.mode == "sharded" and ws > 1
-    t_build = time.time()
-    bin_lo, bin_hi = 0, 4 ** a.nt
-    if sharded:
-        # every rank derives the same shard plan from the same deterministic sample of the DB's bin keys
-        probe = synth_torch.BenchDb(dev, n_species=min(a.species, 32), genome_len=min(a.genome_len, 50_000), k=k,
-                                    nt=a.nt, seed=7)
-        bins = synth_torch.bin_key(probe.kmers[torch.randperm(probe.n_pairs, device=dev)[:1_000_000]], k, a.nt)
-        bounds = kdist.quantile_bin_bounds(bins, 4 ** a.nt, ws)
-        bin_lo, bin_hi = int(bounds[rank]), int(bounds[rank + 1])
-        del probe, bins
-    db = synth_torch.BenchDb(dev, n_species=a.species, genome_len=a.genome_len, k=k, nt=a.nt, seed=7,
-                             bin_lo=bin_lo, bin_hi=bin_hi)
-    db.kmers = db.vals = None
-    torch.cuda.empty_cache()
-    # offsets must be *global* pair indices; in a sharded build they start at 0 for this shard, which is fine:
-    # the library only uses differences and offsets[0] as the base.
-    ctx = capi.Ctx(local_rank)
-    ctx.adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), k, a.nt, 2, bin_lo, bin_hi, keep=db)
-    ids_t, par_t = db.tax.arrays()
-    ctax = capi.Tax(ids=ids_t, parents=par_t)
-    all_values = kdist.allgather_values(ctx.db_values(), dev) if sharded else None
-    ctx.set_taxonomy(ctax, all_values)
-    # reads: own batch per rank (replicas) or the same batch on every rank (sharded)
-    d_seqs, d_off, d_len, _ = db.sample_reads(a.reads, a.read_len, seed=1 if sharded else 1 + rank)
+def make_batch(db, a, seed, dev):
+    """one batch of reads in HBM: (seqs uint8 flat, seq_off int64, seq_len int32, read_len)"""
+    d_seqs, d_off, d_len, _ = db.sample_reads(a.reads, a.read_len, seed=seed)
+    L = a.read_len
     if a.paired:  # read_merger.pl semantics: seq1 . "N" . seq2 (scripts/read_merger.pl:187-191)
-        m2, _, _, _ = db.sample_reads(a.reads, a.read_len, seed=1001 if sharded else 1001 + rank)
-        L = a.read_len
+        m2, _, _, _ = db.sample_reads(a.reads, L, seed=seed + 1000)
         merged = torch.empty((a.reads, 2 * L + 2), dtype=torch.uint8, device=dev)
         merged[:, :L] = d_seqs.view(a.reads, L + 1)[:, :L]
         merged[:, L] = 78
@@ -188,73 +92,196 @@ def main():
         d_seqs = merged.reshape(-1)
         d_off = torch.arange(a.reads, device=dev, dtype=torch.int64) * (2 * L + 2)
         d_len = torch.full((a.reads,), 2 * L + 1, dtype=torch.int32, device=dev)
-        a.read_len = 2 * L + 1
-        del m2, merged
-    n_bytes = d_seqs.numel()
-    d_taxa = torch.zeros(n_bytes, dtype=torch.int32, device=dev)
+        L = 2 * L + 1
+    return d_seqs.reshape(-1), d_off, d_len, L
+
+
+def write_fastq(path, host_rows, read_len):
+    """FASTQ text of the rows of a [n, read_len + 1] uint8 array (ids r000000000 ...), vectorised"""
+    n = host_rows.shape[0]
+    rec = np.empty((n, 1 + 10 + 1 + read_len + 3 + read_len + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(9):
+        rec[:, 2 + d] = 48 + (idx // 10 ** (8 - d)) % 10
+    rec[:, 11] = 10
+    rec[:, 12:12 + read_len] = host_rows[:, :read_len]
+    rec[:, 12 + read_len:15 + read_len] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 15 + read_len:15 + 2 * read_len] = ord("I")
+    rec[:, 15 + 2 * read_len] = 10
+    with open(path, "wb") as f:
+        f.write(rec.tobytes())
+
+
+def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
+    """rank 0, N = 1: CPU baseline (+ parity of the sample), device pipeline, end-to-end executable"""
+    from krakenuniq_amd import capi
+    out = {}
+    cores = a.cpu_threads or host_cores()
+    d_seqs, d_off, d_len = batch
+    stride = read_len + 1
+    tmp_root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 24e9 else None
+    tmp = tempfile.mkdtemp(prefix="ku_bench_", dir=tmp_root)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "classify")
+    cli_bin = os.path.join(ROOT, "krakenuniq_amd", "bin", "classify")
+    try:
+        files = False
+        if os.path.exists(ref_bin) or os.path.exists(cli_bin):
+            # the resident pairs hold slot ids after ku_ctx_set_taxonomy: translate back to taxids for the files
+            db.write_files(tmp, slot_taxid=torch.from_numpy(ctx.counts()["slot_taxid"].astype(np.int64)).to(db.device))
+            files = True
+        # ---- CPU baseline: the reference's classify on a bounded sample of batch 0 + parity of that sample
+        if a.cpu_sample != 0:
+            n_sample = a.cpu_sample if a.cpu_sample > 0 else min(a.reads, 60_000 * cores, 4_000_000)  # ~20 s of CPU work
+            cb = {"cores": cores, "unit": "Mreads/s"}
+            try:
+                host = d_seqs[:n_sample * stride].cpu().numpy()
+                off = np.arange(n_sample, dtype=np.uint64) * stride
+                lens = np.full(n_sample, read_len, dtype=np.uint32)
+                ids = [f"r{i}" for i in range(n_sample)]
+                want_text = capi.format_kraken(host, off, lens, ids, k, calls_gpu[:n_sample], taxa=taxa_gpu[:n_sample * stride])
+                if files and os.path.exists(ref_bin):
+                    with open(os.path.join(tmp, "sample.fa"), "wb") as f:
+                        rows = host.reshape(n_sample, stride)
+                        for i in range(n_sample):
+                            f.write(b">r%d\n" % i)
+                            f.write(rows[i].tobytes())
+                    cmd = [ref_bin, "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB",
+                           "-t", str(cores), "-M", "-o", f"{tmp}/out.tsv", f"{tmp}/sample.fa"]
+                    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                    err = r.stderr.decode(errors="replace")
+                    m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
+                    if r.returncode != 0 or not m:
+                        raise RuntimeError("reference classify failed: " + err[-400:])
+                    secs = float(m.group(3))  # the reference's own timing window (classify.cpp:248-258)
+                    cb.update(kind="reference", value=n_sample / secs / 1e6,
+                              sample=f"{n_sample} reads of batch 0, oracle/_ref/classify -t {cores} -M, "
+                                     f"its report_stats window {secs:.3f}s")
+                    got = sorted(open(f"{tmp}/out.tsv").read().split("\n"))
+                    cb["parity_vs_reference_on_sample"] = got == sorted(want_text.split("\n"))
+                    os.remove(f"{tmp}/sample.fa")
+                    os.remove(f"{tmp}/out.tsv")
+                else:
+                    from oracle import ku_oracle as ko
+                    st = torch.from_numpy(ctx.counts()["slot_taxid"].astype(np.int64)).to(db.device)
+                    raw = db.pairs.clone()
+                    raw[:, 2] = ((st[raw[:, 2].to(torch.int64)] << 32) >> 32).to(torch.int32)
+                    pairs = raw.cpu().numpy().view(np.uint8).reshape(-1)
+                    offs = db.offsets.cpu().numpy().astype(np.uint64)
+                    ids_t, par_t = db.tax.arrays()
+                    odb = ko.Db(pairs=pairs, key_ct=db.n_pairs, k=db.k, offsets=offs, nt=db.nt)
+                    run = ko.Run(odb, ko.Tax(ids=ids_t, parents=par_t), threads=cores)
+                    t0 = time.time()
+                    res = run.classify_packed(host, off, lens, want_taxa=False)
+                    secs = time.time() - t0
+                    cb.update(kind="port", value=n_sample / secs / 1e6,
+                              sample=f"{n_sample} reads of batch 0, oracle/libku_oracle.so OpenMP x{cores}, {secs:.3f}s")
+                    cb["parity_vs_reference_on_sample"] = bool((res["calls"] == calls_gpu[:n_sample]).all())
+            except Exception as e:  # the baseline must never take the bench line down
+                cb.update(value=None, kind="reference", sample=f"failed: {e}")
+            out["cpu_baseline"] = cb
+        if a.no_extras:
+            return out
+        # ---- device pipeline: pinned host buffers -> H2D -> kernels -> RLE -> D2H (ku_classify_batch_rle + ku_fetch_runs)
+        try:
+            n_dp = min(a.reads, 2_000_000)
+            hb = d_seqs[:n_dp * stride].cpu().pin_memory().numpy()
+            off = np.arange(n_dp, dtype=np.uint64) * stride
+            lens = np.full(n_dp, read_len, dtype=np.uint32)
+            ctx.classify_batch_rle(hb, off, lens)
+            t0 = time.perf_counter()
+            r = ctx.classify_batch_rle(hb, off, lens)
+            dt = time.perf_counter() - t0
+            out["device_pipeline"] = {"value": round(n_dp / dt / 1e6, 2), "unit": "Mreads/s", "reads": n_dp,
+                                      "runs_per_read": round(len(r["runs"]) / n_dp, 2),
+                                      "calls_match_device_run": bool((r["calls"] == calls_gpu[:n_dp]).all()),
+                                      "path": "pinned host batch -> H2D -> fused kernel -> RLE kernel -> D2H (calls, runs)"}
+        except Exception as e:
+            out["device_pipeline"] = {"value": None, "error": str(e)[:200]}
+        # ---- end to end: the classify executable on a FASTQ file (parser team | device | formatter + writer)
+        try:
+            if not (files and os.path.exists(cli_bin)) or a.paired:
+                raise RuntimeError("classify executable or database files missing")
+            n_e = min(a.reads, len(calls_gpu))
+            write_fastq(f"{tmp}/reads.fq", d_seqs[:n_e * stride].cpu().numpy().reshape(n_e, stride), read_len)
+            thr = str(min(cores, 16))
+            cmd = [cli_bin, "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB", "-t", thr,
+                   "-o", f"{tmp}/e2e.tsv", f"{tmp}/reads.fq"]
+            t0 = time.time()
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.time() - t0
+            err = r.stderr.decode(errors="replace")
+            m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
+            if r.returncode != 0 or not m:
+                raise RuntimeError("classify failed: " + err[-300:])
+            secs = float(m.group(3))
+            import pandas as pd
+            got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
+            out["e2e"] = {"value": round(n_e / secs / 1e6, 2), "unit": "Mreads/s", "reads": n_e, "threads": int(thr),
+                          "window": "the executable's report_stats window (classify.cpp:248-258): FASTQ parse -> GPU -> Kraken file",
+                          "seconds": secs, "wall_incl_db_load_s": round(wall, 1),
+                          "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
+        except Exception as e:
+            out["e2e"] = {"value": None, "error": str(e)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def shard_bounds(synth_torch, kdist, dev, a, k, ws):
+    """every rank derives the same shard plan from the same deterministic sample of the DB's bin keys"""
+    probe = synth_torch.BenchDb(dev, n_species=min(a.species, 32), genome_len=min(a.genome_len, 50_000), k=k,
+                                nt=a.nt, seed=7)
+    bins = synth_torch.bin_key(probe.kmers[torch.randperm(probe.n_pairs, device=dev)[:1_000_000]], k, a.nt)
+    return kdist.quantile_bin_bounds(bins, 4 ** a.nt, ws)
+
+
+def sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, steps, warmup, stream):
+    """the sharded step through ku_mgpu_step_device; returns (elapsed seconds over `steps`, mg, db, reads per step)"""
+    bounds = shard_bounds(synth_torch, kdist, dev, a, k, ws)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    db = synth_torch.BenchDb(dev, n_species=a.species, genome_len=a.genome_len, k=k, nt=a.nt, seed=7, bin_lo=lo, bin_hi=hi)
+    db.kmers = db.vals = None
+    torch.cuda.empty_cache()
+    mg = capi.Mgpu([local_rank], first_rank=rank, world=ws, unique_id=uid if ws > 1 else None)
+    mg.ctx(0).adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), k, a.nt, 2, lo, hi)
+    ids_t, par_t = db.tax.arrays()
+    mg.set_taxonomy(capi.Tax(ids=ids_t, parents=par_t))
+    nb_batches = max(1, min(a.batches, 2))
+    if rank == 0:
+        batches = [make_batch(db, a, 1 + 17 * i, dev) for i in range(nb_batches)]
+        L = batches[0][3]
+    else:
+        L = 2 * a.read_len + 1 if a.paired else a.read_len
+        stride = L + 1
+        one = (torch.zeros(a.reads * stride + 16, dtype=torch.uint8, device=dev),
+               torch.zeros(a.reads, dtype=torch.int64, device=dev), torch.zeros(a.reads, dtype=torch.int32, device=dev), L)
+        batches = [one]
+    stride = L + 1
+    n_bytes = a.reads * stride
+    d_taxa = torch.zeros(n_bytes + 16, dtype=torch.int32, device=dev)
     d_calls = torch.zeros(a.reads, dtype=torch.int32, device=dev)
-    ptrs = ctx.counts_device_ptrs()
-    build_s = time.time() - t_build
+    rb = [a.reads * r // ws for r in range(ws + 1)]
+    pb = [x * stride for x in rb]
 
-    # a dedicated (non-null) torch stream: kernels, RCCL collectives and the timing events all live on it
-    torch.cuda.synchronize()  # inputs were produced on the default stream: finish them before switching streams
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    r_lo, r_hi = kdist.read_slice(a.reads, rank, ws) if sharded else (0, a.reads)
+    def step(i):
+        b = batches[i % len(batches)]
+        mg.step_device([{"d_seqs": b[0].data_ptr(), "d_seq_off": b[1].data_ptr(), "d_seq_len": b[2].data_ptr(),
+                         "d_calls": d_calls.data_ptr(), "d_taxa": d_taxa.data_ptr(), "stream": stream}],
+                       n_bytes, a.reads, rb, pb, max_read_len=L)
 
-    # torch views (no copy) of the context's live per-taxon state, for the RCCL merge
-    def dev_tensor(ptr, nbytes, dtype):
-        # build a tensor over existing device memory via __cuda_array_interface__
-        class _W:
-            pass
-        w = _W()
-        itemsize = torch.tensor([], dtype=dtype).element_size()
-        w.__cuda_array_interface__ = {"shape": (nbytes // itemsize,), "typestr": {1: "|u1", 8: "<i8"}[itemsize],
-                                      "data": (ptr, False), "version": 2}
-        return torch.as_tensor(w, device=dev)
-
-    st_regs = dev_tensor(ptrs["registers"], ptrs["register_bytes"], torch.uint8)
-    st_kmers = dev_tensor(ptrs["n_kmers"], ptrs["n_slots"] * 8, torch.int64)
-    st_reads = dev_tensor(ptrs["n_reads"], ptrs["n_nodes"] * 8, torch.int64)
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
-    fused = not sharded and os.environ.get("KU_NO_FUSED") is None and (a.read_len - k + 1) <= 192 and ctx.db_layout()["hash"]
-
-    def step(i=None):
-        if fused:
-            # short reads, whole DB resident: ONE fused kernel (wave per read) does lookup + counts + resolve
-            if i is not None:
-                ev[i][0].record()
-            ctx.classify_batch_device(d_seqs.data_ptr(), n_bytes, d_off.data_ptr(), d_len.data_ptr(), a.reads,
-                                      d_calls.data_ptr(), d_taxa.data_ptr(), max_read_len=a.read_len, stream=stream)
-            if i is not None:
-                ev[i][1].record()
-        else:
-            if i is not None:
-                ev[i][0].record()
-            ctx.lookup_device(d_seqs.data_ptr(), n_bytes, d_taxa.data_ptr(),
-                              flags=capi.KU_F_KEEP_SLOTS if sharded else 0, stream=stream)
-            if i is not None:
-                ev[i][1].record()
-            if sharded:
-                kdist.merge_taxa_max(d_taxa)
-            ctx.resolve_device(d_seqs.data_ptr(), d_off[r_lo:].data_ptr(), d_len[r_lo:].data_ptr(), r_hi - r_lo,
-                               d_calls[r_lo:].data_ptr(), d_taxa.data_ptr(), max_read_len=a.read_len, stream=stream)
-        if ws > 1:
-            kdist.reduce_state(st_regs, st_kmers, st_reads)
-
-    for _ in range(a.warmup):
-        step()
-    ctx.reset_counts()
+    for i in range(warmup):
+        step(i)
     torch.cuda.synchronize()
+    mg.ctx(0).reset_counts()
     if ws > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         step(i)
+    mg.reduce_state([stream])
     torch.cuda.synchronize()
     if ws > 1:
         dist.barrier()
@@ -264,58 +291,234 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    lookup_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else 0.0
+    # every read was resolved exactly once over the whole world
+    total_reads = int(mg.ctx(0).counts()["n_reads"].sum())
+    return elapsed, mg, db, total_reads == a.reads * steps
 
-    total_reads = a.reads * a.steps * (1 if sharded else ws)
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws != a.gpus and ws > 1:
+        a.gpus = ws
+    # debugging aid for 1-GPU boxes: KU_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (RCCL refuses that; numbers are
+    # meaningless) -- the N > 1 code path is otherwise exercised by tests/test_gpu_mgpu.py inside one process
+    if os.environ.get("KU_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from krakenuniq_amd import capi, dist as kdist, synth_torch
+    uid = None
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        # the C++ driver's own RCCL communicator: rank 0 makes the id, everybody gets it
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t.copy_(torch.from_numpy(capi.mgpu_unique_id()))
+        dist.broadcast(t, 0)
+        uid = t.cpu().numpy()
+
+    k = 31
+    sharded = a.mode == "sharded"
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(device=dev)  # kernels, RCCL collectives and the timing events all live on it
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    result_extra = {}
+
+    if sharded:
+        t_build = time.time()
+        elapsed, mg, db, ok = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, a.steps, a.warmup, stream)
+        L = 2 * a.read_len + 1 if a.paired else a.read_len
+        value = a.reads * a.steps / elapsed / 1e6
+        ctx = mg.ctx(0)
+        result = {
+            "metric": "Mreads/s (150 bp)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": ws, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic DB ({a.species} taxa x {a.genome_len} bp, nt={a.nt}) sharded by minimizer range over "
+                                   f"{ws} GPU(s), {a.reads} reads of {L} bp per step broadcast from rank 0",
+                       "db_pairs_per_gpu": db.n_pairs, "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species,
+                       "reads_per_step": a.reads, "read_len": L, "parallelism": f"sharded{ws}", "exchange": "RCCL" if mg.uses_rccl() else "none",
+                       "every_read_resolved_once": ok},
+        }
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        mg.close()
+        if ws > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- replicas (N = 1: the plain single-GPU run)
+    t_build = time.time()
+    db = synth_torch.BenchDb(dev, n_species=a.species, genome_len=a.genome_len, k=k, nt=a.nt, seed=7)
+    db.kmers = db.vals = None
+    torch.cuda.empty_cache()
+    mg = None
+    if ws > 1:
+        mg = capi.Mgpu([local_rank], first_rank=rank, world=ws, unique_id=uid, flags=capi.KU_MGPU_REPLICAS)
+        ctx = mg.ctx(0)
+    else:
+        ctx = capi.Ctx(local_rank)
+    ctx.adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), k, a.nt, 2, keep=db)
+    ids_t, par_t = db.tax.arrays()
+    ctax = capi.Tax(ids=ids_t, parents=par_t)
+    if mg:
+        mg.set_taxonomy(ctax)
+    else:
+        ctx.set_taxonomy(ctax)
+    nb_batches = max(1, a.batches)
+    batches = [make_batch(db, a, 1 + 17 * i + 1000 * rank, dev) for i in range(nb_batches)]
+    read_len = batches[0][3]
+    n_bytes = batches[0][0].numel()
+    d_taxa = torch.zeros(n_bytes, dtype=torch.int32, device=dev)
+    d_calls = torch.zeros(a.reads, dtype=torch.int32, device=dev)
+    build_s = time.time() - t_build
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    fused = os.environ.get("KU_NO_FUSED") is None and (read_len - k + 1) <= 192 and ctx.db_layout()["hash"]
+
+    def step(i, timed):
+        b = batches[i % nb_batches]
+        if i % nb_batches == 0:  # a fresh run every rotation: the registers start empty
+            tstream.synchronize()
+            ctx.reset_counts()
+        if fused:  # short reads, whole DB resident: ONE fused kernel (wave per read) does lookup + counts + resolve
+            if timed:
+                ev[i][0].record()
+            ctx.classify_batch_device(b[0].data_ptr(), n_bytes, b[1].data_ptr(), b[2].data_ptr(), a.reads,
+                                      d_calls.data_ptr(), d_taxa.data_ptr(), max_read_len=read_len, stream=stream)
+            if timed:
+                ev[i][1].record()
+        else:
+            if timed:
+                ev[i][0].record()
+            ctx.lookup_device(b[0].data_ptr(), n_bytes, d_taxa.data_ptr(), stream=stream)
+            if timed:
+                ev[i][1].record()
+            ctx.resolve_device(b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), a.reads, d_calls.data_ptr(),
+                               d_taxa.data_ptr(), max_read_len=read_len, stream=stream)
+
+    for i in range(a.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, True)
+    if mg:  # end-of-run merge of the per-taxon state over the ranks (C++ driver, RCCL), part of the job
+        mg.reduce_state([stream])
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if ws > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else 0.0
+    state_ok = None
+    if mg:  # the reads of the last (possibly partial) rotation of every rank, summed over the world
+        last_rot = a.steps - ((a.steps - 1) // nb_batches) * nb_batches
+        state_ok = int(ctx.counts()["n_reads"].sum()) == a.reads * last_rot * ws
+
+    total_reads = a.reads * a.steps * ws
     value = total_reads / elapsed / 1e6
-    # roofline of the dominant kernel (lookup): algorithmic bytes per launch / HIP-event time
-    stats = ctx.lookup_stats_device(d_seqs.data_ptr(), n_bytes)
-    bytes_algo = a.reads * (a.read_len + 4) + stats["lookups"] * 20 + 12 * stats["sum_ceil_log2"]
-    achieved = bytes_algo / (lookup_ms * 1e-3) / 1e9 if lookup_ms else 0.0
-    traffic = None
+    # roofline of the dominant kernel: algorithmic bytes per launch (mean over the batches) / HIP-event time
+    stats = [ctx.lookup_stats_device(b[0].data_ptr(), n_bytes) for b in batches]
+    lookups = float(np.mean([s["lookups"] for s in stats]))
+    sum_log = float(np.mean([s["sum_ceil_log2"] for s in stats]))
+    bytes_algo = a.reads * (read_len + 4) + lookups * 20 + 12 * sum_log
+    achieved = bytes_algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+    rev = capi.kernel_rev()
+    traffic, traffic_note = None, "no counter profile of this kernel source in profiles/lookup_traffic.json"
     tpath = os.path.join(ROOT, "profiles", "lookup_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if (tj.get("reads") == a.reads and tj.get("nt") == a.nt and tj.get("species") == a.species
-                    and tj.get("kernel", "").startswith("ku_classify_short" if fused else "ku_lookup")):
+            same_wl = (tj.get("reads") == a.reads and tj.get("nt") == a.nt and tj.get("species") == a.species
+                       and tj.get("read_len", 150) == read_len
+                       and tj.get("kernel", "").startswith("ku_classify_short" if fused else "ku_lookup"))
+            if same_wl and tj.get("kernel_rev") == rev:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_note = tj.get("source", "profiles/lookup_traffic.json")
+            elif same_wl:
+                traffic_note = f"profiles/lookup_traffic.json is of kernel source {tj.get('kernel_rev')}, this is {rev}: refused"
         except Exception:
-            traffic = None
+            pass
     default_cfg = (a.reads == 10_000_000 and a.species == 2000 and a.genome_len == 310_000 and a.nt == 13
                    and not a.paired and a.read_len == 150)
     if default_cfg and ws == 1:
         workload = "configs[1]: 8 GB MiniKraken-style DB (k=31), 10M synthetic 150 bp reads, 1xMI355X"
     else:
         workload = (f"{'configs[1] ' if default_cfg else ''}synthetic DB ({a.species} taxa x {a.genome_len} bp, nt={a.nt}), "
-                    f"{a.reads} {'paired 2x' + str((a.read_len - 1) // 2) if a.paired else str(a.read_len)} bp reads per GPU "
+                    f"{a.reads} {'paired 2x' + str((read_len - 1) // 2) if a.paired else str(read_len)} bp reads per GPU "
                     f"per step, {a.mode} x{ws}")
+    frac_model = achieved / HBM_PEAK_GBS
     result = {
         "metric": "Mreads/s (150 bp)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": ws, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": workload,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": workload, "distinct_batches": nb_batches,
+                   "state": f"per-taxon state zeroed every {nb_batches} steps (a fresh {nb_batches * a.reads // 1_000_000} M-read run per rotation)",
                    "db_pairs_per_gpu": db.n_pairs, "db_bytes_per_gpu": db.n_pairs * 12 + db.offsets.numel() * 8,
-                   "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species, "reads_per_gpu_per_step": a.reads, "read_len": a.read_len,
-                   "parallelism": f"{a.mode}{ws}", "db_build_s": round(build_s, 1)},
-        "roofline": {"bound": "hbm", "kernel": "ku_classify_short_kernel (fused lookup+resolve)" if fused else "ku_lookup_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bytes_algo, "lookups_per_launch": stats["lookups"],
-                     "mean_ceil_log2_bin": round(stats["sum_ceil_log2"] / max(stats["lookups"], 1), 3),
-                     "kernel_ms": round(lookup_ms, 3)},
+                   "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species, "reads_per_gpu_per_step": a.reads,
+                   "read_len": read_len, "parallelism": f"{a.mode}{ws}", "db_build_s": round(build_s, 1)},
+        "roofline": {"bound": "hbm", "kernel": "ku_classify_short_kernel (fused lookup+resolve)" if fused else "ku_lookup_kernel",
+                     "kernel_rev": rev, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(frac_model, 5), "frac_model": round(frac_model, 5),
+                     "frac_hw": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kernel_ms else None,
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "algorithmic_bytes_per_launch": int(bytes_algo), "lookups_per_launch": int(lookups),
+                     "mean_ceil_log2_bin": round(sum_log / max(lookups, 1), 3), "kernel_ms": round(kernel_ms, 3)},
     }
-    if rank == 0 and ws == 1 and a.cpu_sample != 0:
-        cores = a.cpu_threads or host_cores()
-        n_sample = a.cpu_sample if a.cpu_sample > 0 else min(a.reads, 60_000 * cores, 4_000_000)  # ~20 s of CPU work
-        calls = d_calls[:n_sample].cpu().numpy().view(np.uint32)
-        taxa = d_taxa[:n_sample * (a.read_len + 1)].cpu().numpy().view(np.uint32)
+    if mg:
+        result["config"]["state_merge"] = "ku_mgpu_reduce_state (RCCL all-reduce) once, inside the timed region"
+        result["config"]["merged_read_count_ok"] = state_ok
+    if rank == 0 and ws == 1 and not (a.cpu_sample == 0 and a.no_extras):
+        # a run of batch 0 alone for the parity sample / device pipeline legs
+        tstream.synchronize()
+        ctx.reset_counts()
+        b = batches[0]
+        ctx.classify_batch_device(b[0].data_ptr(), n_bytes, b[1].data_ptr(), b[2].data_ptr(), a.reads, d_calls.data_ptr(),
+                                  d_taxa.data_ptr(), max_read_len=read_len, stream=stream)
+        torch.cuda.synchronize()
+        calls = d_calls.cpu().numpy().view(np.uint32)
+        n_host = min(a.reads, 4_000_000)  # per-k-mer codes only for the CPU sample
+        taxa = d_taxa[:n_host * (read_len + 1)].cpu().numpy().view(np.uint32)
         try:
-            result["cpu_baseline"] = cpu_baseline(db, ctx, d_seqs, a.read_len, n_sample, calls, taxa, cores)
-        except Exception as e:  # the baseline must never take the bench line down
-            result["cpu_baseline"] = {"value": None, "unit": "Mreads/s", "cores": cores, "kind": "reference",
+            result.update(host_legs(a, db, ctx, (b[0], b[1], b[2]), read_len, calls, taxa, k))
+        except Exception as e:
+            result["cpu_baseline"] = {"value": None, "unit": "Mreads/s", "cores": host_cores(), "kind": "reference",
                                       "sample": f"failed: {e}"}
+    if ws > 1 and not a.no_extras and not os.environ.get("KU_BENCH_NO_SHARDED_LEG"):
+        # the same world once more with the database sharded by minimizer range (strong scaling, configs[2] layout)
+        try:
+            del batches, d_taxa, d_calls
+            mg.close()
+            mg = None
+            del db
+            torch.cuda.empty_cache()
+            s_steps = max(2, min(a.steps, 4))
+            el, smg, sdb, ok = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, s_steps, 1, stream)
+            result["sharded"] = {"value": round(a.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
+                                 "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sdb.n_pairs,
+                                 "every_read_resolved_once": ok,
+                                 "path": "ku_mgpu_step_device: ncclBroadcast -> owner lookup -> grouped ncclReduce (max) -> per-slice resolve"}
+            smg.close()
+        except Exception as e:
+            result["sharded"] = {"value": None, "error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if mg:
+        mg.close()
     if ws > 1:
         dist.destroy_process_group()
 

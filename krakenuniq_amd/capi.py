@@ -167,6 +167,16 @@ def lib():
     return _lib
 
 
+def kernel_rev():
+    """identity of the kernel sources the library was built from (profiles are only valid for the source they measured)"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for fn in ("ku_device.h", "ku_internal.h", "ku_short.hip", "ku_kernels.hip"):
+        h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _chk(status, where):
     if status != 0:
         raise KuError(status, where)

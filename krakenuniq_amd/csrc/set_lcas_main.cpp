@@ -4,6 +4,7 @@
 // input database file is never modified when -o names another file.
 #include <getopt.h>
 #include <sysexits.h>
+#include <unistd.h>
 
 #include <cctype>
 #include <cstdarg>
@@ -324,17 +325,25 @@ int main(int argc, char **argv) {
     fprintf(stderr, "\rFinished processing %u sequences\n", processed);
   }
 
-  if ((add_for_sequences || add_for_assembly) && !pretend) {  // src/set_lcas.cpp:171-177
-    fprintf(stderr, "Writing new TaxDB ...\n");
-    tt.write(taxdb_name);
+  // the rewritten taxDB goes out only once the run cannot fail on a missing k-mer any more: the reference aborts
+  // inside its processing loop, before src/set_lcas.cpp:171-177
+  auto write_taxdb = [&] {
+    if ((add_for_sequences || add_for_assembly) && !pretend) {
+      fprintf(stderr, "Writing new TaxDB ...\n");
+      tt.write(taxdb_name);
+    }
+  };
+  if (dry) {
+    write_taxdb();
+    return 0;
   }
-  if (dry) return 0;
   std::vector<uint32_t> values(info.key_ct + 1);
   uint64_t n_missing = 0;
   CHECK(ku_setlcas_finish(sl, values.data(), &n_missing));
   ku_setlcas_close(sl);
   if (n_missing && !allow_extra) fatal(EX_DATAERR, "kmer found in sequence that is not in database");
   if (n_missing && verbose) fprintf(stderr, "%llu kmers found in sequences that are not in database\n", (unsigned long long)n_missing);
+  write_taxdb();
 
   if (!counts_name.empty()) {  // KrakenDB::count_taxons (src/krakendb.cpp:90-113)
     fprintf(stderr, "Writing kmer counts to %s...\n", counts_name.c_str());
@@ -362,9 +371,20 @@ int main(int argc, char **argv) {
     for (uint64_t i = 0; i < info.key_ct; ++i) memcpy(dat.data() + hdr + i * ps + info.key_len, &values[i], 4);
     ku_db_close(db);  // unmap before writing over the file
     db = nullptr;
-    FILE *out = fopen(target.c_str(), "wb");
-    if (!out || fwrite(dat.data(), 1, sz, out) != sz) fatal(EX_OSERR, "can't write %s", target.c_str());
-    fclose(out);
+    // never truncate the only copy of a database: the new image goes to a temporary file next to the target, is
+    // flushed to disk, and only then takes the target's name
+    const std::string tmp_name = target + ".tmp";
+    FILE *out = fopen(tmp_name.c_str(), "wb");
+    if (!out) fatal(EX_OSERR, "can't write %s", tmp_name.c_str());
+    const bool ok = fwrite(dat.data(), 1, sz, out) == sz && fflush(out) == 0 && fsync(fileno(out)) == 0;
+    if (fclose(out) != 0 || !ok) {
+      remove(tmp_name.c_str());
+      fatal(EX_OSERR, "can't write %s", tmp_name.c_str());
+    }
+    if (rename(tmp_name.c_str(), target.c_str()) != 0) {
+      remove(tmp_name.c_str());
+      fatal(EX_OSERR, "can't move %s over %s", tmp_name.c_str(), target.c_str());
+    }
   }
   if (db) ku_db_close(db);
   ku_tax_close(tax);

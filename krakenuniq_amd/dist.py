@@ -1,5 +1,9 @@
-"""Multi-GPU orchestration of the classify hot path (torch.distributed; backend
-"nccl" == RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+"""torch.distributed model of the multi-GPU exchange (backend "gloo" in the CPU tests).
+
+The product path is the C++ driver krakenuniq_amd/csrc/ku_mgpu.cpp (RCCL through the C ABI: ku_mgpu_*), which bench.py
+and the classify executable use.  This module states the same exchange protocol on plain torch tensors so that the
+world-size-2 CPU tests (tests/test_dist_gloo.py) can check it -- slice plan, "non-zero wins" max-merge, owner-computes
+accounting, end-of-run state merge -- without a GPU; bench.py also takes its shard-bound helper from here.
 
 The reference shards its database only *in time* (--preload-size chunk mode,
 src/krakendb.cpp:411-526, src/classify.cpp:566-791) and merges per-k-mer taxa with
@@ -65,9 +69,10 @@ def merge_taxa_max(taxa_i32: torch.Tensor) -> torch.Tensor:
 
 
 def reduce_state(registers_u8: torch.Tensor, n_kmers_i64: torch.Tensor, n_reads_i64: torch.Tensor):
-    """end-of-run merge of the per-taxon state across ranks: returns (registers, n_kmers, n_reads) copies"""
+    """end-of-run merge of the per-taxon state across ranks, IN PLACE (as ku_mgpu_reduce_state): registers MAX,
+    counters SUM; returns the three tensors"""
     _, ws = world()
-    r, k, n = registers_u8.clone(), n_kmers_i64.clone(), n_reads_i64.clone()
+    r, k, n = registers_u8, n_kmers_i64, n_reads_i64
     if ws > 1:
         dist.all_reduce(r, op=dist.ReduceOp.MAX)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)

@@ -11,7 +11,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--cpu-sample 0 --steps 2 --warmup 1"
+ARGS="--cpu-sample 0 --no-extras --steps 4 --warmup 1"
 if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $REPO/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 fi

@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/<tag>_{stats,pmc*} (scripts/profile_bench.sh) into profiles/<tag>_kernel_stats.csv,
-profiles/<tag>_pmc_summary.json and profiles/lookup_traffic.json.   usage: scripts/summarize_profile.py <tag> <rev>"""
-import collections, csv, glob, json, sys
-tag, rev = sys.argv[1], sys.argv[2]
+profiles/<tag>_pmc_summary.json and profiles/lookup_traffic.json.   usage: scripts/summarize_profile.py <tag>
+The traffic file carries the hash of the kernel sources it was measured on (capi.kernel_rev()); bench.py refuses it for
+any other source."""
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from krakenuniq_amd import capi
+tag = sys.argv[1]
+rev = capi.kernel_rev()
 out = {}
 for f in sorted(glob.glob(f'gpurun_out/{tag}_pmc*/runc/*counter_collection.csv')):
     agg = collections.defaultdict(list)
@@ -24,7 +29,8 @@ for r in rows[1:]:
 lk = next(v for k, v in out.items() if k.startswith(('ku_classify_short_kernel', 'ku_lookup_kernel<1')))
 kname = next(k for k in out if k.startswith(('ku_classify_short_kernel', 'ku_lookup_kernel<1')))
 fetch_kb, write_kb = lk['FETCH_SIZE']['per_launch_mean'], lk['WRITE_SIZE']['per_launch_mean']
-j = {"reads": 10000000, "nt": 13, "species": 2000, "kernel": kname, "kernel_rev": rev,
+j = {"reads": 10000000, "nt": 13, "species": 2000, "read_len": 150, "kernel": kname, "kernel_rev": rev,
+     "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
      "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
      "correction": "gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM; scripts/calib_gather.hip: a random "
                    "16-B gather moves one 128-B line): read bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 as is (uncalibrated)",
