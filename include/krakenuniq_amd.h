@@ -162,6 +162,23 @@ int ku_ctx_enable_exact(ku_ctx *ctx, uint32_t capacity_log2);
 int ku_counts_export_exact(ku_ctx *ctx, uint64_t *unique_kmers);
 /* zero HLL registers / n_kmers / n_reads (start of a run) */
 int ku_ctx_reset_counts(ku_ctx *ctx);
+/* HyperLogLog++ sparse-mode emulation.  The reference's sketch starts as a set of 32-bit encoded
+ * hashes at precision p' = 25 (hyperloglogplus.cpp:181-204) and turns dense when an insert finds 1024 entries
+ * (:496-498); classify keeps one local sketch per taxon and work unit (`work_unit_nt` nt of reads, classify.cpp:487-564)
+ * and merges it into the global one (sparse + sparse = set union of any size, :601-604).  So a taxon's global sketch
+ * is dense iff one of its per-unit sketches switched, else it holds every distinct encoding of the run and the report
+ * prints a near-exact count.  With the emulation enabled the batches of ku_classify_batch / _rle / ku_batch_finish (in
+ * input order; the two-stage / fused device paths are bypassed) track exactly that next to the dense registers;
+ * ku_sparse_export closes the last unit and returns slot_is_sparse[n_slots] and the (slot << 32 | encoded hash)
+ * pairs of the sparse slots (pairs = NULL to query *n_pairs) for ku_report_sparse.  work_unit_nt = 0: the whole run
+ * is one unit (what the reference's -x chunk mode amounts to: it inserts into the global sketches directly,
+ * classify.cpp:719).  global_log2: cells of the run-wide (slot, encoding) set, 0 = 2^26 (KU_ENOMEM when it fills).
+ * Call after ku_ctx_set_taxonomy; single GPU; at most 2^18 database taxids. */
+int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t global_log2);
+/* the work unit that is still open ends here: call between input files (the reference's units do not span files,
+ * classify.cpp:487-564 runs once per file); no-op without the emulation or with work_unit_nt = 0 */
+int ku_sparse_close_unit(ku_ctx *ctx);
+int ku_sparse_export(ku_ctx *ctx, uint8_t *slot_is_sparse, uint64_t *pairs, uint64_t *n_pairs);
 
 /* ---- set_lcas on the GPU (src/set_lcas.cpp:429-476, the database build step after db_sort): every k-mer of a library
  * sequence that the database holds gets  value = lca(Parent_map, taxid of the sequence, value)  (krakenutil.cpp:90-118).
@@ -406,6 +423,16 @@ int ku_report(const ku_tax *tax, const char *counts_path, const uint32_t *slot_t
 int ku_report_multi(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
                     const uint64_t *n_kmers, const uint8_t *registers, uint64_t n_slots, const uint32_t *node_taxid,
                     const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
+/* The report with the reference's sparse sketches: slot_is_sparse[n_slots] and sparse_pairs[n_pairs] (slot << 32 |
+ * encoded hash) as ku_sparse_export returns them.  A clade's sketch is the merge of its members' by the reference's
+ * rules (HyperLogLogPlusMinus::merge, hyperloglogplus.cpp:586-665): dense as soon as one member is, else the union of
+ * the members' sets; `kmers` is the Ertl estimate of that state (sparse: m = 2^25, q = 39; :356-366,726-753). */
+int ku_report_sparse(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
+                     const uint64_t *n_kmers, const uint8_t *registers, const uint8_t *slot_is_sparse,
+                     const uint64_t *sparse_pairs, uint64_t n_pairs, uint64_t n_slots, const uint32_t *node_taxid,
+                     const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
+/* Ertl estimate of a sparse sketch: its n distinct 32-bit encoded hashes (p = 12, p' = 25), clipped to n_observed */
+uint64_t ku_hll_cardinality_sparse(const uint32_t *encoded, uint64_t n, uint64_t n_observed);
 /* classifyExact's report (classify built with EXACT_COUNTING, classify.cpp:46-53): `kmers` is the exact number of
  * distinct k-mers (ku_counts_export_exact) instead of the HyperLogLog estimate; a clade's count is the sum over its
  * members (a k-mer has one database value, the members' sets are disjoint). */

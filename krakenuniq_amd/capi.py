@@ -93,6 +93,12 @@ SIGNATURES = {
     "ku_ctx_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
     "ku_ctx_count_taxons_db": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u64p, u64p]),
     "ku_ctx_reset_counts": (C.c_int, [C.c_void_p]),
+    "ku_ctx_enable_sparse": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "ku_sparse_export": (C.c_int, [C.c_void_p, u8p, u64p, u64p]),
+    "ku_sparse_close_unit": (C.c_int, [C.c_void_p]),
+    "ku_report_sparse": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u8p, u8p, u64p, C.c_uint64,
+                                   C.c_uint64, u32p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_hll_cardinality_sparse": (C.c_uint64, [u32p, C.c_uint64, C.c_uint64]),
     "ku_ctx_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
     "ku_counts_export_exact": (C.c_int, [C.c_void_p, u64p]),
     "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
@@ -338,6 +344,25 @@ class Ctx:
 
     def reset_counts(self):
         _chk(lib().ku_ctx_reset_counts(self.h), "ku_ctx_reset_counts")
+
+    def enable_sparse(self, work_unit_nt=500000, global_log2=0):
+        """HyperLogLog++ sparse-mode emulation (ku_ctx_enable_sparse): exact reproduction of the reference's report"""
+        _chk(lib().ku_ctx_enable_sparse(self.h, work_unit_nt, global_log2), "ku_ctx_enable_sparse")
+
+    def sparse_close_unit(self):
+        _chk(lib().ku_sparse_close_unit(self.h), "ku_sparse_close_unit")
+
+    def sparse_export(self):
+        """(slot_is_sparse uint8[n_slots], pairs uint64[n] = slot << 32 | encoded hash) -- closes the last work unit"""
+        d = CountsDims()
+        _chk(lib().ku_counts_dims_get(self.h, C.byref(d)), "ku_counts_dims_get")
+        flags = np.zeros(d.n_slots, dtype=np.uint8)
+        n = C.c_uint64()
+        _chk(lib().ku_sparse_export(self.h, _p(flags, u8p), None, C.byref(n)), "ku_sparse_export")
+        pairs = np.zeros(max(n.value, 1), dtype=np.uint64)
+        n2 = C.c_uint64(len(pairs))
+        _chk(lib().ku_sparse_export(self.h, _p(flags, u8p), _p(pairs, u64p), C.byref(n2)), "ku_sparse_export")
+        return flags, pairs[:n2.value]
 
     def classify_batch(self, buf, off, lens, flags=0, min_hits=1, want_taxa=True):
         """Host-buffer entry point.  buf: bytes/np.uint8 with a non-ACGT byte after every read."""
@@ -643,6 +668,27 @@ def report_exact(tax: Tax, counts: dict, unique, counts_paths):
                                _p(unique, u64p), len(counts["slot_taxid"]), _p(counts["node_taxid"], u32p),
                                _p(counts["n_reads"], u64p), len(counts["node_taxid"]), C.byref(out), C.byref(n)),
          "ku_report_exact")
+    s = C.string_at(out, n.value).decode()
+    lib().ku_free(out)
+    return s
+
+
+def hll_cardinality_sparse(encoded, n_observed):
+    e = np.ascontiguousarray(encoded, dtype=np.uint32)
+    return int(lib().ku_hll_cardinality_sparse(_p(e, u32p), len(e), n_observed))
+
+
+def report_sparse(tax: Tax, counts: dict, slot_is_sparse, pairs, counts_paths):
+    """the report with the reference's sparse sketches (ku_report_sparse); counts_paths: list of database.kdb.counts"""
+    out, n = C.c_void_p(), C.c_size_t()
+    regs = np.ascontiguousarray(counts["registers"], dtype=np.uint8)
+    flags = np.ascontiguousarray(slot_is_sparse, dtype=np.uint8)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint64)
+    paths = (C.c_char_p * len(counts_paths))(*[p.encode() for p in counts_paths])
+    _chk(lib().ku_report_sparse(tax.h, paths, len(counts_paths), _p(counts["slot_taxid"], u32p), _p(counts["n_kmers"], u64p),
+                                _p(regs, u8p), _p(flags, u8p), _p(pairs, u64p), len(pairs), len(counts["slot_taxid"]),
+                                _p(counts["node_taxid"], u32p), _p(counts["n_reads"], u64p), len(counts["node_taxid"]),
+                                C.byref(out), C.byref(n)), "ku_report_sparse")
     s = C.string_at(out, n.value).decode()
     lib().ku_free(out)
     return s

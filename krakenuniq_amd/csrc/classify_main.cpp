@@ -12,7 +12,10 @@
 //   -q -m N                             quick mode
 //   -t N                                host threads parsing the input and formatting the output (0 < N <= processors,
 //                                       src/classify.cpp:1085-1088; default 4); the GPU replaces the OpenMP classification team
-//   -u N                                accepted (must be > 0); sets the ingest batch size in nt (default 64 Mi, at least 1 Mi)
+//   -u N                                work unit size in nt as in the reference (default 500000, src/classify.cpp:38): it decides
+//                                       which per-taxon sketches stay sparse, i.e. which `kmers` of the report are near
+//                                       exact (HLL sparse-mode emulation; KU_NO_SPARSE=1 switches it off: dense estimates).
+//                                       The GPU batch size is separate: KU_BATCH_NT (default 64 Mi nt)
 //   -M                                  accepted: the database is always preloaded (into HBM)
 //   -x SIZE                             the database is streamed through HBM in minimizer-range chunks of at most SIZE
 //                                       bytes (src/krakendb.cpp:463-522) when that yields more than one chunk
@@ -184,7 +187,8 @@ int main(int argc, char **argv) {
   bool paired = false, warned_pairs = false;
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
-  uint64_t unit_nt = 64ull << 20;
+  uint64_t unit_nt = 64ull << 20;    // GPU batch size in nt (KU_BATCH_NT)
+  uint64_t work_unit_nt = 500000;   // -u: the reference's Work_unit_size (src/classify.cpp:38)
   uint64_t chunk_bytes = 0;  // -x SIZE: stream the database through HBM in chunks of at most SIZE bytes
   int fmt_threads = 4;  // -t: host threads that format the Kraken lines (the GPU replaces the OpenMP team)
   if (argc > 1 && strcmp(argv[1], "-h") == 0) usage(0);
@@ -220,7 +224,7 @@ int main(int argc, char **argv) {
       case 'u':
         sig = atoll(optarg);
         if (sig <= 0) die(EX_USAGE, "can't use nonpositive work unit size");
-        unit_nt = (uint64_t)sig < (1ull << 20) ? (1ull << 20) : (uint64_t)sig;  // GPU batches: at least 1 Mi nt
+        work_unit_nt = (uint64_t)sig;
         break;
       case 'M': populate = true; break;
       case 'x':
@@ -233,6 +237,10 @@ int main(int argc, char **argv) {
       case 'P': paired = true; break;  // extension: the input files are mate pairs, merged on the fly (scripts/read_merger.pl)
       default: usage(EX_USAGE);
     }
+  }
+  if (const char *e = getenv("KU_BATCH_NT")) {
+    const long long v = atoll(e);
+    if (v > 0) unit_nt = (uint64_t)v < (1ull << 16) ? (1ull << 16) : (uint64_t)v;
   }
   if (dbs.empty()) { fprintf(stderr, "Missing mandatory option -d\n"); usage(EX_USAGE); }
   if (idxs.empty()) { fprintf(stderr, "Missing mandatory option -i\n"); usage(EX_USAGE); }
@@ -344,6 +352,15 @@ int main(int argc, char **argv) {
     for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
     KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
   }
+  // HLL sparse-mode emulation (single GPU): the report's `kmers` as the reference prints them.  -x runs insert into the
+  // global sketches directly (src/classify.cpp:719): one unit for the whole run.
+  bool sparse = !exact && !mg && !getenv("KU_NO_SPARSE");
+  if (sparse) {
+    const char *e = getenv("KU_SPARSE_LOG2");
+    int st = ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, e ? (uint32_t)atoi(e) : 0u);
+    if (st == KU_EUNSUP) { fprintf(stderr, "classify: %s -- the report will carry dense estimates\n", ku_last_error()); sparse = false; }
+    else KU_CHECK(st);
+  }
   if (exact) {  // 2^30 cells = 8 GiB hold ~750 M distinct k-mers; KU_EXACT_LOG2 sizes it for larger runs
     const char *e = getenv("KU_EXACT_LOG2");
     KU_CHECK(ku_ctx_enable_exact(ctx, e ? (uint32_t)atoi(e) : 30u));
@@ -424,6 +441,7 @@ int main(int argc, char **argv) {
         }
         bt->clear();
         bt->fastq = fastq;
+        bt->first_of_file = lo == 0;
         bt->reserve_seq(fastq ? (hi - lo) / 2 + 4096 : hi - lo);  // one allocation: the sequences are at most that long
         const bool whole = ku_seqio::parse_region(data + lo, hi - lo, fastq, *bt, keep_records);
         std::lock_guard<std::mutex> l(mu);
@@ -469,11 +487,13 @@ int main(int argc, char **argv) {
       Reader rd, rd2;
       rd.open(argv[fi], /*prefetch=*/true);
       if (paired) rd2.open(argv[fi + 1], /*prefetch=*/true);
-      bool more = true;
+      bool more = true, first = true;
       while (more) {
         Batch *bt = chunked ? new Batch() : free_q.pop();  // -x: every batch stays alive until the last chunk
         const double t_parse = now_s();
         bt->clear();
+        bt->first_of_file = first;
+        first = false;
         bt->fastq = paired ? false : rd.fastq;  // mate pairs travel as merged FASTA records (read_merger.pl:187-197)
         while (bt->nt < unit_nt) {
           size_t n1 = 0, n2 = 0, lo, hi;
@@ -622,6 +642,7 @@ int main(int argc, char **argv) {
     bt->run_cnt.assign(n, 0);
     ku_opts opts = base_opts;
     uint64_t n_runs = 0;
+    if (sparse && bt->first_of_file) KU_CHECK(ku_sparse_close_unit(ctx));  // work units do not span input files
     if (mg)
       KU_CHECK(ku_mgpu_classify_batch_rle(mg, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
                                           bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
@@ -699,6 +720,15 @@ int main(int argc, char **argv) {
       KU_CHECK(ku_counts_export_exact(ctx, uniq.data()));
       KU_CHECK(ku_report_exact(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), uniq.data(), d.n_slots,
                                ntx.data(), nr.data(), d.n_nodes, &text, &tn));
+    } else if (sparse) {
+      std::vector<uint8_t> is_sparse(d.n_slots);
+      uint64_t np = 0;
+      KU_CHECK(ku_sparse_export(ctx, is_sparse.data(), nullptr, &np));
+      std::vector<uint64_t> pairs(np + 1);
+      uint64_t cap = np;
+      KU_CHECK(ku_sparse_export(ctx, is_sparse.data(), pairs.data(), &cap));
+      KU_CHECK(ku_report_sparse(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), regs.data(), is_sparse.data(),
+                                pairs.data(), cap, d.n_slots, ntx.data(), nr.data(), d.n_nodes, &text, &tn));
     } else
     KU_CHECK(ku_report_multi(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), regs.data(), d.n_slots, ntx.data(),
                              nr.data(), d.n_nodes, &text, &tn));

@@ -386,6 +386,17 @@ struct ku_ctx {
   // exact distinct counting (classifyExact): one global set of canonical k-mers + first-insertion counters per slot
   unsigned long long *d_exact_set = nullptr, *d_exact_unique = nullptr;
   uint64_t exact_mask = 0;
+  // HyperLogLog++ sparse-mode emulation (ku_sparse.hip)
+  struct Sparse {
+    bool on = false;
+    uint64_t unit_nt = 500000;  // Work_unit_size (classify.cpp:38); 0 = the whole run is one unit (-x mode)
+    uint64_t acc_nt = 0;        // nt of the unit that is still open
+    bool open = false;          // ... whose encodings and statistics sit in the carry buffers
+    KuSparseDev dev{};
+    unsigned long long *d_counters = nullptr;  // [0] size of G, [1..2] carry sizes, [3] export size
+    DevBuf unit, carry_l, carry_u, out;
+    uint64_t n_carry_l = 0, n_carry_u = 0, cap_carry_l = 0, cap_carry_u = 0;
+  } sp;
 };
 
 hipStream_t ku_ctx_stream_of(ku_ctx *ctx) { return ctx->stream; }
@@ -447,6 +458,14 @@ static void ctx_free_tax(ku_ctx *ctx) {
   if (ctx->d_exact_unique) (void)hipFree(ctx->d_exact_unique);
   ctx->d_exact_set = ctx->d_exact_unique = nullptr;
   ctx->exact_mask = 0;
+  {
+    KuSparseDev &d = ctx->sp.dev;
+    for (void *p : {(void *)d.l_key, (void *)d.l_first, (void *)d.u_key, (void *)d.u_distinct, (void *)d.u_last, (void *)d.u_maxfirst,
+                    (void *)d.g_key, (void *)d.dense, (void *)d.err, (void *)ctx->sp.d_counters})
+      if (p) (void)hipFree(p);
+    for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out}) b->release();
+    ctx->sp = ku_ctx::Sparse{};
+  }
   ctx->cnt = KuCountsDev{};
   ctx->tax_set = false;
 }
@@ -746,11 +765,24 @@ extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
     HIP_TRY(hipMemsetAsync(ctx->d_exact_unique, 0, (size_t)ctx->tax.n_slots * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_scalar + 6, 0, 4, ctx->stream));
   }
+  if (ctx->sp.on) {
+    KuSparseDev &d = ctx->sp.dev;
+    HIP_TRY(hipMemsetAsync(d.g_key, 0, (d.g_mask + 1) * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d.dense, 0, (size_t)ctx->tax.n_slots * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d.err, 0, 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->sp.d_counters, 0, 32, ctx->stream));
+    ctx->sp.acc_nt = 0;
+    ctx->sp.open = false;
+    ctx->sp.n_carry_l = ctx->sp.n_carry_u = 0;
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return KU_OK;
 }
 
 static int check_ready(ku_ctx *ctx);
+static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
+                       const uint32_t *h_len, uint64_t n_reads, uint64_t n_bytes, const uint32_t *d_taxa, uint32_t quick_min_hits,
+                       hipStream_t s);
 
 extern "C" int ku_ctx_enable_exact(ku_ctx *ctx, uint32_t capacity_log2) {
   KU_TRY(check_ready(ctx));
@@ -812,6 +844,167 @@ extern "C" int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *
     for (uint32_t s = 0; s < ns; ++s) if (h[s]) { taxids[j] = ctx->h_slot_taxid[s]; counts[j] = h[s]; ++j; }
   }
   *n = m;
+  return KU_OK;
+}
+
+// ---------------------------------------------------------------------------- HLL sparse-mode emulation
+extern "C" int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t global_log2) {
+  KU_TRY(check_ready(ctx));
+  if (ctx->tax.n_slots > KU_SPARSE_MAX_SLOTS) return fail(KU_EUNSUP, "sparse-mode emulation handles up to 2^18 distinct database taxids");
+  if (global_log2 == 0) global_log2 = 26;
+  if (global_log2 < 10 || global_log2 > 34) return fail(KU_EINVAL, "ku_ctx_enable_sparse: global_log2 out of range (10..34)");
+  if (ctx->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is already enabled");
+  ku_ctx::Sparse &sp = ctx->sp;
+  KuSparseDev &d = sp.dev;
+  const uint32_t l_log2 = 26, u_log2 = 22;
+  d.l_mask = (1ull << l_log2) - 1;
+  d.u_mask = (1ull << u_log2) - 1;
+  d.g_mask = (1ull << global_log2) - 1;
+  sp.cap_carry_l = std::min<uint64_t>(1024ull * ctx->tax.n_slots, 1ull << 25);
+  sp.cap_carry_u = ctx->tax.n_slots;
+  bool ok = hipMalloc((void **)&d.l_key, (d.l_mask + 1) * 8) == hipSuccess && hipMalloc((void **)&d.l_first, (d.l_mask + 1) * 4) == hipSuccess &&
+            hipMalloc((void **)&d.u_key, (d.u_mask + 1) * 8) == hipSuccess && hipMalloc((void **)&d.u_distinct, (d.u_mask + 1) * 4) == hipSuccess &&
+            hipMalloc((void **)&d.u_last, (d.u_mask + 1) * 4) == hipSuccess && hipMalloc((void **)&d.u_maxfirst, (d.u_mask + 1) * 4) == hipSuccess &&
+            hipMalloc((void **)&d.g_key, (d.g_mask + 1) * 8) == hipSuccess && hipMalloc((void **)&d.dense, (size_t)ctx->tax.n_slots * 4) == hipSuccess &&
+            hipMalloc((void **)&d.err, 4) == hipSuccess && hipMalloc((void **)&sp.d_counters, 32) == hipSuccess &&
+            sp.carry_l.reserve(sp.cap_carry_l * 8) == KU_OK && sp.carry_u.reserve(sp.cap_carry_u * 12) == KU_OK;
+  if (!ok) {
+    for (void *p : {(void *)d.l_key, (void *)d.l_first, (void *)d.u_key, (void *)d.u_distinct, (void *)d.u_last, (void *)d.u_maxfirst,
+                    (void *)d.g_key, (void *)d.dense, (void *)d.err, (void *)sp.d_counters})
+      if (p) (void)hipFree(p);
+    sp.carry_l.release();
+    sp.carry_u.release();
+    sp = ku_ctx::Sparse{};
+    return fail(KU_ENOMEM, "device memory for the sparse-mode emulation");
+  }
+  d.g_count = sp.d_counters;
+  sp.unit_nt = work_unit_nt;
+  sp.on = true;
+  return ku_ctx_reset_counts(ctx);
+}
+
+// the reads [r0, r1) of a batch whose taxa[] holds slot ids: one pass of the emulation (at most KU_SPARSE_MAX_UNITS
+// work units and 2^25 bases at a time; a unit that is still open at the end is carried into the next pass)
+static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
+                       const uint32_t *h_len, uint64_t n_reads, uint64_t n_bytes, const uint32_t *d_taxa, uint32_t quick_min_hits,
+                       hipStream_t s) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  KuSparseDev &d = sp.dev;
+  if (n_bytes + 2 >= (1ull << 32)) return fail(KU_EUNSUP, "sparse-mode emulation: batches of at most 4 G bases");
+  for (uint64_t i = 1; i < n_reads; ++i)
+    if (h_off[i] < h_off[i - 1]) return fail(KU_EINVAL, "sparse-mode emulation: the reads of a batch must be in buffer order");
+  std::vector<uint32_t> unit(n_reads);
+  if (sp.unit.reserve(std::max<uint64_t>(n_reads, 1) * 4) != KU_OK) return fail(KU_ENOMEM, "device memory for the work-unit ids");
+  uint64_t r0 = 0;
+  while (r0 < n_reads) {
+    // cut: units and bases of this pass
+    uint32_t cur = 0;
+    uint64_t acc = sp.acc_nt, bases = 0, r1 = r0;
+    while (r1 < n_reads && cur < KU_SPARSE_MAX_UNITS && bases < (1ull << 25)) {
+      unit[r1] = cur;
+      acc += h_len[r1];
+      bases += h_len[r1];
+      ++r1;
+      if (sp.unit_nt && acc >= sp.unit_nt) { ++cur; acc = 0; }  // the unit closes behind the read that fills it (classify.cpp:510-521)
+    }
+    const bool open_after = acc > 0 || (sp.unit_nt == 0 && (sp.open || r1 > r0));
+    const uint32_t n_closed = cur;  // units 0 .. cur-1 are complete; unit `cur` (if any read fell into it) stays open
+    HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(d.u_distinct, 0, (d.u_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_last, 0, (d.u_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
+    if (sp.open) KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p,
+                                                   sp.n_carry_u, s));
+    HIP_TRY(hipMemcpyAsync((uint32_t *)sp.unit.p + r0, unit.data() + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, s));
+    KU_TRY(ku_launch_sparse_insert(d, ctx->m.db.k, (const uint8_t *)d_seqs, d_off + r0, d_len + r0, (const uint32_t *)sp.unit.p + r0, r1 - r0,
+                                   d_taxa, quick_min_hits, ctx->n_cu, s));
+    KU_TRY(ku_launch_sparse_close(d, n_closed, s));
+    sp.n_carry_l = sp.n_carry_u = 0;
+    if (open_after) {
+      HIP_TRY(hipMemsetAsync(sp.d_counters + 1, 0, 16, s));
+      KU_TRY(ku_launch_sparse_carry_out(d, cur, (unsigned long long *)sp.carry_l.p, (uint32_t *)sp.carry_u.p, sp.d_counters + 1, sp.cap_carry_l,
+                                        sp.cap_carry_u, s));
+      unsigned long long c[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(c, sp.d_counters + 1, 16, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      sp.n_carry_l = std::min<uint64_t>(c[0], sp.cap_carry_l);
+      sp.n_carry_u = std::min<uint64_t>(c[1], sp.cap_carry_u);
+    } else {
+      HIP_TRY(hipStreamSynchronize(s));  // `unit` is reused by the next pass
+    }
+    sp.open = open_after;
+    sp.acc_nt = acc;
+    r0 = r1;
+  }
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, d.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (err) return fail(KU_ENOMEM, std::string("sparse-mode emulation: a device table is full (") + ((err & 1) ? "L " : "") + ((err & 2) ? "U " : "") +
+                                      ((err & 4) ? "G: enable it with a larger global_log2" : "") + ")");
+  return KU_OK;
+}
+
+// the unit that is still open ends here (end of an input file / of the run): evaluate and commit what was carried
+static int sparse_close_open_unit(ku_ctx *ctx) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  KuSparseDev &d = sp.dev;
+  hipStream_t s = ctx->stream;
+  if (sp.open) {
+    HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(d.u_distinct, 0, (d.u_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_last, 0, (d.u_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
+    KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p, sp.n_carry_u, s));
+    KU_TRY(ku_launch_sparse_close(d, 1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  sp.open = false;
+  sp.acc_nt = 0;
+  sp.n_carry_l = sp.n_carry_u = 0;
+  return KU_OK;
+}
+
+extern "C" int ku_sparse_close_unit(ku_ctx *ctx) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->sp.on) return KU_OK;
+  if (ctx->sp.unit_nt == 0) return KU_OK;  // one unit for the whole run
+  return sparse_close_open_unit(ctx);
+}
+
+extern "C" int ku_sparse_export(ku_ctx *ctx, uint8_t *slot_is_sparse, uint64_t *pairs, uint64_t *n_pairs) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled (ku_ctx_enable_sparse)");
+  if (!n_pairs) return fail(KU_EINVAL, "ku_sparse_export: null argument");
+  KU_TRY(sparse_close_open_unit(ctx));
+  ku_ctx::Sparse &sp = ctx->sp;
+  KuSparseDev &d = sp.dev;
+  hipStream_t s = ctx->stream;  // end of the run: the last, partial work unit closes (classify.cpp:522-523)
+  unsigned long long total = 0;
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&total, d.g_count, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&err, d.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (err) return fail(KU_ENOMEM, "sparse-mode emulation: a device table overflowed");
+  if (sp.out.reserve(std::max<uint64_t>(total, 1) * 8) != KU_OK) return fail(KU_ENOMEM, "device memory for the sparse export");
+  HIP_TRY(hipMemsetAsync(sp.d_counters + 3, 0, 8, s));
+  KU_TRY(ku_launch_sparse_export(d, (unsigned long long *)sp.out.p, total, sp.d_counters + 3, s));
+  unsigned long long n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, sp.d_counters + 3, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (slot_is_sparse) {
+    std::vector<uint32_t> dense(ctx->tax.n_slots);
+    HIP_TRY(hipMemcpy(dense.data(), d.dense, (size_t)ctx->tax.n_slots * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < ctx->tax.n_slots; ++i) slot_is_sparse[i] = dense[i] ? 0 : 1;
+  }
+  if (pairs) {
+    if (*n_pairs < n) return fail(KU_EINVAL, "ku_sparse_export: output array too small");
+    if (n) HIP_TRY(hipMemcpy(pairs, sp.out.p, n * 8, hipMemcpyDeviceToHost));
+  }
+  *n_pairs = n;
   return KU_OK;
 }
 
@@ -883,16 +1076,21 @@ extern "C" int ku_resolve_device(ku_ctx *ctx, const void *d_seqs, const uint64_t
   return st == KU_OK ? KU_OK : fail(st, "resolve kernel launch failed");
 }
 
-extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
-                                        const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
-                                        uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream) {
+// h_off / h_len: host copies of the read offsets / lengths when the caller has them (the host-buffer entry points);
+// the sparse-mode emulation needs them for the work-unit plan
+static int classify_device_impl(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
+                                const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls,
+                                uint32_t *d_taxa, uint32_t *d_hits, void *stream, const uint64_t *h_off, const uint32_t *h_len) {
   KU_TRY(check_ready(ctx));
   const uint32_t flags = opts ? opts->flags : 0;
   // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
   const bool exact = ctx->d_exact_set != nullptr;
   if (exact && (flags & (KU_F_QUICK | KU_F_KEEP_SLOTS | KU_F_NO_COUNTS)))
     return fail(KU_EUNSUP, "exact counting goes with the plain classification only (no quick mode / slot output / count-less runs)");
-  const uint32_t short_max = (getenv("KU_NO_FUSED") || !ctx->extra.empty() || exact) ? 0 : ku_short_max_kmers(ctx->m.db);
+  const bool sparse = ctx->sp.on && !(flags & KU_F_NO_COUNTS);
+  if (sparse && !h_len) return fail(KU_EUNSUP, "the sparse-mode emulation runs through the host-buffer entry points (it needs the read lengths on the host)");
+  if (sparse && (flags & KU_F_KEEP_SLOTS)) return fail(KU_EUNSUP, "the sparse-mode emulation does not combine with slot output");
+  const uint32_t short_max = (getenv("KU_NO_FUSED") || !ctx->extra.empty() || exact || sparse) ? 0 : ku_short_max_kmers(ctx->m.db);
   if (short_max && !(flags & (KU_F_QUICK | KU_F_KEEP_SLOTS)) && n_reads) {
     if (!d_seqs || !d_seq_off || !d_seq_len || !d_calls || !d_taxa) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -914,6 +1112,9 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
     return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, &o, d_calls, d_taxa, d_hits, stream);
   }
   KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, opts, d_taxa, stream));
+  if (sparse && n_reads)  // between the stages: d_taxa holds slot ids
+    KU_TRY(sparse_pass(ctx, d_seqs, d_seq_off, d_seq_len, h_off, h_len, n_reads, n_bytes, d_taxa,
+                       (flags & KU_F_QUICK) ? std::max(1u, opts ? opts->min_hits : 1u) : 0u, stream ? (hipStream_t)stream : ctx->stream));
   if (exact) {  // between the stages: d_taxa holds slot ids
     if (n_reads && (!d_seqs || !d_seq_off || !d_seq_len || !d_taxa)) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     int st = ku_launch_exact(ctx->m.db.k, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, d_taxa, ctx->d_exact_set,
@@ -922,6 +1123,12 @@ extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_
     if (st != KU_OK) return fail(st, "exact counting kernel launch failed");
   }
   return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, opts, d_calls, d_taxa, d_hits, stream);
+}
+
+extern "C" int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
+                                        const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
+                                        uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream) {
+  return classify_device_impl(ctx, d_seqs, n_bytes, d_seq_off, d_seq_len, n_reads, opts, d_calls, d_taxa, d_hits, stream, nullptr, nullptr);
 }
 
 extern "C" int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
@@ -941,9 +1148,9 @@ extern "C" int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes
   HIP_TRY(hipMemcpyAsync(ctx->b_seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->b_off.p, seq_off, n_reads * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->b_len.p, seq_len, n_reads * 4, hipMemcpyHostToDevice, s));
-  KU_TRY(ku_classify_batch_device(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
-                                  n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
-                                  (uint32_t *)ctx->b_hits.p, s));
+  KU_TRY(classify_device_impl(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
+                              n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
+                              (uint32_t *)ctx->b_hits.p, s, seq_off, seq_len));
   HIP_TRY(hipMemcpyAsync(calls, ctx->b_calls.p, n_reads * 4, hipMemcpyDeviceToHost, s));
   if (taxa) HIP_TRY(hipMemcpyAsync(taxa, ctx->b_taxa.p, n_bytes * 4, hipMemcpyDeviceToHost, s));
   if (hits) HIP_TRY(hipMemcpyAsync(hits, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToHost, s));
@@ -1001,9 +1208,9 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
   HIP_TRY(hipMemcpyAsync(ctx->b_seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->b_off.p, seq_off, n_reads * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ctx->b_len.p, seq_len, n_reads * 4, hipMemcpyHostToDevice, s));
-  KU_TRY(ku_classify_batch_device(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
-                                  n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
-                                  (uint32_t *)ctx->b_hits.p, s));
+  KU_TRY(classify_device_impl(ctx, ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
+                              n_reads, &o, (uint32_t *)ctx->b_calls.p, (uint32_t *)ctx->b_taxa.p,
+                              (uint32_t *)ctx->b_hits.p, s, seq_off, seq_len));
   return rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p, n_reads,
                        runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits, run_off, run_cnt, n_runs);
 }
@@ -1045,6 +1252,8 @@ struct ku_batch {
   void *d_seqs = nullptr;
   uint64_t *d_off = nullptr;
   uint32_t *d_len = nullptr, *d_taxa = nullptr;
+  std::vector<uint64_t> h_off;  // host copies for the sparse-mode emulation's work-unit plan
+  std::vector<uint32_t> h_len;
 };
 
 extern "C" void ku_batch_destroy(ku_batch *b) {
@@ -1067,6 +1276,7 @@ extern "C" int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, 
   }
   ku_batch *b = new ku_batch();
   b->ctx = ctx; b->n_bytes = n_bytes; b->n_reads = n_reads; b->max_len = max_len;
+  if (ctx->sp.on) { b->h_off.assign(seq_off, seq_off + n_reads); b->h_len.assign(seq_len, seq_len + n_reads); }
   hipStream_t s = ctx->stream;
   bool ok = hipMalloc(&b->d_seqs, n_bytes + 16) == hipSuccess && hipMalloc((void **)&b->d_off, std::max<uint64_t>(n_reads, 1) * 8) == hipSuccess &&
             hipMalloc((void **)&b->d_len, std::max<uint64_t>(n_reads, 1) * 4) == hipSuccess &&
@@ -1109,6 +1319,11 @@ extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, ui
       ctx->b_roff.reserve(n_reads * 8) || ctx->b_rcnt.reserve(n_reads * 4))
     return fail(KU_ENOMEM, "device batch buffers");
   hipStream_t s = ctx->stream;
+  if (ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {  // the merged slots of all chunks are in place: the emulation's pass
+    if (b->h_len.size() != n_reads) return fail(KU_ESTATE, "ku_batch_finish: enable the sparse-mode emulation before the batches are created");
+    KU_TRY(sparse_pass(ctx, b->d_seqs, b->d_off, b->d_len, b->h_off.data(), b->h_len.data(), n_reads, b->n_bytes, b->d_taxa,
+                       (o.flags & KU_F_QUICK) ? std::max(1u, o.min_hits) : 0u, s));
+  }
   KU_TRY(ku_resolve_device(ctx, b->d_seqs, b->d_off, b->d_len, n_reads, &o, (uint32_t *)ctx->b_calls.p, b->d_taxa,
                            (uint32_t *)ctx->b_hits.p, s));
   b->finished = true;

@@ -36,21 +36,48 @@ static double ertl_tau(double x) {
   return t / 3.0;
 }
 
-extern "C" uint64_t ku_hll_cardinality(const uint8_t *M, uint32_t p, uint64_t n_observed) {
-  // hyperloglogplus.cpp:722-753 on dense registers: q = 64 - p, m = 2^p
-  if (!M || p < 4 || p > 18) return 0;
-  const uint32_t m = 1u << p, q = 64 - p;
-  std::vector<int> C(q + 2, 0);
-  for (uint32_t i = 0; i < m; ++i) C[std::min<uint32_t>(M[i], q + 1)]++;
-  double den = m * ertl_tau(1.0 - double(C[q + 1]) / double(m));
+// ertlCardinality (hyperloglogplus.cpp:722-753) from the register histogram C[0 .. q+1] of a sketch with m registers
+static uint64_t ertl_from_histogram(const int *C, uint32_t q, double m, uint64_t n_observed) {
+  double den = m * ertl_tau(1.0 - double(C[q + 1]) / m);
   for (int k = (int)q; k >= 1; --k) {
     den += C[k];
     den *= 0.5;
   }
-  den += m * ertl_sigma(double(C[0]) / double(m));
+  den += m * ertl_sigma(double(C[0]) / m);
   double est = (m / (2.0 * std::log(2))) * m / den;
   if (double(n_observed) < est) return n_observed;  // use_n_observed = true (hyperloglogplus.hpp:78)
   return (uint64_t)std::llround(est);
+}
+
+extern "C" uint64_t ku_hll_cardinality(const uint8_t *M, uint32_t p, uint64_t n_observed) {
+  // dense registers: q = 64 - p, m = 2^p
+  if (!M || p < 4 || p > 18) return 0;
+  const uint32_t m = 1u << p, q = 64 - p;
+  std::vector<int> C(q + 2, 0);
+  for (uint32_t i = 0; i < m; ++i) C[std::min<uint32_t>(M[i], q + 1)]++;
+  return ertl_from_histogram(C.data(), q, double(m), n_observed);
+}
+
+// The same estimator on a SPARSE sketch: the set of 32-bit encoded hashes at precision p' = 25
+// (sparseRegisterHistogram, hyperloglogplus.cpp:356-366; cardinality :726-729): m = 2^25 virtual registers, q = 39,
+// one histogram entry per encoded hash at its rank relative to p (getEncodedRank, :152-161), the rest are zero registers.
+extern "C" uint64_t ku_hll_cardinality_sparse(const uint32_t *encoded, uint64_t n, uint64_t n_observed) {
+  const uint32_t pp = 25, p = KU_HLL_P, q = 64 - pp;
+  int C[80] = {0};
+  int64_t m = 1ll << pp;
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint32_t e = encoded[i];
+    uint32_t r;
+    if (e & 1u) r = (pp - p) + ((e >> 1) & 0x3Fu);
+    else {
+      const uint32_t bits = e << p;
+      r = (bits == 0 ? 32 - p : (uint32_t)__builtin_clz(bits)) + 1;
+    }
+    C[r < 79 ? r : 79]++;
+    --m;
+  }
+  C[0] = (int)m;
+  return ertl_from_histogram(C, q, double(1 << pp), n_observed);
 }
 
 // ---------------------------------------------------------------------------- Kraken lines
@@ -190,6 +217,8 @@ struct Clade {
   uint64_t reads = 0, kmers = 0, uniq = 0;
   std::vector<uint8_t> regs;  // dense p=12 registers of the merged sketch (empty until first k-mer source)
   bool present = false;
+  bool dense = false;         // a member's sketch was dense: the merged sketch is (hyperloglogplus.cpp:586-665)
+  std::vector<uint32_t> set;  // else: union of the members' encoded hashes
 };
 struct Sb {
   std::string s;
@@ -213,7 +242,17 @@ extern "C" int ku_report(const ku_tax *tax, const char *counts_path, const uint3
 
 static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
                        const uint64_t *n_kmers, const uint8_t *registers, const uint64_t *unique, uint64_t n_slots,
-                       const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
+                       const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len,
+                       const uint8_t *slot_is_sparse = nullptr, const uint64_t *sparse_pairs = nullptr, uint64_t n_pairs = 0);
+
+extern "C" int ku_report_sparse(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
+                                const uint64_t *n_kmers, const uint8_t *registers, const uint8_t *slot_is_sparse,
+                                const uint64_t *sparse_pairs, uint64_t n_pairs, uint64_t n_slots, const uint32_t *node_taxid,
+                                const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len) {
+  if ((n_slots && (!registers || !slot_is_sparse)) || (n_pairs && !sparse_pairs)) { ku_set_error("ku_report_sparse: null argument"); return KU_EINVAL; }
+  return report_impl(tax, counts_paths, n_paths, slot_taxid, n_kmers, registers, nullptr, n_slots, node_taxid, n_reads, n_nodes, out, out_len,
+                     slot_is_sparse, sparse_pairs, n_pairs);
+}
 
 extern "C" int ku_report_multi(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths,
                                const uint32_t *slot_taxid, const uint64_t *n_kmers, const uint8_t *registers,
@@ -233,7 +272,8 @@ extern "C" int ku_report_exact(const ku_tax *tax, const char *const *counts_path
 
 static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
                        const uint64_t *n_kmers, const uint8_t *registers, const uint64_t *unique, uint64_t n_slots,
-                       const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len) {
+                       const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len,
+                       const uint8_t *slot_is_sparse, const uint64_t *sparse_pairs, uint64_t n_pairs) {
   if (!tax || !out || (n_paths && !counts_paths) || !out_len || (n_slots && (!slot_taxid || !n_kmers || (!registers && !unique))) || (n_nodes && (!node_taxid || !n_reads))) {
     ku_set_error("ku_report: null argument");
     return KU_EINVAL;
@@ -242,13 +282,39 @@ static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint3
   // taxon_counts: taxid -> (n_reads, n_kmers, sketch); an entry exists when either count is non-zero
   // (exact mode, classifyExact: the sketch is a set of k-mers; a k-mer has one database value, so the sets of
   // different taxa are disjoint and a clade's distinct count is the sum of its members')
-  struct TaxCount { uint64_t reads = 0, kmers = 0, uniq = 0; const uint8_t *regs = nullptr; };
+  struct TaxCount {
+    uint64_t reads = 0, kmers = 0, uniq = 0;
+    const uint8_t *regs = nullptr;
+    bool sparse = false;                   // the taxon's sketch stayed in the sparse representation
+    const uint32_t *enc = nullptr;         // ... its encoded hashes
+    uint64_t n_enc = 0;
+  };
   std::unordered_map<uint32_t, TaxCount> tc;
+  // sparse sketches: (slot << 32 | encoded hash) pairs, grouped by slot
+  std::vector<uint64_t> sorted_pairs;
+  std::vector<uint32_t> enc_of;
+  std::vector<uint64_t> enc_begin(n_slots + 1, 0);
+  if (slot_is_sparse && !unique) {
+    sorted_pairs.assign(sparse_pairs, sparse_pairs + n_pairs);
+    std::sort(sorted_pairs.begin(), sorted_pairs.end());
+    enc_of.resize(n_pairs);
+    uint64_t at = 0;
+    for (uint64_t s = 0; s < n_slots; ++s) {
+      enc_begin[s] = at;
+      while (at < n_pairs && (sorted_pairs[at] >> 32) == s) { enc_of[at] = (uint32_t)sorted_pairs[at]; ++at; }
+    }
+    enc_begin[n_slots] = at;
+  }
   for (uint64_t s = 0; s < n_slots; ++s)
     if (n_kmers[s]) {
       auto &e = tc[slot_taxid[s]];
       e.kmers = n_kmers[s];
       if (unique) e.uniq = unique[s]; else e.regs = registers + s * KU_HLL_M;
+      if (slot_is_sparse && !unique && slot_is_sparse[s]) {
+        e.sparse = true;
+        e.enc = enc_of.data() + enc_begin[s];
+        e.n_enc = enc_begin[s + 1] - enc_begin[s];
+      }
     }
   for (uint64_t i = 0; i < n_nodes; ++i)
     if (n_reads[i]) tc[node_taxid[i]].reads = n_reads[i];
@@ -300,8 +366,25 @@ static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint3
       if (kv.second.regs) {
         if (c.regs.empty()) c.regs.assign(kv.second.regs, kv.second.regs + KU_HLL_M);
         else for (int i = 0; i < KU_HLL_M; ++i) c.regs[i] = std::max(c.regs[i], kv.second.regs[i]);
+        // HyperLogLogPlusMinus::merge (hyperloglogplus.cpp:586-665): a dense operand makes the result dense (the
+        // registers above are exact either way: folding a sparse list into registers is lossless, :559-577)
+        if (!kv.second.sparse) c.dense = true;
       }
     }
+  }
+  if (slot_is_sparse && !unique) {  // sparse + sparse = set union, whatever its size (:601-604)
+    for (auto &kv : tc) {
+      if (!kv.second.sparse || kv.second.n_enc == 0) continue;
+      auto it = tax->row.find(kv.first);
+      if (it == tax->row.end()) continue;
+      for (int64_t q = it->second; q >= 0; q = tax->parent_row((size_t)q))
+        if (!clade[q].dense) clade[q].set.insert(clade[q].set.end(), kv.second.enc, kv.second.enc + kv.second.n_enc);
+    }
+    for (Clade &c : clade)
+      if (!c.dense && !c.set.empty()) {
+        std::sort(c.set.begin(), c.set.end());
+        c.set.erase(std::unique(c.set.begin(), c.set.end()), c.set.end());
+      }
   }
   // children lists
   std::vector<std::vector<uint32_t>> kids(nt);
@@ -323,7 +406,10 @@ static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint3
       const Clade &c = clade[fr.row];
       if (!c.present || c.reads == 0) continue;
       const uint8_t *regs = c.regs.empty() ? zero_regs.data() : c.regs.data();
-      const uint64_t uniq = unique ? c.uniq : ku_hll_cardinality(regs, KU_HLL_P, c.kmers);
+      const bool sparse_sketch = slot_is_sparse && !unique && !c.dense;
+      const uint64_t uniq = unique ? c.uniq
+                                   : (sparse_sketch ? ku_hll_cardinality_sparse(c.set.data(), c.set.size(), c.kmers)
+                                                    : ku_hll_cardinality(regs, KU_HLL_P, c.kmers));
       volatile double gs = double(gsize[fr.row] + gchild[fr.row]);
       volatile double kc = double(c.kmers), un = double(uniq);
       auto ti = tc.find(tax->ids[fr.row]);

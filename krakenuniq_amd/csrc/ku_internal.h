@@ -47,6 +47,33 @@ struct KuCountsDev {
   unsigned long long *n_reads;        // n_nodes
 };
 
+// HyperLogLog++ sparse-mode emulation (ku_sparse.hip): tables of one context
+struct KuSparseDev {
+  unsigned long long *l_key;  // (unit + 1) << 50 | slot << 32 | encoding; 0 = empty
+  uint32_t *l_first;          // smallest position the encoding was seen at
+  uint64_t l_mask;
+  unsigned long long *u_key;  // (unit + 1) << 32 | slot; 0 = empty
+  uint32_t *u_distinct, *u_last, *u_maxfirst;
+  uint64_t u_mask;
+  unsigned long long *g_key;  // (slot + 1) << 32 | encoding; 0 = empty
+  uint64_t g_mask;
+  uint32_t *dense;            // per slot
+  uint32_t *err;              // bit 0: L full, bit 1: U full, bit 2: G full
+  unsigned long long *g_count;
+};
+#define KU_SPARSE_MAX_UNITS 16000u  // per batch (14-bit unit field)
+#define KU_SPARSE_MAX_SLOTS (1u << 18)
+int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off,
+                            const uint32_t *d_seq_len, const uint32_t *d_unit, uint64_t n_reads, const uint32_t *d_taxa,
+                            uint32_t quick_min_hits, int n_cu, hipStream_t stream);
+int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream);
+int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,
+                               unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream);
+int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_carry_l, uint64_t n_l, const uint32_t *d_carry_u,
+                              uint64_t n_u, hipStream_t stream);
+int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
+                            hipStream_t stream);
+
 // host-side view of an opened database for the other translation units (ku_api.cpp owns the struct)
 struct ku_db;
 int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets);

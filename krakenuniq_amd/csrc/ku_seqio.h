@@ -35,6 +35,7 @@ struct Batch {
   std::vector<uint64_t> off, idoff, hoff, qoff, run_off;
   std::vector<uint32_t> len, calls, hits, run_cnt;
   bool fastq = false;
+  bool first_of_file = false;  // the batch opens an input file (the reference's work units do not span files)
   uint64_t nt = 0;
   ku_batch *dev = nullptr;    // -x runs: the batch stays on the device across the chunk passes
   bool pinned = true;         // page-locked buffers for the copies to the device; false: plain host memory

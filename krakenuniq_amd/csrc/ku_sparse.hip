@@ -1,0 +1,276 @@
+// ku_sparse.hip -- device side of the HyperLogLog++ SPARSE-mode emulation.
+//
+// The reference's sketch (HyperLogLogPlusMinus<uint64_t>, p = 12) starts sparse: a set of 32-bit encodings of the
+// hashes at precision p' = 25 (encodeHashIn32Bit, hyperloglogplus.cpp:181-204).  A sketch turns dense when an insert
+// finds 1024 entries in its set (the test precedes the insert, :496-498).  classify keeps one LOCAL sketch per taxon and
+// work unit (-u nt of reads, classify.cpp:487-564) and merges it into the global one afterwards; a merge of two sparse
+// sketches is a plain set union without any size test (:601-604).  Hence, for every taxon:
+//     the global sketch is dense  <=>  in some work unit the taxon's local set reached 1024 distinct encodings and at
+//                                      least one more insert (duplicate or not) followed in that unit;
+//     otherwise it is sparse and holds every distinct encoding the run produced for the taxon, however many.
+// The report's `kmers` column is the Ertl estimate of that state (sparse: m = 2^25, near exact).  The dense registers
+// the main kernels keep are exact in both cases (sparse -> dense conversion is lossless, :559-577); this file adds what
+// the sparse case needs:
+//   L  per batch: set of (unit, slot, encoding) with the first position of each, to count distinct encodings per
+//      (unit, slot) and to order "the insert that made the set 1024 big" against "the last insert";
+//   U  per batch: (unit, slot) -> {distinct, last position, largest first position};
+//   dense[slot]   sticky flag; flagged slots are skipped by every later insert (abundant taxa drop out after ~1 unit);
+//   G  whole run: set of (slot, encoding) of the slots that are not dense -- what the host turns into the report.
+// A unit that straddles two batches is carried over (its L / U entries re-enter the next batch as unit 0).
+// One wave per read, run between the lookup and the resolve stage while taxa[] holds slot ids.
+#include "ku_device.h"
+
+#define KS_PPRIME 25
+#define KS_LIMIT 1024u  // m / 4 (hyperloglogplus.cpp:496)
+
+// encodeHashIn32Bit (hyperloglogplus.cpp:181-204), p = 12, p' = 25
+__device__ __forceinline__ uint32_t ks_encode(uint64_t h) {
+  const uint32_t idx = (uint32_t)(h >> (64 - KS_PPRIME)) << (32 - KS_PPRIME);
+  if ((uint32_t)(idx << KU_HLL_P) == 0) {
+    const uint64_t rest = h << KS_PPRIME;
+    const uint32_t add = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KS_PPRIME + 1);
+    return idx | (add << 1) | 1u;
+  }
+  return idx;
+}
+
+__device__ __forceinline__ uint64_t ks_mix(unsigned long long k) {
+  k ^= k >> 31;
+  k *= 0x9E3779B97F4A7C15ULL;
+  k ^= k >> 29;
+  return k;
+}
+
+// find or create the U cell of (unit, slot); returns its index or ~0 when the table is full
+__device__ __forceinline__ uint64_t ks_u_cell(const KuSparseDev &s, uint32_t unit, uint32_t slot) {
+  const unsigned long long key = ((unsigned long long)(unit + 1) << 32) | slot;
+  uint64_t h = ks_mix(key) & s.u_mask;
+  for (uint32_t probe = 0; probe < 4096; ++probe) {
+    unsigned long long cur = __hip_atomic_load(&s.u_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) cur = atomicCAS(&s.u_key[h], 0ull, key);
+    if (cur == 0 || cur == key) return h;
+    h = (h + 1) & s.u_mask;
+  }
+  atomicOr(s.err, 2u);
+  return ~0ull;
+}
+
+// one insert of the reference's local sketch of (unit, slot): encoding `enc` at position `pos`
+__device__ __forceinline__ void ks_insert(const KuSparseDev &s, uint32_t unit, uint32_t slot, uint32_t enc, uint32_t pos) {
+  const unsigned long long key = ((unsigned long long)(unit + 1) << 50) | ((unsigned long long)slot << 32) | enc;
+  uint64_t h = ks_mix(key) & s.l_mask;
+  bool fresh = false, placed = false;
+  for (uint32_t probe = 0; probe < 4096; ++probe) {
+    unsigned long long cur = __hip_atomic_load(&s.l_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) {
+      cur = atomicCAS(&s.l_key[h], 0ull, key);
+      fresh = cur == 0;
+    }
+    if (cur == 0 || cur == key) { placed = true; break; }
+    h = (h + 1) & s.l_mask;
+  }
+  if (!placed) { atomicOr(s.err, 1u); return; }
+  atomicMin(&s.l_first[h], pos);
+  const uint64_t u = ks_u_cell(s, unit, slot);
+  if (u == ~0ull) return;
+  if (fresh && atomicAdd(&s.u_distinct[u], 1u) + 1 > KS_LIMIT) s.dense[slot] = 1u;  // 1025 distinct: dense whatever the order
+  atomicMax(&s.u_last[u], pos);
+}
+
+__global__ __launch_bounds__(64) void ku_sparse_insert_kernel(KuSparseDev s, uint32_t k, const uint8_t *__restrict__ seqs,
+                                                              const uint64_t *__restrict__ seq_off,
+                                                              const uint32_t *__restrict__ seq_len,
+                                                              const uint32_t *__restrict__ unit_of, uint64_t n_reads,
+                                                              const uint32_t *__restrict__ taxa, uint32_t quick_min_hits) {
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t off = seq_off[r];
+    const uint32_t unit = unit_of[r];
+    uint32_t stop = n;
+    if (quick_min_hits) {  // quick mode books the scanned prefix only (classify.cpp:943-944)
+      uint32_t total = 0;
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < n ? taxa[off + i] : 0;
+        const bool hit = v != 0 && v != KU_AMBIG;
+        const unsigned long long m = __ballot(hit);
+        const uint32_t c = (uint32_t)__popcll(m);
+        if (total + c >= quick_min_hits) {
+          const uint32_t need = quick_min_hits - total;
+          const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          const unsigned long long sm = __ballot(hit && before + 1 == need);
+          stop = base + (uint32_t)__ffsll((long long)sm);
+          break;
+        }
+        total += c;
+      }
+    }
+    for (uint32_t i = lane; i < stop; i += 64) {
+      const uint32_t slot = taxa[off + i];
+      if (slot == KU_AMBIG) continue;
+      if (s.dense[slot]) continue;
+      // canonical k-mer straight from the text (positions with a slot are unambiguous)
+      uint64_t fwd = 0;
+      const uint8_t *p = seqs + off + i;
+      for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t c = p[j] & 0xDFu;
+        fwd = (fwd << 2) | (((c >> 1) ^ (c >> 2)) & 3u);
+      }
+      const uint64_t rc = ku_revcomp64(fwd, k);
+      const uint64_t h = ku_fmix64(fwd < rc ? fwd : rc);
+      ks_insert(s, unit, slot, ks_encode(h), (uint32_t)(off + i) + 2u);  // positions 0 / 1 belong to carried-over state
+    }
+  }
+}
+
+// largest first position of a (unit, slot)'s encodings = the insert that brought its set to its final size
+__global__ void ku_sparse_maxfirst_kernel(KuSparseDev s) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.l_mask; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long key = s.l_key[i];
+    if (!key) continue;
+    const uint32_t unit = (uint32_t)(key >> 50) - 1, slot = (uint32_t)(key >> 32) & 0x3FFFFu;
+    const uint64_t u = ks_u_cell(s, unit, slot);
+    if (u != ~0ull) atomicMax(&s.u_maxfirst[u], s.l_first[i]);
+  }
+}
+
+// closed units (unit < n_closed): did the local sketch switch to the dense representation?
+__global__ void ku_sparse_eval_kernel(KuSparseDev s, uint32_t n_closed) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.u_mask; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long key = s.u_key[i];
+    if (!key) continue;
+    const uint32_t unit = (uint32_t)(key >> 32) - 1, slot = (uint32_t)key;
+    if (unit >= n_closed) continue;
+    const uint32_t d = s.u_distinct[i];
+    // exactly 1024 entries: the switch happens iff an insert follows the one that added the 1024th (:496-498)
+    if (d > KS_LIMIT || (d == KS_LIMIT && s.u_last[i] > s.u_maxfirst[i])) s.dense[slot] = 1u;
+  }
+}
+
+// closed units of slots that stayed sparse: their encodings join the run's global set (the sparse + sparse merge)
+__global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.l_mask; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long key = s.l_key[i];
+    if (!key) continue;
+    const uint32_t unit = (uint32_t)(key >> 50) - 1, slot = (uint32_t)(key >> 32) & 0x3FFFFu, enc = (uint32_t)key;
+    if (unit >= n_closed || s.dense[slot]) continue;
+    const unsigned long long gk = ((unsigned long long)(slot + 1) << 32) | enc;
+    uint64_t h = ks_mix(gk) & s.g_mask;
+    bool placed = false;
+    for (uint32_t probe = 0; probe < 4096; ++probe) {
+      unsigned long long cur = __hip_atomic_load(&s.g_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == 0) {
+        cur = atomicCAS(&s.g_key[h], 0ull, gk);
+        if (cur == 0) atomicAdd(s.g_count, 1ull);
+      }
+      if (cur == 0 || cur == gk) { placed = true; break; }
+      h = (h + 1) & s.g_mask;
+    }
+    if (!placed) atomicOr(s.err, 4u);
+  }
+}
+
+// the open unit (index `unit`) moves on to the next batch: its encodings and its (unit, slot) statistics
+__global__ void ku_sparse_carry_out_kernel(KuSparseDev s, uint32_t unit, unsigned long long *carry_l, uint32_t *carry_u,
+                                           unsigned long long *counters, uint64_t cap_l, uint64_t cap_u) {
+  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i <= s.l_mask) {
+      const unsigned long long key = s.l_key[i];
+      if (key && (uint32_t)(key >> 50) - 1 == unit && !s.dense[(uint32_t)(key >> 32) & 0x3FFFFu]) {
+        const unsigned long long e = atomicAdd(&counters[0], 1ull);
+        if (e < cap_l) carry_l[e] = key & 0x3FFFFFFFFFFFFull;  // slot << 32 | encoding
+        else atomicOr(s.err, 1u);
+      }
+    }
+    if (i <= s.u_mask) {
+      const unsigned long long key = s.u_key[i];
+      if (key && (uint32_t)(key >> 32) - 1 == unit && !s.dense[(uint32_t)key]) {
+        const unsigned long long e = atomicAdd(&counters[1], 1ull);
+        if (e < cap_u) {
+          carry_u[3 * e] = (uint32_t)key;
+          carry_u[3 * e + 1] = s.u_distinct[i];
+          carry_u[3 * e + 2] = s.u_last[i] > s.u_maxfirst[i] ? 1u : 0u;  // all that later inserts need of the order
+        } else atomicOr(s.err, 2u);
+      }
+    }
+  }
+}
+// ... and re-enters as unit 0: carried encodings sit at position 0, the carried "last insert" at 0 or 1
+__global__ void ku_sparse_carry_in_kernel(KuSparseDev s, const unsigned long long *carry_l, uint64_t n_l, const uint32_t *carry_u,
+                                          uint64_t n_u) {
+  const uint64_t n = n_l > n_u ? n_l : n_u;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i < n_l) {
+      const unsigned long long key = (1ull << 50) | carry_l[i];
+      uint64_t h = ks_mix(key) & s.l_mask;
+      for (uint32_t probe = 0; probe < 4096; ++probe) {
+        unsigned long long cur = atomicCAS(&s.l_key[h], 0ull, key);
+        if (cur == 0 || cur == key) { s.l_first[h] = 0; break; }
+        h = (h + 1) & s.l_mask;
+        if (probe == 4095) atomicOr(s.err, 1u);
+      }
+    }
+    if (i < n_u) {
+      const uint64_t u = ks_u_cell(s, 0, carry_u[3 * i]);
+      if (u != ~0ull) {
+        s.u_distinct[u] = carry_u[3 * i + 1];
+        s.u_last[u] = carry_u[3 * i + 2];
+      }
+    }
+  }
+}
+
+// run's end: (slot, encoding) of every slot that stayed sparse
+__global__ void ku_sparse_export_kernel(KuSparseDev s, unsigned long long *out, uint64_t cap, unsigned long long *counter) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.g_mask; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long gk = s.g_key[i];
+    if (!gk) continue;
+    const uint32_t slot = (uint32_t)(gk >> 32) - 1;
+    if (s.dense[slot]) continue;
+    const unsigned long long e = atomicAdd(counter, 1ull);
+    if (e < cap) out[e] = ((unsigned long long)slot << 32) | (uint32_t)gk;
+  }
+}
+
+// ---------------------------------------------------------------------------- launch wrappers
+static unsigned ks_grid(uint64_t n) {
+  const uint64_t nb = (n + 255) / 256;
+  return (unsigned)(nb < 16384 ? (nb ? nb : 1) : 16384);
+}
+int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off,
+                            const uint32_t *d_seq_len, const uint32_t *d_unit, uint64_t n_reads, const uint32_t *d_taxa,
+                            uint32_t quick_min_hits, int n_cu, hipStream_t stream) {
+  if (n_reads == 0) return KU_OK;
+  const uint64_t cap = (uint64_t)n_cu * 32;
+  hipLaunchKernelGGL(ku_sparse_insert_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, s, k, d_seqs,
+                     d_seq_off, d_seq_len, d_unit, n_reads, d_taxa, quick_min_hits);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream) {
+  hipLaunchKernelGGL(ku_sparse_maxfirst_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s);
+  hipLaunchKernelGGL(ku_sparse_eval_kernel, dim3(ks_grid(s.u_mask + 1)), dim3(256), 0, stream, s, n_closed);
+  hipLaunchKernelGGL(ku_sparse_commit_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s, n_closed);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,
+                               unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream) {
+  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;
+  hipLaunchKernelGGL(ku_sparse_carry_out_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, s, unit, d_carry_l, d_carry_u, d_counters,
+                     cap_l, cap_u);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_carry_l, uint64_t n_l, const uint32_t *d_carry_u,
+                              uint64_t n_u, hipStream_t stream) {
+  const uint64_t n = n_l > n_u ? n_l : n_u;
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_sparse_carry_in_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, s, d_carry_l, n_l, d_carry_u, n_u);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL(ku_sparse_export_kernel, dim3(ks_grid(s.g_mask + 1)), dim3(256), 0, stream, s, d_out, cap, d_counter);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}

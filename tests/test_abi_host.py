@@ -305,3 +305,42 @@ def test_report_equals_dense_oracle_and_tracks_reference(golden, f1, fixture, re
         assert fa[:3] == fb[:3] and fa[6:] == fb[6:], (a, b)
         if fa[3] != "kmers":
             assert abs(int(fa[3]) - int(fb[3])) <= max(2, 3 * 0.01625 * int(fb[3])), (a, b)
+
+
+def _sparse_from_oracle(run, counts):
+    """the oracle's sparse / dense state per slot -> (slot_is_sparse, pairs) as ku_sparse_export would deliver them"""
+    c = run.counts()
+    flags = np.zeros(len(counts["slot_taxid"]), dtype=np.uint8)
+    pairs = []
+    for s, t in enumerate(counts["slot_taxid"].tolist()):
+        if t in c and c[t]["n_kmers"] and c[t]["sparse"]:
+            flags[s] = 1
+            pairs += [(s << 32) | int(e) for e in c[t]["sketch"].sparse_list()]
+    return flags, np.array(pairs, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("fixture,reads,unit,report", [("f1", "f1/reads.fq", 500000, "report.tsv"),
+                                                        ("f1", "f1/reads.fq", 1000, "report_u1000.tsv"),
+                                                        ("f2", "f2/edge.fa", 500000, "report.tsv"),
+                                                        ("f4", "f4/merged.fa", 500000, "report.tsv")])
+def test_report_with_sparse_sketches_equals_the_reference(golden, f1, fixture, reads, unit, report):
+    """ku_report_sparse fed with the oracle's per-taxon state (dense registers of every slot, which sketches stayed
+    sparse and their encoded hashes) reproduces the reference's report row for row -- no estimator allowance"""
+    d = f1["dir"]
+    ids, seqs = synth.read_seqfile(os.path.join(golden, reads))
+    run = ko.Run(ko.Db(f"{d}/database.kdb", f"{d}/database.idx"), ko.Tax(f"{d}/taxDB"), work_unit_nt=unit)
+    run.classify(seqs)
+    counts = _counts_from_oracle(run)
+    flags, pairs = _sparse_from_oracle(run, counts)
+    got = capi.report_sparse(f1["tax"], counts, flags, pairs, [f"{d}/database.kdb.counts"])
+    assert rows(got) == rows(open(os.path.join(golden, fixture, report)).read())
+    assert flags.any() or unit == 500000
+
+
+def test_sparse_estimator_known_answers():
+    """the default-constructed (sparse) sketch of the reference on x * 0x9E3779B97F4A7C15"""
+    for n, want in ((1, 1), (10, 10), (100, 100), (1000, 1000), (1023, 1023), (1024, 1024)):
+        h = ko.Hll(12, True)
+        h.insert_seq(n, 0x9E3779B97F4A7C15)
+        assert h.is_sparse
+        assert capi.hll_cardinality_sparse(h.sparse_list(), 1 << 40) == want == h.cardinality(False)

@@ -53,14 +53,9 @@ def test_outputs_match_reference(tmp_path):
     assert (shutil_db / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
     text = rep.read_text()
     assert text.startswith("# header written by the wrapper\n%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n")
-    ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{F1}/report.tsv").read().strip().split("\n")}
     got = text.strip().split("\n")[1:]  # column header + rows
-    assert len(got) == len(ref)
-    for ln in got:
-        f = ln.split("\t")
-        assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
-        if f[3] != "kmers":
-            assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
+    # row for row the reference's report, `kmers` / `dup` / `cov` included (HLL sparse-mode emulation)
+    assert sorted(got) == rows(open(f"{F1}/report.tsv").read())
     err = r.stderr.decode()
     assert "1000 sequences (0.15 Mbp) processed in" in err and "sequences classified (74.10%)" in err
     # stdout default, quick mode, -c, -s, gz output, -o off
@@ -73,10 +68,18 @@ def test_outputs_match_reference(tmp_path):
     assert gzip.open(gz).read() == open(f"{F1}/out.tsv", "rb").read()
     r = run(db + ["-o", "off", f"{F1}/reads.fq"])
     assert r.returncode == 0 and r.stdout == b""
-    # -u splits the input into several batches: same output, same per-taxon state
-    r = run(db + ["-u", "1", "-o", str(out), "-r", str(tmp_path / "r2.tsv"), f"{F1}/reads.fq"])
-    assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
-    assert rows((tmp_path / "r2.tsv").read_text()) == sorted(got)
+    # -u 1000: every per-unit sketch stays sparse (the reference's report_u1000.tsv); small GPU batches on top
+    r = run(db + ["-u", "1000", "-o", str(out), "-r", str(tmp_path / "r2.tsv"), f"{F1}/reads.fq"], env={**os.environ, "KU_BATCH_NT": "65536"})
+    assert out.read_bytes() == open(f"{F1}/out_u1000.tsv", "rb").read()
+    assert rows((tmp_path / "r2.tsv").read_text()) == rows(open(f"{F1}/report_u1000.tsv").read())
+    # without the emulation: dense estimates, everything else identical
+    r = run(db + ["-o", str(out), "-r", str(tmp_path / "r3.tsv"), f"{F1}/reads.fq"], env={**os.environ, "KU_NO_SPARSE": "1"})
+    ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{F1}/report.tsv").read().strip().split("\n")}
+    for ln in (tmp_path / "r3.tsv").read_text().strip().split("\n"):
+        f = ln.split("\t")
+        assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
+        if f[3] != "kmers":
+            assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
 
 
 @pytest.mark.gpu
@@ -122,14 +125,7 @@ def test_hierarchical_multi_db_run(tmp_path):
         r = run(first + second + ["-o", str(out), "-r", str(rep)] + common)
         assert r.returncode == 0, r.stderr.decode()
         assert out.read_bytes() == open(f"{g}/f8/out{tag}.tsv", "rb").read()
-        ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{g}/f8/report{tag}.tsv").read().strip().split("\n")}
-        got = rep.read_text().strip().split("\n")
-        assert len(got) == len(ref)
-        for ln in got:
-            f = ln.split("\t")
-            assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
-            if f[3] != "kmers":
-                assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
+        assert rows(rep.read_text()) == rows(open(f"{g}/f8/report{tag}.tsv").read())  # row for row, `kmers` included
     for name in ("f1", "f8"):
         assert (dirs[name] / "database.kdb.counts").read_text() == open(f"{g}/{name}/database.kdb.counts").read()
     assert run(a + b + ["-q", "-m", "2"] + common).stdout == open(f"{g}/f8/out_quick.tsv", "rb").read()
@@ -151,14 +147,7 @@ def test_out_of_core_chunked_run(tmp_path, size):
     assert b"Streaming the database through the GPU in" in r.stderr
     assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
     assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
-    ref = {ln.split("\t")[6]: ln.split("\t") for ln in open(f"{F1}/report_chunk.tsv").read().strip().split("\n")}
-    got = rep.read_text().strip().split("\n")
-    assert len(got) == len(ref)
-    for ln in got:
-        f = ln.split("\t")
-        assert f[:3] == ref[f[6]][:3] and f[6:] == ref[f[6]][6:]
-        if f[3] != "kmers":
-            assert abs(int(f[3]) - int(ref[f[6]][3])) <= max(2, 3 * 0.01625 * int(ref[f[6]][3]))
+    assert rows(rep.read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())  # row for row, `kmers` included
     # identical to the run with everything resident, FASTA + second file included
     g = os.path.join(ROOT, "tests", "golden")
     r1 = run(db + ["-x", size, f"{g}/f2/edge.fa", f"{g}/f4/merged.fa"])

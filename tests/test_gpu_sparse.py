@@ -1,0 +1,201 @@
+"""-m gpu: HyperLogLog++ sparse-mode emulation (ku_ctx_enable_sparse / ku_sparse_export / ku_report_sparse, SURVEY 8a
+A13/A14): the report equals the reference's row for row -- no estimator allowance -- and, stronger, every taxon's
+sparse / dense state and its set of encoded hashes equal the oracle's (which is pinned to the reference's reports)."""
+import os
+
+import numpy as np
+import pytest
+
+from krakenuniq_amd import capi, synth
+from oracle import ku_oracle as ko
+import gpu_common as gc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+F1 = os.path.join(G, "f1")
+K = 31
+
+
+def rows(text):
+    return sorted(text.strip("\n").split("\n"))
+
+
+def split_points(n, k, seed):
+    rng = np.random.default_rng(seed)
+    cuts = sorted(set(rng.integers(1, n, size=k - 1).tolist()))
+    return [0] + cuts + [n]
+
+
+def classify_in_batches(ctx, buf, off, lens, cuts, **kw):
+    """host batches [cuts[i], cuts[i+1]) of the reads, in order"""
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo = int(off[a])
+        hi = int(off[b]) if b < len(off) else len(buf)
+        out.append(ctx.classify_batch_rle(buf[lo:hi], off[a:b] - lo, lens[a:b], **kw))
+    return out
+
+
+def assert_sparse_state_equals_oracle(ctx, run):
+    counts = ctx.counts()
+    flags, pairs = ctx.sparse_export()
+    want = run.counts()
+    slot_of = {int(t): s for s, t in enumerate(counts["slot_taxid"])}
+    got_sets = {}
+    for p in pairs.tolist():
+        got_sets.setdefault(p >> 32, set()).add(p & 0xFFFFFFFF)
+    n_sparse = n_dense = 0
+    for t, c in want.items():
+        if not c["n_kmers"]:
+            continue
+        s = slot_of[t]
+        assert bool(flags[s]) == c["sparse"], (t, c["n_kmers"])
+        if c["sparse"]:
+            assert got_sets.get(s, set()) == set(c["sketch"].sparse_list().tolist()), t
+            n_sparse += 1
+        else:
+            n_dense += 1
+    return counts, flags, pairs, n_sparse, n_dense
+
+
+@pytest.mark.parametrize("fixture,reads,unit,report,n_batches", [
+    ("f1", "f1/reads.fq", 500000, "report.tsv", 1), ("f1", "f1/reads.fq", 500000, "report.tsv", 5),
+    ("f1", "f1/reads.fq", 1000, "report_u1000.tsv", 1), ("f1", "f1/reads.fq", 1000, "report_u1000.tsv", 7),
+    ("f2", "f2/edge.fa", 500000, "report.tsv", 1), ("f4", "f4/merged.fa", 500000, "report.tsv", 3)])
+def test_report_equals_the_reference(fixture, reads, unit, report, n_batches):
+    ids, seqs = synth.read_seqfile(os.path.join(G, reads))
+    buf, off, lens = ko.pack_reads(seqs)
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    ctx.enable_sparse(unit)
+    classify_in_batches(ctx, buf, off, lens, split_points(len(seqs), n_batches, 11) if n_batches > 1 else [0, len(seqs)])
+    run = ko.Run(ko.Db(f"{F1}/database.kdb", f"{F1}/database.idx"), ko.Tax(f"{F1}/taxDB"), work_unit_nt=unit)
+    run.classify(seqs)
+    counts, flags, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(ctx, run)
+    gc.assert_same_counts(counts, run)
+    got = capi.report_sparse(ctax, counts, flags, pairs, [f"{F1}/database.kdb.counts"])
+    assert rows(got) == rows(open(os.path.join(G, fixture, report)).read())
+    if fixture == "f1":
+        assert (n_sparse > 0 and n_dense > 0) if unit == 500000 else n_dense == 0
+
+
+def test_whole_run_as_one_unit_equals_the_chunk_mode_report():
+    """-x: the reference inserts into the global sketches directly (classify.cpp:719): work_unit_nt = 0"""
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    cdb = capi.Db(f"{F1}/database.kdb", f"{F1}/database.idx")
+    ctax = capi.Tax(f"{F1}/taxDB")
+    bounds = cdb.chunk_plan(70 << 10)
+    bounds[-1] = cdb.info.n_bins
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdb, int(bounds[0]), int(bounds[1]))
+    ctx.set_taxonomy(ctax, cdb.values())
+    ctx.enable_sparse(0)
+    cuts = split_points(len(seqs), 4, 5)
+    batches = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(off[a]), (int(off[b]) if b < len(off) else len(buf))
+        batches.append(ctx.batch(buf[lo:hi], off[a:b] - lo, lens[a:b]))
+    for c in range(len(bounds) - 1):
+        if c:
+            ctx.swap_shard(cdb, int(bounds[c]), int(bounds[c + 1]))
+        for bt in batches:
+            bt.lookup()
+    for bt in batches:
+        bt.finish()
+    counts = ctx.counts()
+    flags, pairs = ctx.sparse_export()
+    got = capi.report_sparse(ctax, counts, flags, pairs, [f"{F1}/database.kdb.counts"])
+    assert rows(got) == rows(open(f"{F1}/report_chunk.tsv").read())
+
+
+@pytest.mark.parametrize("order", ["", "_swapped"])
+def test_hierarchical_two_database_report(order):
+    d8 = os.path.join(G, "f8")
+    dirs = [F1, d8] if order == "" else [d8, F1]
+    cdbs = [capi.Db(f"{x}/database.kdb", f"{x}/database.idx") for x in dirs]
+    ctax = capi.Tax(f"{F1}/taxDB")
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdbs[0])
+    ctx.add_db(cdbs[1])
+    ctx.set_taxonomy(ctax)
+    ctx.enable_sparse()
+    ids, seqs = synth.read_seqfile(f"{d8}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    rle = ctx.classify_batch_rle(buf, off, lens)
+    assert capi.format_kraken_rle(buf, off, lens, ids, K, rle) == open(f"{d8}/out{order}.tsv").read()
+    counts = ctx.counts()
+    flags, pairs = ctx.sparse_export()
+    got = capi.report_sparse(ctax, counts, flags, pairs, [f"{x}/database.kdb.counts" for x in dirs])
+    assert rows(got) == rows(open(f"{d8}/report{order}.tsv").read())
+
+
+def test_quick_mode_books_the_scanned_prefix_only():
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    ctx.enable_sparse(20000)
+    classify_in_batches(ctx, buf, off, lens, split_points(len(seqs), 3, 2), flags=capi.KU_F_QUICK, min_hits=2)
+    run = ko.Run(ko.Db(f"{F1}/database.kdb", f"{F1}/database.idx"), ko.Tax(f"{F1}/taxDB"), work_unit_nt=20000, quick=True,
+                 min_hits=2)
+    run.classify(seqs)
+    counts, flags, pairs, *_ = assert_sparse_state_equals_oracle(ctx, run)
+    assert rows(capi.report_sparse(ctax, counts, flags, pairs, [f"{F1}/database.kdb.counts"])) == \
+        rows(run.report(f"{F1}/taxDB", f"{F1}/database.kdb.counts"))
+
+
+def test_files_close_their_last_unit():
+    """work units do not span input files: ku_sparse_close_unit between them"""
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    a, b = seqs[:400], seqs[400:]
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    ctx.enable_sparse(40000)
+    odb, otax = ko.Db(f"{F1}/database.kdb", f"{F1}/database.idx"), ko.Tax(f"{F1}/taxDB")
+    run = ko.Run(odb, otax, work_unit_nt=40000)
+    for part in (a, b):
+        buf, off, lens = ko.pack_reads(part)
+        ctx.sparse_close_unit()
+        ctx.classify_batch_rle(buf, off, lens)
+        run.classify(part)  # one call = one input file: its last, partial unit closes
+    assert_sparse_state_equals_oracle(ctx, run)
+
+
+@pytest.mark.parametrize("unit,seed", [(30000, 1), (150000, 2), (7000, 3)])
+def test_random_database_mixed_sparse_and_dense_taxa(unit, seed):
+    """taxa of very different abundance, several work units, uneven batches: which sketches switch to dense and the
+    exact sets of the ones that do not"""
+    rng = np.random.default_rng(seed)
+    db = gc.random_db(rng, n_genomes=8, glen=6000, k=K, nt=9)
+    tax = db["tax"]
+    weights = np.array([200, 60, 20, 8, 3, 1, 1, 0.3])
+    weights = weights / weights.sum()
+    sp = list(db["genomes"])
+    seqs = []
+    for _ in range(6000):
+        if rng.random() < 0.1:
+            seqs.append(bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(80, 200))).tobytes()))
+            continue
+        g = db["genomes"][sp[int(rng.choice(len(sp), p=weights))]]  # 2-bit codes
+        n = int(rng.integers(60, 260))
+        s = int(rng.integers(0, len(g) - n))
+        c = g[s:s + n]
+        r = bytearray(synth.codes_to_ascii(c if rng.random() < 0.5 else synth.revcomp_codes(c)))
+        if rng.random() < 0.3:
+            r[int(rng.integers(0, n))] = ord("N")
+        seqs.append(bytes(r))
+    buf, off, lens = ko.pack_reads(seqs)
+    ids, par = tax.arrays()
+    ctax, otax = capi.Tax(ids=ids, parents=par), ko.Tax(ids=ids, parents=par)
+    raw = db["pairs"].view(np.uint8).reshape(-1)
+    cdb = capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=K, offsets=db["offsets"], nt=9)
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=K, offsets=db["offsets"], nt=9)
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdb)
+    ctx.set_taxonomy(ctax)
+    ctx.enable_sparse(unit)
+    classify_in_batches(ctx, buf, off, lens, split_points(len(seqs), 6, seed))
+    run = ko.Run(odb, otax, work_unit_nt=unit)
+    run.classify(seqs)
+    counts, flags, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(ctx, run)
+    gc.assert_same_counts(counts, run)
+    assert n_sparse > 0 and n_dense > 0
