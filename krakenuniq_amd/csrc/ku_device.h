@@ -89,13 +89,17 @@ __device__ __forceinline__ void ku_ct_maybe_flush(uint32_t *ct_key, uint32_t *ct
 // The plain pre-check load may be stale (other CUs' updates are not visible in
 // this CU's L1) -- stale values are only ever too small, so the worst case is a
 // redundant CAS, never a lost update.
-__device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot, uint64_t h) {
+// two steps so that a caller with several k-mers in flight can request all their register bytes before it looks at
+// the first one (one memory round trip instead of one per k-mer)
+__device__ __forceinline__ uint8_t *ku_hll_locate(uint8_t *registers, uint32_t slot, uint64_t h, uint32_t &rank) {
   // h = ku_fmix64(canonical k-mer)
-  uint32_t idx = (uint32_t)(h >> (64 - KU_HLL_P));
-  uint64_t rest = h << KU_HLL_P;
-  uint32_t rank = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KU_HLL_P + 1);
-  uint8_t *r = registers + (size_t)slot * KU_HLL_M + idx;
-  if (*r < rank) {
+  const uint32_t idx = (uint32_t)(h >> (64 - KU_HLL_P));
+  const uint64_t rest = h << KU_HLL_P;
+  rank = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KU_HLL_P + 1);
+  return registers + (size_t)slot * KU_HLL_M + idx;
+}
+__device__ __forceinline__ void ku_hll_raise(uint8_t *r, uint32_t seen, uint32_t rank) {
+  if (seen < rank) {
     uint32_t *w = (uint32_t *)((uintptr_t)r & ~(uintptr_t)3);
     uint32_t sh = ((uint32_t)(uintptr_t)r & 3u) * 8;
     uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -106,6 +110,11 @@ __device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot,
       old = prev;
     }
   }
+}
+__device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot, uint64_t h) {
+  uint32_t rank;
+  uint8_t *r = ku_hll_locate(registers, slot, h, rank);
+  ku_hll_raise(r, *r, rank);
 }
 
 // ----------------------------------------------------------------------------
@@ -242,7 +251,8 @@ __device__ __forceinline__ uint64_t ku_locus_assemble(uint64_t canon, uint32_t k
   const uint32_t left = ap, right = w - 1 - ap;
   const bool use_r = right >= left;
   const uint32_t side = use_r ? right : left;
-  const uint32_t flen = side < KU_FLANK ? side : KU_FLANK;
+  // the longer side is at least (w - 1) / 2 positions long: a constant flank length for the usual windows
+  const uint32_t flen = (w - 1) / 2 >= KU_FLANK ? (uint32_t)KU_FLANK : (side < KU_FLANK ? side : KU_FLANK);
   // right flank = offsets [ap+m, ap+m+flen), left flank = [ap-flen, ap); one past the flank's last base:
   const uint32_t end = use_r ? ap + m + flen : ap;
   // bases [end - flen, end) of that strand; on the other strand they are the reverse complement of bases
@@ -277,7 +287,7 @@ __device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lin
   g ^= g >> 15;
   g *= 0x2C1B3C6Du;
   g ^= g >> 13;
-  return __umulhi(g, (uint32_t)n_lines);
+  return __umulhi(g, (uint32_t)n_lines);  // (a 2-multiply variant filled the buckets unevenly: 43 ms instead of 20)
 }
 
 // lca() in node space (krakenutil.cpp:90-118).  Nodes are ranks of taxids in a

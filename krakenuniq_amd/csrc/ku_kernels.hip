@@ -140,8 +140,9 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       pk[j] = 0;
       if (j == KU_ITEMS && (!NEED_MIN || p >= n_pos)) break;
       uint32_t wi = p >> 4, sh = (p & 15u) * 2;
-      uint64_t hi = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
-      uint64_t x = sh ? ((hi << sh) | (uint64_t)(s_codes[wi + 2] >> (32 - sh))) : hi;  // 32 bases from p
+      const uint32_t c0 = s_codes[wi], c1 = s_codes[wi + 1], c2 = s_codes[wi + 2];
+      // 32 bases from p: two 64-bit shifts, no special case for sh = 0
+      uint64_t x = ((((uint64_t)c0 << 32) | c1) << sh >> 32 << 32) | ((((uint64_t)c1 << 32) | c2) << sh >> 32);
       if (NEED_MIN) {  // m-mer starting at p, canonical, scrambled (krakendb.cpp:209)
         uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
         uint32_t mrc = ku_revcomp32(mm, m);
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         hh[j] = ku_fmix64(canon[j]);
-        lp[j] = tab + ku_locus_line(ok[j] ? locus[j] : 0, db.n_lines) * KU_LINE_DWORDS;
+        lp[j] = tab + (ok[j] ? ku_locus_line(locus[j], db.n_lines) : 0) * KU_LINE_DWORDS;
         tag[j] = ku_table_tag(hh[j]);
         slot[j] = 0;
         act[j] = ok[j] && !(ablate & 1u) && !(PRIOR && prior[j]);

@@ -17,6 +17,9 @@
 #include "ku_device.h"
 
 #define KS_WAVES 4  // reads in flight per 256-thread block
+#ifndef KS_KCT_LOG2
+#define KS_KCT_LOG2 8
+#endif
 #define KS_PAD 16   // sentinel elements behind a read's last m-mer (the widest doubling step reads 16 positions ahead)
 #ifdef KU_ABLATION
 #define KS_ABL(bit) ((ablate & (bit)) != 0)
@@ -32,7 +35,7 @@ template <int ITEMS> struct KsGeom {
   static constexpr int NMM = MAXN + 64 + 32;                   // packed window elements: 64 * (ITEMS + 1) positions + the
                                                                // widest step (16) ahead; the last one is the dump slot
   static constexpr int TCAP_LOG2 = ITEMS <= 2 ? 8 : (ITEMS <= 4 ? 9 : 10);  // resolve table >= 2 * MAXN
-  static constexpr int KCT_LOG2 = 8;                           // n_kmers counter table (per wave)
+  static constexpr int KCT_LOG2 = KS_KCT_LOG2;                 // n_kmers counter table (per wave)
   static constexpr int RCT_LOG2 = 6;                           // n_reads counter table (per wave)
 };
 
@@ -50,6 +53,39 @@ __device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32
   for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
     uint32_t kk = key[i];
     if (kk) atomicAdd(&global[kk - 1], (unsigned long long)cnt[i]);
+    key[i] = 0;
+    cnt[i] = 0;
+  }
+  if (lane == 0) *used = 0;
+  ks_wave_sync();
+}
+
+// n_reads counter table of a wave: keys are taxonomy nodes, or KS_RCT_SLOT | slot for the reads that met a single
+// taxon (their node is looked up once per flush instead of once per read)
+#define KS_RCT_SLOT 0x40000000u
+__device__ __forceinline__ uint32_t ks_rct_node(uint32_t id, const KuTaxDev &tax) {
+  return (id & KS_RCT_SLOT) ? ((id & ~KS_RCT_SLOT) ? tax.slot_node[id & ~KS_RCT_SLOT] : 0u) : id;
+}
+template <int LOG2>
+__device__ __forceinline__ void ks_rct_add(uint32_t *key, uint32_t *cnt, uint32_t *used, uint32_t id, const KuTaxDev &tax,
+                                           unsigned long long *global) {
+  uint32_t h = (id * 2654435761u) >> (32 - LOG2);
+#pragma unroll 1
+  for (int probe = 0; probe < 8; ++probe) {
+    uint32_t cur = key[h];
+    if (cur == 0) { key[h] = id + 1; *used += 1; cur = id + 1; }  // one lane of the wave owns the table: no atomics
+    if (cur == id + 1) { cnt[h] += 1; return; }
+    h = (h + 1) & ((1u << LOG2) - 1);
+  }
+  atomicAdd(&global[ks_rct_node(id, tax)], 1ull);
+}
+template <int LOG2>
+__device__ __forceinline__ void ks_rct_flush(uint32_t *key, uint32_t *cnt, uint32_t *used, const KuTaxDev &tax,
+                                             unsigned long long *global, uint32_t lane) {
+  ks_wave_sync();
+  for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
+    uint32_t kk = key[i];
+    if (kk) atomicAdd(&global[ks_rct_node(kk - 1, tax)], (unsigned long long)cnt[i]);
     key[i] = 0;
     cnt[i] = 0;
   }
@@ -107,13 +143,47 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   ks_wave_sync();
 
   const uint64_t n_waves = (uint64_t)gridDim.x * KS_WAVES;
+#ifdef KS_PREFETCH
+  // software pipeline over the wave's reads: the text of the NEXT read is requested before the current one is worked
+  // on (its latency hides behind a whole read's worth of work), its length / offset one read earlier still
+  constexpr bool ONE_PASS = (G::NWORDS * 4 + 63) / 64 == 1;
+  uint64_t r_first = (uint64_t)blockIdx.x * KS_WAVES + wv;
+  uint32_t len_n = r_first < n_reads ? seq_len[r_first] : 0;
+  uint64_t off_n = r_first < n_reads ? seq_off[r_first] : 0;
+  uint32_t pre0 = 0, pre1 = 0;
+  bool pre_ok = false;
+  auto prefetch = [&](uint32_t plen, uint64_t poff) {
+    const uint32_t b0 = 4 * lane;
+    const uint64_t a = poff + b0, a0 = a & ~3ull;
+    pre_ok = ONE_PASS && b0 < plen && a0 + 8 <= n_bytes;
+    if (pre_ok) {
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(seqs + a0);
+      pre0 = q[0];
+      pre1 = q[1];
+    }
+  };
+  if (r_first < n_reads) prefetch(len_n, off_n);
+  uint32_t len_nn = r_first + n_waves < n_reads ? seq_len[r_first + n_waves] : 0;
+  uint64_t off_nn = r_first + n_waves < n_reads ? seq_off[r_first + n_waves] : 0;
+#endif
   for (uint64_t r = (uint64_t)blockIdx.x * KS_WAVES + wv; r < n_reads; r += n_waves) {
+#ifdef KS_PREFETCH
+    const uint32_t len = len_n;
+    const uint64_t off = off_n;
+    const uint32_t cur0 = pre0, cur1 = pre1;
+    const bool cur_ok = pre_ok;
+    len_n = len_nn;
+    off_n = off_nn;
+    if (r + n_waves < n_reads) prefetch(len_n, off_n); else pre_ok = false;
+    if (r + 2 * n_waves < n_reads) { len_nn = seq_len[r + 2 * n_waves]; off_nn = seq_off[r + 2 * n_waves]; }
+#else
     const uint32_t len = seq_len[r];
     const uint64_t off = seq_off[r];
+#endif
     const uint32_t n = len >= k ? len - k + 1 : 0;
     if (DO_COUNTS) {
       if (misc[0] > (1u << G::KCT_LOG2) / 2) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
-      if (misc[1] > (1u << G::RCT_LOG2) / 2) ks_ct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], cnt.n_reads, lane);
+      if (misc[1] > (1u << G::RCT_LOG2) / 2) ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
     }
     uint32_t v[ITEMS];  // slot of every k-mer (0 = miss or ambiguous)
     bool amb_k[ITEMS];  // ambiguous k-mer (reported as KU_AMBIG)
@@ -132,6 +202,11 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
           const uint64_t a = off + b0;
           const uint64_t a0 = a & ~3ull;
           uint32_t d;
+#ifdef KS_PREFETCH
+          if (cur_ok && pl == lane) {
+            d = __builtin_amdgcn_alignbyte(cur1, cur0, (uint32_t)(a & 3ull));
+          } else
+#endif
           if (a0 + 8 <= n_bytes) {  // two aligned dwords cover the four bytes at any alignment
             const uint32_t *q = reinterpret_cast<const uint32_t *>(seqs + a0);
             d = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3ull));
@@ -173,8 +248,9 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         const uint32_t p = j * 64 + lane;
         wr[j] = p < P ? p : (uint32_t)G::NMM - 1u;
         const uint32_t wi = p >> 4, sh = (p & 15u) * 2;
-        const uint64_t hi = ((uint64_t)codes[wi] << 32) | codes[wi + 1];
-        const uint64_t x = sh ? ((hi << sh) | (uint64_t)(codes[wi + 2] >> (32 - sh))) : hi;
+        const uint32_t c0 = codes[wi], c1 = codes[wi + 1], c2 = codes[wi + 2];
+        // 32 bases from position p: two 64-bit shifts, no special case for sh = 0
+        const uint64_t x = ((((uint64_t)c0 << 32) | c1) << sh >> 32 << 32) | ((((uint64_t)c1 << 32) | c2) << sh >> 32);
         const uint32_t mm = (uint32_t)(x >> (64 - 2 * m));
         const uint32_t mrc = ku_revcomp32(mm, m);
         pk[j] = ku_pk_make((mm < mrc ? mm : mrc) ^ db.xor_mask, key_shift, mm <= mrc);
@@ -280,7 +356,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       for (int j = 0; j < ITEMS; ++j) {
         const uint64_t locus = ku_locus_assemble(canon[j], key[j], aoff[j], plus[j], k, m);
         hh[j] = ku_fmix64(canon[j]);
-        lp[j] = tab + ku_locus_line(ok[j] ? locus : 0, db.n_lines) * KU_LINE_DWORDS;
+        const uint64_t line = ku_locus_line(locus, db.n_lines);
+        lp[j] = tab + (ok[j] ? line : 0) * KU_LINE_DWORDS;  // idle lanes share bucket 0 (no stray line fetches)
         tag[j] = ku_table_tag(hh[j]);
         act[j] = ok[j] && !KS_ABL(1u);
         if (KS_ABL(64u)) lp[j] = tab;
@@ -367,7 +444,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) diff |= (v[j] != 0 && v[j] != first);
       if (!__any(diff)) {
-        call_node = first ? tax.slot_node[first] : 0u;  // at most one distinct hit taxon
+        // at most one distinct hit taxon: the call is that taxon (its taxid comes from the slot table below, the read
+        // counter is keyed by the slot)
         uni = true;
         uni_slot = first;
       } else {
@@ -453,10 +531,18 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     // k-mer; n_kmers per read when the read met one taxon at most (two counter updates instead of one per lane)
     if (DO_COUNTS && n > 0) {
       uint32_t n_hit = 0, n_miss = 0;
+      uint8_t *reg[ITEMS];
+      uint32_t rank[ITEMS], seen[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {  // every register byte is requested before the first one is looked at
+        const bool okc = j * 64 + lane < n && !amb_k[j];
+        reg[j] = ku_hll_locate(cnt.registers, okc ? v[j] : 0u, hh[j], rank[j]);
+        seen[j] = (okc && !KS_ABL(2u)) ? (uint32_t)*reg[j] : 0xFFu;
+      }
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
         const bool okc = j * 64 + lane < n && !amb_k[j];
-        if (okc && !KS_ABL(2u)) ku_hll_update(cnt.registers, v[j], hh[j]);
+        ku_hll_raise(reg[j], seen[j], rank[j]);
         if (uni) {
           n_hit += (uint32_t)__popcll(__ballot(okc && v[j] != 0));
           n_miss += (uint32_t)__popcll(__ballot(okc && v[j] == 0));
@@ -473,8 +559,10 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     // ---- outputs
     const uint32_t uni_code = uni && uni_slot ? tax.slot_taxid[uni_slot] : 0u;
     if (lane == 0) {
-      calls[r] = tax.node_taxid[call_node];
-      if (DO_COUNTS) ku_ct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], call_node, 1, cnt.n_reads);
+      calls[r] = uni ? uni_code : tax.node_taxid[call_node];
+      // incrementReadCount (classify.cpp:968): per node; single-taxon reads are booked under their slot and become
+      // nodes when the wave's table is flushed
+      if (DO_COUNTS) ks_rct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], uni ? (KS_RCT_SLOT | uni_slot) : call_node, tax, cnt.n_reads);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -486,7 +574,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   }
   if (DO_COUNTS) {
     ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
-    ks_ct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], cnt.n_reads, lane);
+    ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
   }
 }
 
