@@ -33,6 +33,28 @@ __device__ __forceinline__ uint32_t ku_revcomp32(uint32_t x, uint32_t n) {
   return (~r) >> (32 - 2 * n);
 }
 
+// ---- cross-lane helpers on the VALU's data-parallel-primitive path (no LDS crossbar trip as __shfl takes)
+// value of the quad neighbour lane ^ 1 / lane ^ 2
+__device__ __forceinline__ uint32_t ku_quad_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t ku_quad_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false); }
+// maximum over the wave, the same value in every lane (row shifts, then the two row broadcasts, lane 63 holds it)
+__device__ __forceinline__ uint32_t ku_wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t ku_wave_min_u32(uint32_t v) { return ~ku_wave_max_u32(~v); }
+// value of the lane below (lane 0 gets 0): wave_shr:1
+__device__ __forceinline__ uint32_t ku_wave_up1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, false); }
+// value of lane `src` (the same in every lane: e.g. from a ballot) in every lane
+__device__ __forceinline__ uint32_t ku_wave_bcast(uint32_t x, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, __builtin_amdgcn_readfirstlane((int)src));
+}
+
 // LDS-aggregated counters: id -> count, flushed to a global uint64 array.  `used` counts occupied
 // entries; callers flush + clear at a block-uniform point once the table is half full
 // (ku_ct_maybe_flush), so the 8-probe fallback to a global atomic stays rare whatever the

@@ -116,10 +116,10 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         ku_pack_dword(d, c8, a4);
       }
       uint32_t word = c8 << (24 - 8 * q4), amb = a4 << (12 - 4 * q4);
-      word |= (uint32_t)__shfl_xor((int)word, 1);
-      amb |= (uint32_t)__shfl_xor((int)amb, 1);
-      word |= (uint32_t)__shfl_xor((int)word, 2);
-      amb |= (uint32_t)__shfl_xor((int)amb, 2);
+      word |= ku_quad_xor1(word);
+      amb |= ku_quad_xor1(amb);
+      word |= ku_quad_xor2(word);
+      amb |= ku_quad_xor2(amb);
       if (q4 == 0) {
         s_codes[wi] = word;
         s_amb16[wi ^ 1u] = (uint16_t)amb;  // even word -> high half (little-endian uint16 view)
@@ -567,8 +567,7 @@ template <> struct KuResolveCfg<1> { static constexpr int GROUP = 1024, CAP_LOG2
 template <> struct KuResolveCfg<2> { static constexpr int GROUP = 256, CAP_LOG2 = 0, MAX_N = 0x7fffffff; };
 
 template <int GROUP> __device__ __forceinline__ uint32_t ku_group_max(uint32_t v, uint32_t *s_red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  v = ku_wave_max_u32(v);
   if (GROUP > 64) {
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
@@ -665,7 +664,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
         if (mine == 0) mine = v[c];
       }
       unsigned long long bal = __ballot(mine != 0);
-      uint32_t first = bal ? (uint32_t)__shfl((int)mine, __ffsll((long long)bal) - 1) : 0u;
+      uint32_t first = bal ? ku_wave_bcast(mine, (uint32_t)__ffsll((long long)bal) - 1) : 0u;
       bool diff = false;
 #pragma unroll
       for (int c = 0; c < NV; ++c) diff |= (v[c] != 0 && v[c] != first);
@@ -711,7 +710,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
         unsigned long long todo = __ballot(active);
         while (todo) {
           const int leader = __ffsll((long long)todo) - 1;
-          const uint32_t ls = (uint32_t)__shfl((int)s, leader);
+          const uint32_t ls = ku_wave_bcast(s, (uint32_t)leader);
           const unsigned long long same = __ballot(active && s == ls);
           if ((int)(tid & 63u) == leader) table_insert(ls, (uint32_t)__popcll(same));
           todo &= ~same;
@@ -905,7 +904,7 @@ __global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev 
         bool is_stop = hit && before + 1 == need;
         unsigned long long sm = __ballot(is_stop);
         uint32_t lane = (uint32_t)__ffsll((long long)sm) - 1;
-        call_slot = (uint32_t)__shfl((int)s, (int)lane);
+        call_slot = ku_wave_bcast(s, lane);
         stop = base + lane + 1;
         total = min_hits;
         break;
@@ -1023,11 +1022,11 @@ __global__ __launch_bounds__(64) void ku_rle_kernel(const uint32_t *__restrict__
     for (uint32_t base = 0; base < n; base += 64) {
       const uint32_t i = base + lane;
       const uint32_t v = i < n ? taxa[off + i] : 0u;
-      uint32_t prev = (uint32_t)__shfl_up((int)v, 1);
+      uint32_t prev = ku_wave_up1(v);
       if (lane == 0) prev = carry;
       const bool start = i < n && (i == 0 || v != prev);
       total += (uint32_t)__popcll(__ballot(start));
-      carry = (uint32_t)__shfl((int)v, 63);
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
     }
     unsigned long long basep = 0;
     if (lane == 0) {
@@ -1043,13 +1042,13 @@ __global__ __launch_bounds__(64) void ku_rle_kernel(const uint32_t *__restrict__
     for (uint32_t base = 0; base < n; base += 64) {
       const uint32_t i = base + lane;
       const uint32_t v = i < n ? taxa[off + i] : 0u;
-      uint32_t prev = (uint32_t)__shfl_up((int)v, 1);
+      uint32_t prev = ku_wave_up1(v);
       if (lane == 0) prev = carry;
       const bool start = i < n && (i == 0 || v != prev);
       const unsigned long long m = __ballot(start);
       if (start) runs[basep + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, i);
       done += (uint32_t)__popcll(m);
-      carry = (uint32_t)__shfl((int)v, 63);
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
     }
   }
 }

@@ -220,10 +220,10 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         }
         const uint32_t q4 = pl & 3u;
         uint32_t word = c8 << (24 - 8 * q4), ab = a4 << (12 - 4 * q4);
-        word |= (uint32_t)__shfl_xor((int)word, 1);
-        ab |= (uint32_t)__shfl_xor((int)ab, 1);
-        word |= (uint32_t)__shfl_xor((int)word, 2);
-        ab |= (uint32_t)__shfl_xor((int)ab, 2);
+        word |= ku_quad_xor1(word);
+        ab |= ku_quad_xor1(ab);
+        word |= ku_quad_xor2(word);
+        ab |= ku_quad_xor2(ab);
         const uint32_t wi = pl >> 2;
         if (q4 == 0 && wi < (uint32_t)G::NWORDS) {
           codes[wi] = word;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       for (int j = 0; j < ITEMS; ++j)
         if (mine == 0) mine = v[j];
       const unsigned long long bal = __ballot(mine != 0);
-      const uint32_t first = bal ? (uint32_t)__shfl((int)mine, __ffsll((long long)bal) - 1) : 0u;
+      const uint32_t first = bal ? ku_wave_bcast(mine, (uint32_t)__ffsll((long long)bal) - 1) : 0u;
       bool diff = false;
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) diff |= (v[j] != 0 && v[j] != first);
@@ -495,8 +495,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
           atomicAdd(&t_cnt[pos], score << 16);
           my_max = max(my_max, score);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o));
+        my_max = ku_wave_max_u32(my_max);
         ks_wave_sync();
         // winner; ties -> fold lca() in ascending taxid (= slot) order
         uint32_t last = 0, res = 0;
@@ -508,8 +507,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
             const uint32_t s = t_key[pos] - 1;
             if ((t_cnt[pos] >> 16) == my_max && s > last) my_min = min(my_min, s);
           }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, o));
+          my_min = ku_wave_min_u32(my_min);
           if (my_min == 0xFFFFFFFFu) break;
           const uint32_t node = tax.slot_node[my_min];
           res = firstt ? node : ku_lca_nodes(tax.node_parent, res, node);  // uniform: every lane computes the same
