@@ -80,19 +80,11 @@ def host_cores():
 
 def make_batch(db, a, seed, dev):
     """one batch of reads in HBM: (seqs uint8 flat, seq_off int64, seq_len int32, read_len)"""
+    if a.paired:  # both mates from one fragment, merged as read_merger.pl does: seq1 . "N" . seq2
+        d_seqs, d_off, d_len = db.sample_pairs(a.reads, a.read_len, seed=seed)
+        return d_seqs, d_off, d_len, 2 * a.read_len + 1
     d_seqs, d_off, d_len, _ = db.sample_reads(a.reads, a.read_len, seed=seed)
     L = a.read_len
-    if a.paired:  # read_merger.pl semantics: seq1 . "N" . seq2 (scripts/read_merger.pl:187-191)
-        m2, _, _, _ = db.sample_reads(a.reads, L, seed=seed + 1000)
-        merged = torch.empty((a.reads, 2 * L + 2), dtype=torch.uint8, device=dev)
-        merged[:, :L] = d_seqs.view(a.reads, L + 1)[:, :L]
-        merged[:, L] = 78
-        merged[:, L + 1:2 * L + 1] = m2.view(a.reads, L + 1)[:, :L]
-        merged[:, 2 * L + 1] = 10
-        d_seqs = merged.reshape(-1)
-        d_off = torch.arange(a.reads, device=dev, dtype=torch.int64) * (2 * L + 2)
-        d_len = torch.full((a.reads,), 2 * L + 1, dtype=torch.int32, device=dev)
-        L = 2 * L + 1
     return d_seqs.reshape(-1), d_off, d_len, L
 
 

@@ -375,7 +375,7 @@ struct ku_ctx {
   // taxonomy tables
   std::vector<uint32_t> h_node_taxid, h_slot_taxid;
   uint32_t *d_node_parent = nullptr, *d_node_slot = nullptr, *d_node_taxid = nullptr, *d_slot_node = nullptr,
-           *d_slot_taxid = nullptr;
+           *d_slot_taxid = nullptr, *d_slot_anc_off = nullptr, *d_slot_anc = nullptr;
   KuTaxDev tax{};
   // run state
   KuCountsDev cnt{};
@@ -447,7 +447,8 @@ static void ctx_free_db(ku_ctx *ctx) {
   ctx->db_loaded = false;
 }
 static void ctx_free_tax(ku_ctx *ctx) {
-  for (uint32_t **p : {&ctx->d_node_parent, &ctx->d_node_slot, &ctx->d_node_taxid, &ctx->d_slot_node, &ctx->d_slot_taxid}) {
+  for (uint32_t **p : {&ctx->d_node_parent, &ctx->d_node_slot, &ctx->d_node_taxid, &ctx->d_slot_node, &ctx->d_slot_taxid,
+                       &ctx->d_slot_anc_off, &ctx->d_slot_anc}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -728,6 +729,18 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
     slot_node[s] = nd;
     node_slot[nd] = (uint32_t)s;
   }
+  // root paths in slot space (same walk, same 4096-step guard as the kernels' parent chase had)
+  std::vector<uint32_t> anc_off(slots.size() + 1, 0), anc;
+  for (size_t s = 0; s < slots.size(); ++s) {
+    anc_off[s] = (uint32_t)anc.size();
+    if (s == 0) continue;
+    uint32_t node = slot_node[s];
+    for (uint32_t guard = 0; node > 0 && guard < 4096; ++guard) {
+      if (node_slot[node]) anc.push_back(node_slot[node]);
+      node = node_parent[node];
+    }
+  }
+  anc_off[slots.size()] = (uint32_t)anc.size();
   ctx_free_tax(ctx);
   ctx->h_node_taxid = nodes;
   ctx->h_slot_taxid = slots;
@@ -736,11 +749,15 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
   KU_TRY(upload(&ctx->d_node_taxid, nodes));
   KU_TRY(upload(&ctx->d_slot_node, slot_node));
   KU_TRY(upload(&ctx->d_slot_taxid, slots));
+  KU_TRY(upload(&ctx->d_slot_anc_off, anc_off));
+  KU_TRY(upload(&ctx->d_slot_anc, anc));
   ctx->tax.node_parent = ctx->d_node_parent;
   ctx->tax.node_slot = ctx->d_node_slot;
   ctx->tax.node_taxid = ctx->d_node_taxid;
   ctx->tax.slot_node = ctx->d_slot_node;
   ctx->tax.slot_taxid = ctx->d_slot_taxid;
+  ctx->tax.slot_anc_off = ctx->d_slot_anc_off;
+  ctx->tax.slot_anc = ctx->d_slot_anc;
   ctx->tax.n_nodes = (uint32_t)nodes.size();
   ctx->tax.n_slots = (uint32_t)slots.size();
   ctx->tax.node_one = 1;

@@ -35,6 +35,11 @@ struct KuTaxDev {
   const uint32_t *node_taxid;
   const uint32_t *slot_node;
   const uint32_t *slot_taxid;
+  // root path of every slot, reduced to the nodes that are database values (only those can carry hit counts):
+  // slot_anc[slot_anc_off[s] .. slot_anc_off[s + 1]) = s itself, then its ancestors' slots in walk order.  resolve_tree's
+  // score (krakenutil.cpp:157-177) becomes a scan of one short list instead of a chain of dependent parent lookups.
+  const uint32_t *slot_anc_off;
+  const uint32_t *slot_anc;
   uint32_t n_nodes, n_slots;    // n_slots includes slot 0
   uint32_t node_one;            // node of taxid 1 (0xFFFFFFFF if absent)
   uint32_t pad;

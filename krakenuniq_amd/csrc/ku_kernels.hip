@@ -408,9 +408,21 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     for (int j = 0; j < KU_ITEMS; ++j) {
       uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
       if (PRIOR && prior[j]) slot[j] = prior[j];
-      if (DO_COUNTS && ok[j]) {
-        if (!(ablate & 2u)) ku_hll_update(cnt.registers, slot[j], hh[j]);
-        if (!(ablate & 4u)) ku_ct_add(s_ctk, s_ctc, &s_ctu, slot[j], 1, cnt.n_kmers);
+      if (DO_COUNTS) {
+        if (ok[j] && !(ablate & 2u)) ku_hll_update(cnt.registers, slot[j], hh[j]);
+        // n_kmers: neighbouring k-mers mostly carry one slot -- when the whole wave agrees, one lane books them all
+        // (one LDS update instead of 64 on the same word)
+        const bool okc = ok[j] && !(ablate & 4u);
+        const unsigned long long booked = __ballot(okc);
+        if (booked) {
+          const uint32_t lead = (uint32_t)__ffsll((long long)booked) - 1;
+          const uint32_t s0 = ku_wave_bcast(slot[j], lead);
+          if (__ballot(okc && slot[j] == s0) == booked) {
+            if ((tid & 63u) == lead) ku_ct_add(s_ctk, s_ctc, &s_ctu, s0, (uint32_t)__popcll(booked), cnt.n_kmers);
+          } else if (okc) {
+            ku_ct_add(s_ctk, s_ctc, &s_ctu, slot[j], 1, cnt.n_kmers);
+          }
+        }
       }
       if (pos < n_bytes && !(ablate & 8u) && !((ablate & KU_CTL_MERGE) && foreign[j])) {
         // ambiguous -> KU_AMBIG on every shard; not owned -> 0 (the owner's value wins the max-reduce)
@@ -613,6 +625,17 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
   __shared__ uint32_t s_ctu;
 
   const uint32_t tid = threadIdx.x;
+  // a one-wave group orders its own LDS traffic with a fence (the hardware runs a wave's DS operations in order); a
+  // block barrier would also drain every outstanding global load and store of the read pipeline below
+  auto gsync = [&]() {
+    if (GROUP == 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+    }
+  };
   const uint32_t cap_log2 = MODE == 2 ? ws_cap_log2 : (uint32_t)Cfg::CAP_LOG2;
   const uint32_t cap = 1u << cap_log2;
   uint32_t *t_key, *t_cnt, *t_score, *t_list;
@@ -640,26 +663,50 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
   }
   __syncthreads();
 
+  // MODE 0 keeps the read's codes in registers (<= 6 per lane) and short-cuts the common case of at most
+  // one distinct hit taxon: resolve_tree() then returns that taxon (or 0) without any tree walk.
+  constexpr int NV = MODE == 0 ? (Cfg::MAX_N + 63) / 64 : 1;
+  // MODE 0 is a chain of dependent memory round trips per read (length / offset -> codes -> slot table -> stores) with
+  // almost no arithmetic in between, so the wave runs a software pipeline over its reads: the codes of the NEXT read
+  // are requested before the current one is resolved, its length and offset one read earlier still.
+  const uint64_t stride = gridDim.x;
+  uint32_t p_len = 0, pp_len = 0, pv[NV];
+  uint64_t p_off = 0, pp_off = 0;
+  auto request_codes = [&](uint32_t plen, uint64_t poff) {
+    const uint32_t pn = plen >= k ? plen - k + 1 : 0;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const uint32_t i = c * 64 + tid;
+      pv[c] = (i < pn && pn <= (uint32_t)Cfg::MAX_N) ? taxa[poff + i] : 0u;
+    }
+  };
+  if (MODE == 0) {
+    const uint64_t r0 = blockIdx.x;
+    if (r0 < n_reads) { p_len = seq_len[r0]; p_off = seq_off[r0]; request_codes(p_len, p_off); }
+    if (r0 + stride < n_reads) { pp_len = seq_len[r0 + stride]; pp_off = seq_off[r0 + stride]; }
+  }
+
   for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-    const uint32_t len = seq_len[r];
+    const uint32_t len = MODE == 0 ? p_len : seq_len[r];
+    const uint64_t off = MODE == 0 ? p_off : seq_off[r];
+    uint32_t v[NV];
+    if (MODE == 0) {  // take what was requested for this read, request the next read's
+#pragma unroll
+      for (int c = 0; c < NV; ++c) v[c] = pv[c];
+      p_len = pp_len;
+      p_off = pp_off;
+      if (r + stride < n_reads) request_codes(p_len, p_off);
+      if (r + 2 * stride < n_reads) { pp_len = seq_len[r + 2 * stride]; pp_off = seq_off[r + 2 * stride]; }
+    }
     const uint32_t n = len >= k ? len - k + 1 : 0;
     if (n < min_n || n > (uint32_t)Cfg::MAX_N) continue;  // another MODE's launch handles it
-    const uint64_t off = seq_off[r];
-    ku_ct_maybe_flush<RCT>(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
-    if (tid == 0) s_n_list = 0;
-    __syncthreads();  // the list is appended to by whichever lane claims a table cell
+    if (GROUP > 64 || s_ctu > (1u << RCT) / 2) ku_ct_maybe_flush<RCT>(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
     uint32_t call_node = 0, uni_taxid = 0;
     bool resolved = false;
-    // MODE 0 keeps the read's codes in registers (<= 6 per lane) and short-cuts the common case of at most
-    // one distinct hit taxon: resolve_tree() then returns that taxon (or 0) without any tree walk.
-    constexpr int NV = MODE == 0 ? (Cfg::MAX_N + 63) / 64 : 1;
-    uint32_t v[NV];
     if (MODE == 0) {
       uint32_t mine = 0;
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
-        uint32_t i = c * 64 + tid;
-        v[c] = i < n ? taxa[off + i] : 0u;
         if (v[c] == KU_AMBIG) v[c] = 0;  // ambiguous k-mers carry no hit
         if (mine == 0) mine = v[c];
       }
@@ -676,6 +723,8 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
       }
     }
     if (!resolved) {
+    if (tid == 0) s_n_list = 0;
+    gsync();  // the list is appended to by whichever lane claims a table cell
     // ---- hit_counts[taxon]++ (classify.cpp:941-942)
     auto table_insert = [&](uint32_t s, uint32_t count) {
       uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
@@ -717,7 +766,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
         }
       }
     }
-    __syncthreads();
+    gsync();
     // every distinct taxon of the read is in the list now (appended by the lane that claimed its table cell -- no
     // scan over the table, which for the 16384-cell table of 10 kbp reads cost as much as the lookups)
     const uint32_t n_list = s_n_list;
@@ -726,29 +775,26 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
       uint32_t my_max = 0;
       for (uint32_t e = tid; e < n_list; e += GROUP) {
         uint32_t pos = MODE == 2 ? t_list[e] : (uint32_t)t_list16[e];
-        uint32_t node = tax.slot_node[t_key[pos] - 1];
+        const uint32_t sl = t_key[pos] - 1;
         uint32_t score = 0;
-        for (uint32_t guard = 0; node > 0 && guard < 4096; ++guard) {
-          uint32_t s = tax.node_slot[node];
-          if (s) {
-            uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
-            for (;;) {
-              uint32_t cur = t_key[h];
-              if (cur == s + 1) {
-                score += MODE == 2 ? t_cnt[h] : (t_cnt[h] & 0xffffu);
-                break;
-              }
-              if (cur == 0) break;
-              h = (h + 1) & (cap - 1);
+        for (uint32_t i = tax.slot_anc_off[sl], i_end = tax.slot_anc_off[sl + 1]; i < i_end; ++i) {
+          const uint32_t s = tax.slot_anc[i];
+          uint32_t h = (s * 2654435761u) >> (32 - cap_log2);
+          for (;;) {
+            uint32_t cur = t_key[h];
+            if (cur == s + 1) {
+              score += MODE == 2 ? t_cnt[h] : (t_cnt[h] & 0xffffu);
+              break;
             }
+            if (cur == 0) break;
+            h = (h + 1) & (cap - 1);
           }
-          node = tax.node_parent[node];
         }
         if (MODE == 2) t_score[pos] = score; else atomicAdd(&t_cnt[pos], score << 16);
         my_max = max(my_max, score);
       }
       const uint32_t max_score = ku_group_max<GROUP>(my_max, s_red);
-      __syncthreads();
+      gsync();
       // ---- winner; ties -> fold lca() over the tied taxa in ascending taxid (= slot) order
       uint32_t last = 0;  // slots are >= 1
       bool first = true;
@@ -768,11 +814,11 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
         }
         first = false;
         last = next;
-        __syncthreads();
+        gsync();
       }
-      __syncthreads();
+      gsync();
       call_node = s_bcast;
-      __syncthreads();
+      gsync();
       // ---- reset the used entries for the next read
       for (uint32_t e = tid; e < n_list; e += GROUP) {
         uint32_t pos = MODE == 2 ? t_list[e] : (uint32_t)t_list16[e];
@@ -802,7 +848,7 @@ __global__ __launch_bounds__(KuResolveCfg<MODE>::GROUP) void ku_resolve_kernel(
         }
       }
     }
-    __syncthreads();
+    gsync();
   }
   __syncthreads();
   ku_ct_flush<RCT>(s_ctk, s_ctc, cnt.n_reads);

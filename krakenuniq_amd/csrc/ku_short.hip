@@ -477,20 +477,17 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         uint32_t my_max = 0;
         for (uint32_t e = lane; e < n_list; e += 64) {
           const uint32_t pos = t_list[e];
-          uint32_t node = tax.slot_node[t_key[pos] - 1];
+          const uint32_t sl = t_key[pos] - 1;
           uint32_t score = 0;
-          for (uint32_t guard = 0; node > 0 && guard < 4096; ++guard) {
-            const uint32_t s = tax.node_slot[node];
-            if (s) {
-              uint32_t h = (s * 2654435761u) >> (32 - G::TCAP_LOG2);
-              for (;;) {
-                const uint32_t cur = t_key[h];
-                if (cur == s + 1) { score += t_cnt[h] & 0xffffu; break; }
-                if (cur == 0) break;
-                h = (h + 1) & (TCAP - 1);
-              }
+          for (uint32_t i = tax.slot_anc_off[sl], i_end = tax.slot_anc_off[sl + 1]; i < i_end; ++i) {
+            const uint32_t s = tax.slot_anc[i];
+            uint32_t h = (s * 2654435761u) >> (32 - G::TCAP_LOG2);
+            for (;;) {
+              const uint32_t cur = t_key[h];
+              if (cur == s + 1) { score += t_cnt[h] & 0xffffu; break; }
+              if (cur == 0) break;
+              h = (h + 1) & (TCAP - 1);
             }
-            node = tax.node_parent[node];
           }
           atomicAdd(&t_cnt[pos], score << 16);
           my_max = max(my_max, score);

@@ -255,6 +255,47 @@ class BenchDb:
         seq_len = torch.full((n_reads,), read_len, dtype=torch.int32, device=dev)
         return buf.reshape(-1), seq_off, seq_len, src
 
+    def sample_pairs(self, n_pairs: int, read_len: int = 150, seed: int = 1, frag_lo: int = 200, frag_hi: int = 600,
+                     frac_random: float = 0.2, sub_rate: float = 0.01, n_rate: float = 0.001, chunk: int = 1 << 20):
+        """mate pairs as a sequencer makes them: both mates read inwards from the two ends of ONE fragment of a
+        genome (mate 2 is the reverse complement of the fragment's far end).  Returns the merged records
+        mate1 + 'N' + mate2 (scripts/read_merger.pl:187-191) as an ASCII buffer [n_pairs, 2 * read_len + 2]
+        (last column '\\n'), seq_off int64, seq_len int32."""
+        dev = self.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        L = read_len
+        W = 2 * L + 2
+        buf = torch.empty((n_pairs, W), dtype=torch.uint8, device=dev)
+        ascii_tab = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+        ar = torch.arange(L, device=dev)
+        frag_lo = max(frag_lo, L)
+        for s0 in range(0, n_pairs, chunk):
+            n = min(chunk, n_pairs - s0)
+            sp = torch.randint(0, self.n_species, (n,), generator=g, device=dev)
+            fl = torch.randint(frag_lo, frag_hi + 1, (n,), generator=g, device=dev)
+            st = (torch.rand(n, generator=g, device=dev) * (self.G - fl).to(torch.float32)).to(torch.int64)
+            m1 = self.genomes[sp[:, None], st[:, None] + ar[None, :]].to(torch.int64)
+            m2 = 3 - self.genomes[sp[:, None], (st + fl)[:, None] - 1 - ar[None, :]].to(torch.int64)  # far end, reverse complemented
+            flip = torch.rand(n, generator=g, device=dev) < 0.5  # the fragment came from the other strand
+            a = torch.where(flip[:, None], m2, m1)
+            b = torch.where(flip[:, None], m1, m2)
+            both = torch.cat([a, b], 1)
+            sub = torch.rand((n, 2 * L), generator=g, device=dev) < sub_rate
+            both = torch.where(sub, (both + torch.randint(1, 4, (n, 2 * L), generator=g, device=dev)) & 3, both)
+            rnd = torch.rand(n, generator=g, device=dev) < frac_random
+            both = torch.where(rnd[:, None], torch.randint(0, 4, (n, 2 * L), generator=g, device=dev), both)
+            t = ascii_tab[both]
+            isn = torch.rand((n, 2 * L), generator=g, device=dev) < n_rate
+            t = torch.where(isn, torch.full_like(t, 78), t)
+            buf[s0:s0 + n, :L] = t[:, :L]
+            buf[s0:s0 + n, L + 1:2 * L + 1] = t[:, L:]
+        buf[:, L] = 78
+        buf[:, 2 * L + 1] = 10
+        seq_off = torch.arange(n_pairs, device=dev, dtype=torch.int64) * W
+        seq_len = torch.full((n_pairs,), 2 * L + 1, dtype=torch.int32, device=dev)
+        return buf.reshape(-1), seq_off, seq_len
+
     # ---- export (CPU baseline / parity sample)
     def write_files(self, dirname: str, slot_taxid: torch.Tensor = None):
         """database.kdb / database.idx / taxDB in the reference's on-disk format (full range only).
