@@ -12,6 +12,11 @@
 // Eligibility (checked by the launcher): hash layout, whole bin range resident (not a shard), no quick mode,
 // every read of the batch has at most 64 * ITEMS k-mers (ITEMS = 2 or 3: reads up to 222 bp at k = 31; paired
 // 2 x 150 and longer reads take the flat lookup + resolve kernels).
+// Lane <-> position mapping: lane L owns the positions L, 64 + L (, 128 + L), NOT neighbouring ones.  Measured: a variant
+// with two consecutive positions per lane (one window fetch and one 64-bit reverse complement shared by the pair, 60
+// instead of 104 instructions in stage 2) ran 30.7 ms against 19.4 ms -- a bucket-header load instruction then covers
+// every second k-mer, only two lanes instead of four share a bucket line per instruction, and the number of line
+// requests, the scarce resource of the probe, doubles.
 #include <cstdlib>
 
 #include "ku_device.h"
