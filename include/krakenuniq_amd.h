@@ -261,6 +261,13 @@ int ku_db_values(const ku_db *db, uint32_t *out, uint64_t *n);
 /* replace the resident shard by bins [bin_lo, bin_hi) of `db`, keeping taxonomy, slot numbering and per-taxon state;
  * the slot table given to ku_ctx_set_taxonomy must cover the new shard's values (KU_EINVAL otherwise) */
 int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi);
+/* Double buffering of the chunks: upload bins [bin_lo, bin_hi) and lay them out NEXT TO the resident shard, on a
+ * stream of its own; a following ku_ctx_swap_shard with the same arguments then only exchanges the two.  The one
+ * entry point that may run on a second host thread while the first one issues lookups on the same context (it touches
+ * nothing the lookups use).  Blocking; at most one prefetched chunk at a time. */
+int ku_ctx_prefetch_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi);
+/* free / total memory of the context's device (sizing of resident batches in out-of-core runs) */
+int ku_ctx_mem_info(ku_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 typedef struct ku_batch ku_batch; /* reads + merged per-k-mer slots of one batch, resident on the context's device */
 int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
                     uint64_t n_reads, ku_batch **out);

@@ -72,6 +72,8 @@ SIGNATURES = {
     "ku_setlcas_close": (None, [C.c_void_p]),
     "ku_db_sort_files": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
     "ku_ctx_swap_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "ku_ctx_prefetch_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "ku_ctx_mem_info": (C.c_int, [C.c_void_p, u64p, u64p]),
     "ku_batch_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "ku_batch_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts)]),
     "ku_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts), u32p, u32p, u64p, u32p, u64p]),
@@ -288,6 +290,10 @@ class Ctx:
     def swap_shard(self, db: Db, bin_lo, bin_hi):
         """out-of-core run: make bins [bin_lo, bin_hi) the resident shard, keeping slots and per-taxon state"""
         _chk(lib().ku_ctx_swap_shard(self.h, db.h, int(bin_lo), int(bin_hi)), "ku_ctx_swap_shard")
+
+    def prefetch_shard(self, db: Db, bin_lo, bin_hi):
+        """upload + lay out the next chunk next to the resident one (ku_ctx_prefetch_shard); swap_shard then exchanges them"""
+        _chk(lib().ku_ctx_prefetch_shard(self.h, db.h, int(bin_lo), int(bin_hi)), "ku_ctx_prefetch_shard")
 
     def batch(self, buf, off, lens):
         return Batch(self, buf, off, lens)

@@ -394,6 +394,20 @@ int main(int argc, char **argv) {
   Queue free_q, parsed_q, done_q;
   for (auto &bt : pool) free_q.push(&bt);
   const bool keep_records = print_cls || print_ucls;
+  // -x runs allocate a batch per region instead of recycling a pool: the nucleotides between reader and writer are
+  // bounded instead (set once the device budget is known)
+  uint64_t chunk_budget_nt = ~0ull, inflight_nt = 0;
+  std::mutex inflight_mu;
+  std::condition_variable inflight_cv;
+  auto inflight_add = [&](uint64_t nt) {
+    std::unique_lock<std::mutex> l(inflight_mu);
+    inflight_cv.wait(l, [&] { return inflight_nt == 0 || inflight_nt + nt <= 2 * chunk_budget_nt; });
+    inflight_nt += nt;
+  };
+  auto inflight_sub = [&](uint64_t nt) {
+    { std::lock_guard<std::mutex> l(inflight_mu); inflight_nt -= nt; }
+    inflight_cv.notify_all();
+  };
   double busy_reader = 0, busy_gpu = 0, busy_writer = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
 
   // Plain (uncompressed) regular files: the file is mapped, cut into record-aligned regions of about one work unit
@@ -421,7 +435,7 @@ int main(int argc, char **argv) {
     const double t_parse = now_s();
     // a quarter of a work unit per region: the team's batches are pinned memory, smaller ones are quicker to set up
     // and keep the three stages busier.  FASTQ text is ~2.2 bytes per base (header, '+', qualities), FASTA ~1.05
-    const size_t region_bytes = std::max<size_t>((size_t)1 << 20, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
+    const size_t region_bytes = std::max<size_t>((size_t)1 << 16, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
     std::mutex mu;
     std::condition_variable cv;
     size_t next_cut = 0, next_region = 0, next_out = 0;
@@ -464,7 +478,7 @@ int main(int argc, char **argv) {
       if (ends) stop = true;
       l.unlock();
       if (bt->nt == 0) { if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
-      else parsed_q.push(bt);
+      else { if (chunked) inflight_add(bt->nt); parsed_q.push(bt); }
       if (ends) break;
     }
     for (auto &t : team) t.join();
@@ -533,6 +547,7 @@ int main(int argc, char **argv) {
           if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
           break;
         }
+        if (chunked) inflight_add(bt->nt);
         parsed_q.push(bt);
       }
       rd.close();
@@ -595,41 +610,89 @@ int main(int argc, char **argv) {
       total_sequences += n;
       total_bases += bt->nt;
       fprintf(stderr, "\r Processed %llu sequences (%.2f%% classified)", total_sequences, total_classified * 100.0 / total_sequences);
-      if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
+      if (chunked) { inflight_sub(bt->nt); bt->release(); delete bt; } else free_q.push(bt);
     }
   });
 
   if (chunked) {
-    // out-of-core run (src/classify.cpp:566-791): chunk 0 is searched while the input is still being parsed; then
-    // one pass per further chunk over the batches resident on the device; then calls + hit lists per batch
-    std::vector<Batch *> all;
+    // Out-of-core run (src/classify.cpp:566-791).  The reference re-reads the input once per database chunk; here the
+    // read batches stay on the device and the CHUNKS cycle: the input is taken in super-batches that fit a fixed share
+    // of the HBM; for each super-batch chunk 0 is searched while the reads still arrive, then one pass per further
+    // chunk over the resident batches, then calls + hit lists.  Device and host memory are bounded by the super-batch
+    // whatever the input size; the next chunk is uploaded and laid out by a helper thread (ku_ctx_prefetch_shard)
+    // while the current one is searched.
+    uint64_t free_b = 0, total_b = 0;
+    KU_CHECK(ku_ctx_mem_info(ctx, &free_b, &total_b));
+    uint64_t budget = free_b / 4;  // device bytes of resident batches (5 B per base: text + one slot per position)
+    if (const char *e = getenv("KU_SUPERBATCH_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (uint64_t)v; }
+    {  // the reader stops this far ahead of the writer
+      std::lock_guard<std::mutex> l(inflight_mu);
+      chunk_budget_nt = budget / 5 > unit_nt ? budget / 5 : unit_nt;
+    }
+    inflight_cv.notify_all();
+    const size_t n_chunks = chunk_bounds.size() - 1;
     ku_opts opts = base_opts;
-    for (;;) {
-      Batch *bt = parsed_q.pop();
-      if (!bt) break;
-      KU_CHECK(ku_batch_create(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), bt->off.size(), &bt->dev));
-      KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
-      all.push_back(bt);
-    }
-    for (size_t c = 1; c + 1 < chunk_bounds.size(); ++c) {
-      fprintf(stderr, "\r Database chunk %zu of %zu", c + 1, chunk_bounds.size() - 1);
-      KU_CHECK(ku_ctx_swap_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]));
-      add_chunk_counts();
-      for (Batch *bt : all) KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
-    }
-    for (Batch *bt : all) {
-      const uint64_t n = bt->off.size();
-      bt->calls.assign(n, 0); bt->hits.assign(n, 0); bt->run_off.assign(n, 0); bt->run_cnt.assign(n, 0);
-      uint64_t n_runs = 0;
-      KU_CHECK(ku_batch_finish(ctx, bt->dev, &opts, bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
-      if (print_kraken && !quick) {
-        bt->reserve_runs(n_runs);
-        KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
+    std::thread prefetcher;
+    int prefetch_status = KU_OK;
+    std::string prefetch_error;
+    auto start_prefetch = [&](size_t c) {
+      prefetcher = std::thread([&, c] {
+        prefetch_status = ku_ctx_prefetch_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]);
+        if (prefetch_status != KU_OK) prefetch_error = ku_last_error();
+      });
+    };
+    auto join_prefetch = [&] {
+      if (prefetcher.joinable()) prefetcher.join();
+      if (prefetch_status != KU_OK) die(exit_code_of(prefetch_status), "%s: %s", ku_strerror(prefetch_status), prefetch_error.c_str());
+    };
+    bool input_done = false, first_super = true;
+    size_t n_super = 0;
+    while (!input_done) {
+      // chunk 0 is resident here (loaded at start-up, or swapped back in at the end of the previous super-batch)
+      if (n_chunks > 1) start_prefetch(1);
+      std::vector<Batch *> all;
+      uint64_t resident = 0;
+      while (resident < budget) {
+        Batch *bt = parsed_q.pop();
+        if (!bt) { input_done = true; break; }
+        KU_CHECK(ku_batch_create(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), bt->off.size(), &bt->dev));
+        KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
+        resident += 5 * (uint64_t)bt->seqs_len + 12 * (uint64_t)bt->off.size();
+        all.push_back(bt);
       }
-      ku_batch_destroy(bt->dev);
-      bt->dev = nullptr;
-      done_q.push(bt);
+      if (all.empty()) { join_prefetch(); break; }
+      ++n_super;
+      for (size_t c = 1; c < n_chunks; ++c) {
+        fprintf(stderr, "\r Database chunk %zu of %zu", c + 1, n_chunks);
+        join_prefetch();
+        KU_CHECK(ku_ctx_swap_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]));
+        if (first_super) add_chunk_counts();
+        // the chunk after this one -- or chunk 0 again for the next super-batch -- comes in underneath the passes
+        if (c + 1 < n_chunks) start_prefetch(c + 1);
+        else if (!input_done) start_prefetch(0);
+        for (Batch *bt : all) KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
+      }
+      for (Batch *bt : all) {
+        const uint64_t n = bt->off.size();
+        bt->calls.assign(n, 0); bt->hits.assign(n, 0); bt->run_off.assign(n, 0); bt->run_cnt.assign(n, 0);
+        uint64_t n_runs = 0;
+        KU_CHECK(ku_batch_finish(ctx, bt->dev, &opts, bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
+        if (print_kraken && !quick) {
+          bt->reserve_runs(n_runs);
+          KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
+        }
+        ku_batch_destroy(bt->dev);
+        bt->dev = nullptr;
+        done_q.push(bt);
+      }
+      first_super = false;
+      if (!input_done && n_chunks > 1) {
+        join_prefetch();
+        KU_CHECK(ku_ctx_swap_shard(ctx, db, chunk_bounds[0], chunk_bounds[1]));
+      }
     }
+    join_prefetch();
+    if (n_super > 1) fprintf(stderr, "\r %zu passes over the %zu database chunks (the input did not fit the device at once)\n", n_super, n_chunks);
   } else
   for (;;) {  // GPU stage
     Batch *bt = parsed_q.pop();

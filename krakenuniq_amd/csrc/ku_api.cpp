@@ -386,6 +386,15 @@ struct ku_ctx {
   // exact distinct counting (classifyExact): one global set of canonical k-mers + first-insertion counters per slot
   unsigned long long *d_exact_set = nullptr, *d_exact_unique = nullptr;
   uint64_t exact_mask = 0;
+  // out-of-core runs: the NEXT chunk, uploaded and laid out on its own stream while the resident one is searched
+  struct Prefetch {
+    bool valid = false;
+    const ku_db *db = nullptr;
+    uint64_t bin_lo = 0, bin_hi = 0;
+    DbStore store;
+    hipStream_t stream = nullptr;
+    uint32_t *d_scalar = nullptr;
+  } pf;
   // HyperLogLog++ sparse-mode emulation (ku_sparse.hip)
   struct Sparse {
     bool on = false;
@@ -441,6 +450,8 @@ static void store_free(DbStore &d) {
   d = DbStore{};
 }
 static void ctx_free_db(ku_ctx *ctx) {
+  if (ctx->pf.valid) store_free(ctx->pf.store);
+  ctx->pf.valid = false;
   store_free(ctx->m);
   for (DbStore &e : ctx->extra) store_free(e);
   ctx->extra.clear();
@@ -481,6 +492,8 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
                     &ctx->b_roff, &ctx->b_rcnt})
     b->release();
   if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
+  if (ctx->pf.d_scalar) (void)hipFree(ctx->pf.d_scalar);
+  if (ctx->pf.stream) (void)hipStreamDestroy(ctx->pf.stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -530,7 +543,9 @@ static void fill_db_dev(DbStore &d, uint64_t n_pairs, uint64_t pair_base, uint32
 }
 
 // host KrakenDB bins [bin_lo, bin_hi) -> device pairs (12-byte form) + offsets slice
-static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi, bool scan_values = true) {
+static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi, bool scan_values = true,
+                        hipStream_t stream = nullptr) {
+  if (!stream) stream = ctx->stream;
   const uint64_t p0 = db->offsets[bin_lo], p1 = db->offsets[bin_hi], np = p1 - p0;
   const uint32_t kl = db->info.key_len, ps = kl + 4;
   HIP_TRY(hipMalloc((void **)&d.d_pairs, std::max<uint64_t>(np, 1) * 12));
@@ -541,8 +556,8 @@ static int store_upload(ku_ctx *ctx, DbStore &d, const ku_db *db, uint64_t bin_l
     void *d_raw = nullptr;
     HIP_TRY(hipMalloc(&d_raw, np * ps));
     hipError_t e = hipMemcpy(d_raw, db->pairs + p0 * ps, np * ps, hipMemcpyHostToDevice);
-    int st = e == hipSuccess ? ku_launch_repack((const uint8_t *)d_raw, np, kl, d.d_pairs, ctx->stream) : KU_EHIP;
-    if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
+    int st = e == hipSuccess ? ku_launch_repack((const uint8_t *)d_raw, np, kl, d.d_pairs, stream) : KU_EHIP;
+    if (st == KU_OK && hipStreamSynchronize(stream) != hipSuccess) st = KU_EHIP;
     (void)hipFree(d_raw);
     if (st != KU_OK) return fail(st, "pair repack failed");
   }
@@ -638,12 +653,14 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
 }
 
 // raw taxids -> slot ids in place, then the probe-table layout (needs ctx->tax / d_slot_taxid)
-static int store_finalize(ku_ctx *ctx, DbStore &d) {
-  HIP_TRY(hipMemsetAsync(ctx->d_scalar, 0, 4, ctx->stream));
-  KU_TRY(ku_launch_remap_values(d.d_pairs, d.db.n_pairs, ctx->d_slot_taxid, ctx->tax.n_slots, ctx->d_scalar, ctx->stream));
+static int store_finalize(ku_ctx *ctx, DbStore &d, hipStream_t stream = nullptr, uint32_t *d_scalar = nullptr) {
+  if (!stream) stream = ctx->stream;
+  if (!d_scalar) d_scalar = ctx->d_scalar;
+  HIP_TRY(hipMemsetAsync(d_scalar, 0, 4, stream));
+  KU_TRY(ku_launch_remap_values(d.d_pairs, d.db.n_pairs, ctx->d_slot_taxid, ctx->tax.n_slots, d_scalar, stream));
   uint32_t err = 0;
-  HIP_TRY(hipMemcpyAsync(&err, ctx->d_scalar, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&err, d_scalar, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
   if (err) return fail(KU_EDATA, "internal: " + std::to_string(err) + " DB values missing from the slot table");
   d.hash_layout = ctx->hash_layout;
   if (d.hash_layout) {
@@ -674,13 +691,13 @@ static int store_finalize(ku_ctx *ctx, DbStore &d) {
   }
   if (d.hash_layout) {
     const uint64_t n_lines = d.table_lines;
-    unsigned long long *d_dup = (unsigned long long *)(ctx->d_scalar + 2);
-    HIP_TRY(hipMemsetAsync(d_dup, 0, 8, ctx->stream));
+    unsigned long long *d_dup = (unsigned long long *)(d_scalar + 2);
+    HIP_TRY(hipMemsetAsync(d_dup, 0, 8, stream));
     KU_TRY(ku_launch_build_table(d.d_pairs, d.db.n_pairs, d.d_table, n_lines, d.db.k, d.db.nt, d.db.xor_mask, d_dup,
-                                 ctx->stream));
+                                 stream));
     unsigned long long dup = 0;
-    HIP_TRY(hipMemcpyAsync(&dup, d_dup, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&dup, d_dup, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     d.n_dup = dup;
     d.db.table = (const uint4 *)d.d_table;
     d.db.n_lines = n_lines;
@@ -1243,6 +1260,34 @@ extern "C" int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs) {
 }
 
 // ---------------------------------------------------------------------------- out-of-core run
+extern "C" int ku_ctx_prefetch_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
+  // Safe to call from a second host thread while the first one runs lookups on the resident shard: it works on its own
+  // stream, its own scratch and its own store and only reads the (frozen) slot table of the context.
+  if (!ctx || !db) return fail(KU_EINVAL, "ku_ctx_prefetch_shard: null argument");
+  if (!ctx->db_loaded || !ctx->tax_set) return fail(KU_ESTATE, "ku_ctx_prefetch_shard: load a shard and the taxonomy first");
+  if (bin_lo > bin_hi || bin_hi > db->info.n_bins) return fail(KU_EINVAL, "bin range out of bounds");
+  if (!ctx->extra.empty()) return fail(KU_EUNSUP, "chunked runs use one database (as the reference's: classify.cpp:639)");
+  if (db->info.k != ctx->m.db.k) return fail(KU_EINVAL, "ku_ctx_prefetch_shard: k differs from the resident shard's");
+  KU_TRY(ctx_activate(ctx));
+  ku_ctx::Prefetch &pf = ctx->pf;
+  if (pf.valid) { store_free(pf.store); pf.valid = false; }
+  if (!pf.stream) HIP_TRY(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
+  if (!pf.d_scalar) HIP_TRY(hipMalloc((void **)&pf.d_scalar, 64));
+  int st = store_upload(ctx, pf.store, db, bin_lo, bin_hi, /*scan_values=*/false, pf.stream);
+  if (st == KU_OK) {
+    pf.store.hash_layout = ctx->hash_layout;
+    st = store_finalize(ctx, pf.store, pf.stream, pf.d_scalar);
+    if (st == KU_EDATA) st = fail(KU_EINVAL, "ku_ctx_prefetch_shard: the slot table does not cover this shard's values "
+                                             "(pass ku_db_values() of the whole database to ku_ctx_set_taxonomy)");
+  }
+  if (st != KU_OK) { store_free(pf.store); return st; }
+  pf.db = db;
+  pf.bin_lo = bin_lo;
+  pf.bin_hi = bin_hi;
+  pf.valid = true;
+  return KU_OK;
+}
+
 extern "C" int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, uint64_t bin_hi) {
   KU_TRY(check_ready(ctx));
   if (!db) return fail(KU_EINVAL, "ku_ctx_swap_shard: null argument");
@@ -1250,6 +1295,14 @@ extern "C" int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, 
   if (!ctx->extra.empty()) return fail(KU_EUNSUP, "chunked runs use one database (as the reference's: classify.cpp:639)");
   if (db->info.k != ctx->m.db.k) return fail(KU_EINVAL, "ku_ctx_swap_shard: k differs from the resident shard's");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->pf.valid && ctx->pf.db == db && ctx->pf.bin_lo == bin_lo && ctx->pf.bin_hi == bin_hi) {
+    // the chunk was prefetched (ku_ctx_prefetch_shard): it only has to change places with the resident one
+    store_free(ctx->m);
+    ctx->m = ctx->pf.store;
+    ctx->pf.store = DbStore{};
+    ctx->pf.valid = false;
+    return KU_OK;
+  }
   store_free(ctx->m);
   ctx->db_loaded = false;
   KU_TRY(store_upload(ctx, ctx->m, db, bin_lo, bin_hi, /*scan_values=*/false));
@@ -1258,6 +1311,16 @@ extern "C" int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, 
                                              "(pass ku_db_values() of the whole database to ku_ctx_set_taxonomy)");
   KU_TRY(st);
   ctx->db_loaded = true;
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_mem_info(ku_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  KU_TRY(ctx_activate(ctx));
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
   return KU_OK;
 }
 

@@ -148,6 +148,16 @@ def test_out_of_core_chunked_run(tmp_path, size):
     assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
     assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
     assert rows(rep.read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())  # row for row, `kmers` included
+    # bounded memory: a device budget of 100 kB holds a fraction of the reads at a time, so the chunks cycle several
+    # times (one pass over all chunks per super-batch); outputs and report stay those of the reference
+    env = {**os.environ, "KU_SUPERBATCH_BYTES": "100000", "KU_BATCH_NT": "65536"}
+    (d / "database.kdb.counts").unlink()
+    r2 = run(db + ["-x", size, "-t", "2", "-o", str(out), "-r", str(tmp_path / "rep2.tsv"), f"{F1}/reads.fq"], env=env)
+    assert r2.returncode == 0, r2.stderr.decode()
+    assert b"passes over the" in r2.stderr
+    assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
+    assert rows((tmp_path / "rep2.tsv").read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())
+    assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
     # identical to the run with everything resident, FASTA + second file included
     g = os.path.join(ROOT, "tests", "golden")
     r1 = run(db + ["-x", size, f"{g}/f2/edge.fa", f"{g}/f4/merged.fa"])
