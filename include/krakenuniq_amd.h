@@ -271,7 +271,10 @@ int ku_ctx_mem_info(ku_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 typedef struct ku_batch ku_batch; /* reads + merged per-k-mer slots of one batch, resident on the context's device */
 int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
                     uint64_t n_reads, ku_batch **out);
-/* one pass against the resident shard (opts->flags: KU_F_QUICK defers the accounting to ku_batch_finish) */
+/* one pass against the resident shard.  Quick mode (KU_F_QUICK) follows the reference's CHUNKED run here
+ * (classify.cpp:686-737), which differs from its normal quick mode: the passes book every unambiguous k-mer of every
+ * read, ku_batch_finish counts the hits up to min_hits ("Q:n") and calls the taxon of the read's LAST unambiguous
+ * k-mer when min_hits was reached */
 int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts);
 /* after the last chunk, once per batch (KU_ESTATE afterwards): resolve_tree / quick call per read + run-length
  * encoding; outputs as ku_classify_batch_rle */

@@ -1377,7 +1377,9 @@ extern "C" int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts) {
   if (b->finished) return fail(KU_ESTATE, "ku_batch_lookup: the batch was already finished");
   if (ctx->d_exact_set) return fail(KU_EUNSUP, "exact counting is not available for resident batches");
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
-  o.flags |= KU_F_MERGE_CHUNK | KU_F_KEEP_SLOTS;
+  // quick mode does not shorten a chunk pass: the reference's chunked run books every k-mer of every read and only
+  // derives the call differently at the end (classify.cpp:686-737)
+  o.flags = (o.flags & ~KU_F_QUICK) | KU_F_MERGE_CHUNK | KU_F_KEEP_SLOTS;
   return ku_lookup_device(ctx, b->d_seqs, b->n_bytes, &o, b->d_taxa, nullptr);
 }
 
@@ -1401,11 +1403,16 @@ extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, ui
   hipStream_t s = ctx->stream;
   if (ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {  // the merged slots of all chunks are in place: the emulation's pass
     if (b->h_len.size() != n_reads) return fail(KU_ESTATE, "ku_batch_finish: enable the sparse-mode emulation before the batches are created");
-    KU_TRY(sparse_pass(ctx, b->d_seqs, b->d_off, b->d_len, b->h_off.data(), b->h_len.data(), n_reads, b->n_bytes, b->d_taxa,
-                       (o.flags & KU_F_QUICK) ? std::max(1u, o.min_hits) : 0u, s));
+    KU_TRY(sparse_pass(ctx, b->d_seqs, b->d_off, b->d_len, b->h_off.data(), b->h_len.data(), n_reads, b->n_bytes, b->d_taxa, 0u, s));
   }
-  KU_TRY(ku_resolve_device(ctx, b->d_seqs, b->d_off, b->d_len, n_reads, &o, (uint32_t *)ctx->b_calls.p, b->d_taxa,
-                           (uint32_t *)ctx->b_hits.p, s));
+  if (o.flags & KU_F_QUICK) {  // the chunked run's quick mode: hits up to min_hits, call = the last k-mer's taxon
+    int st = ku_launch_quick_chunked(ctx->tax, ctx->cnt, ctx->m.db.k, b->d_off, b->d_len, n_reads, o.flags, o.min_hits,
+                                     (uint32_t *)ctx->b_calls.p, b->d_taxa, (uint32_t *)ctx->b_hits.p, ctx->n_cu, s);
+    if (st != KU_OK) return fail(st, "quick-mode kernel launch failed");
+  } else {
+    KU_TRY(ku_resolve_device(ctx, b->d_seqs, b->d_off, b->d_len, n_reads, &o, (uint32_t *)ctx->b_calls.p, b->d_taxa,
+                             (uint32_t *)ctx->b_hits.p, s));
+  }
   b->finished = true;
   return rle_and_fetch(ctx, b->d_taxa, b->d_off, b->d_len, n_reads, runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits,
                        run_off, run_cnt, n_runs);

@@ -115,6 +115,9 @@ int ku_launch_rle(const uint32_t *d_taxa, uint32_t k, const uint64_t *d_seq_off,
                   uint64_t n_reads, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter, uint64_t *d_run_off,
                   uint32_t *d_run_cnt, int n_cu, hipStream_t stream);
 int ku_launch_max_len(const uint32_t *d_seq_len, uint64_t n_reads, uint32_t *d_out, hipStream_t stream);
+int ku_launch_quick_chunked(const KuTaxDev &tax, const KuCountsDev &cnt, uint32_t k, const uint64_t *d_seq_off,
+                            const uint32_t *d_seq_len, uint64_t n_reads, uint32_t flags, uint32_t min_hits, uint32_t *d_calls,
+                            uint32_t *d_taxa, uint32_t *d_hits, int n_cu, hipStream_t stream);
 // element-wise merges of the multi-GPU driver's same-process exchange: dst = max(dst, src) / dst += src
 int ku_launch_merge_max_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream);
 int ku_launch_merge_max_u8(uint8_t *dst, const uint8_t *src, uint64_t n, hipStream_t stream);

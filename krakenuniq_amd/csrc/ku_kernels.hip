@@ -984,6 +984,62 @@ __global__ __launch_bounds__(64) void ku_quick_kernel(KuTaxDev tax, KuCountsDev 
   ku_ct_flush(s_ckk, s_ckc, cnt.n_kmers);
 }
 
+// Quick mode of a CHUNKED run (classify.cpp:686-737): the hits are counted over the merged per-k-mer taxa up to
+// min_hits, every unambiguous k-mer of the read was booked by the chunk passes, and the call is the taxon of the
+// read's LAST unambiguous k-mer when min_hits was reached (0 otherwise) -- the reference's loop leaves that value behind.
+__global__ __launch_bounds__(64) void ku_quick_chunked_kernel(KuTaxDev tax, KuCountsDev cnt, uint32_t k,
+                                                              const uint64_t *__restrict__ seq_off,
+                                                              const uint32_t *__restrict__ seq_len, uint64_t n_reads,
+                                                              uint32_t flags, uint32_t min_hits, uint32_t *__restrict__ calls,
+                                                              uint32_t *__restrict__ taxa, uint32_t *__restrict__ hits_out) {
+  __shared__ uint32_t s_ctk[KU_CT_CAP];
+  __shared__ uint32_t s_ctc[KU_CT_CAP];
+  __shared__ uint32_t s_ctu;
+  const uint32_t tid = threadIdx.x;
+  const bool do_counts = !(flags & KU_F_NO_COUNTS);
+  const bool keep_slots = (flags & KU_F_KEEP_SLOTS) != 0;
+  ku_ct_clear(s_ctk, s_ctc, &s_ctu);
+  __syncthreads();
+  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t off = seq_off[r];
+    __syncthreads();
+    ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, cnt.n_reads);
+    uint32_t total = 0, last_slot = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t i = base + tid;
+      const uint32_t s = i < n ? taxa[off + i] : KU_AMBIG;
+      total += (uint32_t)__popcll(__ballot(s != 0 && s != KU_AMBIG));
+      const unsigned long long clean = __ballot(s != KU_AMBIG);
+      if (clean) last_slot = ku_wave_bcast(s, 63u - (uint32_t)__builtin_clzll(clean));
+    }
+    const uint32_t hits = total < min_hits ? total : min_hits;
+    const uint32_t call_node = hits >= min_hits && last_slot ? tax.slot_node[last_slot] : 0u;
+    if (tid == 0) {
+      calls[r] = tax.node_taxid[call_node];
+      if (hits_out) hits_out[r] = hits;
+      if (do_counts) ku_ct_add(s_ctk, s_ctc, &s_ctu, call_node, 1, cnt.n_reads);
+    }
+    if (!keep_slots)
+      for (uint32_t i = tid; i < n; i += 64) {
+        const uint32_t s = taxa[off + i];
+        if (s != 0 && s != KU_AMBIG) taxa[off + i] = tax.slot_taxid[s];
+      }
+  }
+  __syncthreads();
+  ku_ct_flush(s_ctk, s_ctc, cnt.n_reads);
+}
+int ku_launch_quick_chunked(const KuTaxDev &tax, const KuCountsDev &cnt, uint32_t k, const uint64_t *d_seq_off,
+                            const uint32_t *d_seq_len, uint64_t n_reads, uint32_t flags, uint32_t min_hits, uint32_t *d_calls,
+                            uint32_t *d_taxa, uint32_t *d_hits, int n_cu, hipStream_t stream) {
+  if (n_reads == 0) return KU_OK;
+  const uint64_t mb = (uint64_t)n_cu * 16;
+  hipLaunchKernelGGL(ku_quick_chunked_kernel, dim3((unsigned)(n_reads < mb ? n_reads : mb)), dim3(64), 0, stream, tax, cnt, k,
+                     d_seq_off, d_seq_len, n_reads, flags, min_hits ? min_hits : 1u, d_calls, d_taxa, d_hits);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
 static inline uint32_t ku_ceil_log2(uint64_t v) {
   uint32_t l = 0;
   while ((1ull << l) < v) ++l;

@@ -16,6 +16,7 @@ Fixtures:
         out.tsv/report.tsv (-t 1), report_exact.tsv (classifyExact),
         out_u1000.tsv/report_u1000.tsv (-u 1000: sketches stay sparse),
         out_chunk.tsv/report_chunk.tsv (-x 70K -t 2), out_quick.tsv (-q -m 2),
+        out_chunk_quick.tsv/report_chunk_quick.tsv (-x 70K -t 2 -q -m 2),
         out_c.tsv (-c), database.kdb.counts
   f2/   edge FASTA (short / N / empty / lower-case / multi-line) + outputs
   f4/   paired FASTQs -> read_merger.pl -> merged.fa + outputs
@@ -100,6 +101,8 @@ def make_f1():
     classify(d, ["-u", "1000", "-o", f"{d}/out_u1000.tsv", "-r", f"{d}/report_u1000.tsv"], rd)
     classify(d, ["-x", "70K", "-t", "2", "-o", f"{d}/out_chunk.tsv", "-r", f"{d}/report_chunk.tsv"], rd)
     classify(d, ["-q", "-m", "2", "-o", f"{d}/out_quick.tsv"], rd)
+    # quick mode inside a chunked run: every k-mer is booked and the call is the LAST k-mer's taxon (classify.cpp:700-737)
+    classify(d, ["-x", "70K", "-t", "2", "-q", "-m", "2", "-o", f"{d}/out_chunk_quick.tsv", "-r", f"{d}/report_chunk_quick.tsv"], rd)
     classify(d, ["-c", "-o", f"{d}/out_c.tsv"], rd)
     classify(d, ["-s", "-o", f"{d}/out_s.tsv"], rd)
     assert open(f"{d}/out.tsv", "rb").read() == open(f"{d}/out_exact.tsv", "rb").read()

@@ -158,6 +158,12 @@ def test_out_of_core_chunked_run(tmp_path, size):
     assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
     assert rows((tmp_path / "rep2.tsv").read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())
     assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
+    # quick mode inside a chunked run has the reference's own semantics (classify.cpp:686-737)
+    (d / "database.kdb.counts").unlink()
+    r3 = run(db + ["-x", size, "-t", "2", "-q", "-m", "2", "-o", str(out), "-r", str(tmp_path / "rep3.tsv"), f"{F1}/reads.fq"])
+    assert r3.returncode == 0, r3.stderr.decode()
+    assert out.read_bytes() == open(f"{F1}/out_chunk_quick.tsv", "rb").read()
+    assert rows((tmp_path / "rep3.tsv").read_text()) == rows(open(f"{F1}/report_chunk_quick.tsv").read())
     # identical to the run with everything resident, FASTA + second file included
     g = os.path.join(ROOT, "tests", "golden")
     r1 = run(db + ["-x", size, f"{g}/f2/edge.fa", f"{g}/f4/merged.fa"])
