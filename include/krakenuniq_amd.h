@@ -215,7 +215,9 @@ typedef struct ku_opts {
  * at least one byte that is not one of ACGTacgt (raw FASTA/FASTQ text with its
  * line terminators qualifies).  Any byte outside ACGTacgt makes the k-mers that
  * cover it ambiguous (krakenutil.cpp:252-274); '\n'/'\r' *inside* a read are
- * not skipped (the reference's readers never leave them there).
+ * not skipped: a '\r' closing a read (CRLF files) behaves as in the reference
+ * (one more, ambiguous, k-mer), the CLI reader removes the ones inside
+ * multi-line CRLF FASTA sequences before the batch is built.
  * Per-k-mer output `taxa` is parallel to `seqs`: taxa[seq_off[i] + j] is the
  * taxid (0 = miss, KU_AMBIG = ambiguous) of the k-mer starting at base j of read
  * i, j < seq_len[i]-k+1; other entries are unspecified.  `calls[i]` is the

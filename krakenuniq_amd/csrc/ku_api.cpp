@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,10 @@ struct ku_db {
   ku_db_info info{};
   void *map_kdb = nullptr, *map_idx = nullptr;
   size_t map_kdb_sz = 0, map_idx_sz = 0;
+  // ku_db_values: the distinct values, scanned once (callers ask for the count first and the list second)
+  mutable std::mutex values_mu;
+  mutable std::vector<uint32_t> values;
+  mutable bool values_ready = false;
 };
 
 static void *map_file(const char *path, size_t *sz) {
@@ -127,7 +132,11 @@ extern "C" int ku_db_open(const char *kdb_path, const char *idx_path, ku_db **ou
   db->info.k = (uint32_t)(key_bits / 2);
   db->info.key_len = (uint32_t)(key_bits / 8 + !!(key_bits % 8));
   db->info.key_ct = key_ct;
-  if (db->map_kdb_sz < hdr + key_ct * (db->info.key_len + 4)) { ku_db_close(db); return fail(KU_EDATA, "database file truncated"); }
+  // key_ct comes from the file: a crafted count must not wrap the product and pass the size test
+  if (db->map_kdb_sz < hdr || key_ct > (db->map_kdb_sz - hdr) / (db->info.key_len + 4)) {
+    ku_db_close(db);
+    return fail(KU_EDATA, "database file truncated");
+  }
   db->pairs = kp + hdr;
   // krakendb.cpp:534-544
   if (db->map_idx_sz < 8) { ku_db_close(db); return fail(KU_EDATA, "illegal Kraken DB index format"); }
@@ -234,41 +243,60 @@ int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets) 
 
 extern "C" int ku_db_values(const ku_db *db, uint32_t *out, uint64_t *n) {
   if (!db || !n) return fail(KU_EINVAL, "ku_db_values: null argument");
-  // one bit per possible value, set by a team of scanning threads (the 4-byte value sits behind every key)
-  const uint64_t np = db->info.key_ct, ps = db->info.key_len + 4, kl = db->info.key_len;
-  std::vector<std::atomic<uint64_t>> bits(1ull << 26);
-  for (auto &w : bits) w.store(0, std::memory_order_relaxed);
-  unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (np < (1u << 20)) nthr = 1;
-  std::vector<std::thread> team;
-  for (unsigned t = 0; t < nthr; ++t)
-    team.emplace_back([&, t] {
-      const uint64_t lo = np * t / nthr, hi = np * (t + 1) / nthr;
-      uint32_t last = 0;
-      for (uint64_t i = lo; i < hi; ++i) {
-        uint32_t v;
-        memcpy(&v, db->pairs + i * ps + kl, 4);
-        if (v == last) continue;  // values come in long runs inside a bin
-        last = v;
-        std::atomic<uint64_t> &w = bits[v >> 6];
-        const uint64_t m = 1ull << (v & 63);
-        if (!(w.load(std::memory_order_relaxed) & m)) w.fetch_or(m, std::memory_order_relaxed);
+  std::lock_guard<std::mutex> lk(db->values_mu);
+  if (!db->values_ready) {
+    // one bit per value below 2^26 (taxon ids in practice), set by a team of scanning threads (the 4-byte value sits
+    // behind every key); the rare larger ones go to a per-thread list
+    const uint64_t np = db->info.key_ct, ps = db->info.key_len + 4, kl = db->info.key_len;
+    constexpr uint32_t SMALL = 1u << 26;
+    std::vector<std::atomic<uint64_t>> bits(SMALL / 64);
+    for (auto &w : bits) w.store(0, std::memory_order_relaxed);
+    unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (np < (1u << 20)) nthr = 1;
+    std::vector<std::vector<uint32_t>> large(nthr);
+    std::vector<std::thread> team;
+    for (unsigned t = 0; t < nthr; ++t)
+      team.emplace_back([&, t] {
+        const uint64_t lo = np * t / nthr, hi = np * (t + 1) / nthr;
+        uint32_t last = 0;
+        for (uint64_t i = lo; i < hi; ++i) {
+          uint32_t v;
+          memcpy(&v, db->pairs + i * ps + kl, 4);
+          if (v == last) continue;  // values come in long runs inside a bin
+          last = v;
+          if (v >= SMALL) {
+            large[t].push_back(v);
+            if (large[t].size() >= (1u << 20)) {
+              std::sort(large[t].begin(), large[t].end());
+              large[t].erase(std::unique(large[t].begin(), large[t].end()), large[t].end());
+            }
+            continue;
+          }
+          std::atomic<uint64_t> &w = bits[v >> 6];
+          const uint64_t m = 1ull << (v & 63);
+          if (!(w.load(std::memory_order_relaxed) & m)) w.fetch_or(m, std::memory_order_relaxed);
+        }
+      });
+    for (auto &th : team) th.join();
+    std::vector<uint32_t> &vals = db->values;
+    for (uint64_t wi = 0; wi < bits.size(); ++wi) {
+      uint64_t w = bits[wi].load(std::memory_order_relaxed);
+      if (wi == 0) w &= ~1ull;  // value 0 is "no taxon", never a slot
+      while (w) {
+        vals.push_back((uint32_t)(wi * 64 + (uint64_t)__builtin_ctzll(w)));
+        w &= w - 1;
       }
-    });
-  for (auto &th : team) th.join();
-  uint64_t count = 0;
-  for (uint64_t wi = 0; wi < bits.size(); ++wi) {
-    uint64_t w = bits[wi].load(std::memory_order_relaxed);
-    if (wi == 0) w &= ~1ull;  // value 0 is "no taxon", never a slot
-    while (w) {
-      const uint32_t v = (uint32_t)(wi * 64 + (uint64_t)__builtin_ctzll(w));
-      w &= w - 1;
-      if (out) {
-        if (count >= *n) return fail(KU_EINVAL, "ku_db_values: output array too small");
-        out[count] = v;
-      }
-      ++count;
     }
+    const size_t n_small = vals.size();
+    for (auto &l : large) vals.insert(vals.end(), l.begin(), l.end());
+    std::sort(vals.begin() + n_small, vals.end());
+    vals.erase(std::unique(vals.begin() + n_small, vals.end()), vals.end());
+    db->values_ready = true;
+  }
+  const uint64_t count = db->values.size();
+  if (out) {
+    if (count > *n) return fail(KU_EINVAL, "ku_db_values: output array too small");
+    memcpy(out, db->values.data(), count * 4);
   }
   *n = count;
   return KU_OK;
@@ -778,12 +806,22 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
   ctx->tax.n_nodes = (uint32_t)nodes.size();
   ctx->tax.n_slots = (uint32_t)slots.size();
   ctx->tax.node_one = 1;
-  KU_TRY(store_finalize(ctx, ctx->m));
-  for (DbStore &e : ctx->extra) KU_TRY(store_finalize(ctx, e));
-  // per-taxon state
-  HIP_TRY(hipMalloc((void **)&ctx->cnt.registers, (size_t)slots.size() * KU_HLL_M));
-  HIP_TRY(hipMalloc((void **)&ctx->cnt.n_kmers, slots.size() * 8));
-  HIP_TRY(hipMalloc((void **)&ctx->cnt.n_reads, nodes.size() * 8));
+  // per-taxon state before the stores are finalized: store_finalize remaps the values in place and drops the raw
+  // pairs, so nothing that can fail for lack of memory may come after it
+  if (hipMalloc((void **)&ctx->cnt.registers, (size_t)slots.size() * KU_HLL_M) != hipSuccess ||
+      hipMalloc((void **)&ctx->cnt.n_kmers, slots.size() * 8) != hipSuccess ||
+      hipMalloc((void **)&ctx->cnt.n_reads, nodes.size() * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx_free_tax(ctx);
+    return fail(KU_ENOMEM, "device memory for the per-taxon counters");
+  }
+  int st = store_finalize(ctx, ctx->m);
+  for (size_t e = 0; st == KU_OK && e < ctx->extra.size(); ++e) st = store_finalize(ctx, ctx->extra[e]);
+  if (st != KU_OK) {  // a store may be half remapped: the context needs its database loaded again
+    ctx_free_tax(ctx);
+    ctx->db_loaded = false;
+    return st;
+  }
   ctx->tax_set = true;
   return ku_ctx_reset_counts(ctx);
 }

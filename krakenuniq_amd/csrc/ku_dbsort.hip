@@ -147,7 +147,7 @@ extern "C" int ku_db_sort_files(int device, const char *in_path, const char *out
   const uint32_t k = (uint32_t)(key_bits / 2), key_len = (uint32_t)((key_bits + 7) / 8);
   if (nt > k) return fail(KU_EINVAL, "bin key longer than the k-mers");
   const size_t hdr = 72 + 2 * (4 + 8 * key_bits), ps = key_len + 4;
-  if (in_sz < hdr + key_ct * ps) return fail(KU_EDATA, "database file truncated");
+  if (in_sz < hdr || key_ct > (in_sz - hdr) / ps) return fail(KU_EDATA, "database file truncated");
   const uint64_t n = key_ct, n_bins = 1ull << (2 * nt);
   const uint64_t INDEX2_XOR_MASK = 0xe37e28c4271b5a2dULL;  // krakendb.cpp:45 (db_sort always writes KRAKIX2)
   const uint32_t xor_mask = (uint32_t)(INDEX2_XOR_MASK & (n_bins - 1));

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -246,6 +247,18 @@ inline void split_id(const char *h, size_t n, size_t &lo, size_t &hi) {
   while (hi < n && !ws(h[hi])) ++hi;
 }
 
+// Multi-line FASTA with CRLF line ends.  The reference keeps every '\r' in the sequence string (getline,
+// src/seqreader.cpp:60-75) and its scanner steps over them (src/krakenutil.cpp:266-270) -- but that step also loses
+// the k-mer ending at the first base of the next line, and the reported length counts the '\r's.  Here the line ends
+// inside a sequence are dropped and every k-mer is classified; said once, because the per-read output then differs
+// from the reference's for such files (FASTQ and one-line-per-sequence FASTA are byte-identical, tests/golden/f10).
+inline void crlf_note() {
+  static std::atomic<bool> said{false};
+  if (!said.exchange(true))
+    fprintf(stderr, "classify: warning: multi-line FASTA with CRLF line ends: the carriage returns inside sequences are "
+                    "removed (the reference skips one k-mer per line break on such input)\n");
+}
+
 // One record of `rd`: sequence pieces appended to the read currently open in `bt`; header (without '>'/'@') and
 // quality line to `header` / `quals` when wanted.  false when the stream is exhausted or malformed
 // (reader->is_valid() == false); a malformed record ends the stream with the reference's warning.
@@ -289,8 +302,12 @@ inline bool next_record(Reader &rd, Batch &bt, std::string *header, std::string 
   if (header) header->assign(rd.at(1), h_hi - 1);
   rd.pos += h_next;
   size_t l_hi, l_next;
+  const size_t read_lo = bt.seqs_len;
   while (rd.line_at(0, l_hi, l_next)) {
     if (l_hi > 0 && *rd.at(0) == '>') break;  // next record: not consumed
+    // CRLF files: the '\r' closing a line that another sequence line follows is dropped (see crlf_note()); the one
+    // closing the record stays -- it is what the reference scans too (one more, ambiguous, k-mer; length + 1)
+    if (l_hi > 0 && bt.seqs_len > read_lo && bt.seqs[bt.seqs_len - 1] == '\r') { --bt.seqs_len; crlf_note(); }
     bt.append(rd.at(0), l_hi);
     *seq_bytes += l_hi;
     rd.pos += l_next;

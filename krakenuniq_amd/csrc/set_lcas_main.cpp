@@ -367,7 +367,7 @@ int main(int argc, char **argv) {
     if (fread(dat.data(), 1, sz, in) != sz) fatal(EX_OSERR, "can't read %s", db_name.c_str());
     fclose(in);
     const size_t ps = info.key_len + 4, hdr = 72 + 2 * (4 + 8 * 2 * (size_t)info.k);  // krakendb.cpp:177
-    if (sz < hdr + info.key_ct * ps) fatal(EX_DATAERR, "database file truncated");
+    if (sz < hdr || info.key_ct > (sz - hdr) / ps) fatal(EX_DATAERR, "database file truncated");
     for (uint64_t i = 0; i < info.key_ct; ++i) memcpy(dat.data() + hdr + i * ps + info.key_len, &values[i], 4);
     ku_db_close(db);  // unmap before writing over the file
     db = nullptr;

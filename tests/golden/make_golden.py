@@ -23,6 +23,7 @@ Fixtures:
   f7/   legacy KRAKIDX (type 1) index variant of f1 + outputs
   f9/   set_lcas: library FASTA + seqid map -> the reference's database.kdb / counts
   f8/   second database + reads for hierarchical multi-database runs (both orders, quick mode)
+  f10/  CRLF inputs (FASTQ, one-line-per-sequence FASTA, multi-line FASTA) of f1 reads + outputs
   kat.json  per-function known-answer vectors from ref_kat
 """
 import json
@@ -288,6 +289,26 @@ class Kat:
         return [self.p.stdout.readline().split() for _ in range(n)]
 
 
+def make_f10(f1):
+    """CRLF line ends: reads 0..59 of f1 as FASTQ, reads 60..119 as FASTA with one and with several lines per sequence"""
+    d = os.path.join(HERE, "f10")
+    os.makedirs(d, exist_ok=True)
+    ids, seqs = synth.read_seqfile(f"{f1}/reads.fq")
+    with open(f"{d}/crlf.fq", "wb") as f:
+        for i, s in zip(ids[:60], seqs[:60]):
+            f.write(b"@" + i.encode() + b"\r\n" + s + b"\r\n+\r\n" + b"I" * len(s) + b"\r\n")
+    with open(f"{d}/crlf_oneline.fa", "wb") as f:
+        for i, s in zip(ids[60:120], seqs[60:120]):
+            f.write(b">" + i.encode() + b" some description\r\n" + s + b"\r\n")
+    with open(f"{d}/crlf_multiline.fa", "wb") as f:
+        for i, s in zip(ids[60:120], seqs[60:120]):
+            f.write(b">" + i.encode() + b" some description\r\n")
+            for o in range(0, len(s), 60):
+                f.write(s[o:o + 60] + b"\r\n")
+    for name in ("crlf.fq", "crlf_oneline.fa", "crlf_multiline.fa"):
+        classify(f1, ["-o", f"{d}/{name.rsplit('.', 1)[0]}.out.tsv"], [f"{d}/{name}"])
+
+
 def make_kat(f1):
     rng = np.random.default_rng(3)
     kat = {"k": K}
@@ -421,6 +442,9 @@ def main():
         gp = np.concatenate([g6[2000:2300], synth.procedural_genome(7, 99, 300)])
         make_f9(os.path.join(HERE, "f1"), {4: g4, 5: g5, 6: g6, 1000000001: gp})
         return
+    if sys.argv[1:] == ["f10"]:
+        make_f10(os.path.join(HERE, "f1"))
+        return
     if sys.argv[1:] == ["f8"]:  # add the multi-database fixture without regenerating the others
         g4 = synth.procedural_genome(7, 4, 3000)
         make_f8(os.path.join(HERE, "f1"), {4: g4, 6: synth.procedural_genome(7, 6, 3000)})
@@ -431,6 +455,7 @@ def main():
     make_f2(f1)
     make_f4(f1, genomes)
     make_f7(f1)
+    make_f10(f1)
     make_kat(f1)
     # count_unique known answer (HLL p=12 on the reads' k-mers)
     r = run([os.path.join(REF, "count_unique"), "-k", "31", "-p", "12"], stdin=open(f"{HERE}/f2/edge.fa", "rb"))

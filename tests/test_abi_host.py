@@ -71,6 +71,14 @@ def test_db_open_and_errors(f1, tmp_path):
     with pytest.raises(capi.KuError) as e:
         capi.Db(f"{f1['dir']}/database.kdb", str(badidx))
     assert e.value.status == -2
+    # a pair count whose byte size wraps around 2^64 to something small must not pass the truncation test
+    img = bytearray(open(f"{f1['dir']}/database.kdb", "rb").read())
+    img[48:56] = ((1 << 64) // 12 + 1).to_bytes(8, "little")
+    wrap = tmp_path / "wrap.kdb"
+    wrap.write_bytes(bytes(img))
+    with pytest.raises(capi.KuError) as e:
+        capi.Db(str(wrap), f"{f1['dir']}/database.idx")
+    assert e.value.status == -2 and "truncated" in str(e.value)
 
 
 def test_shard_plan_balanced_and_contiguous(f1):
