@@ -451,6 +451,22 @@ uint64_t ku_hll_cardinality_sparse(const uint32_t *encoded, uint64_t n, uint64_t
 int ku_report_exact(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
                     const uint64_t *n_kmers, const uint64_t *unique_kmers, uint64_t n_slots, const uint32_t *node_taxid,
                     const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len);
+/* The report text from per-entry clade summaries, arrays parallel to the taxDB entries (n_rows = their number, file
+ * order): present[r] = the clade of entry r was counted, clade_reads / clade_kmers = sums over the clade, tax_reads =
+ * the entry's own reads, clade_uniq = distinct k-mers of the clade's merged sketch.  Rows, order and number formats
+ * of TaxReport::printReport (taxdb.hpp:1004-1123); what ku_report* and ku_ctx_report end in. */
+int ku_report_rows(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint8_t *present,
+                   const uint64_t *clade_reads, const uint64_t *tax_reads, const uint64_t *clade_kmers,
+                   const uint64_t *clade_uniq, uint64_t n_rows, char **out, size_t *out_len);
+/* The report straight from the context's device-resident state: the clade roll-up of the TaxReport
+ * constructor (taxdb.hpp:928-982: every counted taxon's sketch merged into each of its ancestors') runs on the GPU --
+ * one workgroup per counted clade takes the byte-wise maximum over its members' HLL registers and reduces it to the
+ * register histogram the estimator needs; clades whose members all stayed sparse (ku_ctx_enable_sparse) get the
+ * histogram of the union of their members' encoded hashes from a device hash set.  Only the histograms (320 B per
+ * clade) and the per-taxon counters come back; estimator and text are host work as in the reference.  Same text as
+ * ku_report_multi / ku_report_sparse / ku_report_exact on the exported state (whichever mode the context is in). */
+int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, char **out,
+                  size_t *out_len);
 void ku_free(void *p);
 /* Page-locked host memory for batch buffers (fast, truly asynchronous H2D / D2H in ku_classify_batch). */
 int ku_host_alloc(size_t bytes, void **out);

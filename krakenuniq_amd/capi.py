@@ -101,6 +101,10 @@ SIGNATURES = {
     "ku_report_sparse": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u8p, u8p, u64p, C.c_uint64,
                                    C.c_uint64, u32p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_hll_cardinality_sparse": (C.c_uint64, [u32p, C.c_uint64, C.c_uint64]),
+    "ku_report_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u8p, u64p, u64p, u64p, u64p, C.c_uint64,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_ctx_report": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_size_t)]),
     "ku_ctx_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
     "ku_counts_export_exact": (C.c_int, [C.c_void_p, u64p]),
     "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
@@ -357,6 +361,15 @@ class Ctx:
 
     def sparse_close_unit(self):
         _chk(lib().ku_sparse_close_unit(self.h), "ku_sparse_close_unit")
+
+    def report(self, tax: "Tax", counts_paths=()):
+        """the report from the device-resident state, clade roll-up on the GPU (ku_ctx_report)"""
+        out, n = C.c_void_p(), C.c_size_t()
+        paths = (C.c_char_p * len(counts_paths))(*[p.encode() for p in counts_paths])
+        _chk(lib().ku_ctx_report(self.h, tax.h, paths, len(counts_paths), C.byref(out), C.byref(n)), "ku_ctx_report")
+        s = C.string_at(out, n.value).decode()
+        lib().ku_free(out)
+        return s
 
     def sparse_export(self):
         """(slot_is_sparse uint8[n_slots], pairs uint64[n] = slot << 32 | encoded hash) -- closes the last work unit"""
@@ -682,6 +695,19 @@ def report_exact(tax: Tax, counts: dict, unique, counts_paths):
 def hll_cardinality_sparse(encoded, n_observed):
     e = np.ascontiguousarray(encoded, dtype=np.uint32)
     return int(lib().ku_hll_cardinality_sparse(_p(e, u32p), len(e), n_observed))
+
+
+def report_rows(tax: Tax, present, clade_reads, tax_reads, clade_kmers, clade_uniq, counts_paths=()):
+    """the report text from per-taxDB-entry clade summaries (ku_report_rows)"""
+    out, n = C.c_void_p(), C.c_size_t()
+    paths = (C.c_char_p * len(counts_paths))(*[p.encode() for p in counts_paths])
+    arrs = [np.ascontiguousarray(present, dtype=np.uint8)] + [np.ascontiguousarray(a, dtype=np.uint64)
+                                                              for a in (clade_reads, tax_reads, clade_kmers, clade_uniq)]
+    _chk(lib().ku_report_rows(tax.h, paths, len(counts_paths), _p(arrs[0], u8p), *[_p(a, u64p) for a in arrs[1:]], len(arrs[0]),
+                              C.byref(out), C.byref(n)), "ku_report_rows")
+    s = C.string_at(out, n.value).decode()
+    lib().ku_free(out)
+    return s
 
 
 def report_sparse(tax: Tax, counts: dict, slot_is_sparse, pairs, counts_paths):

@@ -771,30 +771,10 @@ int main(int argc, char **argv) {
     std::vector<const char *> cpaths;
     for (const std::string &c : cnames) cpaths.push_back(c.c_str());
     if (mg) KU_CHECK(ku_mgpu_reduce_state(mg, nullptr));  // every rank's registers / counters into rank 0's context
-    ku_counts_dims d;
-    KU_CHECK(ku_counts_dims_get(ctx, &d));
-    std::vector<uint32_t> st(d.n_slots), ntx(d.n_nodes);
-    std::vector<uint64_t> nk(d.n_slots), nr(d.n_nodes);
-    std::vector<uint8_t> regs(d.n_slots * (size_t)KU_HLL_M);
-    KU_CHECK(ku_counts_export(ctx, st.data(), nk.data(), regs.data(), ntx.data(), nr.data()));
+    // clade roll-up on the device, from the registers / counters / sparse sets where they lie (ku_ctx_report); in a
+    // group rank 0's context holds the reduced state
     char *text = nullptr; size_t tn = 0;
-    if (exact) {
-      std::vector<uint64_t> uniq(d.n_slots);
-      KU_CHECK(ku_counts_export_exact(ctx, uniq.data()));
-      KU_CHECK(ku_report_exact(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), uniq.data(), d.n_slots,
-                               ntx.data(), nr.data(), d.n_nodes, &text, &tn));
-    } else if (sparse) {
-      std::vector<uint8_t> is_sparse(d.n_slots);
-      uint64_t np = 0;
-      KU_CHECK(ku_sparse_export(ctx, is_sparse.data(), nullptr, &np));
-      std::vector<uint64_t> pairs(np + 1);
-      uint64_t cap = np;
-      KU_CHECK(ku_sparse_export(ctx, is_sparse.data(), pairs.data(), &cap));
-      KU_CHECK(ku_report_sparse(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), regs.data(), is_sparse.data(),
-                                pairs.data(), cap, d.n_slots, ntx.data(), nr.data(), d.n_nodes, &text, &tn));
-    } else
-    KU_CHECK(ku_report_multi(tax, cpaths.data(), (uint32_t)cpaths.size(), st.data(), nk.data(), regs.data(), d.n_slots, ntx.data(),
-                             nr.data(), d.n_nodes, &text, &tn));
+    KU_CHECK(ku_ctx_report(ctx, tax, cpaths.data(), (uint32_t)cpaths.size(), &text, &tn));
     if (tn == 0) fprintf(stderr, "total number of reads is zero - not creating a report!\n");
     Sink rs;
     if (!rs.open(report_out, /*append=*/true)) die(EX_OSERR, "can't open %s", report_out.c_str());

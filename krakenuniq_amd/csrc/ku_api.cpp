@@ -1487,6 +1487,146 @@ extern "C" int ku_counts_export(ku_ctx *ctx, uint32_t *slot_taxid, uint64_t *n_k
   return KU_OK;
 }
 
+// ---------------------------------------------------------------------------- report from the resident state
+namespace {
+struct DevTmp {  // device scratch of one ku_ctx_report call
+  std::vector<void *> ptrs;
+  ~DevTmp() { for (void *p : ptrs) (void)hipFree(p); }
+  template <typename T> int put(T **dst, const std::vector<T> &src) {
+    if (hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)) != hipSuccess) { *dst = nullptr; return KU_ENOMEM; }
+    ptrs.push_back(*dst);
+    if (!src.empty() && hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return KU_EHIP;
+    return KU_OK;
+  }
+  template <typename T> int zeros(T **dst, size_t n) {
+    if (hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { *dst = nullptr; return KU_ENOMEM; }
+    ptrs.push_back(*dst);
+    return hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? KU_OK : KU_EHIP;
+  }
+};
+}  // namespace
+
+extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, char **out,
+                             size_t *out_len) {
+  if (!ctx || !tax || !out || !out_len) return fail(KU_EINVAL, "ku_ctx_report: null argument");
+  if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  KU_TRY(ctx_activate(ctx));
+  const size_t ns = ctx->tax.n_slots, nn = ctx->tax.n_nodes, nt = tax->ids.size();
+  const bool exact = ctx->d_exact_unique != nullptr, sparse = ctx->sp.on && !exact;
+  // the run-wide (slot, encoding) set of the sparse sketches stays on the device (ctx->sp.out)
+  uint64_t n_pairs = 0;
+  std::vector<uint8_t> slot_sparse(ns, 0);
+  if (sparse) KU_TRY(ku_sparse_export(ctx, slot_sparse.data(), nullptr, &n_pairs));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  std::vector<uint64_t> nk(ns), nr(nn), uq;
+  HIP_TRY(hipMemcpy(nk.data(), ctx->cnt.n_kmers, ns * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(nr.data(), ctx->cnt.n_reads, nn * 8, hipMemcpyDeviceToHost));
+  if (exact) {
+    uq.resize(ns);
+    HIP_TRY(hipMemcpy(uq.data(), ctx->d_exact_unique, ns * 8, hipMemcpyDeviceToHost));
+  }
+  // counted taxa (taxon_counts entries, classify.cpp:939,968) -> every entry of their root paths is a counted clade
+  // (taxdb.hpp:928-973); taxa without a taxDB entry are dropped ("No entry for X in database!")
+  std::vector<uint8_t> present(nt, 0);
+  std::vector<uint64_t> c_reads(nt, 0), t_reads(nt, 0), c_kmers(nt, 0), c_uniq(nt, 0);
+  std::vector<int32_t> clade_of(nt, -1);
+  std::vector<uint32_t> clade_row;
+  std::vector<std::pair<uint32_t, uint32_t>> memb;  // (clade, slot) over the root paths of the slots with k-mers
+  std::vector<uint8_t> clade_dense;
+  auto clade_id = [&](size_t row) {
+    if (clade_of[row] < 0) { clade_of[row] = (int32_t)clade_row.size(); clade_row.push_back((uint32_t)row); clade_dense.push_back(0); present[row] = 1; }
+    return (uint32_t)clade_of[row];
+  };
+  auto walk = [&](uint32_t taxid, auto &&visit) {
+    auto it = tax->row.find(taxid);
+    if (it == tax->row.end()) return;
+    int64_t q = it->second;
+    for (uint32_t guard = 0; q >= 0 && guard < 4096; ++guard, q = tax->parent_row((size_t)q)) visit((size_t)q);
+  };
+  for (size_t s = 0; s < ns; ++s) {
+    if (!nk[s]) continue;
+    const bool dense = !exact && !(sparse && slot_sparse[s]);
+    walk(ctx->h_slot_taxid[s], [&](size_t row) {
+      const uint32_t c = clade_id(row);
+      c_kmers[row] += nk[s];
+      if (exact) c_uniq[row] += uq[s];
+      else memb.emplace_back(c, (uint32_t)s);
+      if (dense) clade_dense[c] = 1;
+    });
+  }
+  for (size_t i = 0; i < nn; ++i) {
+    if (!nr[i]) continue;
+    bool first = true;
+    walk(ctx->h_node_taxid[i], [&](size_t row) {
+      clade_id(row);
+      c_reads[row] += nr[i];
+      if (first) { t_reads[row] = nr[i]; first = false; }
+    });
+  }
+  const uint32_t n_clades = (uint32_t)clade_row.size();
+  if (!exact && n_clades) {
+    DevTmp tmp;
+    // members per clade (CSR)
+    std::sort(memb.begin(), memb.end());
+    std::vector<uint32_t> m_off(n_clades + 1, 0), m_slot(memb.size());
+    for (size_t j = 0; j < memb.size(); ++j) { ++m_off[memb[j].first + 1]; m_slot[j] = memb[j].second; }
+    for (uint32_t c = 0; c < n_clades; ++c) m_off[c + 1] += m_off[c];
+    uint32_t *d_moff = nullptr, *d_mslot = nullptr, *d_hist = nullptr;
+    uint8_t *d_dense = nullptr;
+    int st = tmp.put(&d_moff, m_off);
+    if (st == KU_OK) st = tmp.put(&d_mslot, m_slot);
+    if (st == KU_OK) st = tmp.put(&d_dense, clade_dense);
+    if (st == KU_OK) st = tmp.zeros(&d_hist, (size_t)n_clades * KU_ROLLUP_BINS);
+    if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the clade roll-up");
+    KU_TRY(ku_launch_rollup_dense(ctx->cnt.registers, d_moff, d_mslot, d_dense, n_clades, d_hist, ctx->stream));
+    if (sparse && n_pairs) {
+      // all-sparse clades per slot (its root path up to the first clade with a dense member: density is inherited upwards)
+      std::vector<uint32_t> s_off(ns + 1, 0), s_clade;
+      for (size_t s = 0; s < ns; ++s) {
+        s_off[s] = (uint32_t)s_clade.size();
+        if (!nk[s] || !slot_sparse[s]) continue;
+        walk(ctx->h_slot_taxid[s], [&](size_t row) { if (!clade_dense[clade_of[row]]) s_clade.push_back((uint32_t)clade_of[row]); });
+      }
+      s_off[ns] = (uint32_t)s_clade.size();
+      uint32_t *d_per_slot = nullptr, *d_soff = nullptr, *d_sclade = nullptr, *d_err = nullptr;
+      unsigned long long *d_set = nullptr;
+      st = tmp.zeros(&d_per_slot, ns);
+      if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the clade roll-up");
+      KU_TRY(ku_launch_count_pairs((const unsigned long long *)ctx->sp.out.p, n_pairs, d_per_slot, ctx->n_cu, ctx->stream));
+      std::vector<uint32_t> per_slot(ns);
+      HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      uint64_t inserts = 0;
+      for (size_t s = 0; s < ns; ++s) inserts += (uint64_t)per_slot[s] * (s_off[s + 1] - s_off[s]);
+      uint64_t cells = 1024;
+      while (cells < 2 * inserts) cells <<= 1;
+      st = tmp.put(&d_soff, s_off);
+      if (st == KU_OK) st = tmp.put(&d_sclade, s_clade);
+      if (st == KU_OK) st = tmp.zeros(&d_err, 1);
+      if (st == KU_OK) st = tmp.zeros(&d_set, cells);
+      if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
+      KU_TRY(ku_launch_rollup_sparse((const unsigned long long *)ctx->sp.out.p, n_pairs, d_soff, d_sclade, d_set, cells - 1, d_hist,
+                                     d_err, ctx->n_cu, ctx->stream));
+      uint32_t err = 0;
+      HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (err) return fail(KU_EHIP, "ku_ctx_report: the sparse-union set overflowed");
+    }
+    std::vector<uint32_t> hist((size_t)n_clades * KU_ROLLUP_BINS);
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t c = 0; c < n_clades; ++c) {
+      const size_t row = clade_row[c];
+      if (c_reads[row] == 0) continue;  // not printed
+      const bool has_members = m_off[c + 1] > m_off[c];
+      // a clade counted through reads only has an empty sketch
+      c_uniq[row] = has_members ? ku_hll_estimate_hist(hist.data() + (size_t)c * KU_ROLLUP_BINS, sparse && !clade_dense[c], c_kmers[row]) : 0;
+    }
+  }
+  return ku_report_rows(tax, counts_paths, n_paths, present.data(), c_reads.data(), t_reads.data(), c_kmers.data(), c_uniq.data(), nt,
+                        out, out_len);
+}
+
 extern "C" int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_register_bytes,
                                      uint64_t **d_n_kmers, uint64_t *n_slots, uint64_t **d_n_reads, uint64_t *n_nodes) {
   if (!ctx) return fail(KU_EINVAL, "null context");

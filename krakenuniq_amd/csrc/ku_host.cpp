@@ -270,6 +270,117 @@ extern "C" int ku_report_exact(const ku_tax *tax, const char *const *counts_path
   return report_impl(tax, counts_paths, n_paths, slot_taxid, n_kmers, nullptr, unique_kmers, n_slots, node_taxid, n_reads, n_nodes, out, out_len);
 }
 
+// The report text from per-entry clade summaries (rows parallel to the taxDB entries): DFS from the roots, children by
+// descending (reads, kmers) -- TaxReport::printReport (taxdb.hpp:1004-1123).  `clade_uniq` is the distinct k-mer count
+// (estimate) of the clade's merged sketch.
+extern "C" int ku_report_rows(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint8_t *present,
+                              const uint64_t *clade_reads, const uint64_t *tax_reads, const uint64_t *clade_kmers,
+                              const uint64_t *clade_uniq, uint64_t n_rows, char **out, size_t *out_len) {
+  if (!tax || !out || !out_len || (n_paths && !counts_paths)) { ku_set_error("ku_report_rows: null argument"); return KU_EINVAL; }
+  const size_t nt = tax->ids.size();
+  if (n_rows != nt || (nt && (!present || !clade_reads || !tax_reads || !clade_kmers || !clade_uniq))) {
+    ku_set_error("ku_report_rows: the arrays must have one element per taxDB entry");
+    return KU_EINVAL;
+  }
+  // genome sizes: readGenomeSizes (taxdb.hpp:867-885).  "while(!eof){in >> id >> size; set(id,size);}" applies
+  // the LAST pair twice when the file ends in whitespace (the failed extraction leaves both values unchanged).
+  std::vector<uint64_t> gsize(nt, 0), gchild(nt, 0);
+  auto set_genome_size = [&](uint32_t id, uint64_t size) {  // taxdb.hpp:850-865
+    auto it = tax->row.find(id);
+    if (it == tax->row.end()) return;
+    gsize[it->second] += size;
+    for (int64_t q = tax->parent_row(it->second); q >= 0; q = tax->parent_row((size_t)q)) gchild[q] += size;
+  };
+  for (uint32_t pi = 0; pi < n_paths; ++pi) {  // one counts file per database, in order (classify.cpp:263-285)
+    const char *counts_path = counts_paths[pi];
+    if (!counts_path) continue;
+    FILE *f = fopen(counts_path, "r");
+    if (!f) { ku_set_error(std::string("unable to open file ") + counts_path); return KU_ENOINPUT; }
+    std::string data;
+    char tmp[65536];
+    size_t got;
+    while ((got = fread(tmp, 1, sizeof(tmp), f)) > 0) data.append(tmp, got);
+    fclose(f);
+    const char *p = data.c_str();
+    unsigned long long id = 0, size = 0;
+    bool have = false, trailing = false;
+    for (;;) {
+      char *e1, *e2;
+      unsigned long long a = strtoull(p, &e1, 10);
+      if (e1 == p) break;
+      unsigned long long b = strtoull(e1, &e2, 10);
+      if (e2 == e1) break;
+      id = a; size = b; have = true; p = e2;
+      trailing = *p != 0;
+      set_genome_size((uint32_t)id, size);
+    }
+    if (have && trailing) set_genome_size((uint32_t)id, size);
+  }
+  // children lists
+  std::vector<std::vector<uint32_t>> kids(nt);
+  for (size_t i = 0; i < nt; ++i) { int64_t p = tax->parent_row(i); if (p >= 0) kids[p].push_back((uint32_t)i); }
+  uint64_t total = 0;
+  const uint32_t roots[3] = {0u, 1u, 0xFFFFFFFFu};  // taxdb.hpp:1004
+  for (uint32_t r : roots) { auto it = tax->row.find(r); if (it != tax->row.end() && present[it->second]) total += clade_reads[it->second]; }
+  Sb sb;
+  if (total) {
+    sb.s += "%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n";  // classify.cpp:305-314
+    // iterative DFS (taxdb.hpp:1049-1076)
+    struct Frame { uint32_t row; unsigned depth; };
+    std::vector<Frame> stack;
+    for (int i = 2; i >= 0; --i) { auto it = tax->row.find(roots[i]); if (it != tax->row.end()) stack.push_back({it->second, 0}); }
+    while (!stack.empty()) {
+      Frame fr = stack.back();
+      stack.pop_back();
+      const uint32_t r = fr.row;
+      if (!present[r] || clade_reads[r] == 0) continue;
+      const uint64_t uniq = clade_uniq[r];
+      volatile double gs = double(gsize[r] + gchild[r]);
+      volatile double kc = double(clade_kmers[r]), un = double(uniq);
+      sb.printf("%.4g\t", 100.0 * double(clade_reads[r]) / double(total));
+      sb.printf("%llu\t%llu\t%llu\t", (unsigned long long)clade_reads[r], (unsigned long long)tax_reads[r], (unsigned long long)uniq);
+      sb.printf("%.3g\t", kc / un);
+      if (gs == 0) sb.s += "NA\t"; else sb.printf("%.4g\t", un / gs);
+      if (tax->ids[r] == 0xFFFFFFFFu) sb.s += "-1\t"; else sb.printf("%d\t", (int32_t)tax->ids[r]);
+      sb.s += tax->ranks[r];
+      sb.s += '\t';
+      sb.s.append(2 * fr.depth, ' ');
+      sb.s += tax->names[r];
+      sb.s += '\n';
+      std::vector<uint32_t> ch;
+      for (uint32_t x : kids[r]) if (present[x]) ch.push_back(x);
+      // descending (reads, kmers) (readcounts.hpp:90-98); ties: ascending taxid
+      std::sort(ch.begin(), ch.end(), [&](uint32_t a, uint32_t b) {
+        if (clade_reads[a] != clade_reads[b]) return clade_reads[a] > clade_reads[b];
+        if (clade_kmers[a] != clade_kmers[b]) return clade_kmers[a] > clade_kmers[b];
+        return tax->ids[a] < tax->ids[b];
+      });
+      for (auto it = ch.rbegin(); it != ch.rend(); ++it) stack.push_back({*it, fr.depth + 1});
+    }
+  }
+  char *buf = (char *)malloc(sb.s.size() + 1);
+  if (!buf) return KU_ENOMEM;
+  memcpy(buf, sb.s.c_str(), sb.s.size() + 1);
+  *out = buf;
+  *out_len = sb.s.size();
+  return KU_OK;
+}
+
+// HLL estimate from a register histogram computed on the device (ku_ctx_report): dense p = 12 sketches (bins 0 .. 53)
+// and sparse p' = 25 ones (bins 1 .. 79 = ranks of the distinct encoded hashes; bin 0 is filled in here)
+uint64_t ku_hll_estimate_hist(const uint32_t *bins, bool sparse, uint64_t n_observed) {
+  int C[80];
+  if (!sparse) {
+    const uint32_t q = 64 - KU_HLL_P;
+    for (uint32_t i = 0; i <= q + 1; ++i) C[i] = (int)bins[i];
+    return ertl_from_histogram(C, q, double(KU_HLL_M), n_observed);
+  }
+  int64_t m = 1ll << 25;
+  for (int i = 1; i < 80; ++i) { C[i] = (int)bins[i]; m -= bins[i]; }
+  C[0] = (int)m;
+  return ertl_from_histogram(C, 64 - 25, double(1 << 25), n_observed);
+}
+
 static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint32_t *slot_taxid,
                        const uint64_t *n_kmers, const uint8_t *registers, const uint64_t *unique, uint64_t n_slots,
                        const uint32_t *node_taxid, const uint64_t *n_reads, uint64_t n_nodes, char **out, size_t *out_len,
@@ -318,40 +429,6 @@ static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint3
     }
   for (uint64_t i = 0; i < n_nodes; ++i)
     if (n_reads[i]) tc[node_taxid[i]].reads = n_reads[i];
-  // genome sizes: readGenomeSizes (taxdb.hpp:867-885).  "while(!eof){in >> id >> size; set(id,size);}" applies
-  // the LAST pair twice when the file ends in whitespace (the failed extraction leaves both values unchanged).
-  std::vector<uint64_t> gsize(nt, 0), gchild(nt, 0);
-  auto set_genome_size = [&](uint32_t id, uint64_t size) {  // taxdb.hpp:850-865
-    auto it = tax->row.find(id);
-    if (it == tax->row.end()) return;
-    gsize[it->second] += size;
-    for (int64_t q = tax->parent_row(it->second); q >= 0; q = tax->parent_row((size_t)q)) gchild[q] += size;
-  };
-  for (uint32_t pi = 0; pi < n_paths; ++pi) {  // one counts file per database, in order (classify.cpp:263-285)
-    const char *counts_path = counts_paths[pi];
-    if (!counts_path) continue;
-    FILE *f = fopen(counts_path, "r");
-    if (!f) { ku_set_error(std::string("unable to open file ") + counts_path); return KU_ENOINPUT; }
-    std::string data;
-    char tmp[65536];
-    size_t got;
-    while ((got = fread(tmp, 1, sizeof(tmp), f)) > 0) data.append(tmp, got);
-    fclose(f);
-    const char *p = data.c_str();
-    unsigned long long id = 0, size = 0;
-    bool have = false, trailing = false;
-    for (;;) {
-      char *e1, *e2;
-      unsigned long long a = strtoull(p, &e1, 10);
-      if (e1 == p) break;
-      unsigned long long b = strtoull(e1, &e2, 10);
-      if (e2 == e1) break;
-      id = a; size = b; have = true; p = e2;
-      trailing = *p != 0;
-      set_genome_size((uint32_t)id, size);
-    }
-    if (have && trailing) set_genome_size((uint32_t)id, size);
-  }
   // clade roll-up (taxdb.hpp:928-973): every counted taxon contributes to itself and all ancestors
   std::vector<Clade> clade(nt);
   for (auto &kv : tc) {
@@ -386,59 +463,25 @@ static int report_impl(const ku_tax *tax, const char *const *counts_paths, uint3
         c.set.erase(std::unique(c.set.begin(), c.set.end()), c.set.end());
       }
   }
-  // children lists
-  std::vector<std::vector<uint32_t>> kids(nt);
-  for (size_t i = 0; i < nt; ++i) { int64_t p = tax->parent_row(i); if (p >= 0) kids[p].push_back((uint32_t)i); }
-  uint64_t total = 0;
-  const uint32_t roots[3] = {0u, 1u, 0xFFFFFFFFu};  // taxdb.hpp:1004
-  for (uint32_t r : roots) { auto it = tax->row.find(r); if (it != tax->row.end() && clade[it->second].present) total += clade[it->second].reads; }
-  Sb sb;
-  if (total) {
-    sb.s += "%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n";  // classify.cpp:305-314
-    static const std::vector<uint8_t> zero_regs(KU_HLL_M, 0);
-    // iterative DFS (taxdb.hpp:1049-1076)
-    struct Frame { uint32_t row; unsigned depth; };
-    std::vector<Frame> stack;
-    for (int i = 2; i >= 0; --i) { auto it = tax->row.find(roots[i]); if (it != tax->row.end()) stack.push_back({it->second, 0}); }
-    while (!stack.empty()) {
-      Frame fr = stack.back();
-      stack.pop_back();
-      const Clade &c = clade[fr.row];
-      if (!c.present || c.reads == 0) continue;
-      const uint8_t *regs = c.regs.empty() ? zero_regs.data() : c.regs.data();
-      const bool sparse_sketch = slot_is_sparse && !unique && !c.dense;
-      const uint64_t uniq = unique ? c.uniq
-                                   : (sparse_sketch ? ku_hll_cardinality_sparse(c.set.data(), c.set.size(), c.kmers)
-                                                    : ku_hll_cardinality(regs, KU_HLL_P, c.kmers));
-      volatile double gs = double(gsize[fr.row] + gchild[fr.row]);
-      volatile double kc = double(c.kmers), un = double(uniq);
-      auto ti = tc.find(tax->ids[fr.row]);
-      const uint64_t tax_reads = ti == tc.end() ? 0 : ti->second.reads;
-      sb.printf("%.4g\t", 100.0 * double(c.reads) / double(total));
-      sb.printf("%llu\t%llu\t%llu\t", (unsigned long long)c.reads, (unsigned long long)tax_reads, (unsigned long long)uniq);
-      sb.printf("%.3g\t", kc / un);
-      if (gs == 0) sb.s += "NA\t"; else sb.printf("%.4g\t", un / gs);
-      if (tax->ids[fr.row] == 0xFFFFFFFFu) sb.s += "-1\t"; else sb.printf("%d\t", (int32_t)tax->ids[fr.row]);
-      sb.s += tax->ranks[fr.row];
-      sb.s += '\t';
-      sb.s.append(2 * fr.depth, ' ');
-      sb.s += tax->names[fr.row];
-      sb.s += '\n';
-      std::vector<uint32_t> ch;
-      for (uint32_t x : kids[fr.row]) if (clade[x].present) ch.push_back(x);
-      // descending (reads, kmers) (readcounts.hpp:90-98); ties: ascending taxid
-      std::sort(ch.begin(), ch.end(), [&](uint32_t a, uint32_t b) {
-        if (clade[a].reads != clade[b].reads) return clade[a].reads > clade[b].reads;
-        if (clade[a].kmers != clade[b].kmers) return clade[a].kmers > clade[b].kmers;
-        return tax->ids[a] < tax->ids[b];
-      });
-      for (auto it = ch.rbegin(); it != ch.rend(); ++it) stack.push_back({*it, fr.depth + 1});
-    }
+  // estimator per present clade, then the text
+  static const std::vector<uint8_t> zero_regs(KU_HLL_M, 0);
+  std::vector<uint8_t> present(nt, 0);
+  std::vector<uint64_t> c_reads(nt, 0), t_reads(nt, 0), c_kmers(nt, 0), c_uniq(nt, 0);
+  for (size_t r = 0; r < nt; ++r) {
+    const Clade &c = clade[r];
+    if (!c.present) continue;
+    present[r] = 1;
+    c_reads[r] = c.reads;
+    c_kmers[r] = c.kmers;
+    auto ti = tc.find(tax->ids[r]);
+    t_reads[r] = ti == tc.end() ? 0 : ti->second.reads;
+    if (c.reads == 0) continue;  // not printed
+    const uint8_t *regs = c.regs.empty() ? zero_regs.data() : c.regs.data();
+    const bool sparse_sketch = slot_is_sparse && !unique && !c.dense;
+    c_uniq[r] = unique ? c.uniq
+                       : (sparse_sketch ? ku_hll_cardinality_sparse(c.set.data(), c.set.size(), c.kmers)
+                                        : ku_hll_cardinality(regs, KU_HLL_P, c.kmers));
   }
-  char *buf = (char *)malloc(sb.s.size() + 1);
-  if (!buf) return KU_ENOMEM;
-  memcpy(buf, sb.s.c_str(), sb.s.size() + 1);
-  *out = buf;
-  *out_len = sb.s.size();
-  return KU_OK;
+  return ku_report_rows(tax, counts_paths, n_paths, present.data(), c_reads.data(), t_reads.data(), c_kmers.data(), c_uniq.data(), nt,
+                        out, out_len);
 }

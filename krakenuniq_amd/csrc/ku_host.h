@@ -42,3 +42,5 @@ struct ku_tax {
 };
 
 void ku_set_error(const std::string &s);
+// Ertl estimate from a register histogram (80 bins) built on the device: dense p = 12 or sparse p' = 25 sketch
+uint64_t ku_hll_estimate_hist(const uint32_t *bins, bool sparse, uint64_t n_observed);

@@ -79,6 +79,15 @@ int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_
 int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
                             hipStream_t stream);
 
+// clade roll-up of the report (ku_report.hip): histograms of KU_ROLLUP_BINS bins per clade
+#define KU_ROLLUP_BINS 80
+int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_off, const uint32_t *d_member_slot,
+                           const uint8_t *d_clade_dense, uint32_t n_clades, uint32_t *d_hist, hipStream_t stream);
+int ku_launch_rollup_sparse(const unsigned long long *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_off,
+                            const uint32_t *d_slot_clade, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
+                            uint32_t *d_err, int n_cu, hipStream_t stream);
+int ku_launch_count_pairs(const unsigned long long *d_pairs, uint64_t n_pairs, uint32_t *d_per_slot, int n_cu, hipStream_t stream);
+
 // host-side view of an opened database for the other translation units (ku_api.cpp owns the struct)
 struct ku_db;
 int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets);

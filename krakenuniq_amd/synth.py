@@ -180,11 +180,12 @@ def random_taxonomy(n_species: int, rng: np.random.Generator, levels=(20, 60, 18
     for lvl, width in enumerate(levels):
         width = max(1, min(width, n_species))
         cur = []
+        rank = ranks[lvl] if lvl < len(ranks) else f"clade{lvl}"
         for i in range(width):
             tid = next_id
             next_id += int(rng.integers(1, 40))
             t.add(tid, prev[i % len(prev)] if i < len(prev) else prev[int(rng.integers(0, len(prev)))],
-                  f"{ranks[lvl]}_{tid}", ranks[lvl])
+                  f"{rank}_{tid}", rank)
             cur.append(tid)
         prev = cur
     species = []
