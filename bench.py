@@ -6,9 +6,10 @@
 Workload at N = 1 (BASELINE.json configs[1]): ~8 GB MiniKraken-style database (k = 31, minimizer nt = 13, ~0.61 G
 pairs, 2000 species) built directly in HBM by krakenuniq_amd/synth_torch.py; FOUR distinct batches of 10 M synthetic
 150 bp reads resident in HBM.  One "step" = one pass of the whole hot path over one 10 M-read batch
-(ku_classify_batch_device): for reads of up to 222 bp the fused wave-per-read kernel (scan, canonical k-mer, anchor /
-minimizer, bucket probe, HLL + n_kmers, hit counts, resolve_tree / LCA, n_reads, per-k-mer taxids); for longer reads
-and --paired the two stages ku_lookup_device + ku_resolve_device.  The steps rotate through the batches and the
+(ku_classify_batch_device): the fused wave-per-read kernel (scan, canonical k-mer, anchor / minimizer, bucket probe,
+HLL + n_kmers, hit counts, resolve_tree / LCA, n_reads, per-k-mer taxids) -- in one pass for reads of up to 222 bp, in
+windows of 128 k-mers for longer ones (--paired, --read-len 10000); with KU_NO_FUSED=1 / KU_NO_WINDOWED=1 or reads beyond
+65535 k-mers the two stages ku_lookup_device + ku_resolve_device.  The steps rotate through the batches and the
 per-taxon state is zeroed at the start of every rotation (inside the timed region), so each rotation is a fresh 40 M-read
 run: HyperLogLog registers start empty and their compare-and-swap updates are part of what is timed.
 
@@ -372,7 +373,9 @@ def main():
     torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    fused = os.environ.get("KU_NO_FUSED") is None and (read_len - k + 1) <= 192 and ctx.db_layout()["hash"]
+    n_k = read_len - k + 1
+    fused = (os.environ.get("KU_NO_FUSED") is None and ctx.db_layout()["hash"]
+             and (n_k <= 192 or (n_k <= 65535 and os.environ.get("KU_NO_WINDOWED") is None)))
 
     def step(i, timed):
         b = batches[i % nb_batches]

@@ -1173,9 +1173,18 @@ static int classify_device_impl(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
       HIP_TRY(hipStreamSynchronize(s));
     }
     const uint32_t max_n = max_len >= ctx->m.db.k ? max_len - ctx->m.db.k + 1 : 0;
-    if (max_n <= short_max) {
+    // longer reads (mate pairs, long reads up to 65535 k-mers): the same kernel in windows of 128 k-mers -- when its
+    // spill workspace can be had; KU_NO_WINDOWED=1 keeps them on the flat lookup + resolve kernels
+    bool fused = max_n <= short_max;
+    if (!fused && max_n <= ku_short_max_kmers_windowed(ctx->m.db) && !getenv("KU_NO_WINDOWED")) {
+      const uint64_t ws = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, n_reads, ctx->n_cu);
+      if (ws > ctx->b_ws.cap) HIP_TRY(hipStreamSynchronize(s));
+      fused = ctx->b_ws.reserve(ws) == KU_OK;
+      if (!fused) (void)hipGetLastError();
+    }
+    if (fused) {
       int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len,
-                                        n_reads, max_n, flags, d_calls, d_taxa, d_hits, ctx->n_cu, s);
+                                        n_reads, max_n, flags, d_calls, d_taxa, d_hits, ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s);
       return st == KU_OK ? KU_OK : fail(st, "fused short-read kernel launch failed");
     }
     ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};

@@ -111,11 +111,13 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
                       uint32_t *d_hits, void *d_workspace, uint64_t workspace_bytes, int n_cu,
                       hipStream_t stream);
 // fused wave-per-read path for short reads (ku_short.hip)
-uint32_t ku_short_max_kmers(const KuDbDev &db);
+uint32_t ku_short_max_kmers(const KuDbDev &db);           // reads taken in one pass
+uint32_t ku_short_max_kmers_windowed(const KuDbDev &db);  // ... in windows of 128 k-mers (ku_short.hip)
+uint64_t ku_short_workspace_bytes(uint32_t max_kmers, uint32_t n_slots, uint64_t n_reads, int n_cu);
 int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
                              uint64_t n_bytes, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                              uint32_t max_kmers, uint32_t flags, uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits,
-                             int n_cu, hipStream_t stream);
+                             void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream);
 uint64_t ku_resolve_workspace_bytes(uint32_t max_read_len, uint32_t k, int n_cu);
 int ku_launch_exact(uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                     const uint32_t *d_taxa, unsigned long long *d_set, uint64_t mask, unsigned long long *d_unique,

@@ -98,6 +98,169 @@ __device__ __forceinline__ void ks_rct_flush(uint32_t *key, uint32_t *cnt, uint3
   ks_wave_sync();
 }
 
+// ---- hit_counts of one read (classify.cpp:941) in a wave-private LDS table: open addressing, key = slot + 1, hit count
+// in the low 16 bits of the value, the root-path score in the high 16 (a read has at most 65535 k-mers here)
+template <int LOG2, bool TRACK>
+__device__ __forceinline__ void ks_tab_add(uint32_t *t_key, uint32_t *t_cnt, uint32_t *n_distinct, uint32_t slot, uint32_t count) {
+  uint32_t h = (slot * 2654435761u) >> (32 - LOG2);
+  for (;;) {
+    uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (cur == 0) {
+      uint32_t old = atomicCAS(&t_key[h], 0u, slot + 1);
+      if (TRACK && old == 0) atomicAdd(n_distinct, 1u);
+      cur = old == 0 ? slot + 1 : old;
+    }
+    if (cur == slot + 1) {
+      atomicAdd(&t_cnt[h], count);
+      break;
+    }
+    h = (h + 1) & ((1u << LOG2) - 1);
+  }
+}
+
+// resolve_tree (krakenutil.cpp:149-200) over the wave's table: score(t) = sum of the hit counts on t's root path, the
+// best score wins, ties fold lca() in ascending taxid (= slot) order.  Leaves the table empty.  Returns the node.
+template <int LOG2>
+__device__ __forceinline__ uint32_t ks_tab_resolve(uint32_t *t_key, uint32_t *t_cnt, uint16_t *t_list, uint32_t *list_len,
+                                                   const KuTaxDev &tax, uint32_t lane) {
+  constexpr uint32_t TCAP = 1u << LOG2;
+  if (lane == 0) *list_len = 0;
+  ks_wave_sync();
+  for (uint32_t i = lane; i < TCAP; i += 64)
+    if (t_key[i]) t_list[atomicAdd(list_len, 1u)] = (uint16_t)i;
+  ks_wave_sync();
+  const uint32_t n_list = *list_len;
+  uint32_t my_max = 0;
+  for (uint32_t e = lane; e < n_list; e += 64) {
+    const uint32_t pos = t_list[e];
+    const uint32_t sl = t_key[pos] - 1;
+    uint32_t score = 0;
+    for (uint32_t i = tax.slot_anc_off[sl], i_end = tax.slot_anc_off[sl + 1]; i < i_end; ++i) {
+      const uint32_t s = tax.slot_anc[i];
+      uint32_t h = (s * 2654435761u) >> (32 - LOG2);
+      for (;;) {
+        const uint32_t cur = t_key[h];
+        if (cur == s + 1) { score += t_cnt[h] & 0xffffu; break; }
+        if (cur == 0) break;
+        h = (h + 1) & (TCAP - 1);
+      }
+    }
+    atomicAdd(&t_cnt[pos], score << 16);
+    my_max = max(my_max, score);
+  }
+  my_max = ku_wave_max_u32(my_max);
+  ks_wave_sync();
+  uint32_t last = 0, res = 0;
+  bool firstt = true;
+  for (;;) {
+    uint32_t my_min = 0xFFFFFFFFu;
+    for (uint32_t e = lane; e < n_list; e += 64) {
+      const uint32_t pos = t_list[e];
+      const uint32_t s = t_key[pos] - 1;
+      if ((t_cnt[pos] >> 16) == my_max && s > last) my_min = min(my_min, s);
+    }
+    my_min = ku_wave_min_u32(my_min);
+    if (my_min == 0xFFFFFFFFu) break;
+    const uint32_t node = tax.slot_node[my_min];
+    res = firstt ? node : ku_lca_nodes(tax.node_parent, res, node);  // uniform: every lane computes the same
+    firstt = false;
+    last = my_min;
+  }
+  ks_wave_sync();
+  for (uint32_t e = lane; e < n_list; e += 64) {
+    const uint32_t pos = t_list[e];
+    t_key[pos] = 0;
+    t_cnt[pos] = 0;
+  }
+  ks_wave_sync();
+  return res;
+}
+
+// ---- the same table in global memory, for the rare long read that meets more distinct taxa than the LDS table holds
+// (windowed variant only).  One region of `cap` keys + `cap` values per wave; device-scope atomics and atomic loads
+// (the wave's own earlier atomics must be visible to its later loads past the L1).
+__device__ __forceinline__ uint32_t ks_gload(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __noinline__ void ks_spill_add(uint32_t *g_key, uint32_t *g_cnt, uint32_t mask, uint32_t slot, uint32_t count) {
+  uint32_t h = (slot * 2654435761u) & mask;
+  for (;;) {
+    uint32_t cur = ks_gload(&g_key[h]);
+    if (cur == 0) {
+      uint32_t old = atomicCAS(&g_key[h], 0u, slot + 1);
+      cur = old == 0 ? slot + 1 : old;
+    }
+    if (cur == slot + 1) {
+      atomicAdd(&g_cnt[h], count);
+      break;
+    }
+    h = (h + 1) & mask;
+  }
+}
+__device__ __noinline__ void ks_spill_migrate(uint32_t *t_key, uint32_t *t_cnt, uint32_t tcap, uint32_t *g_key, uint32_t *g_cnt,
+                                              uint32_t mask, bool wipe, uint32_t lane) {
+  if (wipe) {  // first use by this wave in this launch: the workspace holds whatever ran before
+    for (uint32_t i = lane; i <= mask; i += 64) { g_key[i] = 0; g_cnt[i] = 0; }
+    __threadfence();
+  }
+  ks_wave_sync();
+  for (uint32_t i = lane; i < tcap; i += 64) {
+    const uint32_t kk = t_key[i];
+    if (kk) {
+      ks_spill_add(g_key, g_cnt, mask, kk - 1, t_cnt[i] & 0xffffu);
+      t_key[i] = 0;
+      t_cnt[i] = 0;
+    }
+  }
+  ks_wave_sync();
+}
+// (the taxonomy arrays come as plain pointers: a reference to the kernel's KuTaxDev argument would pin that struct to
+// scratch memory for every user)
+__device__ __noinline__ uint32_t ks_spill_resolve(uint32_t *g_key, uint32_t *g_cnt, uint32_t mask, const uint32_t *slot_anc_off,
+                                                  const uint32_t *slot_anc, const uint32_t *slot_node, const uint32_t *node_parent,
+                                                  uint32_t lane) {
+  __threadfence();
+  uint32_t my_max = 0;
+  for (uint32_t pos = lane; pos <= mask; pos += 64) {
+    const uint32_t kk = ks_gload(&g_key[pos]);
+    if (!kk) continue;
+    uint32_t score = 0;
+    for (uint32_t i = slot_anc_off[kk - 1], i_end = slot_anc_off[kk]; i < i_end; ++i) {
+      const uint32_t s = slot_anc[i];
+      uint32_t h = (s * 2654435761u) & mask;
+      for (;;) {
+        const uint32_t cur = ks_gload(&g_key[h]);
+        if (cur == s + 1) { score += ks_gload(&g_cnt[h]) & 0xffffu; break; }
+        if (cur == 0) break;
+        h = (h + 1) & mask;
+      }
+    }
+    atomicAdd(&g_cnt[pos], score << 16);
+    my_max = max(my_max, score);
+  }
+  my_max = ku_wave_max_u32(my_max);
+  __threadfence();
+  uint32_t last = 0, res = 0;
+  bool firstt = true;
+  for (;;) {
+    uint32_t my_min = 0xFFFFFFFFu;
+    for (uint32_t pos = lane; pos <= mask; pos += 64) {
+      const uint32_t kk = ks_gload(&g_key[pos]);
+      if (kk && (ks_gload(&g_cnt[pos]) >> 16) == my_max && kk - 1 > last) my_min = min(my_min, kk - 1);
+    }
+    my_min = ku_wave_min_u32(my_min);
+    if (my_min == 0xFFFFFFFFu) break;
+    const uint32_t node = slot_node[my_min];
+    res = firstt ? node : ku_lca_nodes(node_parent, res, node);
+    firstt = false;
+    last = my_min;
+  }
+  for (uint32_t pos = lane; pos <= mask; pos += 64)
+    if (ks_gload(&g_key[pos])) { g_key[pos] = 0; g_cnt[pos] = 0; }
+  __threadfence();
+  return res;
+}
+
 // waves per SIMD the variant is compiled for: 2 k-mers per lane fit 80 VGPRs (6 waves, 8 B of scratch; LDS allows 6
 // blocks per CU), 3 per lane need 128 (4 waves)
 #ifndef KS_OCC2
@@ -107,11 +270,18 @@ __device__ __forceinline__ void ks_rct_flush(uint32_t *key, uint32_t *cnt, uint3
 // KK / MM: compile-time k-mer and minimizer lengths of the common database geometries (0 = read them from `db`):
 // every shift count and the window length become literals instead of loop-invariant scalars that the register
 // allocator has to park in VGPR lanes and read back in the read loop.
-template <int ITEMS, bool DO_COUNTS, int KK, int MM>
+// WIN: reads of any length up to 65535 k-mers, taken in windows of 64 * ITEMS k-mer positions -- a window is a read of
+// its own to stages 1-4 (the minimizer windows of a k-mer lie inside the k-mer, so nothing crosses a window's last
+// base); the hit counts accumulate over the windows (one taxon so far: two scalars; else the wave's LDS table; more
+// distinct taxa than that holds: the wave's region of `spill`), the call is resolved behind the last window.  A window
+// does not start on k-mers already known to be ambiguous: mate pairs joined by 'N' (2 x 150: k-mers 0-119 and
+// 151-270) take two windows, not three.
+template <int ITEMS, bool DO_COUNTS, int KK, int MM, bool WIN>
 __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_short_kernel(
     KuDbDev db, KuTaxDev tax, KuCountsDev cnt, const uint8_t *__restrict__ seqs, uint64_t n_bytes,
     const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, uint64_t n_reads,
-    uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t ablate) {
+    uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t ablate, uint32_t *__restrict__ spill,
+    uint32_t spill_cap) {
   // KS_ABL(bit): measurement knob, compiled in only with -DKU_ABLATION (then env KU_ABLATE selects the bits; the
   // production build has no trace of it -- the flag checks cost scalar registers and branches in the read loop):
   // 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
@@ -123,7 +293,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   __shared__ uint32_t s_mm[KS_WAVES][G::NMM];
   __shared__ uint32_t s_tkey[KS_WAVES][TCAP];   // resolve table: slot + 1
   __shared__ uint32_t s_tcnt[KS_WAVES][TCAP];   // hit count (low 16) | root-path score (high 16)
-  __shared__ uint16_t s_tlist[KS_WAVES][G::MAXN];
+  __shared__ uint16_t s_tlist[KS_WAVES][WIN ? (int)TCAP : G::MAXN];
   __shared__ uint32_t s_kk[KS_WAVES][1 << G::KCT_LOG2], s_kc[KS_WAVES][1 << G::KCT_LOG2];
   __shared__ uint32_t s_rk[KS_WAVES][1 << G::RCT_LOG2], s_rc[KS_WAVES][1 << G::RCT_LOG2];
   __shared__ uint32_t s_misc[KS_WAVES][4];      // [0] n_kmers table fill, [1] n_reads table fill, [2] list length, [3] bcast
@@ -148,6 +318,10 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   ks_wave_sync();
 
   const uint64_t n_waves = (uint64_t)gridDim.x * KS_WAVES;
+  // WIN: this wave's region of the spill workspace (keys, then values), wiped on first use
+  uint32_t *g_key = WIN ? spill + ((uint64_t)blockIdx.x * KS_WAVES + wv) * 2ull * spill_cap : nullptr;
+  uint32_t *g_cnt = WIN ? g_key + spill_cap : nullptr;
+  bool spill_used = false;
 #ifdef KS_PREFETCH
   // software pipeline over the wave's reads: the text of the NEXT read is requested before the current one is worked
   // on (its latency hides behind a whole read's worth of work), its length / offset one read earlier still
@@ -173,8 +347,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #endif
   for (uint64_t r = (uint64_t)blockIdx.x * KS_WAVES + wv; r < n_reads; r += n_waves) {
 #ifdef KS_PREFETCH
-    const uint32_t len = len_n;
-    const uint64_t off = off_n;
+    const uint32_t rlen = len_n;
+    const uint64_t roff = off_n;
     const uint32_t cur0 = pre0, cur1 = pre1;
     const bool cur_ok = pre_ok;
     len_n = len_nn;
@@ -182,13 +356,22 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     if (r + n_waves < n_reads) prefetch(len_n, off_n); else pre_ok = false;
     if (r + 2 * n_waves < n_reads) { len_nn = seq_len[r + 2 * n_waves]; off_nn = seq_off[r + 2 * n_waves]; }
 #else
-    const uint32_t len = seq_len[r];
-    const uint64_t off = seq_off[r];
+    const uint32_t rlen = seq_len[r];
+    const uint64_t roff = seq_off[r];
 #endif
+    // WIN: the read's hit counts so far -- one taxon (rd_first, rd_cnt) until a second one shows up, then the table
+    const uint32_t n_all = rlen >= k ? rlen - k + 1 : 0;
+    uint32_t rd_first = 0, rd_cnt = 0, win0 = 0;
+    bool rd_table = false, rd_spill = false;
+    uint32_t call_node = 0;
+    do {  // one pass per window (exactly one without WIN)
+    const uint32_t len = WIN ? min(rlen - win0, (uint32_t)G::MAXN + k - 1) : rlen;
+    const uint64_t off = roff + win0;
     const uint32_t n = len >= k ? len - k + 1 : 0;
     if (DO_COUNTS) {
       if (misc[0] > (1u << G::KCT_LOG2) / 2) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
-      if (misc[1] > (1u << G::RCT_LOG2) / 2) ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
+      if (!WIN || win0 == 0)
+        if (misc[1] > (1u << G::RCT_LOG2) / 2) ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
     }
     uint32_t v[ITEMS];  // slot of every k-mer (0 = miss or ambiguous)
     bool amb_k[ITEMS];  // ambiguous k-mer (reported as KU_AMBIG)
@@ -208,7 +391,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
           const uint64_t a0 = a & ~3ull;
           uint32_t d;
 #ifdef KS_PREFETCH
-          if (cur_ok && pl == lane) {
+          if (cur_ok && pl == lane && win0 == 0) {
             d = __builtin_amdgcn_alignbyte(cur1, cur0, (uint32_t)(a & 3ull));
           } else
 #endif
@@ -435,8 +618,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     }
 
     // ---- resolve_tree (krakenutil.cpp:149-200) from registers
-    uint32_t call_node = 0;
-    bool uni = false;        // at most one distinct hit taxon in the read (the common case)
+    bool uni = false;        // at most one distinct hit taxon in the read / window (the common case)
     uint32_t uni_slot = 0;   // that taxon's slot (0 = no hit at all)
     if (!KS_ABL(32u)) {
       uint32_t mine = 0;
@@ -448,82 +630,56 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       bool diff = false;
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) diff |= (v[j] != 0 && v[j] != first);
-      if (!__any(diff)) {
+      uni = !__any(diff);
+      uni_slot = uni ? first : 0u;
+      if (!WIN) {
         // at most one distinct hit taxon: the call is that taxon (its taxid comes from the slot table below, the read
-        // counter is keyed by the slot)
-        uni = true;
-        uni_slot = first;
-      } else {
-        // hit_counts in the wave's LDS table
-        if (lane == 0) misc[2] = 0;
+        // counter is keyed by the slot); else hit_counts in the wave's LDS table
+        if (!uni) {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j)
-          if (v[j] != 0) {
-            uint32_t h = (v[j] * 2654435761u) >> (32 - G::TCAP_LOG2);
-            for (;;) {
-              uint32_t cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (cur == 0) {
-                uint32_t old = atomicCAS(&t_key[h], 0u, v[j] + 1);
-                cur = old == 0 ? v[j] + 1 : old;
-              }
-              if (cur == v[j] + 1) {
-                atomicAdd(&t_cnt[h], 1u);
-                break;
-              }
-              h = (h + 1) & (TCAP - 1);
+          for (int j = 0; j < ITEMS; ++j)
+            if (v[j] != 0) ks_tab_add<G::TCAP_LOG2, false>(t_key, t_cnt, nullptr, v[j], 1u);
+          call_node = ks_tab_resolve<G::TCAP_LOG2>(t_key, t_cnt, t_list, &misc[2], tax, lane);
+        }
+      } else if (bal) {
+        // the window's hits join the read's: (rd_first, rd_cnt) while a single taxon has been met, the table from the
+        // second one on
+        uint32_t w_hits = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) w_hits += (uint32_t)__popcll(__ballot(v[j] != 0));
+        if (!rd_table && !(uni && (rd_first == 0 || rd_first == first))) {
+          if (rd_first && lane == 0) ks_tab_add<G::TCAP_LOG2, true>(t_key, t_cnt, &misc[3], rd_first, rd_cnt);
+          rd_table = true;
+        }
+        if (!rd_table) {
+          rd_first = first;
+          rd_cnt += w_hits;
+        } else {
+          ks_wave_sync();
+          // a window adds at most MAXN distinct taxa: beyond this fill the table moves to the wave's spill region
+          if (!rd_spill && misc[3] > TCAP - (uint32_t)G::MAXN - 32u) {
+            ks_spill_migrate(t_key, t_cnt, TCAP, g_key, g_cnt, spill_cap - 1, !spill_used, lane);
+            spill_used = true;
+            rd_spill = true;
+          }
+          if (!rd_spill) {
+            if (uni) {
+              if (lane == 0) ks_tab_add<G::TCAP_LOG2, true>(t_key, t_cnt, &misc[3], first, w_hits);
+            } else {
+#pragma unroll
+              for (int j = 0; j < ITEMS; ++j)
+                if (v[j] != 0) ks_tab_add<G::TCAP_LOG2, true>(t_key, t_cnt, &misc[3], v[j], 1u);
+            }
+          } else {
+            if (uni) {
+              if (lane == 0) ks_spill_add(g_key, g_cnt, spill_cap - 1, first, w_hits);
+            } else {
+#pragma unroll
+              for (int j = 0; j < ITEMS; ++j)
+                if (v[j] != 0) ks_spill_add(g_key, g_cnt, spill_cap - 1, v[j], 1u);
             }
           }
-        ks_wave_sync();
-        for (uint32_t i = lane; i < TCAP; i += 64)
-          if (t_key[i]) t_list[atomicAdd(&misc[2], 1u)] = (uint16_t)i;
-        ks_wave_sync();
-        const uint32_t n_list = misc[2];
-        // score(t) = sum of the hit counts on t's root path
-        uint32_t my_max = 0;
-        for (uint32_t e = lane; e < n_list; e += 64) {
-          const uint32_t pos = t_list[e];
-          const uint32_t sl = t_key[pos] - 1;
-          uint32_t score = 0;
-          for (uint32_t i = tax.slot_anc_off[sl], i_end = tax.slot_anc_off[sl + 1]; i < i_end; ++i) {
-            const uint32_t s = tax.slot_anc[i];
-            uint32_t h = (s * 2654435761u) >> (32 - G::TCAP_LOG2);
-            for (;;) {
-              const uint32_t cur = t_key[h];
-              if (cur == s + 1) { score += t_cnt[h] & 0xffffu; break; }
-              if (cur == 0) break;
-              h = (h + 1) & (TCAP - 1);
-            }
-          }
-          atomicAdd(&t_cnt[pos], score << 16);
-          my_max = max(my_max, score);
         }
-        my_max = ku_wave_max_u32(my_max);
-        ks_wave_sync();
-        // winner; ties -> fold lca() in ascending taxid (= slot) order
-        uint32_t last = 0, res = 0;
-        bool firstt = true;
-        for (;;) {
-          uint32_t my_min = 0xFFFFFFFFu;
-          for (uint32_t e = lane; e < n_list; e += 64) {
-            const uint32_t pos = t_list[e];
-            const uint32_t s = t_key[pos] - 1;
-            if ((t_cnt[pos] >> 16) == my_max && s > last) my_min = min(my_min, s);
-          }
-          my_min = ku_wave_min_u32(my_min);
-          if (my_min == 0xFFFFFFFFu) break;
-          const uint32_t node = tax.slot_node[my_min];
-          res = firstt ? node : ku_lca_nodes(tax.node_parent, res, node);  // uniform: every lane computes the same
-          firstt = false;
-          last = my_min;
-        }
-        call_node = res;
-        ks_wave_sync();
-        for (uint32_t e = lane; e < n_list; e += 64) {
-          const uint32_t pos = t_list[e];
-          t_key[pos] = 0;
-          t_cnt[pos] = 0;
-        }
-        ks_wave_sync();
       }
     }
 
@@ -558,19 +714,59 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 
     // ---- outputs
     const uint32_t uni_code = uni && uni_slot ? tax.slot_taxid[uni_slot] : 0u;
-    if (lane == 0) {
-      calls[r] = uni ? uni_code : tax.node_taxid[call_node];
-      // incrementReadCount (classify.cpp:968): per node; single-taxon reads are booked under their slot and become
-      // nodes when the wave's table is flushed
-      if (DO_COUNTS) ks_rct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], uni ? (KS_RCT_SLOT | uni_slot) : call_node, tax, cnt.n_reads);
-    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t p = j * 64 + lane;
       if (p < n && !KS_ABL(8u))
         taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (uni ? uni_code : tax.slot_taxid[v[j]]) : 0u);
     }
-    ks_wave_sync();  // the next read reuses the wave's LDS arrays
+    if (!WIN) {
+      if (lane == 0) {
+        calls[r] = uni ? uni_code : tax.node_taxid[call_node];
+        // incrementReadCount (classify.cpp:968): per node; single-taxon reads are booked under their slot and become
+        // nodes when the wave's table is flushed
+        if (DO_COUNTS) ks_rct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], uni ? (KS_RCT_SLOT | uni_slot) : call_node, tax, cnt.n_reads);
+      }
+      ks_wave_sync();  // the next read reuses the wave's LDS arrays
+      break;
+    }
+    // next window: behind this one, and behind every k-mer that holds the last ambiguous base seen so far (those
+    // k-mers are ambiguous whatever follows: they get their code here and no lane of a window)
+    uint32_t nxt = win0 + (uint32_t)G::MAXN;
+    if (nxt < n_all) {
+      uint32_t last1 = 0;  // 1 + window index of the last ambiguous base among the window's `len` bases
+      if (lane < (uint32_t)G::NAMB) {
+        const uint32_t lo = 32u * lane;
+        uint32_t wd = lo < len ? amb[lane] : 0u;
+        if (len - lo < 32u && lo < len) wd &= ~0u << (32u - (len - lo));
+        if (wd) last1 = lo + 32u - (uint32_t)__builtin_ctz(wd);
+      }
+      last1 = ku_wave_max_u32(last1);
+      if (last1 > (uint32_t)G::MAXN) {  // base MAXN or later: the k-mers at window positions MAXN .. last1 - 1 hold it
+        const uint32_t skip_to = min(win0 + last1, n_all);
+        if (nxt + lane < skip_to) taxa[roff + nxt + lane] = KU_AMBIG;  // at most k - 1 positions
+        nxt = skip_to;
+      }
+    }
+    ks_wave_sync();  // the next window reuses the wave's LDS arrays
+    win0 = nxt;
+    } while (win0 < n_all);
+    if (WIN) {
+      // behind the last window: the call (a read without k-mers or hits: 0)
+      uint32_t code;
+      if (!rd_table) code = rd_first ? tax.slot_taxid[rd_first] : 0u;
+      else {
+        call_node = rd_spill ? ks_spill_resolve(g_key, g_cnt, spill_cap - 1, tax.slot_anc_off, tax.slot_anc, tax.slot_node, tax.node_parent, lane)
+                             : ks_tab_resolve<G::TCAP_LOG2>(t_key, t_cnt, t_list, &misc[2], tax, lane);
+        if (lane == 0) misc[3] = 0;
+        code = tax.node_taxid[call_node];
+      }
+      if (lane == 0) {
+        calls[r] = code;
+        if (DO_COUNTS) ks_rct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], rd_table ? call_node : (KS_RCT_SLOT | rd_first), tax, cnt.n_reads);
+      }
+      ks_wave_sync();
+    }
   }
   if (DO_COUNTS) {
     ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
@@ -578,44 +774,74 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   }
 }
 
-// k-mers per read the fused kernel can take (0 = not eligible)
+// k-mers per read the fused kernel can take (0 = not eligible): in one pass / in windows
 uint32_t ku_short_max_kmers(const KuDbDev &db) {
   const bool whole = db.bin_lo == 0 && db.bin_hi == (1ull << (2 * db.nt));
-  return (db.table && whole) ? 64 * 3 : 0;  // longer reads: the flat lookup + resolve kernels (register budget)
+  return (db.table && whole) ? 64 * 3 : 0;  // longer reads: the windowed variant, or the flat lookup + resolve kernels
+}
+uint32_t ku_short_max_kmers_windowed(const KuDbDev &db) {
+  return ku_short_max_kmers(db) ? 65535u : 0u;  // 16-bit hit counts and scores per read
+}
+
+static unsigned ks_grid(uint64_t n_reads, int items, int n_cu) {
+  // persistent grid: two rounds of the blocks a CU holds at once (KS_OCC blocks of KS_WAVES = 4 waves per CU)
+  const char *oe = getenv("KU_SHORT_BLOCKS_PER_CU");
+  const uint64_t per_cu = oe ? (uint64_t)atoi(oe) : 2ull * KS_OCC(items);
+  const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * per_cu;
+  return (unsigned)(want < cap ? want : cap);
+}
+// entries of a wave's spill table: twice the distinct taxa a read can meet
+static uint32_t ks_spill_cap(uint32_t max_kmers, uint32_t n_slots) {
+  const uint32_t distinct = max_kmers < n_slots ? max_kmers : n_slots;
+  uint32_t cap = 1024;
+  while (cap < 2 * distinct) cap <<= 1;
+  return cap;
+}
+// workspace of the windowed variant (0 when the reads fit one pass)
+uint64_t ku_short_workspace_bytes(uint32_t max_kmers, uint32_t n_slots, uint64_t n_reads, int n_cu) {
+  if (max_kmers <= 192) return 0;
+  return (uint64_t)ks_grid(n_reads, 2, n_cu) * KS_WAVES * 2ull * ks_spill_cap(max_kmers, n_slots) * 4ull;
 }
 
 int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
                              uint64_t n_bytes, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                              uint32_t max_kmers, uint32_t flags, uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits,
-                             int n_cu, hipStream_t stream) {
+                             void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream) {
   if (n_reads == 0) return KU_OK;
   const bool counts = !(flags & KU_F_NO_COUNTS);
   if (flags & KU_F_KEEP_SLOTS) return KU_EINVAL;  // slot ids are for the sharded path, which does not come here
   if (d_hits && hipMemsetAsync(d_hits, 0, n_reads * 4, stream) != hipSuccess) return KU_EHIP;  // "Q:n" is quick mode only
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
-  // persistent grid: two rounds of the blocks a CU holds at once (KS_OCC blocks of KS_WAVES = 4 waves per CU)
-  const int items = max_kmers <= 128 ? 2 : 3;
-  const char *oe = getenv("KU_SHORT_BLOCKS_PER_CU");
-  const uint64_t per_cu = oe ? (uint64_t)atoi(oe) : 2ull * KS_OCC(items);
-  const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * per_cu;
-  const dim3 grid((unsigned)(want < cap ? want : cap)), block(64 * KS_WAVES);
-#define KS_LAUNCH(I, C, K, M)                                                                                       \
-  hipLaunchKernelGGL((ku_classify_short_kernel<I, C, K, M>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes,  \
-                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate)
+  const bool windowed = max_kmers > 192;
+  const int items = max_kmers <= 128 || windowed ? 2 : 3;
+  const dim3 grid(ks_grid(n_reads, items, n_cu)), block(64 * KS_WAVES);
+  uint32_t spill_cap = 0;
+  if (windowed) {
+    if (max_kmers > 65535u) return KU_EINVAL;
+    spill_cap = ks_spill_cap(max_kmers, tax.n_slots);
+    if (!d_workspace || workspace_bytes < (uint64_t)grid.x * KS_WAVES * 2ull * spill_cap * 4ull) return KU_EINVAL;
+  }
+#define KS_LAUNCH(I, C, K, M, W)                                                                                       \
+  hipLaunchKernelGGL((ku_classify_short_kernel<I, C, K, M, W>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes, \
+                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate, (uint32_t *)d_workspace, spill_cap)
   // specialised geometries (accounting runs only): k = 31 with nt = 13 (MiniKraken-size databases) or 15 (standard)
   const int geo = !counts || db.k != 31 ? 0 : (db.nt == 13 ? 13 : (db.nt == 15 ? 15 : 0));
-  if (max_kmers > 192) return KU_EINVAL;
-  if (max_kmers <= 128) {
-    if (!counts) KS_LAUNCH(2, false, 0, 0);
-    else if (geo == 13) KS_LAUNCH(2, true, 31, 13);
-    else if (geo == 15) KS_LAUNCH(2, true, 31, 15);
-    else KS_LAUNCH(2, true, 0, 0);
+  if (windowed) {
+    if (!counts) KS_LAUNCH(2, false, 0, 0, true);
+    else if (geo == 13) KS_LAUNCH(2, true, 31, 13, true);
+    else if (geo == 15) KS_LAUNCH(2, true, 31, 15, true);
+    else KS_LAUNCH(2, true, 0, 0, true);
+  } else if (max_kmers <= 128) {
+    if (!counts) KS_LAUNCH(2, false, 0, 0, false);
+    else if (geo == 13) KS_LAUNCH(2, true, 31, 13, false);
+    else if (geo == 15) KS_LAUNCH(2, true, 31, 15, false);
+    else KS_LAUNCH(2, true, 0, 0, false);
   } else {
-    if (!counts) KS_LAUNCH(3, false, 0, 0);
-    else if (geo == 13) KS_LAUNCH(3, true, 31, 13);
-    else if (geo == 15) KS_LAUNCH(3, true, 31, 15);
-    else KS_LAUNCH(3, true, 0, 0);
+    if (!counts) KS_LAUNCH(3, false, 0, 0, false);
+    else if (geo == 13) KS_LAUNCH(3, true, 31, 13, false);
+    else if (geo == 15) KS_LAUNCH(3, true, 31, 15, false);
+    else KS_LAUNCH(3, true, 0, 0, false);
   }
 #undef KS_LAUNCH
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
