@@ -375,7 +375,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     n_k = read_len - k + 1
     fused = (os.environ.get("KU_NO_FUSED") is None and ctx.db_layout()["hash"]
-             and (n_k <= 192 or (n_k <= 65535 and os.environ.get("KU_NO_WINDOWED") is None)))
+             and (n_k <= int(os.environ.get('KU_SHORT_ONE_PASS_MAX', 192)) or (n_k <= 65535 and os.environ.get("KU_NO_WINDOWED") is None)))
 
     def step(i, timed):
         b = batches[i % nb_batches]

@@ -1,4 +1,5 @@
-// ku_short.hip -- fused classification of SHORT reads: one wavefront per read, from ASCII to call.
+// ku_short.hip -- fused classification, one wavefront per read, from ASCII to call (short reads in one pass, longer
+// ones in windows).
 //
 // The flat kernel (ku_kernels.hip) + the resolve kernel are the general path (any read length, sharded mode,
 // sorted layout).  For the headline workload -- 100-300 bp reads against the resident probe table -- this kernel
@@ -9,9 +10,10 @@
 // There is no block-level barrier anywhere: the 4 waves of a block are independent, so a wave that waits for
 // HBM never holds the others back, the per-k-mer codes never make a round trip through HBM between a lookup and a
 // resolve kernel, and no lane is spent on the separator bytes between reads.
-// Eligibility (checked by the launcher): hash layout, whole bin range resident (not a shard), no quick mode,
-// every read of the batch has at most 64 * ITEMS k-mers (ITEMS = 2 or 3: reads up to 222 bp at k = 31; paired
-// 2 x 150 and longer reads take the flat lookup + resolve kernels).
+// Eligibility (checked by the launcher): hash layout, whole bin range resident (not a shard), no quick mode.
+// Reads of at most 64 * ITEMS k-mers (ITEMS = 2 or 3: up to 222 bp at k = 31) take one pass; longer ones (mate pairs
+// 2 x 150 joined by 'N', long reads up to 65535 k-mers) the windowed instance (WIN, see the kernel's comment), beyond
+// that the flat lookup + resolve kernels.
 // Lane <-> position mapping: lane L owns the positions L, 64 + L (, 128 + L), NOT neighbouring ones.  Measured: a variant
 // with two consecutive positions per lane (one window fetch and one 64-bit reverse complement shared by the pair, 60
 // instead of 104 instructions in stage 2) ran 30.7 ms against 19.4 ms -- a bucket-header load instruction then covers
@@ -775,9 +777,10 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 }
 
 // k-mers per read the fused kernel can take (0 = not eligible): in one pass / in windows
+static uint32_t ks_one_pass_max() { return getenv("KU_SHORT_ONE_PASS_MAX") ? (uint32_t)atoi(getenv("KU_SHORT_ONE_PASS_MAX")) : 192u; }
 uint32_t ku_short_max_kmers(const KuDbDev &db) {
   const bool whole = db.bin_lo == 0 && db.bin_hi == (1ull << (2 * db.nt));
-  return (db.table && whole) ? 64 * 3 : 0;  // longer reads: the windowed variant, or the flat lookup + resolve kernels
+  return (db.table && whole) ? ks_one_pass_max() : 0;  // longer reads: the windowed variant, or the flat lookup + resolve kernels
 }
 uint32_t ku_short_max_kmers_windowed(const KuDbDev &db) {
   return ku_short_max_kmers(db) ? 65535u : 0u;  // 16-bit hit counts and scores per read
@@ -799,7 +802,7 @@ static uint32_t ks_spill_cap(uint32_t max_kmers, uint32_t n_slots) {
 }
 // workspace of the windowed variant (0 when the reads fit one pass)
 uint64_t ku_short_workspace_bytes(uint32_t max_kmers, uint32_t n_slots, uint64_t n_reads, int n_cu) {
-  if (max_kmers <= 192) return 0;
+  if (max_kmers <= ks_one_pass_max()) return 0;
   return (uint64_t)ks_grid(n_reads, 2, n_cu) * KS_WAVES * 2ull * ks_spill_cap(max_kmers, n_slots) * 4ull;
 }
 
@@ -813,7 +816,7 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
   if (d_hits && hipMemsetAsync(d_hits, 0, n_reads * 4, stream) != hipSuccess) return KU_EHIP;  // "Q:n" is quick mode only
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
-  const bool windowed = max_kmers > 192;
+  const bool windowed = max_kmers > ks_one_pass_max();
   const int items = max_kmers <= 128 || windowed ? 2 : 3;
   const dim3 grid(ks_grid(n_reads, items, n_cu)), block(64 * KS_WAVES);
   uint32_t spill_cap = 0;
