@@ -29,6 +29,7 @@ run-length encoding -> D2H through ku_classify_batch_rle) and `e2e` (the classif
 /dev/shm against the same database, its own timing window).
 """
 import argparse
+import threading
 import json
 import os
 import re
@@ -303,16 +304,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from krakenuniq_amd import capi, dist as kdist, synth_torch
-    uid = None
-    if ws > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        # the C++ driver's own RCCL communicator: rank 0 makes the id, everybody gets it
+    def fresh_uid():
+        """id of one RCCL communicator of the C++ driver: rank 0 makes it, everybody gets it (an id serves one init)"""
+        if ws <= 1:
+            return None
         t = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             t.copy_(torch.from_numpy(capi.mgpu_unique_id()))
         dist.broadcast(t, 0)
-        uid = t.cpu().numpy()
+        return t.cpu().numpy()
+
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    uid = fresh_uid()
 
     k = 31
     sharded = a.mode == "sharded"
@@ -495,6 +500,15 @@ def main():
                                       "sample": f"failed: {e}"}
     if ws > 1 and not a.no_extras and not os.environ.get("KU_BENCH_NO_SHARDED_LEG"):
         # the same world once more with the database sharded by minimizer range (strong scaling, configs[2] layout)
+        # an exchange that never returns must not take the line measured above with it
+        def give_up():
+            if rank == 0:
+                result["sharded"] = {"value": None, "error": "the sharded leg did not finish within its time limit"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("KU_BENCH_SHARDED_LEG_LIMIT", "300")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             del batches, d_taxa, d_calls
             mg.close()
@@ -502,7 +516,7 @@ def main():
             del db
             torch.cuda.empty_cache()
             s_steps = max(2, min(a.steps, 4))
-            el, smg, sdb, ok = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, s_steps, 1, stream)
+            el, smg, sdb, ok = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, 1, stream)
             result["sharded"] = {"value": round(a.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
                                  "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sdb.n_pairs,
                                  "every_read_resolved_once": ok,
@@ -510,6 +524,7 @@ def main():
             smg.close()
         except Exception as e:
             result["sharded"] = {"value": None, "error": str(e)[:300]}
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if mg:
