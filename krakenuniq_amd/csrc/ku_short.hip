@@ -347,6 +347,14 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   uint32_t len_nn = r_first + n_waves < n_reads ? seq_len[r_first + n_waves] : 0;
   uint64_t off_nn = r_first + n_waves < n_reads ? seq_off[r_first + n_waves] : 0;
 #endif
+#ifndef KS_PREFETCH
+  uint32_t len_n = 0;
+  uint64_t off_n = 0;
+  {
+    const uint64_t r0 = (uint64_t)blockIdx.x * KS_WAVES + wv;
+    if (r0 < n_reads) { len_n = seq_len[r0]; off_n = seq_off[r0]; }
+  }
+#endif
   for (uint64_t r = (uint64_t)blockIdx.x * KS_WAVES + wv; r < n_reads; r += n_waves) {
 #ifdef KS_PREFETCH
     const uint32_t rlen = len_n;
@@ -358,8 +366,14 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     if (r + n_waves < n_reads) prefetch(len_n, off_n); else pre_ok = false;
     if (r + 2 * n_waves < n_reads) { len_nn = seq_len[r + 2 * n_waves]; off_nn = seq_off[r + 2 * n_waves]; }
 #else
-    const uint32_t rlen = seq_len[r];
-    const uint64_t roff = seq_off[r];
+    // length and offset were requested one read ahead (two scalar loads off the chain of dependent round trips)
+    const uint32_t rlen = len_n;
+    const uint64_t roff = off_n;
+    {
+      const uint64_t rn = r + n_waves;
+      len_n = rn < n_reads ? seq_len[rn] : 0u;
+      off_n = rn < n_reads ? seq_off[rn] : 0ull;
+    }
 #endif
     // WIN: the read's hit counts so far -- one taxon (rd_first, rd_cnt) until a second one shows up, then the table
     const uint32_t n_all = rlen >= k ? rlen - k + 1 : 0;
@@ -564,12 +578,15 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         h1[j] = lp[j][4];
       }
       KuPair pr[ITEMS];
+      const uint32_t *ep[ITEMS];
 #pragma unroll
-      for (int j = 0; j < ITEMS; ++j) {
-        cand[j] = act[j] ? ku_tag_matches(h4[j], h1[j], tag[j]) : 0u;
+      for (int j = 0; j < ITEMS; ++j) {  // no branch between the header wait and the entry loads of all items
+        cand[j] = ku_tag_matches(h4[j], h1[j], tag[j]) & (act[j] ? 0x1FFu : 0u);
         ovf[j] = act[j] && (h4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
-        pr[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (cand[j] ? __builtin_ctz(cand[j]) : 0));
+        ep[j] = lp[j] + 5 + 3 * (__builtin_ctz(cand[j] | 0x200u) % 9u);  // no candidate: entry 0 (bit 9 -> 9 % 9)
       }
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) pr[j] = *reinterpret_cast<const KuPair *>(ep[j]);
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
         const bool hit = cand[j] != 0 && (((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo) == canon[j];
@@ -685,6 +702,9 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       }
     }
 
+    // the taxid of the single taxon is requested here: its round trip runs under the HLL loads below
+    const uint32_t uni_code = uni && uni_slot ? tax.slot_taxid[uni_slot] : 0u;
+
     // ---- ReadCounts::add_kmer for every unambiguous k-mer, misses included (classify.cpp:939): HLL register per
     // k-mer; n_kmers per read when the read met one taxon at most (two counter updates instead of one per lane)
     if (DO_COUNTS && n > 0) {
@@ -715,12 +735,18 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     }
 
     // ---- outputs
-    const uint32_t uni_code = uni && uni_slot ? tax.slot_taxid[uni_slot] : 0u;
+    uint32_t tcode[ITEMS];  // taxid per k-mer: slot 0 (miss) is taxid 0; the lookups of all items go out together
+    if (uni) {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) tcode[j] = v[j] ? uni_code : 0u;
+    } else {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) tcode[j] = tax.slot_taxid[v[j]];
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const uint32_t p = j * 64 + lane;
-      if (p < n && !KS_ABL(8u))
-        taxa[off + p] = amb_k[j] ? KU_AMBIG : (v[j] ? (uni ? uni_code : tax.slot_taxid[v[j]]) : 0u);
+      if (p < n && !KS_ABL(8u)) taxa[off + p] = amb_k[j] ? KU_AMBIG : tcode[j];
     }
     if (!WIN) {
       if (lane == 0) {
