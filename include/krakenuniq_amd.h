@@ -172,12 +172,17 @@ int ku_ctx_reset_counts(ku_ctx *ctx);
  * ku_sparse_export closes the last unit and returns slot_is_sparse[n_slots] and the (slot << 32 | encoded hash)
  * pairs of the sparse slots (pairs = NULL to query *n_pairs) for ku_report_sparse.  work_unit_nt = 0: the whole run
  * is one unit (what the reference's -x chunk mode amounts to: it inserts into the global sketches directly,
- * classify.cpp:719).  global_log2: cells of the run-wide (slot, encoding) set, 0 = 2^26 (KU_ENOMEM when it fills).
+ * classify.cpp:719).  global_log2: initial cells of the run-wide (slot, encoding) set, 0 = 2^26; it moves to a larger
+ * table whenever a pass could fill it beyond 1/2 (KU_ENOMEM when the device has no room for that).
  * Call after ku_ctx_set_taxonomy; single GPU; at most 2^18 database taxids. */
 int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t global_log2);
 /* the work unit that is still open ends here: call between input files (the reference's units do not span files,
  * classify.cpp:487-564 runs once per file); no-op without the emulation or with work_unit_nt = 0 */
 int ku_sparse_close_unit(ku_ctx *ctx);
+/* 0 = emulation off, 1 = on, 2 = it was on and gave up: a batch found no device memory for its tables (they hold every
+ * distinct k-mer of the taxa that stay sparse).  The batch and the run went on; ku_ctx_report and the exported state
+ * are those of a run without the emulation (dense-register estimates), ku_sparse_export returns KU_ESTATE. */
+int ku_ctx_sparse_state(const ku_ctx *ctx);
 int ku_sparse_export(ku_ctx *ctx, uint8_t *slot_is_sparse, uint64_t *pairs, uint64_t *n_pairs);
 
 /* ---- set_lcas on the GPU (src/set_lcas.cpp:429-476, the database build step after db_sort): every k-mer of a library

@@ -103,6 +103,7 @@ SIGNATURES = {
     "ku_hll_cardinality_sparse": (C.c_uint64, [u32p, C.c_uint64, C.c_uint64]),
     "ku_report_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u8p, u64p, u64p, u64p, u64p, C.c_uint64,
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "ku_ctx_sparse_state": (C.c_int, [C.c_void_p]),
     "ku_ctx_report": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_size_t)]),
     "ku_ctx_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -362,6 +363,10 @@ class Ctx:
     def sparse_close_unit(self):
         _chk(lib().ku_sparse_close_unit(self.h), "ku_sparse_close_unit")
 
+    def sparse_state(self):
+        """0 = emulation off, 1 = on, 2 = gave up for lack of device memory (ku_ctx_sparse_state)"""
+        return lib().ku_ctx_sparse_state(self.h)
+
     def report(self, tax: "Tax", counts_paths=()):
         """the report from the device-resident state, clade roll-up on the GPU (ku_ctx_report)"""
         out, n = C.c_void_p(), C.c_size_t()
@@ -397,22 +402,27 @@ class Ctx:
                                      _p(calls, u32p), _p(taxa, u32p), _p(hits, u32p)), "ku_classify_batch")
         return {"calls": calls[:n], "taxa": taxa, "hits": hits[:n]}
 
-    def classify_batch_rle(self, buf, off, lens, flags=0, min_hits=1):
-        """Host-buffer entry point with run-length encoded per-k-mer codes (ku_classify_batch_rle + ku_fetch_runs)."""
+    def classify_batch_rle(self, buf, off, lens, flags=0, min_hits=1, out=None):
+        """Host-buffer entry point with run-length encoded per-k-mer codes (ku_classify_batch_rle + ku_fetch_runs).
+        out: optional dict of caller-owned arrays (page-locked ones make the copies back DMA transfers): calls, hits,
+        run_cnt (uint32[n]), run_off (uint64[n]), runs (uint32[cap, 2], cap >= the batch's run total)."""
         arr = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf
         off = np.ascontiguousarray(off, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         n = len(lens)
-        calls = np.zeros(max(n, 1), dtype=np.uint32)
-        hits = np.zeros(max(n, 1), dtype=np.uint32)
-        roff = np.zeros(max(n, 1), dtype=np.uint64)
-        rcnt = np.zeros(max(n, 1), dtype=np.uint32)
+        out = out or {}
+        calls = out["calls"] if "calls" in out else np.zeros(max(n, 1), dtype=np.uint32)
+        hits = out["hits"] if "hits" in out else np.zeros(max(n, 1), dtype=np.uint32)
+        roff = out["run_off"] if "run_off" in out else np.zeros(max(n, 1), dtype=np.uint64)
+        rcnt = out["run_cnt"] if "run_cnt" in out else np.zeros(max(n, 1), dtype=np.uint32)
         o = Opts(flags, min_hits, 0, 0)
         total = C.c_uint64()
         _chk(lib().ku_classify_batch_rle(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n, C.byref(o),
                                          _p(calls, u32p), _p(hits, u32p), _p(roff, u64p), _p(rcnt, u32p),
                                          C.byref(total)), "ku_classify_batch_rle")
-        runs = np.zeros((max(total.value, 1), 2), dtype=np.uint32)
+        runs = out.get("runs")
+        if runs is None or len(runs) < total.value:
+            runs = np.zeros((max(total.value, 1), 2), dtype=np.uint32)
         _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
         return {"calls": calls[:n], "hits": hits[:n], "runs": runs[:total.value], "run_off": roff[:n], "run_cnt": rcnt[:n]}
 

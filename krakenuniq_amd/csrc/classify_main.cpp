@@ -352,9 +352,11 @@ int main(int argc, char **argv) {
     for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
     KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, nullptr, 0));
   }
-  // HLL sparse-mode emulation (single GPU): the report's `kmers` as the reference prints them.  -x runs insert into the
-  // global sketches directly (src/classify.cpp:719): one unit for the whole run.
-  bool sparse = !exact && !mg && !getenv("KU_NO_SPARSE");
+  // HLL sparse-mode emulation (single GPU): the report's `kmers` as the reference prints them -- so only when a report
+  // was asked for; the emulation keeps every distinct k-mer of the taxa whose sketches stay sparse and is by far the most
+  // expensive part of a run with many low-abundance taxa.  -x runs insert into the global sketches directly
+  // (src/classify.cpp:719): one unit for the whole run.
+  bool sparse = want_report && !exact && !mg && !getenv("KU_NO_SPARSE");
   if (sparse) {
     const char *e = getenv("KU_SPARSE_LOG2");
     int st = ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, e ? (uint32_t)atoi(e) : 0u);
@@ -705,7 +707,7 @@ int main(int argc, char **argv) {
     bt->run_cnt.assign(n, 0);
     ku_opts opts = base_opts;
     uint64_t n_runs = 0;
-    if (sparse && bt->first_of_file) KU_CHECK(ku_sparse_close_unit(ctx));  // work units do not span input files
+    if (sparse && bt->first_of_file && ku_ctx_sparse_state(ctx) == 1) KU_CHECK(ku_sparse_close_unit(ctx));  // work units do not span input files
     if (mg)
       KU_CHECK(ku_mgpu_classify_batch_rle(mg, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
                                           bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
@@ -771,6 +773,9 @@ int main(int argc, char **argv) {
     std::vector<const char *> cpaths;
     for (const std::string &c : cnames) cpaths.push_back(c.c_str());
     if (mg) KU_CHECK(ku_mgpu_reduce_state(mg, nullptr));  // every rank's registers / counters into rank 0's context
+    if (sparse && ku_ctx_sparse_state(ctx) == 2)
+      fprintf(stderr, "classify: warning: the sparse-sketch emulation ran out of device memory during the run -- the report's kmers / dup / "
+                      "cov columns are dense-register estimates (within 3 sigma = 4.9 %% of the reference's)\n");
     // clade roll-up on the device, from the registers / counters / sparse sets where they lie (ku_ctx_report); in a
     // group rank 0's context holds the reduced state
     char *text = nullptr; size_t tn = 0;

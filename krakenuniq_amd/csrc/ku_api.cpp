@@ -433,6 +433,8 @@ struct ku_ctx {
     unsigned long long *d_counters = nullptr;  // [0] size of G, [1..2] carry sizes, [3] export size
     DevBuf unit, carry_l, carry_u, out;
     uint64_t n_carry_l = 0, n_carry_u = 0, cap_carry_l = 0, cap_carry_u = 0;
+    uint64_t g_count = 0;       // entries of the global set after the last pass (host copy of d_counters[0])
+    bool gave_up = false;       // the emulation ran out of device memory during the run and was switched off
   } sp;
 };
 
@@ -485,6 +487,14 @@ static void ctx_free_db(ku_ctx *ctx) {
   ctx->extra.clear();
   ctx->db_loaded = false;
 }
+static void ctx_free_sparse(ku_ctx *ctx) {
+  KuSparseDev &d = ctx->sp.dev;
+  for (void *p : {(void *)d.l_key, (void *)d.l_first, (void *)d.u_key, (void *)d.u_distinct, (void *)d.u_last, (void *)d.u_maxfirst,
+                  (void *)d.g_key, (void *)d.dense, (void *)d.err, (void *)ctx->sp.d_counters})
+    if (p) (void)hipFree(p);
+  for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out}) b->release();
+  ctx->sp = ku_ctx::Sparse{};
+}
 static void ctx_free_tax(ku_ctx *ctx) {
   for (uint32_t **p : {&ctx->d_node_parent, &ctx->d_node_slot, &ctx->d_node_taxid, &ctx->d_slot_node, &ctx->d_slot_taxid,
                        &ctx->d_slot_anc_off, &ctx->d_slot_anc}) {
@@ -498,14 +508,7 @@ static void ctx_free_tax(ku_ctx *ctx) {
   if (ctx->d_exact_unique) (void)hipFree(ctx->d_exact_unique);
   ctx->d_exact_set = ctx->d_exact_unique = nullptr;
   ctx->exact_mask = 0;
-  {
-    KuSparseDev &d = ctx->sp.dev;
-    for (void *p : {(void *)d.l_key, (void *)d.l_first, (void *)d.u_key, (void *)d.u_distinct, (void *)d.u_last, (void *)d.u_maxfirst,
-                    (void *)d.g_key, (void *)d.dense, (void *)d.err, (void *)ctx->sp.d_counters})
-      if (p) (void)hipFree(p);
-    for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out}) b->release();
-    ctx->sp = ku_ctx::Sparse{};
-  }
+  ctx_free_sparse(ctx);
   ctx->cnt = KuCountsDev{};
   ctx->tax_set = false;
 }
@@ -846,6 +849,7 @@ extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
     ctx->sp.acc_nt = 0;
     ctx->sp.open = false;
     ctx->sp.n_carry_l = ctx->sp.n_carry_u = 0;
+    ctx->sp.g_count = 0;
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return KU_OK;
@@ -955,6 +959,38 @@ extern "C" int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t
   return ku_ctx_reset_counts(ctx);
 }
 
+// room in the run-wide (slot, encoding) set for `incoming` more entries at load <= 1/2: a larger table takes over when
+// the current one could fill (the set only grows with the distinct k-mers of the taxa that stay sparse -- on a run of
+// many taxa that is most of what the reads hold)
+static int sparse_reserve_global(ku_ctx *ctx, uint64_t incoming, hipStream_t s) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  KuSparseDev &d = sp.dev;
+  const uint64_t need = 2 * (sp.g_count + incoming);
+  if (need <= d.g_mask + 1) return KU_OK;
+  uint64_t cells = (d.g_mask + 1) * 2;
+  while (cells < need) cells *= 2;
+  const char *cap_env = getenv("KU_SPARSE_MAX_LOG2");  // test hook: a small ceiling stands in for a full device
+  if (cells > (1ull << (cap_env ? atoi(cap_env) : 36))) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set outgrew its ceiling");
+  unsigned long long *nk = nullptr;
+  if (hipMalloc((void **)&nk, cells * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(KU_ENOMEM, "sparse-mode emulation: device memory for the run-wide set of encoded hashes (" + std::to_string(cells >> 17) + " MiB)");
+  }
+  unsigned long long *old = d.g_key;
+  const uint64_t old_cells = d.g_mask + 1;
+  HIP_TRY(hipMemsetAsync(nk, 0, cells * 8, s));
+  HIP_TRY(hipMemsetAsync(d.g_count, 0, 8, s));
+  d.g_key = nk;
+  d.g_mask = cells - 1;
+  KU_TRY(ku_launch_sparse_rehash(d, old, old_cells, s));
+  unsigned long long n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, d.g_count, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(old);
+  sp.g_count = n;
+  return KU_OK;
+}
+
 // the reads [r0, r1) of a batch whose taxa[] holds slot ids: one pass of the emulation (at most KU_SPARSE_MAX_UNITS
 // work units and 2^25 bases at a time; a unit that is still open at the end is carried into the next pass)
 static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
@@ -981,6 +1017,7 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
     }
     const bool open_after = acc > 0 || (sp.unit_nt == 0 && (sp.open || r1 > r0));
     const uint32_t n_closed = cur;  // units 0 .. cur-1 are complete; unit `cur` (if any read fell into it) stays open
+    KU_TRY(sparse_reserve_global(ctx, bases + sp.n_carry_l, s));
     HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
     HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
     HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
@@ -998,13 +1035,17 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
       HIP_TRY(hipMemsetAsync(sp.d_counters + 1, 0, 16, s));
       KU_TRY(ku_launch_sparse_carry_out(d, cur, (unsigned long long *)sp.carry_l.p, (uint32_t *)sp.carry_u.p, sp.d_counters + 1, sp.cap_carry_l,
                                         sp.cap_carry_u, s));
-      unsigned long long c[2] = {0, 0};
-      HIP_TRY(hipMemcpyAsync(c, sp.d_counters + 1, 16, hipMemcpyDeviceToHost, s));
+      unsigned long long c[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpyAsync(c, sp.d_counters, 24, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      sp.n_carry_l = std::min<uint64_t>(c[0], sp.cap_carry_l);
-      sp.n_carry_u = std::min<uint64_t>(c[1], sp.cap_carry_u);
+      sp.g_count = c[0];
+      sp.n_carry_l = std::min<uint64_t>(c[1], sp.cap_carry_l);
+      sp.n_carry_u = std::min<uint64_t>(c[2], sp.cap_carry_u);
     } else {
+      unsigned long long c = 0;
+      HIP_TRY(hipMemcpyAsync(&c, sp.d_counters, 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));  // `unit` is reused by the next pass
+      sp.g_count = c;
     }
     sp.open = open_after;
     sp.acc_nt = acc;
@@ -1014,7 +1055,7 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
   HIP_TRY(hipMemcpyAsync(&err, d.err, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (err) return fail(KU_ENOMEM, std::string("sparse-mode emulation: a device table is full (") + ((err & 1) ? "L " : "") + ((err & 2) ? "U " : "") +
-                                      ((err & 4) ? "G: enable it with a larger global_log2" : "") + ")");
+                                      ((err & 4) ? "G" : "") + ")");
   return KU_OK;
 }
 
@@ -1024,6 +1065,7 @@ static int sparse_close_open_unit(ku_ctx *ctx) {
   KuSparseDev &d = sp.dev;
   hipStream_t s = ctx->stream;
   if (sp.open) {
+    KU_TRY(sparse_reserve_global(ctx, sp.n_carry_l, s));
     HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
     HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
     HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
@@ -1032,13 +1074,18 @@ static int sparse_close_open_unit(ku_ctx *ctx) {
     HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
     KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p, sp.n_carry_u, s));
     KU_TRY(ku_launch_sparse_close(d, 1, s));
+    unsigned long long c = 0;
+    HIP_TRY(hipMemcpyAsync(&c, sp.d_counters, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    sp.g_count = c;
   }
   sp.open = false;
   sp.acc_nt = 0;
   sp.n_carry_l = sp.n_carry_u = 0;
   return KU_OK;
 }
+
+extern "C" int ku_ctx_sparse_state(const ku_ctx *ctx) { return !ctx ? 0 : (ctx->sp.on ? 1 : (ctx->sp.gave_up ? 2 : 0)); }
 
 extern "C" int ku_sparse_close_unit(ku_ctx *ctx) {
   KU_TRY(check_ready(ctx));
@@ -1193,9 +1240,18 @@ static int classify_device_impl(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
     return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, &o, d_calls, d_taxa, d_hits, stream);
   }
   KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, opts, d_taxa, stream));
-  if (sparse && n_reads)  // between the stages: d_taxa holds slot ids
-    KU_TRY(sparse_pass(ctx, d_seqs, d_seq_off, d_seq_len, h_off, h_len, n_reads, n_bytes, d_taxa,
-                       (flags & KU_F_QUICK) ? std::max(1u, opts ? opts->min_hits : 1u) : 0u, stream ? (hipStream_t)stream : ctx->stream));
+  if (sparse && n_reads) {  // between the stages: d_taxa holds slot ids
+    int st = sparse_pass(ctx, d_seqs, d_seq_off, d_seq_len, h_off, h_len, n_reads, n_bytes, d_taxa,
+                         (flags & KU_F_QUICK) ? std::max(1u, opts ? opts->min_hits : 1u) : 0u, stream ? (hipStream_t)stream : ctx->stream);
+    if (st == KU_ENOMEM) {
+      // no room for the emulation's tables: the classification itself does not depend on them -- the run goes on with
+      // the dense registers alone and says so (ku_ctx_sparse_state; the reports then carry their estimates)
+      (void)hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream);
+      (void)hipGetLastError();
+      ctx_free_sparse(ctx);
+      ctx->sp.gave_up = true;
+    } else if (st != KU_OK) return st;
+  }
   if (exact) {  // between the stages: d_taxa holds slot ids
     if (n_reads && (!d_seqs || !d_seq_off || !d_seq_len || !d_taxa)) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     int st = ku_launch_exact(ctx->m.db.k, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, d_taxa, ctx->d_exact_set,
@@ -1450,7 +1506,13 @@ extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, ui
   hipStream_t s = ctx->stream;
   if (ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {  // the merged slots of all chunks are in place: the emulation's pass
     if (b->h_len.size() != n_reads) return fail(KU_ESTATE, "ku_batch_finish: enable the sparse-mode emulation before the batches are created");
-    KU_TRY(sparse_pass(ctx, b->d_seqs, b->d_off, b->d_len, b->h_off.data(), b->h_len.data(), n_reads, b->n_bytes, b->d_taxa, 0u, s));
+    int sst = sparse_pass(ctx, b->d_seqs, b->d_off, b->d_len, b->h_off.data(), b->h_len.data(), n_reads, b->n_bytes, b->d_taxa, 0u, s);
+    if (sst == KU_ENOMEM) {  // as in classify_device_impl: the run goes on without the emulation
+      (void)hipStreamSynchronize(s);
+      (void)hipGetLastError();
+      ctx_free_sparse(ctx);
+      ctx->sp.gave_up = true;
+    } else if (sst != KU_OK) return sst;
   }
   if (o.flags & KU_F_QUICK) {  // the chunked run's quick mode: hits up to min_hits, call = the last k-mer's taxon
     int st = ku_launch_quick_chunked(ctx->tax, ctx->cnt, ctx->m.db.k, b->d_off, b->d_len, n_reads, o.flags, o.min_hits,
@@ -1606,16 +1668,33 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       uint64_t inserts = 0;
-      for (size_t s = 0; s < ns; ++s) inserts += (uint64_t)per_slot[s] * (s_off[s + 1] - s_off[s]);
+      std::vector<uint64_t> clade_pairs(n_clades, 0);  // entries each clade's union is offered
+      for (size_t s = 0; s < ns; ++s) {
+        inserts += (uint64_t)per_slot[s] * (s_off[s + 1] - s_off[s]);
+        for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) clade_pairs[s_clade[j]] += per_slot[s];
+      }
+      // the busiest clades (the ones near the root) count in LDS
+      std::vector<uint32_t> hot_clades(n_clades);
+      for (uint32_t c = 0; c < n_clades; ++c) hot_clades[c] = c;
+      const uint32_t n_hot = std::min<uint32_t>(KU_ROLLUP_HOT, n_clades);
+      std::partial_sort(hot_clades.begin(), hot_clades.begin() + n_hot, hot_clades.end(),
+                        [&](uint32_t a, uint32_t b) { return clade_pairs[a] != clade_pairs[b] ? clade_pairs[a] > clade_pairs[b] : a < b; });
+      hot_clades.resize(n_hot);
+      std::vector<uint16_t> clade_hot(n_clades, 0xFFFFu);
+      for (uint32_t h = 0; h < n_hot; ++h) clade_hot[hot_clades[h]] = (uint16_t)h;
+      uint16_t *d_chot = nullptr;
+      uint32_t *d_hotc = nullptr;
       uint64_t cells = 1024;
       while (cells < 2 * inserts) cells <<= 1;
       st = tmp.put(&d_soff, s_off);
       if (st == KU_OK) st = tmp.put(&d_sclade, s_clade);
       if (st == KU_OK) st = tmp.zeros(&d_err, 1);
+      if (st == KU_OK) st = tmp.put(&d_chot, clade_hot);
+      if (st == KU_OK) st = tmp.put(&d_hotc, hot_clades);
       if (st == KU_OK) st = tmp.zeros(&d_set, cells);
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
-      KU_TRY(ku_launch_rollup_sparse((const unsigned long long *)ctx->sp.out.p, n_pairs, d_soff, d_sclade, d_set, cells - 1, d_hist,
-                                     d_err, ctx->n_cu, ctx->stream));
+      KU_TRY(ku_launch_rollup_sparse((const unsigned long long *)ctx->sp.out.p, n_pairs, d_soff, d_sclade, d_chot, d_hotc, n_hot, d_set,
+                                     cells - 1, d_hist, d_err, ctx->n_cu, ctx->stream));
       uint32_t err = 0;
       HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));

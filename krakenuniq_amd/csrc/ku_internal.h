@@ -76,6 +76,8 @@ int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned lon
                                unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream);
 int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_carry_l, uint64_t n_l, const uint32_t *d_carry_u,
                               uint64_t n_u, hipStream_t stream);
+// s.g_key / s.g_mask: the new (zeroed) table; s.g_count zeroed by the caller
+int ku_launch_sparse_rehash(const KuSparseDev &s, const unsigned long long *d_old_keys, uint64_t old_cells, hipStream_t stream);
 int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
                             hipStream_t stream);
 
@@ -83,9 +85,11 @@ int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uin
 #define KU_ROLLUP_BINS 80
 int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_off, const uint32_t *d_member_slot,
                            const uint8_t *d_clade_dense, uint32_t n_clades, uint32_t *d_hist, hipStream_t stream);
+#define KU_ROLLUP_HOT 48  // clades whose histogram is pre-aggregated in LDS
 int ku_launch_rollup_sparse(const unsigned long long *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
-                            uint32_t *d_err, int n_cu, hipStream_t stream);
+                            const uint32_t *d_slot_clade, const uint16_t *d_clade_hot, const uint32_t *d_hot_clades,
+                            uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist, uint32_t *d_err,
+                            int n_cu, hipStream_t stream);
 int ku_launch_count_pairs(const unsigned long long *d_pairs, uint64_t n_pairs, uint32_t *d_per_slot, int n_cu, hipStream_t stream);
 
 // host-side view of an opened database for the other translation units (ku_api.cpp owns the struct)

@@ -61,11 +61,19 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
   return (bits == 0 ? 32 - KU_HLL_P : (uint32_t)__clz(bits)) + 1;
 }
 
+// The clades near the root take an entry from (almost) every pair: their histogram bins are counted in the block's LDS
+// and flushed once per block -- one global address per (clade, rank) would serialise the whole grid.  `clade_hot[c]` is
+// the clade's row in that LDS table (0xFFFF: none), `hot_clades[h]` the reverse map.
 __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ pairs, uint64_t n_pairs,
                                                                 const uint32_t *__restrict__ slot_off,
                                                                 const uint32_t *__restrict__ slot_clade,
+                                                                const uint16_t *__restrict__ clade_hot,
+                                                                const uint32_t *__restrict__ hot_clades, uint32_t n_hot,
                                                                 unsigned long long *__restrict__ set, uint64_t mask,
                                                                 uint32_t *__restrict__ hist, uint32_t *__restrict__ err) {
+  __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
+  for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
+  __syncthreads();
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long p = pairs[i];
     const uint32_t slot = (uint32_t)(p >> 32), enc = (uint32_t)p;
@@ -78,12 +86,19 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
       bool done = false;
       for (uint32_t probe = 0; probe < 4096 && !done; ++probe, ++h) {
         const unsigned long long old = atomicCAS(&set[h & mask], 0ull, key);
-        if (old == 0ull) { atomicAdd(&hist[(size_t)c * KU_ROLLUP_BINS + r], 1u); done = true; }
-        else if (old == key) done = true;
+        if (old == 0ull) {
+          const uint32_t hi = clade_hot[c];
+          if (hi != 0xFFFFu) atomicAdd(&hot[hi * KU_ROLLUP_BINS + r], 1u);
+          else atomicAdd(&hist[(size_t)c * KU_ROLLUP_BINS + r], 1u);
+          done = true;
+        } else if (old == key) done = true;
       }
       if (!done) atomicOr(err, 1u);
     }
   }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n_hot * KU_ROLLUP_BINS; i += blockDim.x)
+    if (hot[i]) atomicAdd(&hist[(size_t)hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
 }
 
 __global__ __launch_bounds__(256) void ku_count_pairs_kernel(const unsigned long long *__restrict__ pairs, uint64_t n_pairs,
@@ -102,12 +117,14 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 }
 
 int ku_launch_rollup_sparse(const unsigned long long *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
-                            uint32_t *d_err, int n_cu, hipStream_t stream) {
+                            const uint32_t *d_slot_clade, const uint16_t *d_clade_hot, const uint32_t *d_hot_clades,
+                            uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist, uint32_t *d_err,
+                            int n_cu, hipStream_t stream) {
   if (!n_pairs) return KU_OK;
   const uint64_t want = (n_pairs + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_pairs, n_pairs, d_slot_off, d_slot_clade, d_set, mask, d_hist, d_err);
+  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_pairs, n_pairs, d_slot_off, d_slot_clade, d_clade_hot, d_hot_clades, n_hot, d_set,
+                                                       mask, d_hist, d_err);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   __shared__ uint16_t s_tlist[KS_WAVES][WIN ? (int)TCAP : G::MAXN];
   __shared__ uint32_t s_kk[KS_WAVES][1 << G::KCT_LOG2], s_kc[KS_WAVES][1 << G::KCT_LOG2];
   __shared__ uint32_t s_rk[KS_WAVES][1 << G::RCT_LOG2], s_rc[KS_WAVES][1 << G::RCT_LOG2];
-  __shared__ uint32_t s_misc[KS_WAVES][4];      // [0] n_kmers table fill, [1] n_reads table fill, [2] list length, [3] bcast
+  __shared__ uint32_t s_misc[KS_WAVES][4];      // [0] n_kmers table fill, [1] n_reads table fill, [2] list length, [3] WIN: distinct taxa in the table
 
   const uint32_t lane = threadIdx.x & 63u;
   // the wave index is uniform: telling the compiler so moves the per-read metadata (r, len, off, n) and the wave's LDS

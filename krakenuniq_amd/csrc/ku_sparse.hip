@@ -136,6 +136,13 @@ __global__ void ku_sparse_maxfirst_kernel(KuSparseDev s) {
   }
 }
 
+// sum of a per-lane count over the wave, one atomic per wave (every lane of the wave must arrive)
+__device__ __forceinline__ void ks_count_add(unsigned long long *counter, unsigned long long mine) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d, 64);
+  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(counter, mine);
+}
+
 // closed units (unit < n_closed): did the local sketch switch to the dense representation?
 __global__ void ku_sparse_eval_kernel(KuSparseDev s, uint32_t n_closed) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.u_mask; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -151,6 +158,7 @@ __global__ void ku_sparse_eval_kernel(KuSparseDev s, uint32_t n_closed) {
 
 // closed units of slots that stayed sparse: their encodings join the run's global set (the sparse + sparse merge)
 __global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed) {
+  unsigned long long n_new = 0;  // one add to the set's size per wave, not per entry (a single hot address otherwise)
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.l_mask; i += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long key = s.l_key[i];
     if (!key) continue;
@@ -163,13 +171,14 @@ __global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed) {
       unsigned long long cur = __hip_atomic_load(&s.g_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == 0) {
         cur = atomicCAS(&s.g_key[h], 0ull, gk);
-        if (cur == 0) atomicAdd(s.g_count, 1ull);
+        if (cur == 0) ++n_new;
       }
       if (cur == 0 || cur == gk) { placed = true; break; }
       h = (h + 1) & s.g_mask;
     }
     if (!placed) atomicOr(s.err, 4u);
   }
+  ks_count_add(s.g_count, n_new);
 }
 
 // the open unit (index `unit`) moves on to the next batch: its encodings and its (unit, slot) statistics
@@ -223,15 +232,40 @@ __global__ void ku_sparse_carry_in_kernel(KuSparseDev s, const unsigned long lon
   }
 }
 
+// the global set moves to a larger table (the entries of slots that turned dense meanwhile are dropped, g_count is recounted)
+__global__ void ku_sparse_rehash_kernel(KuSparseDev s, const unsigned long long *old_keys, uint64_t old_cells) {
+  unsigned long long n_new = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < old_cells; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long gk = old_keys[i];
+    if (!gk || s.dense[(uint32_t)(gk >> 32) - 1]) continue;
+    uint64_t h = ks_mix(gk) & s.g_mask;
+    bool placed = false;
+    for (uint32_t probe = 0; probe < 4096; ++probe) {
+      const unsigned long long cur = atomicCAS(&s.g_key[h], 0ull, gk);
+      if (cur == 0) { ++n_new; placed = true; break; }
+      h = (h + 1) & s.g_mask;
+    }
+    if (!placed) atomicOr(s.err, 4u);
+  }
+  ks_count_add(s.g_count, n_new);
+}
+
 // run's end: (slot, encoding) of every slot that stayed sparse
 __global__ void ku_sparse_export_kernel(KuSparseDev s, unsigned long long *out, uint64_t cap, unsigned long long *counter) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.g_mask; i += (uint64_t)gridDim.x * blockDim.x) {
+    // the table size is a power of two >= 1024: the lanes of a wave run the same number of rounds (ballots are safe);
+    // one add to the output counter per wave and round
     const unsigned long long gk = s.g_key[i];
-    if (!gk) continue;
-    const uint32_t slot = (uint32_t)(gk >> 32) - 1;
-    if (s.dense[slot]) continue;
-    const unsigned long long e = atomicAdd(counter, 1ull);
-    if (e < cap) out[e] = ((unsigned long long)slot << 32) | (uint32_t)gk;
+    const uint32_t slot = gk ? (uint32_t)(gk >> 32) - 1 : 0u;
+    const bool emit = gk && !s.dense[slot];
+    const unsigned long long bal = __ballot(emit);
+    if (!bal) continue;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0;
+    if (lane == (uint32_t)__ffsll((long long)bal) - 1) base = atomicAdd(counter, (unsigned long long)__popcll(bal));
+    base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+    const unsigned long long e = base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+    if (emit && e < cap) out[e] = ((unsigned long long)slot << 32) | (uint32_t)gk;
   }
 }
 
@@ -253,6 +287,10 @@ int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t 
   hipLaunchKernelGGL(ku_sparse_maxfirst_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s);
   hipLaunchKernelGGL(ku_sparse_eval_kernel, dim3(ks_grid(s.u_mask + 1)), dim3(256), 0, stream, s, n_closed);
   hipLaunchKernelGGL(ku_sparse_commit_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s, n_closed);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_rehash(const KuSparseDev &s, const unsigned long long *d_old_keys, uint64_t old_cells, hipStream_t stream) {
+  hipLaunchKernelGGL(ku_sparse_rehash_kernel, dim3(ks_grid(old_cells)), dim3(256), 0, stream, s, d_old_keys, old_cells);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,

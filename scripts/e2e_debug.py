@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""debug aid (run through gpurun): the bench database on disk, a FASTQ file, the classify executable; prints rc + stderr tail"""
+import os, shutil, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from krakenuniq_amd import synth_torch
+import bench
+n_species = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
+tmp = "/dev/shm/ku_e2e"
+shutil.rmtree(tmp, ignore_errors=True)
+os.makedirs(tmp)
+dev = torch.device("cuda:0")
+db = synth_torch.BenchDb(dev, n_species=n_species, genome_len=310_000, k=31, nt=13, seed=7)
+db.kmers = db.vals = None
+db.write_files(tmp)
+s, _, _, _ = db.sample_reads(n, 150, seed=1)
+bench.write_fastq(f"{tmp}/reads.fq", s.view(n, 151).cpu().numpy(), 150)
+del db, s
+torch.cuda.empty_cache()
+env = dict(os.environ)
+extra = []
+for kv in sys.argv[3:]:
+    k, v = kv.split("=", 1)
+    if k == "REPORT":
+        extra = ["-r", f"{tmp}/report.tsv"]
+    else:
+        env[k] = v
+cmd = [f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB",
+       "-t", "16", "-o", f"{tmp}/out.tsv"] + extra + [f"{tmp}/reads.fq"]
+r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+err = r.stderr.decode(errors="replace").replace("\r", "\n").split("\n")
+print("rc", r.returncode)
+print("\n".join(l[-300:] for l in err[-8:]))
+if extra and os.path.exists(f"{tmp}/report.tsv"):
+    print("".join(open(f"{tmp}/report.tsv").readlines()[:6]))
+shutil.rmtree(tmp, ignore_errors=True)

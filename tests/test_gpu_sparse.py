@@ -79,6 +79,48 @@ def test_report_equals_the_reference(fixture, reads, unit, report, n_batches):
         assert (n_sparse > 0 and n_dense > 0) if unit == 500000 else n_dense == 0
 
 
+def test_run_wide_set_grows_on_demand():
+    """the (slot, encoding) set starts with 2^10 cells and takes the run's tens of thousands of entries by moving to
+    larger tables between passes; slots that turned dense meanwhile are dropped on the way"""
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    ctx.enable_sparse(1000, 10)
+    classify_in_batches(ctx, buf, off, lens, split_points(len(seqs), 9, 4))
+    run = ko.Run(ko.Db(f"{F1}/database.kdb", f"{F1}/database.idx"), ko.Tax(f"{F1}/taxDB"), work_unit_nt=1000)
+    run.classify(seqs)
+    counts, flags, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(ctx, run)
+    assert len(pairs) > 4096
+    assert rows(ctx.report(ctax, [f"{F1}/database.kdb.counts"])) == rows(open(f"{F1}/report_u1000.tsv").read())
+    ctx.reset_counts()  # a second run in the grown table
+    classify_in_batches(ctx, buf, off, lens, [0, len(seqs)])
+    assert rows(ctx.report(ctax, [f"{F1}/database.kdb.counts"])) == rows(open(f"{F1}/report_u1000.tsv").read())
+
+
+def test_out_of_memory_switches_the_emulation_off_and_the_run_goes_on(monkeypatch):
+    """no room for the run-wide set (test hook: a ceiling of 2^11 cells): classification is untouched, the state says so,
+    the report is the dense-register one"""
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    monkeypatch.setenv("KU_SPARSE_MAX_LOG2", "11")
+    ctx.enable_sparse(1000, 10)
+    assert ctx.sparse_state() == 1
+    rle = classify_in_batches(ctx, buf, off, lens, split_points(len(seqs), 5, 8))
+    assert ctx.sparse_state() == 2
+    text = ""
+    cuts = split_points(len(seqs), 5, 8)
+    for (a, b), r in zip(zip(cuts[:-1], cuts[1:]), rle):
+        lo = int(off[a])
+        hi = int(off[b]) if b < len(off) else len(buf)
+        text += capi.format_kraken_rle(buf[lo:hi], off[a:b] - lo, lens[a:b], ids[a:b], K, r)
+    assert text == open(f"{F1}/out.tsv").read()
+    paths = [f"{F1}/database.kdb.counts"]
+    assert ctx.report(ctax, paths) == capi.report(ctax, ctx.counts(), paths)
+    with pytest.raises(capi.KuError):
+        ctx.sparse_export()
+
+
 def test_whole_run_as_one_unit_equals_the_chunk_mode_report():
     """-x: the reference inserts into the global sketches directly (classify.cpp:719): work_unit_nt = 0"""
     ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
