@@ -1306,7 +1306,7 @@ static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_
     HIP_TRY(hipMemsetAsync(ctx->b_roff.p, 0, n_reads * 8, s));
     HIP_TRY(hipMemsetAsync(ctx->b_rcnt.p, 0, n_reads * 4, s));
   } else {
-    KU_TRY(ku_launch_rle(d_taxa, ctx->m.db.k, d_off, d_len, n_reads, ctx->b_runs.p, runs_cap, d_counter,
+    KU_TRY(ku_launch_rle(d_taxa, ctx->m.db.k, d_off, d_len, n_reads, runs_cap /* ~ bases of the batch */, ctx->b_runs.p, runs_cap, d_counter,
                          (uint64_t *)ctx->b_roff.p, (uint32_t *)ctx->b_rcnt.p, ctx->n_cu, s));
   }
   unsigned long long total = 0;

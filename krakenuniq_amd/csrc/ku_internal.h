@@ -127,8 +127,8 @@ int ku_launch_exact(uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off
                     const uint32_t *d_taxa, unsigned long long *d_set, uint64_t mask, unsigned long long *d_unique,
                     uint32_t *d_overflow, int n_cu, hipStream_t stream);
 int ku_launch_rle(const uint32_t *d_taxa, uint32_t k, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
-                  uint64_t n_reads, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter, uint64_t *d_run_off,
-                  uint32_t *d_run_cnt, int n_cu, hipStream_t stream);
+                  uint64_t n_reads, uint64_t n_bytes, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter,
+                  uint64_t *d_run_off, uint32_t *d_run_cnt, int n_cu, hipStream_t stream);
 int ku_launch_max_len(const uint32_t *d_seq_len, uint64_t n_reads, uint32_t *d_out, hipStream_t stream);
 int ku_launch_quick_chunked(const KuTaxDev &tax, const KuCountsDev &cnt, uint32_t k, const uint64_t *d_seq_off,
                             const uint32_t *d_seq_len, uint64_t n_reads, uint32_t flags, uint32_t min_hits, uint32_t *d_calls,

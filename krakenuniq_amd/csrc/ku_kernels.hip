@@ -1106,63 +1106,97 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
 // ----------------------------------------------------------------------------
 // ku_rle_kernel: run-length encoding of the per-k-mer codes (hitlist_string, classify.cpp:826-861)
 // ----------------------------------------------------------------------------
-// One wave per read.  A run is stored as {code, start index}; its length is the next run's start (or the
-// read's k-mer count) minus its own -- the host formatter recovers it.  Space for a read's runs is claimed
-// from a global bump counter, so `runs` is dense but not in read order; (run_off, run_cnt) say where.
-__global__ __launch_bounds__(64) void ku_rle_kernel(const uint32_t *__restrict__ taxa, uint32_t k,
-                                                    const uint64_t *__restrict__ seq_off,
-                                                    const uint32_t *__restrict__ seq_len, uint64_t n_reads,
-                                                    uint2 *runs, unsigned long long runs_cap, unsigned long long *counter,
-                                                    uint64_t *run_off, uint32_t *run_cnt) {
-  const uint32_t lane = threadIdx.x;
-  for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-    const uint32_t len = seq_len[r];
-    const uint32_t n = len >= k ? len - k + 1 : 0;
-    const uint64_t off = seq_off[r];
-    // pass 1: count the run starts
-    uint32_t total = 0, carry = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-      const uint32_t i = base + lane;
-      const uint32_t v = i < n ? taxa[off + i] : 0u;
-      uint32_t prev = ku_wave_up1(v);
-      if (lane == 0) prev = carry;
-      const bool start = i < n && (i == 0 || v != prev);
-      total += (uint32_t)__popcll(__ballot(start));
-      carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+// One wave per group of `chunk` consecutive reads (64 for short reads, fewer for long ones).  A run is stored as {code,
+// start index}; its length is the next run's start (or the read's k-mer count) minus its own -- the host formatter
+// recovers it.  Pass 1 counts the runs of the group's reads (lane j keeps read j's count), a wave prefix sum turns the
+// counts into places and ONE add to the global bump counter claims the group's space (one add per read had the whole
+// grid queue on a single address: 12 ns per read, several times the classification itself); pass 2 writes.  `runs` is
+// dense, in read order within a group; (run_off, run_cnt) say where.
+__global__ __launch_bounds__(256) void ku_rle_kernel(const uint32_t *__restrict__ taxa, uint32_t k,
+                                                     const uint64_t *__restrict__ seq_off,
+                                                     const uint32_t *__restrict__ seq_len, uint64_t n_reads, uint32_t chunk,
+                                                     uint2 *runs, unsigned long long runs_cap, unsigned long long *counter,
+                                                     uint64_t *run_off, uint32_t *run_cnt) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t n_groups = (n_reads + chunk - 1) / chunk;
+  const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+  for (uint64_t g = wave; g < n_groups; g += n_waves) {
+    const uint64_t r0 = g * chunk;
+    const uint32_t n_here = (uint32_t)(n_reads - r0 < chunk ? n_reads - r0 : chunk);
+    const uint64_t my_r = r0 + lane;
+    const uint32_t my_len = lane < n_here ? seq_len[my_r] : 0u;
+    const uint64_t my_off = lane < n_here ? seq_off[my_r] : 0ull;
+    // pass 1: count the run starts of every read of the group
+    uint32_t my_total = 0;
+    for (uint32_t j = 0; j < n_here; ++j) {
+      const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)my_len, (int)j);
+      const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_off >> 32), (int)j) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_off, (int)j);
+      const uint32_t n = len >= k ? len - k + 1 : 0;
+      uint32_t total = 0, carry = 0;
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < n ? taxa[off + i] : 0u;
+        uint32_t prev = ku_wave_up1(v);
+        if (lane == 0) prev = carry;
+        const bool start = i < n && (i == 0 || v != prev);
+        total += (uint32_t)__popcll(__ballot(start));
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+      }
+      if (lane == j) my_total = total;
     }
+    // places: exclusive prefix sum of the counts over the lanes
+    uint32_t incl = my_total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    const uint32_t group_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     unsigned long long basep = 0;
-    if (lane == 0) {
-      basep = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
-      run_off[r] = basep;
-      run_cnt[r] = basep + total <= runs_cap ? total : 0xFFFFFFFFu;  // overflow marker: caller retries bigger
+    if (lane == 0 && group_total) basep = atomicAdd(counter, (unsigned long long)group_total);
+    basep = __shfl(basep, 0, 64);
+    const bool fits = basep + group_total <= runs_cap;
+    if (lane < n_here) {
+      run_off[my_r] = basep + (incl - my_total);
+      run_cnt[my_r] = fits ? my_total : 0xFFFFFFFFu;  // overflow marker: the caller retries with a larger array
     }
-    basep = __shfl(basep, 0);
-    if (basep + total > runs_cap) continue;
+    if (!fits) continue;
     // pass 2: write {code, start}
-    uint32_t done = 0;
-    carry = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-      const uint32_t i = base + lane;
-      const uint32_t v = i < n ? taxa[off + i] : 0u;
-      uint32_t prev = ku_wave_up1(v);
-      if (lane == 0) prev = carry;
-      const bool start = i < n && (i == 0 || v != prev);
-      const unsigned long long m = __ballot(start);
-      if (start) runs[basep + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, i);
-      done += (uint32_t)__popcll(m);
-      carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    const uint32_t my_excl = incl - my_total;
+    for (uint32_t j = 0; j < n_here; ++j) {
+      const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)my_len, (int)j);
+      const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_off >> 32), (int)j) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_off, (int)j);
+      const uint64_t at = basep + (uint32_t)__builtin_amdgcn_readlane((int)my_excl, (int)j);
+      const uint32_t n = len >= k ? len - k + 1 : 0;
+      uint32_t done = 0, carry = 0;
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < n ? taxa[off + i] : 0u;
+        uint32_t prev = ku_wave_up1(v);
+        if (lane == 0) prev = carry;
+        const bool start = i < n && (i == 0 || v != prev);
+        const unsigned long long m = __ballot(start);
+        if (start) runs[at + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, i);
+        done += (uint32_t)__popcll(m);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+      }
     }
   }
 }
 int ku_launch_rle(const uint32_t *d_taxa, uint32_t k, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
-                  uint64_t n_reads, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter, uint64_t *d_run_off,
-                  uint32_t *d_run_cnt, int n_cu, hipStream_t stream) {
+                  uint64_t n_reads, uint64_t n_bytes, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter,
+                  uint64_t *d_run_off, uint32_t *d_run_cnt, int n_cu, hipStream_t stream) {
   if (hipMemsetAsync(d_counter, 0, 8, stream) != hipSuccess) return KU_EHIP;
   if (n_reads == 0) return KU_OK;
-  const uint64_t cap = (uint64_t)n_cu * 32;
-  hipLaunchKernelGGL(ku_rle_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, d_taxa, k,
-                     d_seq_off, d_seq_len, n_reads, (uint2 *)d_runs, (unsigned long long)runs_cap, d_counter, d_run_off,
-                     d_run_cnt);
+  // reads per wave: 64 short ones, fewer long ones (about 8 K positions per group, and enough groups to fill the chip)
+  uint32_t chunk = 64;
+  const uint64_t avg = n_bytes / n_reads + 1;
+  while (chunk > 1 && ((uint64_t)chunk * avg > 8192 || (n_reads + chunk - 1) / chunk < (uint64_t)n_cu * 8)) chunk >>= 1;
+  const uint64_t n_groups = (n_reads + chunk - 1) / chunk, want = (n_groups + 3) / 4, cap = (uint64_t)n_cu * 16;
+  hipLaunchKernelGGL(ku_rle_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, d_taxa, k, d_seq_off,
+                     d_seq_len, n_reads, chunk, (uint2 *)d_runs, (unsigned long long)runs_cap, d_counter, d_run_off, d_run_cnt);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

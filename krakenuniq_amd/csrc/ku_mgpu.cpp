@@ -591,7 +591,7 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
       M_HIP(hipMemsetAsync((uint64_t *)r.roff.p + lq, 0, nr * 8, s));
       M_HIP(hipMemsetAsync((uint32_t *)r.rcnt.p + lq, 0, nr * 4, s));
     } else {
-      M_TRY(ku_launch_rle(d_taxa, ku_ctx_k_of(r.ctx), d_off + lq, d_len + lq, nr, r.runs.p, runs_cap, d_counter,
+      M_TRY(ku_launch_rle(d_taxa, ku_ctx_k_of(r.ctx), d_off + lq, d_len + lq, nr, runs_cap /* ~ bases */, r.runs.p, runs_cap, d_counter,
                           (uint64_t *)r.roff.p + lq, (uint32_t *)r.rcnt.p + lq, ku_ctx_cus_of(r.ctx), s));
     }
     unsigned long long total = 0;
