@@ -21,7 +21,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
              "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
              "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "ku_(lookup|resolve|classify_short)_kernel" --output-format csv \
+    timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "ku_(lookup|resolve|classify_short|rle)_kernel" --output-format csv \
       -d $OUT/${TAG}_pmc$i -- python $REPO/bench.py $ARGS > $OUT/${TAG}_pmc$i.log 2>&1
     echo "pmc group $i ($grp): rc=$?"
   done

@@ -9,7 +9,17 @@ from krakenuniq_amd import capi
 tag = sys.argv[1]
 rev = capi.kernel_rev()
 out = {}
-for f in sorted(glob.glob(f'gpurun_out/{tag}_pmc*/runc/*counter_collection.csv')):
+def newest(pattern):
+    """one result file per output directory: the latest (gpurun merges into gpurun_out/, older runs may still lie there)"""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+for f in newest(f'gpurun_out/{tag}_pmc*/runc/*counter_collection.csv'):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r['Kernel_Name'].split('(')[0].replace('void ', '')
@@ -18,7 +28,7 @@ for f in sorted(glob.glob(f'gpurun_out/{tag}_pmc*/runc/*counter_collection.csv')
         vv = v[1:] if len(v) > 1 else v   # first dispatch = untimed warm-up step
         out.setdefault(kn, {})[c] = {"per_launch_mean": sum(vv) / len(vv), "launches": len(vv)}
 json.dump(out, open(f'profiles/{tag}_pmc_summary.json', 'w'), indent=1, sort_keys=True)
-rows = list(csv.reader(open(glob.glob(f'gpurun_out/{tag}_stats/runc/*kernel_stats.csv')[0])))
+rows = list(csv.reader(open(newest(f'gpurun_out/{tag}_stats/runc/*kernel_stats.csv')[0])))
 with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
     w = csv.writer(f); w.writerow(rows[0])
     for r in rows[1:]:
@@ -26,6 +36,17 @@ with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
             w.writerow([r[0][:160]] + r[1:])
 for r in rows[1:]:
     if 'ku_' in r[0]: print(r[0][:44], 'calls', r[1], 'avg_ns', r[3])
+# the other read shapes (scripts/profile_configs.sh)
+for c in ("paired", "long", "nt15"):
+    fs = newest(f'gpurun_out/{tag}_{c}_stats/runc/*kernel_stats.csv')
+    if not fs:
+        continue
+    rr = list(csv.reader(open(fs[0])))
+    with open(f'profiles/{tag}_{c}_kernel_stats.csv', 'w', newline='') as f:
+        w = csv.writer(f); w.writerow(rr[0])
+        for r in rr[1:]:
+            if 'ku_' in r[0] or float(r[4]) >= 1.0:
+                w.writerow([r[0][:160]] + r[1:])
 lk = next(v for k, v in out.items() if k.startswith(('ku_classify_short_kernel', 'ku_lookup_kernel<1')))
 kname = next(k for k in out if k.startswith(('ku_classify_short_kernel', 'ku_lookup_kernel<1')))
 fetch_kb, write_kb = lk['FETCH_SIZE']['per_launch_mean'], lk['WRITE_SIZE']['per_launch_mean']
