@@ -1,0 +1,47 @@
+"""-m gpu: bench.py's contract with the driver on a small workload -- exactly one JSON line on stdout, the driver's
+fields, `roofline` measured in the run and `cpu_baseline` from the compiled reference (or the oracle) with its parity
+flag, the host-buffer and end-to-end legs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--reads", "200000",
+                        "--species", "60", "--genome-len", "60000", *extra], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_shape_line():
+    d = run_bench("--cpu-sample", "20000")
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0
+    assert rf["traffic"] is None or rf["traffic"] > 0  # counter bytes only for the profiled workload and kernel source
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["parity_vs_reference_on_sample"] is True
+    assert d["device_pipeline"]["calls_match_device_run"] is True and d["device_pipeline"]["value"] > 0
+    assert d["e2e"]["calls_match_device_run"] is True and d["e2e"]["value"] > 0
+
+
+@pytest.mark.parametrize("shape", [("--paired",), ("--read-len", "3000", "--reads", "20000"), ("--nt", "15")])
+def test_other_shapes_run(shape):
+    d = run_bench("--cpu-sample", "0", "--no-extras", *shape)
+    assert d["value"] > 0 and d["roofline"]["kernel"].startswith("ku_classify_short_kernel")
