@@ -527,7 +527,7 @@ def main():
             result["sharded"] = {"value": round(a.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
                                  "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sdb.n_pairs,
                                  "every_read_resolved_once": ok,
-                                 "path": "ku_mgpu_step_device: ncclBroadcast -> owner lookup -> grouped ncclReduce (max) -> per-slice resolve"}
+                                 "path": "ku_mgpu_step_device: ncclBroadcast -> owner lookup -> all-to-all (grouped ncclSend/ncclRecv) + max-merge -> per-slice resolve"}
             smg.close()
         except Exception as e:
             result["sharded"] = {"value": None, "error": str(e)[:300]}

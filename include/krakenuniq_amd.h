@@ -348,8 +348,8 @@ int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_regist
  * at the end of the run ku_mgpu_reduce_state merges the per-taxon state (registers MAX, n_kmers / n_reads SUM).
  * A ku_mgpu drives `n_local` ranks of a `world` of ranks from this process, one host thread per rank:
  *   - one process, all ranks (first_rank = 0, n_local = world, id = NULL): what the classify executable does for
- *     KU_DEVICES=0,1,...; the collectives are RCCL (ncclBroadcast, grouped ncclReduce = reduce-scatter with read-aligned
- *     slices, ncclAllReduce) over xGMI when the devices are distinct, and device-to-device copies + merge kernels when
+ *     KU_DEVICES=0,1,...; the collectives are RCCL (ncclBroadcast, grouped ncclSend / ncclRecv + merge = reduce-scatter
+ *     with read-aligned slices, ncclAllReduce) over xGMI when the devices are distinct, and device-to-device copies + merge kernels when
  *     a device is listed more than once (several ranks on one GPU: tests, 1-GPU boxes; RCCL allows one rank per device);
  *   - one process per GPU (n_local = 1, the launcher hands every process the id rank 0 made with ku_mgpu_unique_id):
  *     RCCL through ncclCommInitRank; bench.py under torch.distributed.run.

@@ -52,6 +52,8 @@ struct Rccl {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -80,6 +82,8 @@ void rccl_load() {
   KU_SYM(CommDestroy, "ncclCommDestroy")
   KU_SYM(Broadcast, "ncclBroadcast")
   KU_SYM(Reduce, "ncclReduce")
+  KU_SYM(Send, "ncclSend")
+  KU_SYM(Recv, "ncclRecv")
   KU_SYM(AllReduce, "ncclAllReduce")
   KU_SYM(AllGather, "ncclAllGather")
   KU_SYM(GroupStart, "ncclGroupStart")
@@ -231,6 +235,34 @@ int comm_reduce_slices_max(ku_mgpu *m, ku_mgpu::Rank &r, int st, uint32_t *taxa,
   if (comm_noop(m)) return st;
   if (m->use_rccl) {
     if (st != KU_OK) return st;
+    const uint64_t lo = pos[r.rank], n_mine = pos[r.rank + 1] - lo;
+    static const bool ring_reduce = getenv("KU_MGPU_EXCHANGE") && !strcmp(getenv("KU_MGPU_EXCHANGE"), "reduce");
+    if (!ring_reduce) {
+      // all-to-all over the point-to-point xGMI links: every rank sends slice q of its array straight to rank q (each
+      // pair of GPUs has its own link, so the world - 1 transfers of a rank run side by side) and folds the world - 1
+      // slices it receives into its own with the merge kernel.  A ring / tree ncclReduce per slice would push every
+      // slice through every link.
+      const uint32_t peers = m->world - 1;
+      M_TRY(r.scratch.reserve(std::max<uint64_t>(1, (uint64_t)peers * n_mine) * 4));
+      uint32_t *stage = (uint32_t *)r.scratch.p;
+      M_NCCL(g_rccl.GroupStart());
+      ncclResult_t e = ncclSuccess;
+      uint32_t slot = 0;
+      for (uint32_t q = 0; q < m->world && e == ncclSuccess; ++q) {
+        if (q == r.rank) continue;
+        const uint64_t n_q = pos[q + 1] - pos[q];
+        if (n_q) e = g_rccl.Send(taxa + pos[q], n_q, ncclUint32, (int)q, r.comm, s);
+        if (e == ncclSuccess && n_mine) e = g_rccl.Recv(stage + (uint64_t)slot * n_mine, n_mine, ncclUint32, (int)q, r.comm, s);
+        ++slot;
+      }
+      if (e != ncclSuccess) {
+        (void)g_rccl.GroupEnd();
+        return mfail(KU_EHIP, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(e));
+      }
+      M_NCCL(g_rccl.GroupEnd());
+      for (uint32_t i = 0; i < peers && n_mine; ++i) M_TRY(ku_launch_merge_max_u32(taxa + lo, stage + (uint64_t)i * n_mine, n_mine, s));
+      return KU_OK;
+    }
     M_NCCL(g_rccl.GroupStart());
     for (uint32_t q = 0; q < m->world; ++q) {
       const uint64_t n = pos[q + 1] - pos[q];
