@@ -390,7 +390,8 @@ int main(int argc, char **argv) {
   // (ku_classify_batch_rle: H2D, kernels, run-length encoding, D2H) | writer thread (Kraken lines formatted by `fmt_threads` helpers,
   // files written in input order).  Batches circulate through two bounded queues.
   // a team of parser threads for plain-text inputs (-t, at most 8): every member owns one batch while it parses
-  const int parse_team = paired ? 1 : (fmt_threads < 8 ? fmt_threads : 8);
+  const int team_cap = getenv("KU_PARSE_TEAM") ? std::max(1, atoi(getenv("KU_PARSE_TEAM"))) : 8;
+  const int parse_team = paired ? 1 : (fmt_threads < team_cap ? fmt_threads : team_cap);
   const int n_batches = 3 + (parse_team > 1 ? parse_team : 0);
   std::vector<Batch> pool(n_batches);
   Queue free_q, parsed_q, done_q;
