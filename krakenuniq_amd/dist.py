@@ -16,8 +16,10 @@ live on different GPUs at once:
             (src/classify.cpp:541-544) across ranks.
   sharded   rank r holds the bins [bounds[r], bounds[r+1]); every rank scans the same
             read batch and looks up only the k-mers it owns (is_minimizer_in_chunk);
-            per-k-mer slot ids are merged with all_reduce(MAX) (exactly one rank is
-            non-zero per k-mer, ambiguous k-mers are 0xFFFFFFFF = -1 on every rank),
+            per-k-mer slot ids are merged by MAX (exactly one rank is non-zero per
+            k-mer, ambiguous k-mers are 0xFFFFFFFF = -1 on every rank) -- as a
+            reduce-scatter over read-aligned slices done with point-to-point transfers
+            (exchange_slices_max; merge_taxa_max is the plain all-reduce form) -- and
             each rank then resolves its own slice of the reads.  HLL / n_kmers are
             owner-computes (the bin owner also accounts the misses), merged as above.
 
@@ -65,6 +67,35 @@ def merge_taxa_max(taxa_i32: torch.Tensor) -> torch.Tensor:
     _, ws = world()
     if ws > 1:
         dist.all_reduce(taxa_i32, op=dist.ReduceOp.MAX)
+    return taxa_i32
+
+
+def exchange_slices_max(taxa_i32: torch.Tensor, pos) -> torch.Tensor:
+    """the sharded step's reduce-scatter as the C++ driver does it over xGMI (comm_reduce_slices_max, ku_mgpu.cpp): an
+    all-to-all of point-to-point transfers -- slice q = [pos[q], pos[q+1]) of every rank's array goes straight to rank q,
+    which folds the world-1 slices it receives into its own with a max.  In place; afterwards this rank's slice holds
+    the merged slots (the other slices keep the local values)."""
+    rank, ws = world()
+    if ws == 1:
+        return taxa_i32
+    lo, hi = int(pos[rank]), int(pos[rank + 1])
+    stage = [torch.empty(hi - lo, dtype=taxa_i32.dtype) for _ in range(ws - 1)]
+    ops, k = [], 0
+    for q in range(ws):
+        if q == rank:
+            continue
+        a, b = int(pos[q]), int(pos[q + 1])
+        if b > a:
+            ops.append(dist.P2POp(dist.isend, taxa_i32[a:b].contiguous(), q))
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, stage[k], q))
+        k += 1
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for st in stage:
+        if hi > lo:
+            torch.maximum(taxa_i32[lo:hi], st, out=taxa_i32[lo:hi])
     return taxa_i32
 
 

@@ -69,10 +69,17 @@ def _worker(rank, ws, port, ret):
                 n_kmers[int(sl[j])] += 1
         for s, h in sketches.items():
             regs[s] = h.registers()
-        merged = kdist.merge_taxa_max(torch.from_numpy(np.concatenate(local)))
-        assert (merged.numpy() == np.concatenate(full)).all()
+        want_all = np.concatenate(full)
         # n_reads: each rank resolves its own slice of the reads
         r0, r1 = kdist.read_slice(len(seqs), rank, ws)
+        # the exchange as the C++ driver does it: all-to-all of read-aligned slices + max-merge of the received ones
+        starts = np.concatenate([[0], np.cumsum([len(x) for x in local])]).astype(np.int64)
+        pos = [int(starts[kdist.read_slice(len(seqs), q, ws)[0]]) for q in range(ws)] + [int(starts[-1])]
+        mine_after = kdist.exchange_slices_max(torch.from_numpy(np.concatenate(local).copy()), pos).numpy()
+        assert (mine_after[pos[rank]:pos[rank + 1]] == want_all[pos[rank]:pos[rank + 1]]).all()
+        # ... and as one all-reduce (round 1's form)
+        merged = kdist.merge_taxa_max(torch.from_numpy(np.concatenate(local)))
+        assert (merged.numpy() == want_all).all()
         node_ids = sorted({int(c) for c in res["calls"]})
         n_reads = np.zeros(len(node_ids), dtype=np.int64)
         for c in res["calls"][r0:r1]:
@@ -90,12 +97,13 @@ def _worker(rank, ws, port, ret):
         dist.destroy_process_group()
 
 
-def test_sharded_merge_world2():
+@pytest.mark.parametrize("ws", [2, 3])
+def test_sharded_merge(ws):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    assert dict(ret) == {0: "ok", 1: "ok"}
+    mp.spawn(_worker, args=(ws, port, ret), nprocs=ws, join=True)
+    assert dict(ret) == {r: "ok" for r in range(ws)}
 
 
 def _replica_worker(rank, ws, port, ret):
