@@ -99,6 +99,9 @@ int ku_tax_open(const char *taxdb_path, ku_tax **out);
 int ku_tax_from_arrays(const uint32_t *ids, const uint32_t *parents, uint64_t n, ku_tax **out);
 void ku_tax_close(ku_tax *tax);
 uint64_t ku_tax_size(const ku_tax *tax);
+/* the entries' taxids in the order of the object's rows (file order, duplicates dropped, "unclassified" = 0 added behind
+ * them when the file has none): the layout ku_report_rows expects.  ids[ku_tax_size(tax)] */
+int ku_tax_ids(const ku_tax *tax, uint32_t *ids);
 /* Parent_map value, 0 = none/root; returns KU_AMBIG when the taxid has no entry */
 uint32_t ku_tax_parent(const ku_tax *tax, uint32_t taxid);
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "ku_report_sparse": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u32p, u64p, u8p, u8p, u64p, C.c_uint64,
                                    C.c_uint64, u32p, u64p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_hll_cardinality_sparse": (C.c_uint64, [u32p, C.c_uint64, C.c_uint64]),
+    "ku_tax_ids": (C.c_int, [C.c_void_p, u32p]),
     "ku_report_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u8p, u64p, u64p, u64p, u64p, C.c_uint64,
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_ctx_sparse_state": (C.c_int, [C.c_void_p]),
@@ -253,6 +254,12 @@ class Tax:
             parents = np.ascontiguousarray(parents, dtype=np.uint32)
             _chk(lib().ku_tax_from_arrays(_p(ids, u32p), _p(parents, u32p), len(ids), C.byref(self.h)),
                  "ku_tax_from_arrays")
+
+    def ids(self):
+        """taxids of the entries in row order (the layout report_rows expects)"""
+        out = np.zeros(max(int(lib().ku_tax_size(self.h)), 1), dtype=np.uint32)
+        _chk(lib().ku_tax_ids(self.h, _p(out, u32p)), "ku_tax_ids")
+        return out[:int(lib().ku_tax_size(self.h))]
 
     def close(self):
         if self.h and _lib is not None:

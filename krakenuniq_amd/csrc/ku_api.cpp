@@ -352,6 +352,11 @@ extern "C" int ku_tax_from_arrays(const uint32_t *ids, const uint32_t *parents, 
 }
 extern "C" void ku_tax_close(ku_tax *t) { delete t; }
 extern "C" uint64_t ku_tax_size(const ku_tax *t) { return t ? t->ids.size() : 0; }
+extern "C" int ku_tax_ids(const ku_tax *t, uint32_t *ids) {
+  if (!t || (!ids && !t->ids.empty())) return fail(KU_EINVAL, "ku_tax_ids: null argument");
+  if (!t->ids.empty()) memcpy(ids, t->ids.data(), t->ids.size() * 4);
+  return KU_OK;
+}
 extern "C" uint32_t ku_tax_parent(const ku_tax *t, uint32_t taxid) {
   if (!t || taxid == 0) return KU_AMBIG;  // getParentMap skips key 0 (taxdb.hpp:388-389)
   auto it = t->row.find(taxid);

@@ -352,3 +352,46 @@ def test_sparse_estimator_known_answers():
         h.insert_seq(n, 0x9E3779B97F4A7C15)
         assert h.is_sparse
         assert capi.hll_cardinality_sparse(h.sparse_list(), 1 << 40) == want == h.cardinality(False)
+
+
+def test_report_rows_formats_caller_side_roll_ups(golden, f1):
+    """ku_report_rows: the text from per-entry clade summaries laid out by ku_tax_ids -- here the roll-up is done in
+    Python over the oracle's per-taxon state and must give the reference's report (rows, order inside a parent, number
+    formats, genome sizes from database.kdb.counts incl. the last line applied twice)"""
+    d = f1["dir"]
+    ids, seqs = synth.read_seqfile(f"{d}/reads.fq")
+    run = ko.Run(ko.Db(f"{d}/database.kdb", f"{d}/database.idx"), ko.Tax(f"{d}/taxDB"))
+    run.classify(seqs)
+    counts = run.counts()
+    tax = f1["tax"]
+    rows = tax.ids()
+    assert len(rows) == 8 and set(rows.tolist()) == {0, 1, 2, 3, 4, 5, 6, 1000000001}
+    parent = {int(t): int(capi.lib().ku_tax_parent(tax.h, int(t))) for t in rows if t}
+    members = {int(t): [] for t in rows}
+    for t, c in counts.items():
+        if t not in members:
+            continue
+        q = t
+        while True:
+            members[q].append(t)
+            if q == 0 or parent.get(q, 0) == 0:
+                break
+            q = parent[q]
+    present = np.zeros(len(rows), np.uint8)
+    c_reads, t_reads, c_kmers, c_uniq = (np.zeros(len(rows), np.uint64) for _ in range(4))
+    for i, t in enumerate(rows.tolist()):
+        ms = members[t]
+        if not ms:
+            continue
+        present[i] = 1
+        c_reads[i] = sum(counts[m]["n_reads"] for m in ms)
+        c_kmers[i] = sum(counts[m]["n_kmers"] for m in ms)
+        t_reads[i] = counts[t]["n_reads"] if t in counts else 0
+        sk = ko.Hll(12, True)  # taxon_counts[ancestor] += counts, from a default-constructed entry (taxdb.hpp:928-973)
+        for m in ms:
+            sk.merge(counts[m]["sketch"])
+        c_uniq[i] = sk.cardinality()
+    got = capi.report_rows(tax, present, c_reads, t_reads, c_kmers, c_uniq, [f"{d}/database.kdb.counts"])
+    assert got == open(f"{d}/report.tsv").read()
+    with pytest.raises(capi.KuError):  # one element per entry
+        capi.report_rows(tax, present[:-1], c_reads[:-1], t_reads[:-1], c_kmers[:-1], c_uniq[:-1])
