@@ -209,10 +209,22 @@ int gate_out(ku_mgpu *m, int st) {
   return st;
 }
 bool comm_noop(const ku_mgpu *m) { return m->world == 1 && !m->use_rccl; }
+// RCCL path: a rank that failed before a collective must not leave the others waiting inside it.  The ranks of one
+// process agree on skipping it through the shared flag (several processes cannot, short of another collective: there a
+// failed rank ends its process and the launcher takes the job down).
+int rccl_gate(ku_mgpu *m, int st) {
+  if (m->n_local > 1) {
+    gate_in(m, st);
+    barrier(m);
+    st = gate_out(m, st);
+  }
+  return st;
+}
 
 int comm_broadcast(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *buf, size_t bytes, hipStream_t s) {
   if (comm_noop(m) || bytes == 0) return st;
   if (m->use_rccl) {
+    st = rccl_gate(m, st);
     if (st != KU_OK) return st;
     M_NCCL(g_rccl.Broadcast(buf, buf, bytes, ncclUint8, 0, r.comm, s));
     return KU_OK;
@@ -234,6 +246,7 @@ int comm_broadcast(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *buf, size_t bytes
 int comm_reduce_slices_max(ku_mgpu *m, ku_mgpu::Rank &r, int st, uint32_t *taxa, const uint64_t *pos, hipStream_t s) {
   if (comm_noop(m)) return st;
   if (m->use_rccl) {
+    st = rccl_gate(m, st);
     if (st != KU_OK) return st;
     const uint64_t lo = pos[r.rank], n_mine = pos[r.rank + 1] - lo;
     static const bool ring_reduce = getenv("KU_MGPU_EXCHANGE") && !strcmp(getenv("KU_MGPU_EXCHANGE"), "reduce");
@@ -305,6 +318,7 @@ int comm_allreduce_state(ku_mgpu *m, ku_mgpu::Rank &r, hipStream_t s) {
   uint64_t n_regs = 0, n_slots = 0, n_nodes = 0, *nk = nullptr, *nr = nullptr;
   int st = ku_counts_device_ptrs(r.ctx, &regs, &n_regs, &nk, &n_slots, &nr, &n_nodes);
   if (m->use_rccl) {
+    st = rccl_gate(m, st);
     if (st != KU_OK) return st;
     M_NCCL(g_rccl.GroupStart());
     ncclResult_t e1 = g_rccl.AllReduce(regs, regs, n_regs, ncclUint8, ncclMax, r.comm, s);
@@ -357,6 +371,7 @@ int comm_allgather_values(ku_mgpu *m, ku_mgpu::Rank &r, int st, const std::vecto
   all = mine;
   if (comm_noop(m)) return st;
   if (m->use_rccl) {
+    st = rccl_gate(m, st);
     if (st != KU_OK) return st;
     hipStream_t s = ku_ctx_stream_of(r.ctx);
     M_TRY(r.small.reserve(8ull * m->world + 8));
