@@ -472,7 +472,8 @@ int ku_report_rows(const ku_tax *tax, const char *const *counts_paths, uint32_t 
  * register histogram the estimator needs; clades whose members all stayed sparse (ku_ctx_enable_sparse) get the
  * histogram of the union of their members' encoded hashes from a device hash set.  Only the histograms (320 B per
  * clade) and the per-taxon counters come back; estimator and text are host work as in the reference.  Same text as
- * ku_report_multi / ku_report_sparse / ku_report_exact on the exported state (whichever mode the context is in). */
+ * ku_report_multi / ku_report_sparse / ku_report_exact on the exported state (whichever mode the context is in).  With the
+ * sparse-mode emulation on it ends the work unit that is still open, like ku_sparse_export: a call for the end of a run. */
 int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, char **out,
                   size_t *out_len);
 void ku_free(void *p);
