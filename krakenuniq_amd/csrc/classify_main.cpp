@@ -299,6 +299,25 @@ int main(int argc, char **argv) {
     const char *dev_env = getenv("KU_DEVICE");
     KU_CHECK(ku_ctx_create(devices.size() == 1 ? devices[0] : (dev_env ? atoi(dev_env) : 0), &ctx));
   }
+  // The batch buffers of the host pipeline (below) are page-locked memory, which is slow to allocate (a few hundred MB
+  // take longer than classifying the first millions of reads).  A helper sizes the pool's buffers for plain-text
+  // regions while this thread loads the database; it is joined before the first read is looked at.
+  const int team_cap = getenv("KU_PARSE_TEAM") ? std::max(1, atoi(getenv("KU_PARSE_TEAM"))) : 8;
+  const int parse_team = paired ? 1 : (fmt_threads < team_cap ? fmt_threads : team_cap);
+  const int n_batches = 3 + (parse_team > 1 ? parse_team : 0);
+  ku_seqio::PinSwitch::enabled = !chunk_bytes;  // per-read arrays of the batches page-locked too (before any batch exists)
+  std::vector<Batch> pool(n_batches);
+  std::thread pool_setup([&] {
+    if (chunk_bytes) return;  // -x runs allocate a batch per region (plain memory), the pool stays empty
+    const size_t seq_bytes = (size_t)((double)(unit_nt / 4) * 1.2) + 8192;  // a region's sequences (see region_bytes below)
+    const size_t reads = seq_bytes / 100 + 1024;                           // per-read arrays: grow on demand for shorter reads
+    for (auto &bt : pool) {
+      bt.reserve_seq(seq_bytes);
+      bt.reserve_runs(seq_bytes / 32);  // ~ 3 runs per 100 bases; grows on demand
+      bt.off.reserve(reads); bt.len.reserve(reads); bt.calls.reserve(reads); bt.hits.reserve(reads);
+      bt.run_off.reserve(reads); bt.run_cnt.reserve(reads);
+    }
+  });
   // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference; one chunk = everything resident as usual
   std::vector<uint64_t> chunk_bounds;
   if (chunk_bytes) {
@@ -381,6 +400,7 @@ int main(int argc, char **argv) {
   if (print_ucls && !s_ucls.open(ucls_out)) die(EX_OSERR, "can't open %s", ucls_out.c_str());
 
   unsigned long long total_sequences = 0, total_classified = 0, total_bases = 0;
+  pool_setup.join();
   timeval tv1, tv2;
   gettimeofday(&tv1, nullptr);
   const ku_opts base_opts = {quick ? KU_F_QUICK : 0u, min_hits, 0, 0};
@@ -390,10 +410,7 @@ int main(int argc, char **argv) {
   // (ku_classify_batch_rle: H2D, kernels, run-length encoding, D2H) | writer thread (Kraken lines formatted by `fmt_threads` helpers,
   // files written in input order).  Batches circulate through two bounded queues.
   // a team of parser threads for plain-text inputs (-t, at most 8): every member owns one batch while it parses
-  const int team_cap = getenv("KU_PARSE_TEAM") ? std::max(1, atoi(getenv("KU_PARSE_TEAM"))) : 8;
-  const int parse_team = paired ? 1 : (fmt_threads < team_cap ? fmt_threads : team_cap);
-  const int n_batches = 3 + (parse_team > 1 ? parse_team : 0);
-  std::vector<Batch> pool(n_batches);
+  // (team and pool are set up above, next to the database load)
   Queue free_q, parsed_q, done_q;
   for (auto &bt : pool) free_q.push(&bt);
   const bool keep_records = print_cls || print_ucls;
@@ -702,10 +719,10 @@ int main(int argc, char **argv) {
     if (!bt) break;
     const uint64_t n = bt->off.size();
     const double t_gpu = now_s();
-    bt->calls.assign(n, 0);
-    bt->hits.assign(n, 0);
-    bt->run_off.assign(n, 0);
-    bt->run_cnt.assign(n, 0);
+    bt->calls.resize(n);  // every element is written by the copies back from the device
+    bt->hits.resize(n);
+    bt->run_off.resize(n);
+    bt->run_cnt.resize(n);
     ku_opts opts = base_opts;
     uint64_t n_runs = 0;
     if (sparse && bt->first_of_file && ku_ctx_sparse_state(ctx) == 1) KU_CHECK(ku_sparse_close_unit(ctx));  // work units do not span input files

@@ -27,14 +27,34 @@ namespace ku_seqio {
 [[noreturn]] void fatal(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));  // provided by the program
 
 // ---- a batch of reads travelling through the pipeline; the big arrays live in pinned host memory
+// Allocator of the per-read arrays that cross PCIe (offsets, lengths, calls, hit counts, run index): page-locked memory
+// when `enabled` (set once at program start, before any batch exists), so that their copies are DMA transfers instead
+// of staged ones; plain memory otherwise (tools without a device, -x runs with one batch per region).
+struct PinSwitch { static inline bool enabled = false; };
+template <class T> struct PinAlloc {
+  using value_type = T;
+  PinAlloc() = default;
+  template <class U> PinAlloc(const PinAlloc<U> &) {}
+  T *allocate(size_t n) {
+    void *p = nullptr;
+    if (PinSwitch::enabled ? ku_host_alloc(n * sizeof(T), &p) != KU_OK : (p = malloc(n * sizeof(T))) == nullptr) fatal(71, "out of host memory");
+    return (T *)p;
+  }
+  void deallocate(T *p, size_t) { if (PinSwitch::enabled) ku_host_free(p); else free(p); }
+  template <class U> bool operator==(const PinAlloc<U> &) const { return true; }
+  template <class U> bool operator!=(const PinAlloc<U> &) const { return false; }
+};
+template <class T> using PinVec = std::vector<T, PinAlloc<T>>;
+
 struct Batch {
   char *seqs = nullptr;       // reads, each followed by '\n' (the separator the C ABI asks for)
   size_t seqs_len = 0, seqs_cap = 0;
   ku_run *runs = nullptr;     // run-length encoded per-k-mer codes (ku_classify_batch_rle)
   size_t runs_cap = 0;
   std::string ids, headers, quals;
-  std::vector<uint64_t> off, idoff, hoff, qoff, run_off;
-  std::vector<uint32_t> len, calls, hits, run_cnt;
+  PinVec<uint64_t> off, run_off;
+  PinVec<uint32_t> len, calls, hits, run_cnt;
+  std::vector<uint64_t> idoff, hoff, qoff;
   bool fastq = false;
   bool first_of_file = false;  // the batch opens an input file (the reference's work units do not span files)
   uint64_t nt = 0;
