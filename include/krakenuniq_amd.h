@@ -179,6 +179,9 @@ int ku_ctx_reset_counts(ku_ctx *ctx);
  * table whenever a pass could fill it beyond 1/2 (KU_ENOMEM when the device has no room for that).
  * Call after ku_ctx_set_taxonomy; single GPU; at most 2^18 database taxids. */
 int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t global_log2);
+/* frees the emulation's tables: later batches only keep the dense registers (ku_ctx_sparse_state = 0).  Enabling it
+ * again -- also on a context where it is still on -- starts afresh, with the per-taxon state of the run reset. */
+int ku_ctx_disable_sparse(ku_ctx *ctx);
 /* the work unit that is still open ends here: call between input files (the reference's units do not span files,
  * classify.cpp:487-564 runs once per file); no-op without the emulation or with work_unit_nt = 0 */
 int ku_sparse_close_unit(ku_ctx *ctx);

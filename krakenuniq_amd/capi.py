@@ -105,6 +105,7 @@ SIGNATURES = {
     "ku_report_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u8p, u64p, u64p, u64p, u64p, C.c_uint64,
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_ctx_sparse_state": (C.c_int, [C.c_void_p]),
+    "ku_ctx_disable_sparse": (C.c_int, [C.c_void_p]),
     "ku_ctx_report": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_size_t)]),
     "ku_ctx_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
@@ -366,6 +367,9 @@ class Ctx:
     def enable_sparse(self, work_unit_nt=500000, global_log2=0):
         """HyperLogLog++ sparse-mode emulation (ku_ctx_enable_sparse): exact reproduction of the reference's report"""
         _chk(lib().ku_ctx_enable_sparse(self.h, work_unit_nt, global_log2), "ku_ctx_enable_sparse")
+
+    def disable_sparse(self):
+        _chk(lib().ku_ctx_disable_sparse(self.h), "ku_ctx_disable_sparse")
 
     def sparse_close_unit(self):
         _chk(lib().ku_sparse_close_unit(self.h), "ku_sparse_close_unit")

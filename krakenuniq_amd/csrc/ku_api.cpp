@@ -401,7 +401,7 @@ struct ku_ctx {
   hipStream_t stream = nullptr;
   bool db_loaded = false, tax_set = false;
   bool hash_layout = true;   // KU_LAYOUT=sorted keeps the on-disk order + binary search (A/B and fallback for HBM-tight shards)
-  double load_factor = 0.2;  // keys per bucket slot (9 slots per 128-byte line); KU_LOAD_FACTOR fixes it
+  double load_factor = 0.2;  // keys per bucket slot (8 slots per 128-byte line); KU_LOAD_FACTOR fixes it
   bool load_factor_set = false;
   DbStore m;                   // the (first) database: the only one that may be a strict minimizer-range shard
   std::vector<DbStore> extra;  // further whole databases of a hierarchical run, searched in order after `m`
@@ -712,11 +712,11 @@ static int store_finalize(ku_ctx *ctx, DbStore &d, hipStream_t stream = nullptr,
     // first choice
     std::vector<double> chain;
     if (ctx->load_factor_set) chain.push_back(ctx->load_factor);
-    else if ((double)d.db.n_pairs / 0.2 / 9.0 * 128.0 <= 0.4 * (double)free_b) chain.push_back(0.2);
+    else if ((double)d.db.n_pairs / 0.2 / 8.0 * 128.0 <= 0.4 * (double)free_b) chain.push_back(0.2);
     for (double lf : {0.3, 0.45, 0.6, 0.8})
       if (chain.empty() || lf > chain.back()) chain.push_back(lf);
     for (double lf : chain) {
-      n_lines = (uint64_t)((double)d.db.n_pairs / lf / 9.0) + 1;
+      n_lines = (uint64_t)((double)d.db.n_pairs / lf / 8.0) + 1;  // 8 entries per line: load factors up to 0.9 leave free slots
       if (n_lines >= (1ull << 32)) { n_lines = 0; continue; }  // ku_locus_line() reduces to 32 bits
       if (hipMalloc(&d.d_table, n_lines * 128) == hipSuccess) { d.table_lines = n_lines; break; }
       (void)hipGetLastError();
@@ -934,7 +934,10 @@ extern "C" int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t
   if (ctx->tax.n_slots > KU_SPARSE_MAX_SLOTS) return fail(KU_EUNSUP, "sparse-mode emulation handles up to 2^18 distinct database taxids");
   if (global_log2 == 0) global_log2 = 26;
   if (global_log2 < 10 || global_log2 > 34) return fail(KU_EINVAL, "ku_ctx_enable_sparse: global_log2 out of range (10..34)");
-  if (ctx->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is already enabled");
+  if (ctx->sp.on) {  // a second call starts afresh with the new work-unit size
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx_free_sparse(ctx);
+  }
   ku_ctx::Sparse &sp = ctx->sp;
   KuSparseDev &d = sp.dev;
   const uint32_t l_log2 = 26, u_log2 = 22;
@@ -1087,6 +1090,14 @@ static int sparse_close_open_unit(ku_ctx *ctx) {
   sp.open = false;
   sp.acc_nt = 0;
   sp.n_carry_l = sp.n_carry_u = 0;
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_disable_sparse(ku_ctx *ctx) {
+  if (!ctx) return fail(KU_EINVAL, "null context");
+  KU_TRY(ctx_activate(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx_free_sparse(ctx);
   return KU_OK;
 }
 

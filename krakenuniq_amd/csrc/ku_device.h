@@ -172,36 +172,40 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
 
 // Hash layout (LAYOUT 1, default): at upload time the shard's pairs are re-laid out as a bucketised hash table,
 // one bucket per 128-byte line:
-//     dword 0      count (low 16 bits) | tag 0 (high 16 bits)
-//     dwords 1..4  tags 1..8, two 16-bit tags per dword
-//     dwords 5..31 nine 12-byte entries {key_lo, key_hi, slot}
+//     dwords 0..3   eight 16-bit tag fields, field i in the (i & 1 ? high : low) half of dword i >> 1:
+//                   low 15 bits = tag of entry i (1 .. 0x7FFF; 0 = entry unused); bit 15 of field 0 = the bucket
+//                   received more than eight keys and spilled into the following line(s)
+//     dwords 4..27  eight 12-byte entries {key_lo, key_hi, slot};  dwords 28..31 unused
 // MI355X moves 128 B per L2 miss and sustains ~48 G random line fetches/s whatever the access width
 // (scripts/calib_gather.hip), so a lookup costs the number of distinct lines it touches -- and, per wave, the
 // number of *dependent* round trips of its slowest lane.  The sorted-bin binary search touches ~2.5 lines in ~8
-// dependent probes; here the 20-byte header answers "which entry, if any" in ONE round trip (16-bit tags, false
-// positive rate 9 * 2^-16), the entry itself is then an L1/L2 hit in the same line.  A bucket that received more
-// than 9 keys has count > 9 and spills into the following line(s) (1.7 % of the buckets at load factor 0.5).
+// dependent probes; here the 16-byte header -- ONE dwordx4 load per k-mer; the nine-entry line of rounds 1-2 had a
+// 20-byte header whose fifth dword was a load instruction of its own and cost 4 % of the fused kernel -- answers
+// "which entry, if any" in one round trip (15-bit tags, false positive rate 8 * 2^-15), the entry itself is then an
+// L1/L2 hit in the same line.  A bucket that received more than 8 keys spills into the following line(s).
 #define KU_LINE_DWORDS 32
-#define KU_LINE_SLOTS 9
-// 16-bit entry tag from h = fmix64(kmer + 1) (the HLL hash, reused; the HLL consumes bits 63..52 and the
-// leading zeros below them, the tag takes bits 43..28)
-__device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) { return (uint32_t)(h >> 28) & 0xFFFFu; }
-// bit i set <=> tag i of the header equals `tag` (i < min(count, 9))
-__device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t h1, uint32_t tag) {
-  const uint32_t cnt = h4.x & 0xFFFFu;
-  const uint32_t n = cnt < KU_LINE_SLOTS ? cnt : KU_LINE_SLOTS;
-  uint32_t m = 0;
-  m |= ((h4.x >> 16) == tag) << 0;
-  m |= ((h4.y & 0xFFFFu) == tag) << 1;
-  m |= ((h4.y >> 16) == tag) << 2;
-  m |= ((h4.z & 0xFFFFu) == tag) << 3;
-  m |= ((h4.z >> 16) == tag) << 4;
-  m |= ((h4.w & 0xFFFFu) == tag) << 5;
-  m |= ((h4.w >> 16) == tag) << 6;
-  m |= ((h1 & 0xFFFFu) == tag) << 7;
-  m |= ((h1 >> 16) == tag) << 8;
-  return m & ((1u << n) - 1u);
+#define KU_LINE_SLOTS 8
+#define KU_LINE_ENTRY0 4  // first entry dword
+// 15-bit non-zero entry tag from h = fmix64(kmer + 1) (the HLL hash, reused; the HLL consumes bits 63..52 and the
+// leading zeros below them, the tag takes bits 42..28)
+__device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) {
+  const uint32_t t = (uint32_t)(h >> 28) & 0x7FFFu;
+  return t ? t : 1u;
 }
+// bit i set <=> tag field i of the header equals `tag` (unused fields are 0, tags are not)
+__device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t tag) {
+  uint32_t m = 0;
+  m |= ((h4.x & 0x7FFFu) == tag) << 0;  // field 0 carries the spill flag in bit 15
+  m |= ((h4.x >> 16) == tag) << 1;
+  m |= ((h4.y & 0xFFFFu) == tag) << 2;
+  m |= ((h4.y >> 16) == tag) << 3;
+  m |= ((h4.z & 0xFFFFu) == tag) << 4;
+  m |= ((h4.z >> 16) == tag) << 5;
+  m |= ((h4.w & 0xFFFFu) == tag) << 6;
+  m |= ((h4.w >> 16) == tag) << 7;
+  return m;
+}
+__device__ __forceinline__ bool ku_line_spilled(uint4 h4) { return (h4.x & 0x8000u) != 0; }
 
 // Locality-aware bucket choice.  Consecutive k-mers of a read share their minimizer *occurrence* ~(k-nt+1)/2
 // times in a row.  The bucket of a k-mer is therefore derived not from the k-mer itself but from its "locus

@@ -15,7 +15,7 @@
 // 0 = taxid 0) instead of the raw taxid.
 struct KuDbDev {
   const uint32_t *pairs;    // sorted layout: 3 dwords per pair: key_lo, key_hi, slot (nullptr once the table is built)
-  const uint4 *table;       // hash layout: n_lines buckets of 128 B (20-byte tag header + 9 x 12-byte entries)
+  const uint4 *table;       // hash layout: n_lines buckets of 128 B (16-byte tag header + 8 x 12-byte entries)
   uint64_t n_lines;         // 128-byte lines in the table
   const uint64_t *offsets;  // bin_hi - bin_lo + 1 global pair indices
   uint64_t pair_base;       // global index of pairs[0]

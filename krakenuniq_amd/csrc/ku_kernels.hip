@@ -282,7 +282,6 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       uint32_t tag[KU_ITEMS], cand[KU_ITEMS];
       bool act[KU_ITEMS], ovf[KU_ITEMS];
       uint4 h4[KU_ITEMS];
-      uint32_t h1[KU_ITEMS];
       const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
@@ -292,20 +291,17 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         slot[j] = 0;
         act[j] = ok[j] && !(ablate & 1u) && !(PRIOR && prior[j]);
       }
-      // round trip 1: the 20-byte bucket headers of all items
+      // round trip 1: the 16-byte bucket headers of all items
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j)
-        if (act[j]) {
-          h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
-          h1[j] = lp[j][4];
-        }
+        if (act[j]) h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         cand[j] = 0;
         ovf[j] = false;
         if (act[j]) {
-          cand[j] = ku_tag_matches(h4[j], h1[j], tag[j]);
-          ovf[j] = (h4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+          cand[j] = ku_tag_matches(h4[j], tag[j]);
+          ovf[j] = ku_line_spilled(h4[j]);
           act[j] = cand[j] != 0 || ovf[j];
         }
       }
@@ -313,7 +309,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       KuPair pr[KU_ITEMS];
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j)
-        if (cand[j]) pr[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+        if (cand[j]) pr[j] = *reinterpret_cast<const KuPair *>(lp[j] + KU_LINE_ENTRY0 + 3 * (__builtin_ctz(cand[j])));
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j)
         if (cand[j]) {
@@ -334,17 +330,15 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         any = false;
         KuPair e[KU_ITEMS];
         uint4 a4[KU_ITEMS];
-        uint32_t a1[KU_ITEMS];
 #pragma unroll
         for (int j = 0; j < KU_ITEMS; ++j) {
           if (act[j]) {
             if (cand[j]) {
-              e[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+              e[j] = *reinterpret_cast<const KuPair *>(lp[j] + KU_LINE_ENTRY0 + 3 * (__builtin_ctz(cand[j])));
             } else {  // ovf[j]: continue in the next line
               lp[j] += KU_LINE_DWORDS;
               if (lp[j] == tab + db.n_lines * KU_LINE_DWORDS) lp[j] = tab;
               a4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
-              a1[j] = lp[j][4];
             }
           }
         }
@@ -358,8 +352,8 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
                 act[j] = false;
               }
             } else {
-              cand[j] = ku_tag_matches(a4[j], a1[j], tag[j]);
-              ovf[j] = (a4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+              cand[j] = ku_tag_matches(a4[j], tag[j]);
+              ovf[j] = ku_line_spilled(a4[j]);
             }
             if (act[j]) act[j] = cand[j] != 0 || ovf[j];
             any |= act[j];
@@ -493,33 +487,26 @@ __global__ void ku_build_table_kernel(const uint32_t *__restrict__ pairs, uint64
     uint64_t line = ku_locus_line(ku_locus_key(key, k, m, xor_mask, bin), n_lines);
     for (uint32_t hops = 0;; ++hops) {
       uint32_t *lp = table + line * KU_LINE_DWORDS;
-      // claim the next free entry of the bucket: count lives in the low half of dword 0
-      uint32_t w0 = __hip_atomic_load(lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // claim the first unused entry of the bucket: its tag field goes from 0 to the (non-zero) tag with a CAS on the
+      // dword that holds it (the neighbour field and the spill flag may change under it: retry on the fresh value)
       int got = -1;
-      for (;;) {
-        uint32_t c = w0 & 0xFFFFu;
-        if (c >= KU_LINE_SLOTS) {
-          // full: make sure the bucket is marked "spilled" (count = 10) before moving on.  The CAS can also lose
-          // against a tag-0 atomicOr, so retry until the mark is visible.
-          while ((w0 & 0xFFFFu) == KU_LINE_SLOTS) {
-            uint32_t prev = atomicCAS(lp, w0, w0 + 1);
-            if (prev == w0) break;
-            w0 = prev;
-          }
-          break;
+      for (int i = 0; i < KU_LINE_SLOTS && got < 0; ++i) {
+        uint32_t *w = lp + (i >> 1);
+        const uint32_t sh = (i & 1) * 16;
+        uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (((cur >> sh) & 0x7FFFu) == 0) {
+          const uint32_t prev = atomicCAS(w, cur, cur | (tag << sh));
+          if (prev == cur) { got = i; break; }
+          cur = prev;
         }
-        uint32_t prev = atomicCAS(lp, w0, w0 + 1);
-        if (prev == w0) { got = (int)c; break; }
-        w0 = prev;
       }
       if (got >= 0) {
-        if (got == 0) atomicOr(lp, tag << 16);
-        else atomicOr(lp + ((got + 1) >> 1), (got & 1) ? tag : tag << 16);
-        uint32_t *e = lp + 5 + 3 * got;
+        uint32_t *e = lp + KU_LINE_ENTRY0 + 3 * got;
         e[0] = klo; e[1] = khi; e[2] = val;
         if (hops) atomicAdd(n_spilled, 1ull);
         break;
       }
+      atomicOr(lp, 0x8000u);  // full: the bucket is marked "spilled" before the key moves on
       line = line + 1 == n_lines ? 0 : line + 1;
     }
   }
@@ -547,9 +534,8 @@ __global__ __launch_bounds__(256) void ku_count_table_kernel(const uint32_t *__r
     uint64_t l = base + threadIdx.x;
     if (l < n_lines) {
       const uint32_t *lp = table + l * KU_LINE_DWORDS;
-      uint32_t c = lp[0] & 0xFFFFu;
-      if (c > KU_LINE_SLOTS) c = KU_LINE_SLOTS;
-      for (uint32_t i = 0; i < c; ++i) ku_ct_add(s_ctk, s_ctc, &s_ctu, lp[5 + 3 * i + 2], 1, counts);
+      for (uint32_t i = 0; i < KU_LINE_SLOTS; ++i)
+        if ((lp[i >> 1] >> ((i & 1) * 16)) & 0x7FFFu) ku_ct_add(s_ctk, s_ctc, &s_ctu, lp[KU_LINE_ENTRY0 + 3 * i + 2], 1, counts);
     }
     __syncthreads();
     ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, counts);

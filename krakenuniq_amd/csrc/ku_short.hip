@@ -571,19 +571,15 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       // header loads and the first-candidate entry load are issued for every lane (inactive lanes point at
       // bucket 0): the instructions are issued per wave anyway, predicating them only costs exec-mask juggling
       uint4 h4[ITEMS];
-      uint32_t h1[ITEMS];
 #pragma unroll
-      for (int j = 0; j < ITEMS; ++j) {
-        h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
-        h1[j] = lp[j][4];
-      }
+      for (int j = 0; j < ITEMS; ++j) h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
       KuPair pr[ITEMS];
       const uint32_t *ep[ITEMS];
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {  // no branch between the header wait and the entry loads of all items
-        cand[j] = ku_tag_matches(h4[j], h1[j], tag[j]) & (act[j] ? 0x1FFu : 0u);
-        ovf[j] = act[j] && (h4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
-        ep[j] = lp[j] + 5 + 3 * (__builtin_ctz(cand[j] | 0x200u) % 9u);  // no candidate: entry 0 (bit 9 -> 9 % 9)
+        cand[j] = ku_tag_matches(h4[j], tag[j]) & (act[j] ? 0xFFu : 0u);
+        ovf[j] = act[j] && ku_line_spilled(h4[j]);
+        ep[j] = lp[j] + KU_LINE_ENTRY0 + 3 * (__builtin_ctz(cand[j] | 0x100u) & 7u);  // no candidate: entry 0 (bit 8 -> 0)
       }
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) pr[j] = *reinterpret_cast<const KuPair *>(ep[j]);
@@ -601,17 +597,15 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         any = false;
         KuPair e[ITEMS];
         uint4 a4[ITEMS];
-        uint32_t a1[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
           if (act[j]) {
             if (cand[j]) {
-              e[j] = *reinterpret_cast<const KuPair *>(lp[j] + 5 + 3 * (__builtin_ctz(cand[j])));
+              e[j] = *reinterpret_cast<const KuPair *>(lp[j] + KU_LINE_ENTRY0 + 3 * (__builtin_ctz(cand[j])));
             } else {
               lp[j] += KU_LINE_DWORDS;
               if (lp[j] == tab + db.n_lines * KU_LINE_DWORDS) lp[j] = tab;
               a4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
-              a1[j] = lp[j][4];
             }
           }
         }
@@ -625,8 +619,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
                 act[j] = false;
               }
             } else {
-              cand[j] = ku_tag_matches(a4[j], a1[j], tag[j]);
-              ovf[j] = (a4[j].x & 0xFFFFu) > KU_LINE_SLOTS;
+              cand[j] = ku_tag_matches(a4[j], tag[j]);
+              ovf[j] = ku_line_spilled(a4[j]);
             }
             if (act[j]) act[j] = cand[j] != 0 || ovf[j];
             any |= act[j];

@@ -225,8 +225,9 @@ class BenchDb:
 
     # ---- reads
     def sample_reads(self, n_reads: int, read_len: int = 150, seed: int = 1, frac_random: float = 0.2,
-                     sub_rate: float = 0.01, n_rate: float = 0.001, chunk: int = 1 << 20):
-        """ASCII read buffer [n_reads, read_len + 1] (last column '\\n'), seq_off int64, seq_len int32, source taxid."""
+                     sub_rate: float = 0.01, n_rate: float = 0.001, chunk: int = 1 << 20, species=None):
+        """ASCII read buffer [n_reads, read_len + 1] (last column '\\n'), seq_off int64, seq_len int32, source taxid.
+        species: optional int64 tensor of species indices the reads are drawn from (default: all, uniformly)."""
         dev = self.device
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
@@ -237,6 +238,8 @@ class BenchDb:
         for s0 in range(0, n_reads, chunk):
             n = min(chunk, n_reads - s0)
             sp = torch.randint(0, self.n_species, (n,), generator=g, device=dev)
+            if species is not None:
+                sp = species[sp % species.numel()]
             st = torch.randint(0, self.G - read_len + 1, (n,), generator=g, device=dev)
             codes = self.genomes[sp[:, None], st[:, None] + ar[None, :]].to(torch.int64)
             rc = torch.rand(n, generator=g, device=dev) < 0.5

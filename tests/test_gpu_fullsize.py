@@ -272,3 +272,69 @@ def test_configs4_shape_100k_reads_of_10kbp_vs_oracle_sample(world):
     calls_s, taxa_s = compare_with_oracle(w, w["odb"], w["otax"], ctx, seqs, ns, LL, w["cores"])
     assert torch.equal(calls_s, calls_all[:ns]) and torch.equal(taxa_s, taxa_all[:ns * (LL + 1)])
     assert int((calls_all != 0).sum()) > NR // 2
+
+
+# ---------------------------------------------------------------------------- configs[1]: the report at BASELINE size
+def sparse_pairs_of_oracle(run, slot_of):
+    """(slot << 32 | encoded hash) of every taxon whose oracle sketch stayed sparse, ascending; and the sparse flags"""
+    parts, sparse_slots, dense_slots = [], [], []
+    for t, c in run.counts().items():
+        if not c["n_kmers"]:
+            continue
+        s = slot_of[t]
+        if c["sparse"]:
+            sparse_slots.append(s)
+            parts.append((np.uint64(s) << np.uint64(32)) | c["sketch"].sparse_list().astype(np.uint64))
+        else:
+            dense_slots.append(s)
+    allp = np.sort(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.uint64)
+    return allp, sparse_slots, dense_slots
+
+
+@pytest.mark.parametrize("unit,n,glog2", [(500000, 1_000_000, 20), (60000, 300_000, 0)])
+def test_configs1_report_with_sparse_sketches_vs_oracle(world, tmp_path, unit, n, glog2):
+    """ku_ctx_enable_sparse + ku_ctx_report on the 8 GB database against the oracle's report (reference sketch semantics:
+    sparse sets per work unit, dense switch at 1024): row for row, plus every taxon's sparse / dense state and encoded
+    set.  Ten species are over-represented so that their sketches turn dense while ~2000 others stay sparse; the run-wide
+    set starts at 2^20 cells (first case) and has to move to larger tables several times (ku_sparse_rehash_kernel)."""
+    w, torch = world, world["torch"]
+    db, ctx, dev = w["db"], w["ctx"], w["dev"]
+    hot = torch.arange(0, 10, device=dev, dtype=torch.int64) * 37 % db.n_species
+    n_hot = n // 6
+    s_u, _, _, _ = db.sample_reads(n - n_hot, L, seed=77)
+    s_h, _, _, _ = db.sample_reads(n_hot, L, seed=78, species=hot)
+    rows = torch.cat([s_u.view(-1, L + 1), s_h.view(-1, L + 1)])
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    rows = rows[torch.randperm(n, generator=g, device=dev)]
+    host = rows.reshape(-1).cpu().numpy()
+    del rows, s_u, s_h
+    off = np.arange(n, dtype=np.uint64) * (L + 1)
+    lens = np.full(n, L, dtype=np.uint32)
+    ctx.enable_sparse(unit, glog2)
+    cuts = [0, n // 7, n // 2 + 13, n]  # uneven host batches: work units straddle them
+    calls = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        r = ctx.classify_batch_rle(host[a * (L + 1):b * (L + 1)], off[:b - a], lens[:b - a])
+        calls.append(r["calls"])
+    assert ctx.sparse_state() == 1
+    run = ko.Run(w["odb"], w["otax"], work_unit_nt=unit, threads=w["cores"])
+    res = run.classify_packed(host, off, lens, want_taxa=False)
+    assert np.array_equal(np.concatenate(calls), res["calls"])
+    counts = ctx.counts()
+    assert_counts_equal_oracle(counts, run)
+    flags, pairs = ctx.sparse_export()
+    slot_of = {int(t): s for s, t in enumerate(counts["slot_taxid"])}
+    want_pairs, sparse_slots, dense_slots = sparse_pairs_of_oracle(run, slot_of)
+    assert len(dense_slots) >= 5 and len(sparse_slots) > 1000, (len(dense_slots), len(sparse_slots))
+    assert all(flags[s] == 1 for s in sparse_slots) and all(flags[s] == 0 for s in dense_slots)
+    assert np.array_equal(np.sort(pairs), want_pairs)
+    if glog2:
+        assert len(pairs) > 8 * (1 << glog2)  # the set outgrew its first table several times over
+    taxdb = str(tmp_path / "taxDB")
+    db.tax.write(taxdb)
+    got = ctx.report(capi.Tax(taxdb))
+    want = run.report(taxdb)
+    assert sorted(got.strip("\n").split("\n")) == sorted(want.strip("\n").split("\n"))
+    ctx.disable_sparse()  # the shared context goes on without the emulation's tables
+    ctx.reset_counts()

@@ -1,7 +1,9 @@
 """-m gpu, the configs[2] shape on one MI355X: a minimizer-range shard of 36 GB (3 G pairs, nt = 15) + the rest of that
 database as a second shard, SHARDED lookup kernels, per-k-mer slots merged with max ("non-zero wins",
 classify.cpp:445-452), resolve on the merge -- calls, per-k-mer codes, HLL registers, n_kmers and n_reads against the
-oracle on a 200 k-read sample.  The oracle cannot hold that database on the host; it runs against the sub-database of
+oracle on a 200 k-read sample, followed by the configs[3] / configs[4] shapes on the same standard-geometry shards (40 k mate
+pairs 2 x 150 + N and 600 reads of 10 kbp: the sharded lookup kernel at nt = 15 + the one-wave and the block-per-read
+resolve kernels on the merged slots).  The oracle cannot hold that database on the host; it runs against the sub-database of
 every pair whose k-mer occurs in the sampled reads: a k-mer outside it is a miss in both, so its answers for these
 reads are those of the full database (the GPU side always searches the full shards).  Own module: the build needs
 most of the 288 GB."""
@@ -49,9 +51,19 @@ def test_configs2_shape_36GB_nt15_shard_merge_vs_oracle_sample():
             # canonical k-mers of the sampled reads (N -> A: a superset of the unambiguous ones is fine)
             rows = seqs.view(n_reads, L + 1)[:n_sample, :L]
             codes = ((rows >> 1) ^ (rows >> 2)) & 3
-            q = synth_torch.canonical(synth_torch.kmers_of_rows(codes, K).reshape(-1), K)
-            q = torch.unique(q)
+            q = [torch.unique(synth_torch.canonical(synth_torch.kmers_of_rows(codes, K).reshape(-1), K))]
+            # configs[3] / configs[4] shapes against the same shards
+            ps, po, pl = sh.sample_pairs(40_000, L, seed=6)
+            ls, lo_, ll, _ = sh.sample_reads(600, 10_000, seed=8)
+            extra = [("pairs", ps, po, pl, 40_000, 2 * L + 1), ("long", ls, lo_, ll, 600, 10_000)]
+            for _, es, _, _, en, eL in extra:
+                r2 = es.view(en, eL + 1)[:, :eL]
+                c2 = ((r2 >> 1) ^ (r2 >> 2)) & 3
+                q.append(torch.unique(synth_torch.canonical(synth_torch.kmers_of_rows(c2, K).reshape(-1), K)))
+            q = torch.unique(torch.cat(q))
             w["q"] = q
+            w["extra"] = extra
+            w["extra_merged"] = [None] * len(extra)
         # pairs of this shard whose k-mer occurs in the sample
         q = w["q"]
         for c0 in range(0, sh.n_pairs, 1 << 28):  # torch's index kernels stop at 2^31 elements
@@ -75,6 +87,12 @@ def test_configs2_shape_36GB_nt15_shard_merge_vs_oracle_sample():
         c.lookup_device(ss.data_ptr(), ss.numel(), t.data_ptr(), flags=capi.KU_F_KEEP_SLOTS)
         c.synchronize()
         merged = t if merged is None else torch.maximum(merged, t)
+        for ei, (_, es, _, _, _, _) in enumerate(w["extra"]):  # booked into the same per-taxon state as the 150 bp sample
+            te = torch.zeros(es.numel(), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            c.lookup_device(es.data_ptr(), es.numel(), te.data_ptr(), flags=capi.KU_F_KEEP_SLOTS)
+            c.synchronize()
+            w["extra_merged"][ei] = te if w["extra_merged"][ei] is None else torch.maximum(w["extra_merged"][ei], te)
         counts.append(c.counts())
         # the full 2 M-read batch through the shard as well (size, not compared with the oracle)
         big = torch.zeros(seqs.numel(), dtype=torch.int32, device=dev)
@@ -94,6 +112,13 @@ def test_configs2_shape_36GB_nt15_shard_merge_vs_oracle_sample():
     ctxs[0].resolve_device(seqs.data_ptr(), off[:n_sample].data_ptr(), lens[:n_sample].data_ptr(), n_sample,
                            calls.data_ptr(), merged.data_ptr(), max_read_len=L)
     ctxs[0].synchronize()
+    extra_calls = []
+    for (_, es, eo, el, en, eL), em in zip(w["extra"], w["extra_merged"]):
+        ce = torch.zeros(en, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctxs[0].resolve_device(es.data_ptr(), eo.data_ptr(), el.data_ptr(), en, ce.data_ptr(), em.data_ptr(), max_read_len=eL)
+        ctxs[0].synchronize()
+        extra_calls.append(ce)
     n_reads_state = ctxs[0].counts()
     # oracle on the sub-database: a bin lives in exactly one shard and the shards were taken in bin order, so the
     # concatenation is in KrakenDB order already; only the index is rebuilt
@@ -117,6 +142,14 @@ def test_configs2_shape_36GB_nt15_shard_merge_vs_oracle_sample():
     want[res["ambig"].reshape(n_sample, nk) != 0] = capi.KU_AMBIG
     got = merged.view(n_sample, L + 1)[:, :nk].cpu().numpy().view(np.uint32)
     assert np.array_equal(got, want)
+    for (name, es, eo, el, en, eL), em, ce in zip(w["extra"], w["extra_merged"], extra_calls):
+        re_ = run.classify_packed(es.cpu().numpy(), eo.cpu().numpy().astype(np.uint64), el.cpu().numpy().astype(np.uint32))
+        nke = eL - K + 1
+        assert np.array_equal(ce.cpu().numpy().view(np.uint32), re_["calls"]), name
+        we = re_["taxa"].reshape(en, nke).copy()
+        we[re_["ambig"].reshape(en, nke) != 0] = capi.KU_AMBIG
+        assert np.array_equal(em.view(en, eL + 1)[:, :nke].cpu().numpy().view(np.uint32), we), name
+        assert int((ce != 0).sum()) > en // 2
     tot = dict(counts[0])
     tot["registers"] = np.maximum(counts[0]["registers"], counts[1]["registers"])
     tot["n_kmers"] = counts[0]["n_kmers"] + counts[1]["n_kmers"]
