@@ -195,9 +195,10 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
             r = ctx.classify_batch_rle(hb, off, lens, out=obuf)
             dt = time.perf_counter() - t0
             out["device_pipeline"] = {"value": round(n_dp / dt / 1e6, 2), "unit": "Mreads/s", "reads": n_dp,
-                                      "runs_per_read": round(len(r["runs"]) / n_dp, 2),
+                                      "runs_per_read": round(float(r["run_cnt"].sum()) / n_dp, 2),
                                       "calls_match_device_run": bool((r["calls"] == calls_gpu[:n_dp]).all()),
-                                      "path": "pinned host buffers -> H2D -> fused kernel -> RLE kernel -> D2H (calls, runs) -> pinned host buffers"}
+                                      "path": "pinned host buffers -> H2D in segments on a copy stream || fused kernel with run-length "
+                                              "encoded output -> D2H (calls, runs) -> pinned host buffers"}
         except Exception as e:
             out["device_pipeline"] = {"value": None, "error": str(e)[:200]}
         # ---- end to end: the classify executable on a FASTQ file (parser team | device | formatter + writer)

@@ -249,7 +249,9 @@ int ku_classify_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uin
  * the batch's total *n_runs; ku_fetch_runs then copies that many runs out of the context (valid until the next
  * batch call on it).  Read i owns runs[run_off[i] .. run_off[i] + run_cnt[i]); a run is {code, start}: code =
  * taxid / 0 / KU_AMBIG, start = index of its first k-mer; its length is the next run's start (or the read's k-mer
- * count) minus its own.  Reads shorter than k own no runs. */
+ * count) minus its own.  Reads shorter than k own no runs.  *n_runs is the extent of the context's run array, not the
+ * number of runs: the fused kernel's waves claim the array in chunks, so there may be unused entries between the reads'
+ * runs (sum of run_cnt <= *n_runs). */
 typedef struct ku_run {
   uint32_t code;
   uint32_t start;

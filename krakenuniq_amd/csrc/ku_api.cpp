@@ -414,6 +414,10 @@ struct ku_ctx {
   KuCountsDev cnt{};
   // scratch for the host-buffer entry point
   DevBuf b_seqs, b_off, b_len, b_calls, b_taxa, b_hits, b_ws, b_runs, b_roff, b_rcnt;
+  // ku_classify_batch_rle through the fused kernel: the batch goes up in segments on a stream of its own while the
+  // segments before are classified (one event per segment)
+  hipStream_t h2d_stream = nullptr;
+  std::vector<hipEvent_t> seg_events;
   uint32_t *d_scalar = nullptr;
   uint64_t n_runs = 0;  // runs of the last ku_classify_batch_rle, still in b_runs
   // exact distinct counting (classifyExact): one global set of canonical k-mers + first-insertion counters per slot
@@ -437,6 +441,7 @@ struct ku_ctx {
     KuSparseDev dev{};
     unsigned long long *d_counters = nullptr;  // [0] size of G, [1..2] carry sizes, [3] export size
     DevBuf unit, carry_l, carry_u, out;
+    DevBuf u_cnt, u_flag, list;  // fast path: inserts per (unit, slot), per-unit flags, the reads of the flagged units
     uint64_t n_carry_l = 0, n_carry_u = 0, cap_carry_l = 0, cap_carry_u = 0;
     uint64_t g_count = 0;       // entries of the global set after the last pass (host copy of d_counters[0])
     bool gave_up = false;       // the emulation ran out of device memory during the run and was switched off
@@ -497,7 +502,7 @@ static void ctx_free_sparse(ku_ctx *ctx) {
   for (void *p : {(void *)d.l_key, (void *)d.l_first, (void *)d.u_key, (void *)d.u_distinct, (void *)d.u_last, (void *)d.u_maxfirst,
                   (void *)d.g_key, (void *)d.dense, (void *)d.err, (void *)ctx->sp.d_counters})
     if (p) (void)hipFree(p);
-  for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out}) b->release();
+  for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out, &ctx->sp.u_cnt, &ctx->sp.u_flag, &ctx->sp.list}) b->release();
   ctx->sp = ku_ctx::Sparse{};
 }
 static void ctx_free_tax(ku_ctx *ctx) {
@@ -530,6 +535,8 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
   if (ctx->pf.d_scalar) (void)hipFree(ctx->pf.d_scalar);
   if (ctx->pf.stream) (void)hipStreamDestroy(ctx->pf.stream);
+  for (hipEvent_t e : ctx->seg_events) (void)hipEventDestroy(e);
+  if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1337,6 +1344,272 @@ static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_
   return KU_OK;
 }
 
+// ---- ku_classify_batch_rle through the fused kernel with run-length encoded output (ku_short.hip, OUT >= 1): no
+// per-k-mer array, no second kernel; with the sparse-mode emulation on, its fast path.
+// The exact per-unit evaluation of the emulation for the units the fused kernel could not settle by counting:
+// `flagged` (ascending unit numbers of this batch; bit 31 of the companion = every slot tracked).
+static int sparse_fast_exact(ku_ctx *ctx, const uint32_t *h_len, const std::vector<uint64_t> &unit_first_read,
+                             const std::vector<uint32_t> &flagged, const std::vector<uint8_t> &flag_all, bool last_is_open,
+                             const uint32_t *d_u_cnt, hipStream_t s) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  KuSparseDev &d = sp.dev;
+  size_t at = 0;
+  bool first_pass = true;
+  while (at < flagged.size()) {
+    // units of this pass: at most 2^25 bases and KU_SPARSE_MAX_UNITS units (the tables of ku_sparse.hip)
+    size_t end = at;
+    uint64_t bases = 0, n_list = 0;
+    while (end < flagged.size() && end - at < KU_SPARSE_MAX_UNITS) {
+      const uint32_t u = flagged[end];
+      uint64_t ub = 0;
+      for (uint64_t r = unit_first_read[u]; r < unit_first_read[u + 1]; ++r) ub += h_len[r];
+      if (end > at && bases + ub > (1ull << 25)) break;
+      bases += ub;
+      n_list += unit_first_read[u + 1] - unit_first_read[u];
+      ++end;
+    }
+    const bool has_open = last_is_open && end == flagged.size();
+    std::vector<uint32_t> list(3 * n_list);
+    uint64_t li = 0;
+    for (size_t f = at; f < end; ++f) {
+      const uint32_t u = flagged[f];
+      for (uint64_t r = unit_first_read[u]; r < unit_first_read[u + 1]; ++r, ++li) {
+        list[li] = (uint32_t)r;
+        list[n_list + li] = (uint32_t)(f - at) | (flag_all[f] ? 0x80000000u : 0u);
+        list[2 * n_list + li] = u;
+      }
+    }
+    if (sp.list.reserve(std::max<uint64_t>(n_list, 1) * 12) != KU_OK) return fail(KU_ENOMEM, "device memory for the flagged work units' reads");
+    KU_TRY(sparse_reserve_global(ctx, bases + sp.n_carry_l, s));
+    HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(d.u_distinct, 0, (d.u_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_last, 0, (d.u_mask + 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
+    if (first_pass && sp.open)  // the unit carried over from the batch before is local unit 0 of the first pass
+      KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p, sp.n_carry_u, s));
+    if (n_list) HIP_TRY(hipMemcpyAsync(sp.list.p, list.data(), n_list * 12, hipMemcpyHostToDevice, s));
+    const uint32_t *dl = (const uint32_t *)sp.list.p;
+    KU_TRY(ku_launch_sparse_insert_runs(d, ctx->m.db.k, (const uint8_t *)ctx->b_seqs.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
+                                        dl, dl + n_list, dl + 2 * n_list, n_list, ctx->b_runs.p, (const uint64_t *)ctx->b_roff.p,
+                                        (const uint32_t *)ctx->b_rcnt.p, ctx->d_slot_taxid, ctx->tax.n_slots, d_u_cnt, ctx->n_cu, s));
+    const uint32_t n_local = (uint32_t)(end - at);
+    KU_TRY(ku_launch_sparse_close(d, has_open ? n_local - 1 : n_local, s));
+    sp.n_carry_l = sp.n_carry_u = 0;
+    unsigned long long c[3] = {0, 0, 0};
+    if (has_open) {
+      HIP_TRY(hipMemsetAsync(sp.d_counters + 1, 0, 16, s));
+      KU_TRY(ku_launch_sparse_carry_out(d, n_local - 1, (unsigned long long *)sp.carry_l.p, (uint32_t *)sp.carry_u.p, sp.d_counters + 1,
+                                        sp.cap_carry_l, sp.cap_carry_u, s));
+    }
+    HIP_TRY(hipMemcpyAsync(c, sp.d_counters, 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `list` goes out of scope
+    sp.g_count = c[0];
+    if (has_open) {
+      sp.n_carry_l = std::min<uint64_t>(c[1], sp.cap_carry_l);
+      sp.n_carry_u = std::min<uint64_t>(c[2], sp.cap_carry_u);
+    }
+    first_pass = false;
+    at = end;
+  }
+  return KU_OK;
+}
+
+// may the batch take the fused kernel with run-length encoded output?  (the same conditions as the fused path of
+// classify_device_impl, plus what the emulation's fast path needs)
+static bool rle_fused_eligible(ku_ctx *ctx, uint32_t flags, uint32_t max_n, uint64_t n_bytes, uint64_t n_reads, bool monotonic) {
+  if (getenv("KU_NO_FUSED") || getenv("KU_NO_FUSED_RLE") || !ctx->extra.empty() || ctx->d_exact_set) return false;
+  if (flags & (KU_F_QUICK | KU_F_KEEP_SLOTS)) return false;
+  const uint32_t short_max = ku_short_max_kmers(ctx->m.db);
+  if (!short_max) return false;
+  if (max_n > short_max && (max_n > ku_short_max_kmers_windowed(ctx->m.db) || getenv("KU_NO_WINDOWED"))) return false;
+  if (n_reads >= (1ull << 32)) return false;
+  const bool sparse = ctx->sp.on && !(flags & KU_F_NO_COUNTS);
+  if (sparse) {
+    const ku_ctx::Sparse &sp = ctx->sp;
+    if (getenv("KU_NO_SPARSE_FAST") || !monotonic || sp.unit_nt == 0 || sp.unit_nt > (1ull << 24) || n_bytes + 2 >= (1ull << 32)) return false;
+    const uint64_t max_units = n_bytes / sp.unit_nt + 2;
+    if (max_units * ctx->tax.n_slots > (1ull << 29)) return false;  // the (unit, slot) counters: at most 2 GiB
+  }
+  return true;
+}
+
+static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads,
+                         uint64_t runs_cap, bool quick, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
+                         uint32_t *run_cnt, uint64_t *n_runs);
+
+static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
+                           uint64_t n_reads, const ku_opts &o, uint32_t max_n, bool monotonic, uint32_t *calls, uint32_t *hits,
+                           uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs, bool *classified) {
+  hipStream_t s = ctx->stream;
+  *classified = false;
+  const bool counts = !(o.flags & KU_F_NO_COUNTS);
+  const bool sparse = ctx->sp.on && counts;
+  ku_ctx::Sparse &sp = ctx->sp;
+  // ---- segments of the batch: cut at read boundaries, uploaded one after the other on the copy stream while the
+  // compute stream classifies the ones before
+  uint64_t n_seg = 1;
+  if (monotonic && !getenv("KU_NO_H2D_OVERLAP")) n_seg = std::min<uint64_t>(8, std::max<uint64_t>(1, n_bytes / (8ull << 20)));
+  std::vector<uint64_t> seg(n_seg + 1, 0);
+  for (uint64_t g = 1; g < n_seg; ++g) {
+    const uint64_t target = n_bytes / n_seg * g;
+    seg[g] = std::max<uint64_t>(seg[g - 1], (uint64_t)(std::lower_bound(seq_off, seq_off + n_reads, target) - seq_off));
+  }
+  seg[n_seg] = n_reads;
+  uint64_t total_waves = 0, max_seg_reads = 0;
+  for (uint64_t g = 0; g < n_seg; ++g) {
+    total_waves += ku_short_grid_waves(seg[g + 1] - seg[g], max_n, ctx->n_cu);
+    max_seg_reads = std::max(max_seg_reads, seg[g + 1] - seg[g]);
+  }
+  // a wave claims `chunk` run entries at a time: large enough for few claims, small enough that the unused tails of the
+  // last chunks do not dominate a small batch
+  const uint64_t reads_per_wave = n_reads / std::max<uint64_t>(total_waves, 1);
+  const uint32_t chunk = reads_per_wave >= 64 ? 256u : (reads_per_wave >= 16 ? 64u : 16u);
+  // room for ~ one run per 6 bases + the chunk tails; a batch that needs more (many taxa per read) is redone through
+  // the per-k-mer array (below), whose run-length encoder cannot overflow
+  uint64_t runs_cap = n_bytes / 6 + 4 * n_reads + total_waves * chunk + 4096;
+  if (const char *e = getenv("KU_RUNS_CAP")) runs_cap = std::max<uint64_t>(1, (uint64_t)atoll(e));  // test hook
+  uint64_t ws = 0;
+  if (max_n > ku_short_max_kmers(ctx->m.db)) ws = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, max_seg_reads, ctx->n_cu);
+  if (ws > ctx->b_ws.cap || (n_bytes + 16) > ctx->b_seqs.cap) HIP_TRY(hipStreamSynchronize(s));
+  if (ctx->b_seqs.reserve(n_bytes + 16) || ctx->b_off.reserve(n_reads * 8) || ctx->b_len.reserve(n_reads * 4) ||
+      ctx->b_calls.reserve(n_reads * 4) || ctx->b_runs.reserve(runs_cap * 8) || ctx->b_roff.reserve(n_reads * 8) ||
+      ctx->b_rcnt.reserve(n_reads * 4) || ctx->b_ws.reserve(ws))
+    return fail(KU_ENOMEM, "device batch buffers");
+  if (!ctx->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+  while (ctx->seg_events.size() < n_seg) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->seg_events.push_back(e);
+  }
+  // ---- sparse fast path: work-unit plan (the unit closes behind the read that fills it, classify.cpp:510-521)
+  std::vector<uint32_t> unit;
+  std::vector<uint64_t> unit_first_read;
+  uint32_t n_units = 0;
+  bool open_after = false, continuing = false;
+  uint64_t acc_after = 0;
+  KuSparseFast sf{};
+  if (sparse) {
+    unit.resize(n_reads);
+    uint64_t acc = sp.acc_nt;
+    uint32_t cur = 0;
+    continuing = sp.open;
+    unit_first_read.push_back(0);
+    for (uint64_t r = 0; r < n_reads; ++r) {
+      unit[r] = cur;
+      acc += seq_len[r];
+      if (acc >= sp.unit_nt) { ++cur; acc = 0; unit_first_read.push_back(r + 1); }
+    }
+    open_after = acc > 0;
+    acc_after = acc;
+    n_units = cur + (unit_first_read.back() < n_reads ? 1u : 0u);
+    if (unit_first_read.back() < n_reads) unit_first_read.push_back(n_reads);
+    const uint64_t cells = (uint64_t)n_units * ctx->tax.n_slots;
+    if (sp.unit.reserve(n_reads * 4) || sp.u_cnt.reserve(std::max<uint64_t>(cells, 1) * 4) || sp.u_flag.reserve(std::max<uint32_t>(n_units, 1)))
+      return fail(KU_ENOMEM, "device memory for the work-unit counters");
+    uint64_t kmers = 0;  // upper bound of what the fused kernel may add to the run-wide set
+    for (uint64_t r = 0; r < n_reads; ++r) kmers += seq_len[r] >= ctx->m.db.k ? seq_len[r] - ctx->m.db.k + 1 : 0;
+    KU_TRY(sparse_reserve_global(ctx, kmers + sp.n_carry_l, s));
+    HIP_TRY(hipMemsetAsync(sp.u_cnt.p, 0, std::max<uint64_t>(cells, 1) * 4, s));
+    HIP_TRY(hipMemsetAsync(sp.u_flag.p, 0, std::max<uint32_t>(n_units, 1), s));
+    sf.g_key = sp.dev.g_key;
+    sf.g_mask = sp.dev.g_mask;
+    sf.g_count = sp.dev.g_count;
+    sf.dense = sp.dev.dense;
+    sf.u_cnt = (uint32_t *)sp.u_cnt.p;
+    sf.err = sp.dev.err;
+    sf.n_slots = ctx->tax.n_slots;
+    sf.unit_base = 0;
+  }
+  unsigned long long *d_counter = (unsigned long long *)(ctx->d_scalar + 2);
+  HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
+  HIP_TRY(hipEventRecord(ctx->seg_events[0], s));  // the copy stream starts behind whatever used the buffers before
+  HIP_TRY(hipStreamWaitEvent(ctx->h2d_stream, ctx->seg_events[0], 0));
+  KuRunsOut ro{};
+  ro.runs = (uint2 *)ctx->b_runs.p;
+  ro.counter = d_counter;
+  ro.cap = runs_cap;
+  ro.chunk = chunk;
+  for (uint64_t g = 0; g < n_seg; ++g) {
+    const uint64_t a = seg[g], b = seg[g + 1];
+    const uint64_t lo = g == 0 ? 0 : seq_off[a], hi = g + 1 == n_seg ? n_bytes : seq_off[b];
+    hipStream_t cs = n_seg > 1 ? ctx->h2d_stream : s;
+    if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)ctx->b_seqs.p + lo, seqs + lo, hi - lo, hipMemcpyHostToDevice, cs));
+    if (b > a) {
+      HIP_TRY(hipMemcpyAsync((uint64_t *)ctx->b_off.p + a, seq_off + a, (b - a) * 8, hipMemcpyHostToDevice, cs));
+      HIP_TRY(hipMemcpyAsync((uint32_t *)ctx->b_len.p + a, seq_len + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
+      if (sparse) HIP_TRY(hipMemcpyAsync((uint32_t *)sp.unit.p + a, unit.data() + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
+    }
+    if (n_seg > 1) {
+      HIP_TRY(hipEventRecord(ctx->seg_events[g], cs));
+      HIP_TRY(hipStreamWaitEvent(s, ctx->seg_events[g], 0));
+    }
+    if (b == a) continue;
+    ro.run_off = (uint64_t *)ctx->b_roff.p + a;
+    ro.run_cnt = (uint32_t *)ctx->b_rcnt.p + a;
+    sf.unit_of = sparse ? (const uint32_t *)sp.unit.p + a : nullptr;
+    int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p + a,
+                                      (const uint32_t *)ctx->b_len.p + a, b - a, max_n, o.flags, (uint32_t *)ctx->b_calls.p + a, nullptr, nullptr,
+                                      ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
+    if (st != KU_OK) { (void)hipStreamSynchronize(ctx->h2d_stream); (void)hipStreamSynchronize(s); return fail(st, "fused kernel launch failed"); }
+    HIP_TRY(hipMemcpyAsync(calls + a, (uint32_t *)ctx->b_calls.p + a, (b - a) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(run_off + a, (uint64_t *)ctx->b_roff.p + a, (b - a) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(run_cnt + a, (uint32_t *)ctx->b_rcnt.p + a, (b - a) * 4, hipMemcpyDeviceToHost, s));
+  }
+  unsigned long long total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
+  std::vector<uint8_t> h_flag;
+  unsigned long long g_now = 0;
+  uint32_t sp_err = 0;
+  if (sparse) {
+    KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)sp.u_cnt.p, (uint64_t)n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
+                                       (uint8_t *)sp.u_flag.p, s));
+    h_flag.resize(std::max<uint32_t>(n_units, 1));
+    HIP_TRY(hipMemcpyAsync(h_flag.data(), sp.u_flag.p, std::max<uint32_t>(n_units, 1), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&g_now, sp.dev.g_count, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&sp_err, sp.dev.err, 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (hits) memset(hits, 0, n_reads * 4);  // "Q:n" is quick mode only
+  if (total > runs_cap) {
+    // the run array was too small for this batch (reads that change taxon every few k-mers): the per-k-mer codes once more
+    // without any accounting, through the array parallel to the reads and its own run-length encoder
+    if (ctx->b_taxa.reserve((n_bytes + 16) * 4) || ctx->b_runs.reserve((n_bytes + 1) * 8)) return fail(KU_ENOMEM, "device batch buffers");
+    uint64_t ws2 = ws;
+    if (max_n > ku_short_max_kmers(ctx->m.db)) ws2 = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, n_reads, ctx->n_cu);
+    if (ctx->b_ws.reserve(ws2)) return fail(KU_ENOMEM, "device batch buffers");
+    int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p,
+                                      (const uint32_t *)ctx->b_len.p, n_reads, max_n, o.flags | KU_F_NO_COUNTS, (uint32_t *)ctx->b_calls.p,
+                                      (uint32_t *)ctx->b_taxa.p, nullptr, ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s);
+    if (st != KU_OK) return fail(st, "fused kernel launch failed");
+    KU_TRY(rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p, n_reads, n_bytes + 1,
+                         false, calls, nullptr, run_off, run_cnt, n_runs));
+  } else {
+    *n_runs = ctx->n_runs = total;
+  }
+  *classified = true;  // what follows only concerns the emulation's state
+  if (sparse) {
+    if (sp_err) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set is full");
+    sp.g_count = g_now;
+    // units the counting could not settle: flagged by the kernel, and the ones that straddle batches
+    std::vector<uint32_t> flagged;
+    std::vector<uint8_t> flag_all;
+    for (uint32_t u = 0; u < n_units; ++u) {
+      const bool edge = (u == 0 && continuing) || (u + 1 == n_units && open_after);
+      if (h_flag[u] || edge) { flagged.push_back(u); flag_all.push_back(edge ? 1 : 0); }
+    }
+    if (n_units == 0 && continuing) { /* an empty batch leaves the carried unit as it is */ }
+    else KU_TRY(sparse_fast_exact(ctx, seq_len, unit_first_read, flagged, flag_all, open_after, (const uint32_t *)sp.u_cnt.p, s));
+    if (n_units) {
+      sp.open = open_after;
+      sp.acc_nt = acc_after;
+      if (!open_after) sp.n_carry_l = sp.n_carry_u = 0;
+    }
+  }
+  return KU_OK;
+}
+
 extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
                                      const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                                      uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
@@ -1349,8 +1622,29 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   o.flags &= ~KU_F_KEEP_SLOTS;
   if (o.max_read_len == 0) for (uint64_t i = 0; i < n_reads; ++i) o.max_read_len = std::max(o.max_read_len, seq_len[i]);
-  for (uint64_t i = 0; i < n_reads; ++i)
+  bool monotonic = true;
+  for (uint64_t i = 0; i < n_reads; ++i) {
     if (seq_off[i] + seq_len[i] > n_bytes) return fail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
+    if (i && seq_off[i] < seq_off[i - 1] + seq_len[i - 1]) monotonic = false;
+  }
+  {
+    const uint32_t max_n = o.max_read_len >= ctx->m.db.k ? o.max_read_len - ctx->m.db.k + 1 : 0;
+    if (rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic)) {
+      bool classified = false;
+      int st = rle_fused_batch(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, n_runs, &classified);
+      if (st == KU_ENOMEM && ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {
+        // no room for the emulation's tables: the classification itself does not depend on them (see classify_device_impl):
+        // the run goes on with the dense registers alone; a batch that had not been classified yet is taken again
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+        ctx_free_sparse(ctx);
+        ctx->sp.gave_up = true;
+        if (classified) return KU_OK;
+        st = rle_fused_batch(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, n_runs, &classified);
+      }
+      return st;
+    }
+  }
   // a run needs at least one k-mer, so n_bytes bounds the number of runs: the device side cannot overflow
   const uint64_t runs_cap = n_bytes + 1;
   if (ctx->b_seqs.reserve(n_bytes + 16) || ctx->b_off.reserve(n_reads * 8) || ctx->b_len.reserve(n_reads * 4) ||

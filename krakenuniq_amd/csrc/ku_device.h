@@ -139,6 +139,41 @@ __device__ __forceinline__ void ku_hll_update(uint8_t *registers, uint32_t slot,
   ku_hll_raise(r, *r, rank);
 }
 
+// ---- HyperLogLog++ sparse representation (ku_sparse.hip, and the fused kernel's sparse fast path)
+#define KS_PPRIME 25
+// encodeHashIn32Bit (hyperloglogplus.cpp:181-204), p = 12, p' = 25
+__device__ __forceinline__ uint32_t ks_encode(uint64_t h) {
+  const uint32_t idx = (uint32_t)(h >> (64 - KS_PPRIME)) << (32 - KS_PPRIME);
+  if ((uint32_t)(idx << KU_HLL_P) == 0) {
+    const uint64_t rest = h << KS_PPRIME;
+    const uint32_t add = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KS_PPRIME + 1);
+    return idx | (add << 1) | 1u;
+  }
+  return idx;
+}
+
+__device__ __forceinline__ uint64_t ks_mix(unsigned long long k) {
+  k ^= k >> 31;
+  k *= 0x9E3779B97F4A7C15ULL;
+  k ^= k >> 29;
+  return k;
+}
+
+// insert (slot, encoding) into the run-wide set G of the sparse-mode emulation: open addressing over 8-byte cells, one
+// compare-and-swap per probe (an empty cell and "already there" both end the search).  true: the entry is new.
+__device__ __forceinline__ bool ks_g_insert(unsigned long long *g_key, uint64_t g_mask, uint32_t slot, uint32_t enc, uint32_t *err) {
+  const unsigned long long gk = ((unsigned long long)(slot + 1) << 32) | enc;
+  uint64_t h = ks_mix(gk) & g_mask;
+  for (uint32_t probe = 0; probe < 4096; ++probe) {
+    const unsigned long long old = atomicCAS(&g_key[h], 0ull, gk);
+    if (old == 0ull) return true;
+    if (old == gk) return false;
+    h = (h + 1) & g_mask;
+  }
+  atomicOr(err, 4u);
+  return false;
+}
+
 // ----------------------------------------------------------------------------
 // ku_lookup_kernel
 // ----------------------------------------------------------------------------

@@ -76,6 +76,12 @@ int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned lon
                                unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream);
 int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_carry_l, uint64_t n_l, const uint32_t *d_carry_u,
                               uint64_t n_u, hipStream_t stream);
+int ku_launch_sparse_flag_units(const uint32_t *d_u_cnt, uint64_t n_cells, uint32_t n_slots, const uint32_t *d_dense, uint8_t *d_unit_flag,
+                                hipStream_t stream);
+int ku_launch_sparse_insert_runs(const KuSparseDev &s, uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
+                                 const uint32_t *d_list_read, const uint32_t *d_list_unit, const uint32_t *d_list_urow, uint64_t n_list,
+                                 const void *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt, const uint32_t *d_slot_taxid,
+                                 uint32_t n_slots, const uint32_t *d_u_cnt, int n_cu, hipStream_t stream);
 // s.g_key / s.g_mask: the new (zeroed) table; s.g_count zeroed by the caller
 int ku_launch_sparse_rehash(const KuSparseDev &s, const unsigned long long *d_old_keys, uint64_t old_cells, hipStream_t stream);
 int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
@@ -114,6 +120,35 @@ int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev 
                       uint32_t min_hits, uint32_t max_read_len, uint32_t *d_calls, uint32_t *d_taxa,
                       uint32_t *d_hits, void *d_workspace, uint64_t workspace_bytes, int n_cu,
                       hipStream_t stream);
+// Run-length encoded output of the fused kernel (instead of the per-k-mer array): {code, start} pairs as ku_run, every
+// read's runs contiguous in `runs`; a wave claims `chunk` entries at a time from the bump counter (one atomic per
+// ~chunk / runs-per-read reads) and fills them read by read, so the array has unused gaps -- (run_off, run_cnt) say
+// where each read's runs are.  counter > cap afterwards = the array was too small (nothing was written out of bounds).
+struct KuRunsOut {
+  uint2 *runs;
+  unsigned long long *counter;
+  unsigned long long cap;
+  uint64_t *run_off;
+  uint32_t *run_cnt;
+  uint32_t chunk;
+  uint32_t pad;
+};
+// Sparse-mode emulation inside the fused kernel (fast path): every unambiguous k-mer of a slot whose
+// sketch is not known to be dense goes into the run-wide set G straight away, and the number of inserts per (work unit,
+// slot) is counted in a dense array -- a local sketch can only switch to the dense representation in a unit that gave it
+// at least 1025 inserts, so the exact per-unit evaluation (ku_sparse.hip) runs on those units and slots only.
+struct KuSparseFast {
+  unsigned long long *g_key;
+  uint64_t g_mask;
+  unsigned long long *g_count;   // entries of G (one add per wave at the end of the kernel)
+  const uint32_t *dense;         // per slot, sticky
+  uint32_t *u_cnt;               // [unit - unit_base][n_slots] inserts of the (unit, slot) pair
+  const uint32_t *unit_of;       // per read (indexed like seq_off)
+  uint32_t *err;
+  uint32_t n_slots;
+  uint32_t unit_base;
+};
+#define KU_SPARSE_SWITCH_INSERTS 1025u  // fewest inserts with which a sparse sketch can turn dense (hyperloglogplus.cpp:496-498)
 // fused wave-per-read path for short reads (ku_short.hip)
 uint32_t ku_short_max_kmers(const KuDbDev &db);           // reads taken in one pass
 uint32_t ku_short_max_kmers_windowed(const KuDbDev &db);  // ... in windows of 128 k-mers (ku_short.hip)
@@ -121,7 +156,11 @@ uint64_t ku_short_workspace_bytes(uint32_t max_kmers, uint32_t n_slots, uint64_t
 int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
                              uint64_t n_bytes, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                              uint32_t max_kmers, uint32_t flags, uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits,
-                             void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream);
+                             void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream,
+                             const KuRunsOut *runs_out = nullptr, const KuSparseFast *sparse = nullptr);
+// waves of the fused kernel's persistent grid for a batch of n_reads (sizing of the run array: every wave may leave one
+// partly used chunk behind)
+uint64_t ku_short_grid_waves(uint64_t n_reads, uint32_t max_kmers, int n_cu);
 uint64_t ku_resolve_workspace_bytes(uint32_t max_read_len, uint32_t k, int n_cu);
 int ku_launch_exact(uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                     const uint32_t *d_taxa, unsigned long long *d_set, uint64_t mask, unsigned long long *d_unique,

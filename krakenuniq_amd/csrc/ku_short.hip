@@ -278,12 +278,16 @@ __device__ __noinline__ uint32_t ks_spill_resolve(uint32_t *g_key, uint32_t *g_c
 // distinct taxa than that holds: the wave's region of `spill`), the call is resolved behind the last window.  A window
 // does not start on k-mers already known to be ambiguous: mate pairs joined by 'N' (2 x 150: k-mers 0-119 and
 // 151-270) take two windows, not three.
-template <int ITEMS, bool DO_COUNTS, int KK, int MM, bool WIN>
+// OUT: what becomes of the per-k-mer codes -- 0: the array parallel to the read buffer (taxa[]); 1: run-length encoded
+// {code, start} pairs, each read's runs contiguous in a run array the waves claim in chunks (KuRunsOut; everything
+// hitlist_string prints, classify.cpp:826-861, at ~20 B instead of 604 B per 150 bp read -- and no second kernel reads
+// the codes back); 2: as 1, plus the sparse-mode emulation's fast path (KuSparseFast).
+template <int ITEMS, bool DO_COUNTS, int KK, int MM, bool WIN, int OUT>
 __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_short_kernel(
     KuDbDev db, KuTaxDev tax, KuCountsDev cnt, const uint8_t *__restrict__ seqs, uint64_t n_bytes,
     const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, uint64_t n_reads,
     uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t ablate, uint32_t *__restrict__ spill,
-    uint32_t spill_cap) {
+    uint32_t spill_cap, KuRunsOut ro, KuSparseFast sf) {
   // KS_ABL(bit): measurement knob, compiled in only with -DKU_ABLATION (then env KU_ABLATE selects the bits; the
   // production build has no trace of it -- the flag checks cost scalar registers and branches in the read loop):
   // 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
@@ -324,6 +328,32 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   uint32_t *g_key = WIN ? spill + ((uint64_t)blockIdx.x * KS_WAVES + wv) * 2ull * spill_cap : nullptr;
   uint32_t *g_cnt = WIN ? g_key + spill_cap : nullptr;
   bool spill_used = false;
+  // OUT >= 1: the part of the run array this wave claimed and has not filled yet (wave-uniform)
+  unsigned long long ch_pos = 0, ch_end = 0;
+  // make room for `need` more runs: a new chunk when the current one is too short.  `keep` runs of the read in progress
+  // (WIN: a read's runs arrive window by window and must stay contiguous) move along, from `keep_base`.
+  auto runs_room = [&](uint32_t need, uint32_t keep, unsigned long long &keep_base) {
+    if (ch_pos + need <= ch_end) return;
+    const uint32_t want_min = keep ? 2u * (keep + need) : need;  // a growing read doubles its room: O(runs) copies in total
+    const uint32_t want = want_min > ro.chunk ? want_min : ro.chunk;
+    unsigned long long b = 0;
+    if (lane == 0) b = atomicAdd(ro.counter, (unsigned long long)want);
+    b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    if (keep) {
+      __threadfence();  // the wave's own earlier stores
+      for (uint32_t i = lane; i < keep; i += 64) {
+        if (keep_base + i < ro.cap && b + i < ro.cap) {
+          const uint32_t *src = reinterpret_cast<const uint32_t *>(ro.runs + keep_base + i);
+          ro.runs[b + i] = make_uint2(ks_gload(src), ks_gload(src + 1));
+        }
+      }
+      keep_base = b;
+    }
+    ch_pos = b + keep;
+    ch_end = b + want;
+  };
+  uint32_t sp_fresh = 0;  // OUT == 2: entries this wave added to G
 #ifdef KS_PREFETCH
   // software pipeline over the wave's reads: the text of the NEXT read is requested before the current one is worked
   // on (its latency hides behind a whole read's worth of work), its length / offset one read earlier still
@@ -380,6 +410,11 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     uint32_t rd_first = 0, rd_cnt = 0, win0 = 0;
     bool rd_table = false, rd_spill = false;
     uint32_t call_node = 0;
+    // OUT >= 1: where the read's runs start, how many there are so far, and the code of the k-mer in front of the next
+    // window (WIN)
+    unsigned long long run_base = 0;
+    uint32_t run_n = 0, run_prev = 0;
+    bool run_has_prev = false;
     do {  // one pass per window (exactly one without WIN)
     const uint32_t len = WIN ? min(rlen - win0, (uint32_t)G::MAXN + k - 1) : rlen;
     const uint64_t off = roff + win0;
@@ -701,8 +736,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 
     // ---- ReadCounts::add_kmer for every unambiguous k-mer, misses included (classify.cpp:939): HLL register per
     // k-mer; n_kmers per read when the read met one taxon at most (two counter updates instead of one per lane)
+    uint32_t n_hit = 0, n_miss = 0;
     if (DO_COUNTS && n > 0) {
-      uint32_t n_hit = 0, n_miss = 0;
       uint8_t *reg[ITEMS];
       uint32_t rank[ITEMS], seen[ITEMS];
 #pragma unroll
@@ -728,6 +763,39 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       }
     }
 
+    // ---- sparse-mode emulation, fast path (KuSparseFast): inserts per (work unit, slot), and the encoded hash of every
+    // k-mer whose slot is not known to be dense into the run-wide set
+    if (OUT == 2 && DO_COUNTS && n > 0) {
+      uint32_t *urow = sf.u_cnt + (size_t)(sf.unit_of[r] - sf.unit_base) * sf.n_slots;
+      if (uni) {
+        if (lane == 0) {
+          if (n_hit) atomicAdd(&urow[uni_slot], n_hit);
+          if (n_miss) atomicAdd(&urow[0], n_miss);
+        }
+        const bool d_hit = n_hit == 0 || sf.dense[uni_slot] != 0, d_miss = n_miss == 0 || sf.dense[0] != 0;  // uniform
+        if (!(d_hit && d_miss)) {
+#pragma unroll
+          for (int j = 0; j < ITEMS; ++j) {
+            const bool okc = j * 64 + lane < n && !amb_k[j];
+            bool fresh = false;
+            if (okc && !(v[j] ? d_hit : d_miss)) fresh = ks_g_insert(sf.g_key, sf.g_mask, v[j], ks_encode(hh[j]), sf.err);
+            sp_fresh += (uint32_t)__popcll(__ballot(fresh));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+          const bool okc = j * 64 + lane < n && !amb_k[j];
+          bool fresh = false;
+          if (okc) {
+            atomicAdd(&urow[v[j]], 1u);
+            if (!sf.dense[v[j]]) fresh = ks_g_insert(sf.g_key, sf.g_mask, v[j], ks_encode(hh[j]), sf.err);
+          }
+          sp_fresh += (uint32_t)__popcll(__ballot(fresh));
+        }
+      }
+    }
+
     // ---- outputs
     uint32_t tcode[ITEMS];  // taxid per k-mer: slot 0 (miss) is taxid 0; the lookups of all items go out together
     if (uni) {
@@ -737,12 +805,51 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) tcode[j] = tax.slot_taxid[v[j]];
     }
+    if (OUT == 0) {
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-      const uint32_t p = j * 64 + lane;
-      if (p < n && !KS_ABL(8u)) taxa[off + p] = amb_k[j] ? KU_AMBIG : tcode[j];
+      for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t p = j * 64 + lane;
+        if (p < n && !KS_ABL(8u)) taxa[off + p] = amb_k[j] ? KU_AMBIG : tcode[j];
+      }
+    } else {
+      // run starts by neighbour compare (the lane below; lane 0: the last position of the item / window before), their
+      // number per item by ballot; the wave's chunk of the run array takes them in position order
+      unsigned long long sm[ITEMS];
+      uint32_t carry = run_prev, w_runs = 0;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        tcode[j] = amb_k[j] ? KU_AMBIG : tcode[j];
+        uint32_t up = ku_wave_up1(tcode[j]);
+        if (lane == 0) up = carry;
+        const bool first = j == 0 && lane == 0 && !run_has_prev;
+        sm[j] = __ballot(j * 64 + lane < n && (tcode[j] != up || first));
+        w_runs += (uint32_t)__popcll(sm[j]);
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)tcode[j], 63);
+      }
+      if (!WIN || run_n == 0) {
+        unsigned long long none = 0;
+        runs_room(w_runs, 0u, none);
+        run_base = ch_pos;
+      } else {
+        runs_room(w_runs, run_n, run_base);
+      }
+      uint32_t before = 0;
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const unsigned long long at = ch_pos + before + (uint32_t)__popcll(sm[j] & ((1ull << lane) - 1ull));
+        if (((sm[j] >> lane) & 1ull) && at < ro.cap) ro.runs[at] = make_uint2(tcode[j], win0 + j * 64 + lane);
+        before += (uint32_t)__popcll(sm[j]);
+      }
+      ch_pos += w_runs;
+      run_n += w_runs;
+      run_prev = carry;  // (a window that is not the read's last one ends on lane 63 of the last item)
+      run_has_prev = true;
     }
     if (!WIN) {
+      if (OUT != 0 && lane == 0) {
+        ro.run_off[r] = run_base;
+        ro.run_cnt[r] = run_n;
+      }
       if (lane == 0) {
         calls[r] = uni ? uni_code : tax.node_taxid[call_node];
         // incrementReadCount (classify.cpp:968): per node; single-taxon reads are booked under their slot and become
@@ -766,7 +873,15 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       last1 = ku_wave_max_u32(last1);
       if (last1 > (uint32_t)G::MAXN) {  // base MAXN or later: the k-mers at window positions MAXN .. last1 - 1 hold it
         const uint32_t skip_to = min(win0 + last1, n_all);
-        if (nxt + lane < skip_to) taxa[roff + nxt + lane] = KU_AMBIG;  // at most k - 1 positions
+        if (OUT == 0) {
+          if (nxt + lane < skip_to) taxa[roff + nxt + lane] = KU_AMBIG;  // at most k - 1 positions
+        } else if (skip_to > nxt && run_prev != KU_AMBIG) {  // the skipped k-mers open a run of their own
+          runs_room(1u, run_n, run_base);
+          if (lane == 0 && ch_pos < ro.cap) ro.runs[ch_pos] = make_uint2(KU_AMBIG, nxt);
+          ch_pos += 1;
+          run_n += 1;
+          run_prev = KU_AMBIG;
+        }
         nxt = skip_to;
       }
     }
@@ -785,6 +900,10 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       }
       if (lane == 0) {
         calls[r] = code;
+        if (OUT != 0) {
+          ro.run_off[r] = run_base;
+          ro.run_cnt[r] = run_n;
+        }
         if (DO_COUNTS) ks_rct_add<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], rd_table ? call_node : (KS_RCT_SLOT | rd_first), tax, cnt.n_reads);
       }
       ks_wave_sync();
@@ -794,6 +913,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
     ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
   }
+  if (OUT == 2 && lane == 0 && sp_fresh) atomicAdd(sf.g_count, (unsigned long long)sp_fresh);
 }
 
 // k-mers per read the fused kernel can take (0 = not eligible): in one pass / in windows
@@ -826,13 +946,21 @@ uint64_t ku_short_workspace_bytes(uint32_t max_kmers, uint32_t n_slots, uint64_t
   return (uint64_t)ks_grid(n_reads, 2, n_cu) * KS_WAVES * 2ull * ks_spill_cap(max_kmers, n_slots) * 4ull;
 }
 
+uint64_t ku_short_grid_waves(uint64_t n_reads, uint32_t max_kmers, int n_cu) {
+  const bool windowed = max_kmers > ks_one_pass_max();
+  return (uint64_t)ks_grid(n_reads, max_kmers <= 128 || windowed ? 2 : 3, n_cu) * KS_WAVES;
+}
+
 int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
                              uint64_t n_bytes, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                              uint32_t max_kmers, uint32_t flags, uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits,
-                             void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream) {
+                             void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream,
+                             const KuRunsOut *runs_out, const KuSparseFast *sparse) {
   if (n_reads == 0) return KU_OK;
   const bool counts = !(flags & KU_F_NO_COUNTS);
   if (flags & KU_F_KEEP_SLOTS) return KU_EINVAL;  // slot ids are for the sharded path, which does not come here
+  if (sparse && (!runs_out || !counts)) return KU_EINVAL;
+  if (!runs_out && !d_taxa) return KU_EINVAL;
   if (d_hits && hipMemsetAsync(d_hits, 0, n_reads * 4, stream) != hipSuccess) return KU_EHIP;  // "Q:n" is quick mode only
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ab ? (uint32_t)atoi(ab) : 0u;
@@ -845,27 +973,32 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
     spill_cap = ks_spill_cap(max_kmers, tax.n_slots);
     if (!d_workspace || workspace_bytes < (uint64_t)grid.x * KS_WAVES * 2ull * spill_cap * 4ull) return KU_EINVAL;
   }
-#define KS_LAUNCH(I, C, K, M, W)                                                                                       \
-  hipLaunchKernelGGL((ku_classify_short_kernel<I, C, K, M, W>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes, \
-                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate, (uint32_t *)d_workspace, spill_cap)
+  const KuRunsOut ro = runs_out ? *runs_out : KuRunsOut{};
+  const KuSparseFast sf = sparse ? *sparse : KuSparseFast{};
+  const int out = sparse ? 2 : (runs_out ? 1 : 0);
+#define KS_LAUNCH(I, C, K, M, W, O)                                                                                          \
+  hipLaunchKernelGGL((ku_classify_short_kernel<I, C, K, M, W, O>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes,    \
+                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate, (uint32_t *)d_workspace, spill_cap, ro, sf)
   // specialised geometries (accounting runs only): k = 31 with nt = 13 (MiniKraken-size databases) or 15 (standard)
   const int geo = !counts || db.k != 31 ? 0 : (db.nt == 13 ? 13 : (db.nt == 15 ? 15 : 0));
-  if (windowed) {
-    if (!counts) KS_LAUNCH(2, false, 0, 0, true);
-    else if (geo == 13) KS_LAUNCH(2, true, 31, 13, true);
-    else if (geo == 15) KS_LAUNCH(2, true, 31, 15, true);
-    else KS_LAUNCH(2, true, 0, 0, true);
-  } else if (max_kmers <= 128) {
-    if (!counts) KS_LAUNCH(2, false, 0, 0, false);
-    else if (geo == 13) KS_LAUNCH(2, true, 31, 13, false);
-    else if (geo == 15) KS_LAUNCH(2, true, 31, 15, false);
-    else KS_LAUNCH(2, true, 0, 0, false);
-  } else {
-    if (!counts) KS_LAUNCH(3, false, 0, 0, false);
-    else if (geo == 13) KS_LAUNCH(3, true, 31, 13, false);
-    else if (geo == 15) KS_LAUNCH(3, true, 31, 15, false);
-    else KS_LAUNCH(3, true, 0, 0, false);
-  }
+#define KS_GEO(I, W, O)                                      \
+  do {                                                       \
+    if (!counts) KS_LAUNCH(I, false, 0, 0, W, (O) == 2 ? 1 : (O)); \
+    else if (geo == 13) KS_LAUNCH(I, true, 31, 13, W, O);    \
+    else if (geo == 15) KS_LAUNCH(I, true, 31, 15, W, O);    \
+    else KS_LAUNCH(I, true, 0, 0, W, O);                     \
+  } while (0)
+#define KS_OUT(I, W)                  \
+  do {                                \
+    if (out == 0) KS_GEO(I, W, 0);    \
+    else if (out == 1) KS_GEO(I, W, 1); \
+    else KS_GEO(I, W, 2);             \
+  } while (0)
+  if (windowed) KS_OUT(2, true);
+  else if (max_kmers <= 128) KS_OUT(2, false);
+  else KS_OUT(3, false);
+#undef KS_OUT
+#undef KS_GEO
 #undef KS_LAUNCH
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

@@ -20,26 +20,7 @@
 // One wave per read, run between the lookup and the resolve stage while taxa[] holds slot ids.
 #include "ku_device.h"
 
-#define KS_PPRIME 25
 #define KS_LIMIT 1024u  // m / 4 (hyperloglogplus.cpp:496)
-
-// encodeHashIn32Bit (hyperloglogplus.cpp:181-204), p = 12, p' = 25
-__device__ __forceinline__ uint32_t ks_encode(uint64_t h) {
-  const uint32_t idx = (uint32_t)(h >> (64 - KS_PPRIME)) << (32 - KS_PPRIME);
-  if ((uint32_t)(idx << KU_HLL_P) == 0) {
-    const uint64_t rest = h << KS_PPRIME;
-    const uint32_t add = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KS_PPRIME + 1);
-    return idx | (add << 1) | 1u;
-  }
-  return idx;
-}
-
-__device__ __forceinline__ uint64_t ks_mix(unsigned long long k) {
-  k ^= k >> 31;
-  k *= 0x9E3779B97F4A7C15ULL;
-  k ^= k >> 29;
-  return k;
-}
 
 // find or create the U cell of (unit, slot); returns its index or ~0 when the table is full
 __device__ __forceinline__ uint64_t ks_u_cell(const KuSparseDev &s, uint32_t unit, uint32_t slot) {
@@ -121,6 +102,71 @@ __global__ __launch_bounds__(64) void ku_sparse_insert_kernel(KuSparseDev s, uin
       const uint64_t rc = ku_revcomp64(fwd, k);
       const uint64_t h = ku_fmix64(fwd < rc ? fwd : rc);
       ks_insert(s, unit, slot, ks_encode(h), (uint32_t)(off + i) + 2u);  // positions 0 / 1 belong to carried-over state
+    }
+  }
+}
+
+// ---- fast path (KuSparseFast): the fused kernel counted the inserts of every (unit, slot) pair of the batch and put the
+// encodings of all slots that are not dense into G itself.  What is left is the exact per-unit evaluation, and only
+// where a sketch can switch at all: units in which a slot that is not dense yet received >= 1025 inserts, plus the
+// units that straddle two batches (their state is carried as before).
+// unit_flag[u] |= 1 for every unit of the batch with such a slot
+__global__ void ku_sparse_flag_units_kernel(const uint32_t *__restrict__ u_cnt, uint64_t n_cells, uint32_t n_slots,
+                                            const uint32_t *__restrict__ dense, uint8_t *unit_flag) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_cells; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (u_cnt[i] < KU_SPARSE_SWITCH_INSERTS) continue;
+    const uint32_t slot = (uint32_t)(i % n_slots);
+    if (!dense[slot]) unit_flag[i / n_slots] = 1;
+  }
+}
+
+// The reads of the flagged units once more, from the run-length encoded per-k-mer codes the fused kernel left behind:
+// one wave per listed read.  list_read[i] = index of the read, list_unit[i] = local unit number of this pass (bits
+// 0..13), bit 31: every slot of the unit is tracked (a unit that straddles batches), else only the slots with >= 1025
+// inserts; list_urow[i] = the unit's row in u_cnt.  Runs carry taxids: slot_taxid is ascending, a binary search per run
+// finds the slot.
+__global__ __launch_bounds__(64) void ku_sparse_insert_runs_kernel(KuSparseDev s, uint32_t k, const uint8_t *__restrict__ seqs,
+                                                                   const uint64_t *__restrict__ seq_off,
+                                                                   const uint32_t *__restrict__ seq_len,
+                                                                   const uint32_t *__restrict__ list_read,
+                                                                   const uint32_t *__restrict__ list_unit,
+                                                                   const uint32_t *__restrict__ list_urow, uint64_t n_list,
+                                                                   const uint2 *__restrict__ runs, const uint64_t *__restrict__ run_off,
+                                                                   const uint32_t *__restrict__ run_cnt,
+                                                                   const uint32_t *__restrict__ slot_taxid, uint32_t n_slots,
+                                                                   const uint32_t *__restrict__ u_cnt) {
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const uint32_t r = list_read[li], lu = list_unit[li];
+    const uint32_t unit = lu & 0x3FFFu;
+    const bool all = (lu >> 31) != 0;
+    const uint32_t *urow = u_cnt + (size_t)list_urow[li] * n_slots;
+    const uint32_t len = seq_len[r];
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint64_t off = seq_off[r], ro = run_off[r];
+    const uint32_t nr = run_cnt[r];
+    for (uint32_t j = 0; j < nr; ++j) {
+      const uint2 run = runs[ro + j];
+      if (run.x == KU_AMBIG) continue;
+      uint32_t lo = 0, hi = n_slots;  // first slot with slot_taxid >= code (slot 0 = taxid 0 = a miss)
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (slot_taxid[mid] < run.x) lo = mid + 1; else hi = mid;
+      }
+      const uint32_t slot = lo;
+      if (slot >= n_slots || s.dense[slot]) continue;
+      if (!all && urow[slot] < KU_SPARSE_SWITCH_INSERTS) continue;
+      const uint32_t end = j + 1 < nr ? runs[ro + j + 1].y : n;
+      for (uint32_t i = run.y + lane; i < end; i += 64) {
+        uint64_t fwd = 0;
+        const uint8_t *p = seqs + off + i;
+        for (uint32_t b = 0; b < k; ++b) {
+          const uint32_t c = p[b] & 0xDFu;
+          fwd = (fwd << 2) | (((c >> 1) ^ (c >> 2)) & 3u);
+        }
+        const uint64_t rc = ku_revcomp64(fwd, k);
+        ks_insert(s, unit, slot, ks_encode(ku_fmix64(fwd < rc ? fwd : rc)), (uint32_t)(off + i) + 2u);
+      }
     }
   }
 }
@@ -310,5 +356,22 @@ int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_
 int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
                             hipStream_t stream) {
   hipLaunchKernelGGL(ku_sparse_export_kernel, dim3(ks_grid(s.g_mask + 1)), dim3(256), 0, stream, s, d_out, cap, d_counter);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_flag_units(const uint32_t *d_u_cnt, uint64_t n_cells, uint32_t n_slots, const uint32_t *d_dense, uint8_t *d_unit_flag,
+                                hipStream_t stream) {
+  if (n_cells == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_sparse_flag_units_kernel, dim3(ks_grid(n_cells)), dim3(256), 0, stream, d_u_cnt, n_cells, n_slots, d_dense, d_unit_flag);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_insert_runs(const KuSparseDev &s, uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
+                                 const uint32_t *d_list_read, const uint32_t *d_list_unit, const uint32_t *d_list_urow, uint64_t n_list,
+                                 const void *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt, const uint32_t *d_slot_taxid,
+                                 uint32_t n_slots, const uint32_t *d_u_cnt, int n_cu, hipStream_t stream) {
+  if (n_list == 0) return KU_OK;
+  const uint64_t cap = (uint64_t)n_cu * 32;
+  hipLaunchKernelGGL(ku_sparse_insert_runs_kernel, dim3((unsigned)(n_list < cap ? n_list : cap)), dim3(64), 0, stream, s, k, d_seqs, d_seq_off,
+                     d_seq_len, d_list_read, d_list_unit, d_list_urow, n_list, (const uint2 *)d_runs, d_run_off, d_run_cnt, d_slot_taxid,
+                     n_slots, d_u_cnt);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

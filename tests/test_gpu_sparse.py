@@ -202,8 +202,70 @@ def test_files_close_their_last_unit():
     assert_sparse_state_equals_oracle(ctx, run)
 
 
+def classify_in_batches_by_path(ctx, buf, off, lens, cuts, path, monkeypatch):
+    """path: "fast" (the fused kernel's sparse fast path, the default), "staged" (KU_NO_SPARSE_FAST: lookup + emulation
+    pass + resolve kernels) or "mixed" (the batches alternate: both keep the carried-over work unit in the same form)"""
+    out = []
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        staged = path == "staged" or (path == "mixed" and i % 2 == 1)
+        if staged:
+            monkeypatch.setenv("KU_NO_SPARSE_FAST", "1")
+        else:
+            monkeypatch.delenv("KU_NO_SPARSE_FAST", raising=False)
+        lo = int(off[a])
+        hi = int(off[b]) if b < len(off) else len(buf)
+        out.append(ctx.classify_batch_rle(buf[lo:hi], off[a:b] - lo, lens[a:b]))
+    monkeypatch.delenv("KU_NO_SPARSE_FAST", raising=False)
+    return out
+
+
+@pytest.mark.parametrize("path", ["fast", "staged", "mixed"])
+@pytest.mark.parametrize("extra", [0, 1, 2])
+def test_switch_to_dense_at_exactly_1024_entries(extra, path, monkeypatch):
+    """hyperloglogplus.cpp:496-498: the size test precedes the insert.  One work unit gives a taxon exactly 1024 distinct
+    k-mers: with nothing behind them the sketch stays sparse (1024 entries); one more insert -- a duplicate -- switches it.
+    extra = 0: 1024 inserts; 1: + a read with one (known) k-mer; 2: 1023 distinct k-mers + two duplicates (1025 inserts,
+    still sparse).  The fast path counts inserts (>= 1025 makes the unit a candidate), the exact pass decides."""
+    rng = np.random.default_rng(5)
+    db = gc.random_db(rng, n_genomes=4, glen=5000, k=K, nt=9)
+    tax = db["tax"]
+    sp = list(db["genomes"])
+    g = db["genomes"][sp[0]]
+    n_first = 1023 if extra == 2 else 1024
+    seqs = [synth.codes_to_ascii(g[100:100 + n_first + K - 1])]
+    if extra == 1:
+        seqs.append(synth.codes_to_ascii(g[300:300 + K]))
+    if extra == 2:
+        seqs.append(synth.codes_to_ascii(g[300:300 + K + 1]))
+    seqs += [synth.codes_to_ascii(db["genomes"][sp[1]][50:200])]  # another taxon in the same unit
+    buf, off, lens = ko.pack_reads(seqs)
+    ids, par = tax.arrays()
+    ctax, otax = capi.Tax(ids=ids, parents=par), ko.Tax(ids=ids, parents=par)
+    raw = db["pairs"].view(np.uint8).reshape(-1)
+    cdb = capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=K, offsets=db["offsets"], nt=9)
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=K, offsets=db["offsets"], nt=9)
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdb)
+    ctx.set_taxonomy(ctax)
+    ctx.enable_sparse(500000)
+    classify_in_batches_by_path(ctx, buf, off, lens, [0, 1, len(seqs)] if len(seqs) > 2 else [0, len(seqs)], path, monkeypatch)
+    run = ko.Run(odb, otax, work_unit_nt=500000)
+    res = run.classify(seqs)
+    counts, flags, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(ctx, run)
+    # the read's k-mers all carry one taxon and are distinct as encodings (else the scenario does not probe the edge)
+    first = res["taxa"][:n_first]
+    if len(set(first.tolist())) == 1 and first[0] != 0:
+        t = int(first[0])
+        w = run.counts()[t]
+        if extra == 1:
+            assert not w["sparse"]
+        elif len(w["sketch"].sparse_list()) >= 1023:
+            assert w["sparse"]
+
+
+@pytest.mark.parametrize("path", ["fast", "staged", "mixed"])
 @pytest.mark.parametrize("unit,seed", [(30000, 1), (150000, 2), (7000, 3)])
-def test_random_database_mixed_sparse_and_dense_taxa(unit, seed):
+def test_random_database_mixed_sparse_and_dense_taxa(unit, seed, path, monkeypatch):
     """taxa of very different abundance, several work units, uneven batches: which sketches switch to dense and the
     exact sets of the ones that do not"""
     rng = np.random.default_rng(seed)
@@ -235,9 +297,10 @@ def test_random_database_mixed_sparse_and_dense_taxa(unit, seed):
     ctx.load_db(cdb)
     ctx.set_taxonomy(ctax)
     ctx.enable_sparse(unit)
-    classify_in_batches(ctx, buf, off, lens, split_points(len(seqs), 6, seed))
+    rle = classify_in_batches_by_path(ctx, buf, off, lens, split_points(len(seqs), 6, seed), path, monkeypatch)
     run = ko.Run(odb, otax, work_unit_nt=unit)
-    run.classify(seqs)
+    res = run.classify(seqs)
+    assert np.array_equal(np.concatenate([r["calls"] for r in rle]), res["calls"])
     counts, flags, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(ctx, run)
     gc.assert_same_counts(counts, run)
     assert n_sparse > 0 and n_dense > 0
