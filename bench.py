@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- Mreads/s of the classify hot path on synthetic 150 bp reads (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one process per GPU under torch.distributed.run --
+                                                            started that way by the driver, or by bench.py itself when it
+                                                            is called plainly; fewer than N visible GPUs is an error)
+    python bench.py --gpus N --config 2|3|4                (the 8-GPU configurations of BASELINE.json, see PRESETS)
 
 Workload at N = 1 (BASELINE.json configs[1]): ~8 GB MiniKraken-style database (k = 31, minimizer nt = 13, ~0.61 G
 pairs, 2000 species) built directly in HBM by krakenuniq_amd/synth_torch.py; FOUR distinct batches of 10 M synthetic
@@ -20,6 +23,12 @@ N > 1 goes through the product's C++ multi-GPU driver (ku_mgpu, RCCL), one proce
       step broadcasts the batch from rank 0, looks up the owned k-mers, reduce-scatters the per-k-mer slots over the read
       dimension and resolves 1/N of the reads per rank (ku_mgpu_step_device).
   A default N > 1 run also times a few sharded steps afterwards and reports them under "sharded".
+
+--config 2 / 3 / 4 (BASELINE.json configs[2..4]): the standard-geometry database (k = 31, minimizer nt = 15) in EIGHT
+minimizer-range shards of ~37 GB of pairs each (~300 GB in all; rank r holds shard r -- with fewer than 8 ranks the other
+shards' k-mers simply stay unowned, so --gpus 1 --config 2 measures one rank's share of the 8-GPU layout), sharded mode,
+10 M x 150 bp reads / 5 M mate pairs 2 x 150 + N / 100 k x 10 kbp reads per step.  Every sharded line carries the rank's
+own `roofline` (the sharded lookup kernel, timed alone) and the bytes per read that cross the links.
 
 Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel; `frac` = `frac_model` =
 SURVEY 8(d) algorithmic bytes / HIP-event time / 8 TB/s, `frac_hw` = counter-measured HBM bytes of profiles/ for this
@@ -48,6 +57,17 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s per GPU
 
+# BASELINE.json configs[2..4]: the ~300 GB standard database as 8 minimizer-range shards (12 000 species x 310 kbp give
+# ~3.1 G pairs = 37 GB per shard), sharded mode; reads per step chosen so that the resident batch stays around 1.5 GB
+PRESETS = {
+    2: {"name": "configs[2]: standard ~300 GB DB (k=31, nt=15) sharded by minimizer bin, 150 bp reads (100 M = 10 steps of 10 M)",
+        "nt": 15, "species": 96_000, "db_shards": 8, "reads": 10_000_000, "read_len": 150, "paired": False},
+    3: {"name": "configs[3]: standard ~300 GB DB (k=31, nt=15) sharded by minimizer bin, mate pairs 2 x 150 + N (50 M = 10 steps of 5 M)",
+        "nt": 15, "species": 96_000, "db_shards": 8, "reads": 5_000_000, "read_len": 150, "paired": True},
+    4: {"name": "configs[4]: standard ~300 GB DB (k=31, nt=15) sharded by minimizer bin, 10 kbp reads (1 M = 10 steps of 100 k)",
+        "nt": 15, "species": 96_000, "db_shards": 8, "reads": 100_000, "read_len": 10_000, "paired": False},
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -65,7 +85,39 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the device-pipeline / end-to-end / sharded legs")
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[i]; 2-4 = the 300 GB standard-geometry database in 8 shards, sharded mode")
+    ap.add_argument("--db-shards", type=int, default=0,
+                    help="sharded mode: minimizer-range shards the database is cut into (rank r holds shard r; default: one per rank)")
+    a = ap.parse_args()
+    a.preset = None
+    if a.config != 1:
+        pr = PRESETS[a.config]
+        a.preset = pr["name"]
+        a.mode = "sharded"
+        a.nt, a.species, a.reads, a.read_len, a.paired = pr["nt"], pr["species"], pr["reads"], pr["read_len"], pr["paired"]
+        a.db_shards = a.db_shards or pr["db_shards"]
+        a.batches = min(a.batches, 2)
+    return a
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: N ranks on the first N devices under torch.distributed.run.  Never a
+    line that says n_gpus = N from fewer devices."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus and os.environ.get("KU_BENCH_ONE_DEVICE") != "1":
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} was asked for but {n_dev} GPU(s) are visible; refusing to run "
+                         f"(a {a.gpus}-GPU line cannot be measured on {n_dev})\n")
+        sys.exit(2)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def host_cores():
@@ -211,19 +263,49 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
             cmd = [cli_bin, "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB", "-t", thr,
                    "-o", f"{tmp}/e2e.tsv", f"{tmp}/reads.fq"]
             t0 = time.time()
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_CLI_TIMES="1"))
             wall = time.time() - t0
             err = r.stderr.decode(errors="replace")
             m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
             if r.returncode != 0 or not m:
                 raise RuntimeError("classify failed: " + err[-300:])
             secs = float(m.group(3))
+            mb = re.search(r"stage busy seconds: reader ([\d.]+), device ([\d.]+), writer ([\d.]+)", err)
+            busy_plain = float(mb.group(2)) if mb else None
             import pandas as pd
             got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
             out["e2e"] = {"value": round(n_e / secs / 1e6, 2), "unit": "Mreads/s", "reads": n_e, "threads": int(thr),
                           "window": "the executable's report_stats window (classify.cpp:248-258): FASTQ parse -> GPU -> Kraken file",
                           "seconds": secs, "wall_incl_db_load_s": round(wall, 1),
                           "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
+            # the same run as scripts/krakenuniq starts it: with a report (-r), i.e. with the HyperLogLog++ sparse-sketch
+            # emulation inside the timing window and the clade roll-up behind it
+            try:
+                os.remove(f"{tmp}/e2e.tsv")
+                env = dict(os.environ, KU_CLI_TIMES="1")
+                cmd_r = cmd[:-1] + ["-r", f"{tmp}/report.tsv", cmd[-1]]
+                t0 = time.time()
+                r = subprocess.run(cmd_r, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                wall = time.time() - t0
+                err = r.stderr.decode(errors="replace")
+                m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
+                m2 = re.search(r"Report finished in ([\d.]+) seconds", err)
+                m3 = re.search(r"stage busy seconds: reader ([\d.]+), device ([\d.]+), writer ([\d.]+)", err)
+                if r.returncode != 0 or not m or not m2:
+                    raise RuntimeError("classify -r failed: " + err[-300:])
+                secs_r = float(m.group(3))
+                got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
+                n_rows = sum(1 for _ in open(f"{tmp}/report.tsv"))
+                out["e2e"]["with_report"] = {
+                    "value": round(n_e / secs_r / 1e6, 2), "unit": "Mreads/s", "seconds": secs_r,
+                    "report_seconds": float(m2.group(1)), "report_rows": n_rows,
+                    "device_stage_busy_s": float(m3.group(2)) if m3 else None,
+                    "device_stage_busy_s_without_report": busy_plain,
+                    "sparse_emulation": "not switched off" if "ran out of device memory" not in err else "gave up",
+                    "wall_incl_db_load_s": round(wall, 1),
+                    "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
+            except Exception as e:
+                out["e2e"]["with_report"] = {"value": None, "error": str(e)[:200]}
         except Exception as e:
             out["e2e"] = {"value": None, "error": str(e)[:200]}
     finally:
@@ -231,17 +313,19 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
     return out
 
 
-def shard_bounds(synth_torch, kdist, dev, a, k, ws):
+def shard_bounds(synth_torch, kdist, dev, a, k, n_shards):
     """every rank derives the same shard plan from the same deterministic sample of the DB's bin keys"""
     probe = synth_torch.BenchDb(dev, n_species=min(a.species, 32), genome_len=min(a.genome_len, 50_000), k=k,
                                 nt=a.nt, seed=7)
     bins = synth_torch.bin_key(probe.kmers[torch.randperm(probe.n_pairs, device=dev)[:1_000_000]], k, a.nt)
-    return kdist.quantile_bin_bounds(bins, 4 ** a.nt, ws)
+    return kdist.quantile_bin_bounds(bins, 4 ** a.nt, n_shards)
 
 
 def sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, steps, warmup, stream):
-    """the sharded step through ku_mgpu_step_device; returns (elapsed seconds over `steps`, mg, db, reads per step)"""
-    bounds = shard_bounds(synth_torch, kdist, dev, a, k, ws)
+    """the sharded step through ku_mgpu_step_device; returns a dict: elapsed seconds over `steps`, the group, the shard,
+    whether every read was resolved exactly once, and the rank's own kernel measurements"""
+    n_shards = max(a.db_shards or ws, ws)
+    bounds = shard_bounds(synth_torch, kdist, dev, a, k, n_shards)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     db = synth_torch.BenchDb(dev, n_species=a.species, genome_len=a.genome_len, k=k, nt=a.nt, seed=7, bin_lo=lo, bin_hi=hi)
     db.kmers = db.vals = None
@@ -249,7 +333,9 @@ def sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, 
     mg = capi.Mgpu([local_rank], first_rank=rank, world=ws, unique_id=uid if ws > 1 else None)
     mg.ctx(0).adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), k, a.nt, 2, lo, hi)
     ids_t, par_t = db.tax.arrays()
-    mg.set_taxonomy(capi.Tax(ids=ids_t, parents=par_t))
+    mg.set_taxonomy(capi.Tax(ids=ids_t, parents=par_t))  # slots cover the values of the shards that are resident
+    db.pairs = None  # the probe table replaced the pairs (hash layout)
+    torch.cuda.empty_cache()
     nb_batches = max(1, min(a.batches, 2))
     if rank == 0:
         batches = [make_batch(db, a, 1 + 17 * i, dev) for i in range(nb_batches)]
@@ -295,11 +381,48 @@ def sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, 
         elapsed = float(t.item())
     # every read was resolved exactly once over the whole world
     total_reads = int(mg.ctx(0).counts()["n_reads"].sum())
-    return elapsed, mg, db, total_reads == a.reads * steps
+    # ---- this rank's kernels alone (outside the timed region): the sharded lookup kernel over the whole batch, the
+    # resolve kernel over the rank's slice of the reads
+    ctx = mg.ctx(0)
+    b = batches[0]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    reps = 3
+    ctx.lookup_device(b[0].data_ptr(), n_bytes, d_taxa.data_ptr(), flags=capi.KU_F_KEEP_SLOTS, stream=stream)
+    ev[0].record()
+    for _ in range(reps):
+        ctx.lookup_device(b[0].data_ptr(), n_bytes, d_taxa.data_ptr(), flags=capi.KU_F_KEEP_SLOTS, stream=stream)
+    ev[1].record()
+    r0, r1 = rb[rank], rb[rank + 1]
+    ev[2].record()
+    if r1 > r0:
+        ctx.resolve_device(b[0].data_ptr(), b[1][r0:].data_ptr(), b[2][r0:].data_ptr(), r1 - r0, d_calls[r0:].data_ptr(),
+                           d_taxa.data_ptr(), flags=capi.KU_F_NO_COUNTS, max_read_len=L, stream=stream)
+    ev[3].record()
+    torch.cuda.synchronize()
+    lookup_ms = ev[0].elapsed_time(ev[1]) / reps
+    resolve_ms = ev[2].elapsed_time(ev[3])
+    st = ctx.lookup_stats_device(b[0].data_ptr(), n_bytes)
+    # algorithmic bytes of the rank's lookup launch: the whole batch is scanned on every rank (L bytes per read) and the
+    # per-k-mer slot array written (4 B per k-mer position: what the exchange carries), the owned k-mers are searched
+    # (16 + 12 * ceil(log2(n_bin + 1)) + 4 per lookup)
+    bytes_algo = a.reads * L + 4.0 * a.reads * (L - k + 1) + st["lookups"] * 20 + 12 * st["sum_ceil_log2"]
+    achieved = bytes_algo / (lookup_ms * 1e-3) / 1e9 if lookup_ms else 0.0
+    rf = {"bound": "hbm", "kernel": "ku_lookup_kernel<1,1,true,false> (sharded lookup; this rank)", "achieved": round(achieved, 2),
+          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+          "kernel_ms": round(lookup_ms, 3), "resolve_slice_ms": round(resolve_ms, 3), "owned_lookups_per_launch": int(st["lookups"]),
+          "owned_fraction_of_kmers": round(st["lookups"] / max(1.0, a.reads * (L - k + 1.0)), 4),
+          "algorithmic_bytes_per_launch": int(bytes_algo), "mean_ceil_log2_bin": round(st["sum_ceil_log2"] / max(st["lookups"], 1), 3)}
+    wire = {"broadcast_in_bytes_per_read": stride + 12 if ws > 1 else 0,
+            "exchange_out_bytes_per_read": round(4.0 * stride * (ws - 1) / ws, 1) if ws > 1 else 0.0,
+            "exchange_in_bytes_per_read": round(4.0 * stride * (ws - 1) / ws, 1) if ws > 1 else 0.0,
+            "note": "per rank; the exchange is an all-to-all of 4-byte slots per base position (ku_mgpu.cpp)"}
+    return {"elapsed": elapsed, "mg": mg, "db": db, "ok": total_reads == a.reads * steps, "roofline": rf, "wire": wire,
+            "n_shards": n_shards, "read_len": L}
 
 
 def main():
     a = parse()
+    self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -337,19 +460,25 @@ def main():
 
     if sharded:
         t_build = time.time()
-        elapsed, mg, db, ok = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, a.steps, a.warmup, stream)
-        L = 2 * a.read_len + 1 if a.paired else a.read_len
+        sr = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, a.steps, a.warmup, stream)
+        elapsed, mg, db, L = sr["elapsed"], sr["mg"], sr["db"], sr["read_len"]
         value = a.reads * a.steps / elapsed / 1e6
         ctx = mg.ctx(0)
+        what = f"{a.reads} mate pairs 2 x {a.read_len} + N" if a.paired else f"{a.reads} reads of {L} bp"
+        workload = (a.preset + f"; rank r of {ws} holds shard r of {sr['n_shards']}") if a.preset else \
+            (f"synthetic DB ({a.species} taxa x {a.genome_len} bp, nt={a.nt}) in {sr['n_shards']} minimizer-range shards over "
+             f"{ws} GPU(s)")
         result = {
             "metric": "Mreads/s (150 bp)", "value": round(value, 3), "unit": "Mreads/s", "n_gpus": ws, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic DB ({a.species} taxa x {a.genome_len} bp, nt={a.nt}) sharded by minimizer range over "
-                                   f"{ws} GPU(s), {a.reads} reads of {L} bp per step broadcast from rank 0",
-                       "db_pairs_per_gpu": db.n_pairs, "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species,
-                       "reads_per_step": a.reads, "read_len": L, "parallelism": f"sharded{ws}", "exchange": "RCCL" if mg.uses_rccl() else "none",
-                       "every_read_resolved_once": ok},
+            "config": {"workload": workload + f", {what} per step broadcast from rank 0",
+                       "db_pairs_per_gpu": db.n_pairs, "db_bytes_per_gpu": db.n_pairs * 12 + db.offsets.numel() * 8,
+                       "hbm_layout": ctx.db_layout(), "k": k, "nt": a.nt, "taxa": a.species,
+                       "reads_per_step": a.reads, "read_len": L, "parallelism": f"sharded{ws}", "db_shards": sr["n_shards"],
+                       "exchange": "RCCL" if mg.uses_rccl() else "none",
+                       "every_read_resolved_once": sr["ok"], "db_build_s": round(time.time() - t_build - elapsed, 1)},
+            "roofline": sr["roofline"], "wire": sr["wire"],
         }
         if rank == 0:
             print(json.dumps(result), flush=True)
@@ -524,12 +653,13 @@ def main():
             del db
             torch.cuda.empty_cache()
             s_steps = max(2, min(a.steps, 4))
-            el, smg, sdb, ok = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, 1, stream)
+            sr = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, 1, stream)
+            el = sr["elapsed"]
             result["sharded"] = {"value": round(a.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
-                                 "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sdb.n_pairs,
-                                 "every_read_resolved_once": ok,
+                                 "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sr["db"].n_pairs,
+                                 "every_read_resolved_once": sr["ok"], "roofline": sr["roofline"], "wire": sr["wire"],
                                  "path": "ku_mgpu_step_device: ncclBroadcast -> owner lookup -> all-to-all (grouped ncclSend/ncclRecv) + max-merge -> per-slice resolve"}
-            smg.close()
+            sr["mg"].close()
         except Exception as e:
             result["sharded"] = {"value": None, "error": str(e)[:300]}
         watchdog.cancel()

@@ -407,7 +407,9 @@ int ku_mgpu_step_device(ku_mgpu *m, const ku_mgpu_dev_batch *local /* [n_local] 
                         const ku_opts *opts);
 /* merge the per-taxon state over all ranks in place (every rank ends up with the whole run's state): HLL registers
  * MAX, n_kmers and n_reads SUM -- taxon_counts[t] += local[t] (classify.cpp:541-544) across GPUs.  Call once, at the
- * end of the run (a second call would add the sums again); streams[i] = NULL: the context's own stream. */
+ * end of the run: a second call without a batch in between is refused (KU_ESTATE; it would add the sums again --
+ * a caller that resets the contexts' counts itself classifies a batch before it reduces again);
+ * streams[i] = NULL: the context's own stream. */
 int ku_mgpu_reduce_state(ku_mgpu *m, void *const *streams /* [n_local] or NULL */);
 /* database.kdb.counts over all local shards (ku_ctx_count_taxons summed; single-process groups) */
 int ku_mgpu_count_taxons(ku_mgpu *m, uint32_t *taxids, uint64_t *counts, uint64_t *n);

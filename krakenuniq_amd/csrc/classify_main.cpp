@@ -376,6 +376,9 @@ int main(int argc, char **argv) {
   // expensive part of a run with many low-abundance taxa.  -x runs insert into the global sketches directly
   // (src/classify.cpp:719): one unit for the whole run.
   bool sparse = want_report && !exact && !mg && !getenv("KU_NO_SPARSE");
+  if (want_report && !exact && mg)
+    fprintf(stderr, "classify: several GPUs: the report's kmers / dup / cov columns are dense HyperLogLog estimates (the reference's sparse "
+                    "sketches are reproduced on one GPU only)\n");
   if (sparse) {
     const char *e = getenv("KU_SPARSE_LOG2");
     int st = ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, e ? (uint32_t)atoi(e) : 0u);
@@ -460,6 +463,7 @@ int main(int argc, char **argv) {
     std::condition_variable cv;
     size_t next_cut = 0, next_region = 0, next_out = 0;
     bool stop = false;  // the stream ended inside a region: nothing behind it counts
+    bool file_start_pending = false;  // the file's first region held no bases: the next batch that goes on opens the file
     std::map<size_t, std::pair<Batch *, bool>> ready;
     auto member = [&] {
       for (;;) {
@@ -497,8 +501,15 @@ int main(int argc, char **argv) {
       const bool ends = !whole || bt->nt == 0;  // malformed record, or a unit without nucleotides (src/classify.cpp:522-523)
       if (ends) stop = true;
       l.unlock();
-      if (bt->nt == 0) { if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
-      else { if (chunked) inflight_add(bt->nt); parsed_q.push(bt); }
+      if (bt->nt == 0) {
+        file_start_pending |= bt->first_of_file;
+        if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
+      } else {
+        bt->first_of_file |= file_start_pending;
+        file_start_pending = false;
+        if (chunked) inflight_add(bt->nt);
+        parsed_q.push(bt);
+      }
       if (ends) break;
     }
     for (auto &t : team) t.join();
@@ -655,7 +666,12 @@ int main(int argc, char **argv) {
     std::thread prefetcher;
     int prefetch_status = KU_OK;
     std::string prefetch_error;
+    // -x SIZE is the reference's bound on ONE resident chunk (src/krakendb.cpp:463-522).  Double buffering needs room for a
+    // second one next to it: when the device has none (KU_ENOMEM from the helper) the run goes on with one chunk at a time --
+    // ku_ctx_swap_shard then uploads synchronously, as before there was a prefetch
+    bool prefetch_off = getenv("KU_NO_PREFETCH") != nullptr;
     auto start_prefetch = [&](size_t c) {
+      if (prefetch_off) return;
       prefetcher = std::thread([&, c] {
         prefetch_status = ku_ctx_prefetch_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]);
         if (prefetch_status != KU_OK) prefetch_error = ku_last_error();
@@ -663,6 +679,11 @@ int main(int argc, char **argv) {
     };
     auto join_prefetch = [&] {
       if (prefetcher.joinable()) prefetcher.join();
+      if (prefetch_status == KU_ENOMEM) {
+        fprintf(stderr, "\rclassify: no device memory for a second database chunk next to the resident one: chunks are uploaded one at a time from here on\n");
+        prefetch_status = KU_OK;
+        prefetch_off = true;
+      }
       if (prefetch_status != KU_OK) die(exit_code_of(prefetch_status), "%s: %s", ku_strerror(prefetch_status), prefetch_error.c_str());
     };
     bool input_done = false, first_super = true;

@@ -1879,10 +1879,14 @@ struct DevTmp {  // device scratch of one ku_ctx_report call
     if (!src.empty() && hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return KU_EHIP;
     return KU_OK;
   }
+  // zeroed ON THE STREAM the kernels run on: a plain hipMemset goes to the null stream, which a non-blocking stream does not
+  // wait for -- a large table could still be being cleared when the first kernel had already put entries into it (the
+  // union sets of the sparse roll-up lost a few entries that way and counted their duplicates again)
+  hipStream_t stream = nullptr;
   template <typename T> int zeros(T **dst, size_t n) {
     if (hipMalloc((void **)dst, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { *dst = nullptr; return KU_ENOMEM; }
     ptrs.push_back(*dst);
-    return hipMemset(*dst, 0, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? KU_OK : KU_EHIP;
+    return hipMemsetAsync(*dst, 0, std::max<size_t>(n, 1) * sizeof(T), stream) == hipSuccess ? KU_OK : KU_EHIP;
   }
 };
 }  // namespace
@@ -1947,6 +1951,7 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
   const uint32_t n_clades = (uint32_t)clade_row.size();
   if (!exact && n_clades) {
     DevTmp tmp;
+    tmp.stream = ctx->stream;
     // members per clade (CSR)
     std::sort(memb.begin(), memb.end());
     std::vector<uint32_t> m_off(n_clades + 1, 0), m_slot(memb.size());

@@ -151,6 +151,7 @@ struct ku_mgpu {
   std::vector<Rank> ranks;
   Shared sh;
   bool loaded = false, tax_set = false;
+  bool reduced = false;  // ku_mgpu_reduce_state ran and no batch was classified since: a second call would add the sums again
 };
 
 namespace {
@@ -551,6 +552,7 @@ extern "C" int ku_mgpu_step_device(ku_mgpu *m, const ku_mgpu_dev_batch *local, u
   if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_step_device: load the database and the taxonomy first");
   if (m->flags & KU_MGPU_REPLICAS) return mfail(KU_EINVAL, "ku_mgpu_step_device is the sharded step; replicas classify through their own contexts");
   const ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  m->reduced = false;
   return run_all(m, [&](ku_mgpu::Rank &r) -> int {
     const ku_mgpu_dev_batch &b = local[r.local];
     if (n_bytes && (!b.d_seqs || !b.d_taxa)) return mfail(KU_EINVAL, "ku_mgpu_step_device: null buffer");
@@ -570,6 +572,7 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
   *n_runs = 0;
   for (auto &r : m->ranks) r.n_runs = r.run_base = 0;
   if (n_reads == 0) return KU_OK;
+  m->reduced = false;
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   o.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
   uint32_t max_len = 0;
@@ -685,10 +688,13 @@ extern "C" int ku_mgpu_fetch_runs(ku_mgpu *m, ku_run *runs, uint64_t n_runs) {
 extern "C" int ku_mgpu_reduce_state(ku_mgpu *m, void *const *streams) {
   if (!m) return mfail(KU_EINVAL, "ku_mgpu_reduce_state: null argument");
   if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_reduce_state: no taxonomy set");
-  return run_all(m, [&](ku_mgpu::Rank &r) -> int {
+  if (m->reduced) return mfail(KU_ESTATE, "ku_mgpu_reduce_state: the state is reduced already (another call would add the counters again)");
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
     hipStream_t s = (streams && streams[r.local]) ? (hipStream_t)streams[r.local] : ku_ctx_stream_of(r.ctx);
     return comm_allreduce_state(m, r, s);
-  });
+  }));
+  m->reduced = true;
+  return KU_OK;
 }
 
 extern "C" int ku_mgpu_count_taxons(ku_mgpu *m, uint32_t *taxids, uint64_t *counts, uint64_t *n) {

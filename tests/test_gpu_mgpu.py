@@ -80,6 +80,10 @@ def test_group_quick_mode(f1, devices):
     ctx, _, _ = gc.make_ctx(F1)
     ctx.classify_batch_rle(f1["buf"], f1["off"], f1["lens"], flags=capi.KU_F_QUICK, min_hits=2)
     assert same_counts(mg.ctx(0).counts(), ctx.counts())
+    with pytest.raises(capi.KuError) as e:  # a second reduce would add the counters of every rank once more
+        mg.reduce_state()
+    assert e.value.status == -6
+    assert same_counts(mg.ctx(0).counts(), ctx.counts())
     mg.close()
 
 

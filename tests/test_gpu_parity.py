@@ -269,7 +269,7 @@ def test_rle_output_path_matches_reference_output(golden, f1, fixture, reads):
     ctx = f1["ctx"]
     ctx.reset_counts()
     rle = ctx.classify_batch_rle(buf, off, lens)
-    assert int(rle["run_cnt"].sum()) == len(rle["runs"])
+    assert int(rle["run_cnt"].sum()) <= len(rle["runs"])  # the run array has unused entries between the waves' chunks
     assert capi.format_kraken_rle(buf, off, lens, ids, K, rle) == open(os.path.join(golden, fixture, "out.tsv")).read()
     dec = _decode_runs(rle, off, lens, len(taxa))
     m = valid_mask(off, lens, K, len(taxa))
