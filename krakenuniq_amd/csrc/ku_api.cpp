@@ -1006,6 +1006,26 @@ static int sparse_reserve_global(ku_ctx *ctx, uint64_t incoming, hipStream_t s) 
   return KU_OK;
 }
 
+// The per-pass tables L / U of the exact evaluation, sized for what the pass holds: a prefix of the allocated arrays (the
+// kernels that close a unit scan whole tables -- with 2^26 cells for a few hundred thousand entries those scans and the
+// memsets were most of the emulation's cost in a `classify -r` run).  Returns the device view to hand to the kernels.
+static int sparse_pass_tables(ku_ctx *ctx, uint64_t n_entries, KuSparseDev *view, hipStream_t s) {
+  const KuSparseDev &d = ctx->sp.dev;
+  uint64_t l_cells = 1ull << 14, u_cells = 1ull << 12;
+  while (l_cells < 4 * n_entries && l_cells < d.l_mask + 1) l_cells <<= 1;
+  while (u_cells < 2 * n_entries && u_cells < d.u_mask + 1) u_cells <<= 1;
+  *view = d;
+  view->l_mask = l_cells - 1;
+  view->u_mask = u_cells - 1;
+  HIP_TRY(hipMemsetAsync(d.l_key, 0, l_cells * 8, s));
+  HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, l_cells * 4, s));
+  HIP_TRY(hipMemsetAsync(d.u_key, 0, u_cells * 8, s));
+  HIP_TRY(hipMemsetAsync(d.u_distinct, 0, u_cells * 4, s));
+  HIP_TRY(hipMemsetAsync(d.u_last, 0, u_cells * 4, s));
+  HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, u_cells * 4, s));
+  return KU_OK;
+}
+
 // the reads [r0, r1) of a batch whose taxa[] holds slot ids: one pass of the emulation (at most KU_SPARSE_MAX_UNITS
 // work units and 2^25 bases at a time; a unit that is still open at the end is carried into the next pass)
 static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
@@ -1077,16 +1097,11 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
 // the unit that is still open ends here (end of an input file / of the run): evaluate and commit what was carried
 static int sparse_close_open_unit(ku_ctx *ctx) {
   ku_ctx::Sparse &sp = ctx->sp;
-  KuSparseDev &d = sp.dev;
   hipStream_t s = ctx->stream;
   if (sp.open) {
     KU_TRY(sparse_reserve_global(ctx, sp.n_carry_l, s));
-    HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(d.u_distinct, 0, (d.u_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_last, 0, (d.u_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
+    KuSparseDev d;
+    KU_TRY(sparse_pass_tables(ctx, sp.n_carry_l + sp.n_carry_u, &d, s));
     KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p, sp.n_carry_u, s));
     KU_TRY(ku_launch_sparse_close(d, 1, s));
     unsigned long long c = 0;
@@ -1352,7 +1367,6 @@ static int sparse_fast_exact(ku_ctx *ctx, const uint32_t *h_len, const std::vect
                              const std::vector<uint32_t> &flagged, const std::vector<uint8_t> &flag_all, bool last_is_open,
                              const uint32_t *d_u_cnt, hipStream_t s) {
   ku_ctx::Sparse &sp = ctx->sp;
-  KuSparseDev &d = sp.dev;
   size_t at = 0;
   bool first_pass = true;
   while (at < flagged.size()) {
@@ -1381,12 +1395,8 @@ static int sparse_fast_exact(ku_ctx *ctx, const uint32_t *h_len, const std::vect
     }
     if (sp.list.reserve(std::max<uint64_t>(n_list, 1) * 12) != KU_OK) return fail(KU_ENOMEM, "device memory for the flagged work units' reads");
     KU_TRY(sparse_reserve_global(ctx, bases + sp.n_carry_l, s));
-    HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(d.u_distinct, 0, (d.u_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_last, 0, (d.u_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
+    KuSparseDev d;  // this pass's view: the run-wide set as it is now, L / U sized for the pass
+    KU_TRY(sparse_pass_tables(ctx, bases + sp.n_carry_l + sp.n_carry_u, &d, s));
     if (first_pass && sp.open)  // the unit carried over from the batch before is local unit 0 of the first pass
       KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p, sp.n_carry_u, s));
     if (n_list) HIP_TRY(hipMemcpyAsync(sp.list.p, list.data(), n_list * 12, hipMemcpyHostToDevice, s));
@@ -1898,10 +1908,23 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
   KU_TRY(ctx_activate(ctx));
   const size_t ns = ctx->tax.n_slots, nn = ctx->tax.n_nodes, nt = tax->ids.size();
   const bool exact = ctx->d_exact_unique != nullptr, sparse = ctx->sp.on && !exact;
-  // the run-wide (slot, encoding) set of the sparse sketches stays on the device (ctx->sp.out)
+  // the run-wide (slot, encoding) set of the sparse sketches is read where it lies (no compacted copy): the end of the run
+  // closes the last, partial work unit (classify.cpp:522-523)
   uint64_t n_pairs = 0;
   std::vector<uint8_t> slot_sparse(ns, 0);
-  if (sparse) KU_TRY(ku_sparse_export(ctx, slot_sparse.data(), nullptr, &n_pairs));
+  if (sparse) {
+    KU_TRY(sparse_close_open_unit(ctx));
+    std::vector<uint32_t> dense(ns);
+    unsigned long long total = 0;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&total, ctx->sp.dev.g_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&err, ctx->sp.dev.err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dense.data(), ctx->sp.dev.dense, ns * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (err) return fail(KU_ENOMEM, "sparse-mode emulation: a device table overflowed");
+    for (size_t i = 0; i < ns; ++i) slot_sparse[i] = dense[i] ? 0 : 1;
+    n_pairs = total;  // entries of the set (an upper bound of the sparse slots' entries)
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   std::vector<uint64_t> nk(ns), nr(nn), uq;
   HIP_TRY(hipMemcpy(nk.data(), ctx->cnt.n_kmers, ns * 8, hipMemcpyDeviceToHost));
@@ -1974,19 +1997,26 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
         walk(ctx->h_slot_taxid[s], [&](size_t row) { if (!clade_dense[clade_of[row]]) s_clade.push_back((uint32_t)clade_of[row]); });
       }
       s_off[ns] = (uint32_t)s_clade.size();
-      uint32_t *d_per_slot = nullptr, *d_soff = nullptr, *d_sclade = nullptr, *d_err = nullptr;
-      unsigned long long *d_set = nullptr;
+      uint32_t *d_soff = nullptr, *d_sclade = nullptr, *d_err = nullptr;
+      unsigned long long *d_set = nullptr, *d_per_slot = nullptr;
+      uint8_t *d_single = nullptr;
+      const KuSparseDev &sd = ctx->sp.dev;
       st = tmp.zeros(&d_per_slot, ns);
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the clade roll-up");
-      KU_TRY(ku_launch_count_pairs((const unsigned long long *)ctx->sp.out.p, n_pairs, d_per_slot, ctx->n_cu, ctx->stream));
-      std::vector<uint32_t> per_slot(ns);
-      HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 4, hipMemcpyDeviceToHost, ctx->stream));
+      KU_TRY(ku_launch_count_g_slots(sd.g_key, sd.g_mask + 1, sd.dense, d_per_slot, ctx->n_cu, ctx->stream));
+      std::vector<unsigned long long> per_slot(ns);
+      HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 8, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
-      uint64_t inserts = 0;
-      std::vector<uint64_t> clade_pairs(n_clades, 0);  // entries each clade's union is offered
+      // a clade with one member is that member's own set (distinct already): no union set, histogram only
+      std::vector<uint8_t> clade_single(n_clades, 0);
+      for (uint32_t c = 0; c < n_clades; ++c) clade_single[c] = m_off[c + 1] - m_off[c] == 1 ? 1 : 0;
+      uint64_t inserts = 0;  // upper bound of the union sets' entries: every entry in every clade with several members
+      std::vector<uint64_t> clade_pairs(n_clades, 0);  // entries each clade's histogram may receive
       for (size_t s = 0; s < ns; ++s) {
-        inserts += (uint64_t)per_slot[s] * (s_off[s + 1] - s_off[s]);
-        for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) clade_pairs[s_clade[j]] += per_slot[s];
+        for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) {
+          clade_pairs[s_clade[j]] += per_slot[s];
+          if (!clade_single[s_clade[j]]) inserts += per_slot[s];
+        }
       }
       // the busiest clades (the ones near the root) count in LDS
       std::vector<uint32_t> hot_clades(n_clades);
@@ -2006,10 +2036,11 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       if (st == KU_OK) st = tmp.zeros(&d_err, 1);
       if (st == KU_OK) st = tmp.put(&d_chot, clade_hot);
       if (st == KU_OK) st = tmp.put(&d_hotc, hot_clades);
+      if (st == KU_OK) st = tmp.put(&d_single, clade_single);
       if (st == KU_OK) st = tmp.zeros(&d_set, cells);
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
-      KU_TRY(ku_launch_rollup_sparse((const unsigned long long *)ctx->sp.out.p, n_pairs, d_soff, d_sclade, d_chot, d_hotc, n_hot, d_set,
-                                     cells - 1, d_hist, d_err, ctx->n_cu, ctx->stream));
+      KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_single, d_chot, d_hotc, n_hot, d_set, cells - 1,
+                                     d_hist, d_err, ctx->n_cu, ctx->stream));
       uint32_t err = 0;
       HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -92,11 +92,12 @@ int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uin
 int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_off, const uint32_t *d_member_slot,
                            const uint8_t *d_clade_dense, uint32_t n_clades, uint32_t *d_hist, hipStream_t stream);
 #define KU_ROLLUP_HOT 48  // clades whose histogram is pre-aggregated in LDS
-int ku_launch_rollup_sparse(const unsigned long long *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, const uint16_t *d_clade_hot, const uint32_t *d_hot_clades,
-                            uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist, uint32_t *d_err,
+int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
+                            const uint32_t *d_slot_clade, const uint8_t *d_clade_single, const uint16_t *d_clade_hot,
+                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
+                            uint32_t *d_err, int n_cu, hipStream_t stream);
+int ku_launch_count_g_slots(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, unsigned long long *d_per_slot,
                             int n_cu, hipStream_t stream);
-int ku_launch_count_pairs(const unsigned long long *d_pairs, uint64_t n_pairs, uint32_t *d_per_slot, int n_cu, hipStream_t stream);
 
 // host-side view of an opened database for the other translation units (ku_api.cpp owns the struct)
 struct ku_db;

@@ -64,36 +64,51 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
 // The clades near the root take an entry from (almost) every pair: their histogram bins are counted in the block's LDS
 // and flushed once per block -- one global address per (clade, rank) would serialise the whole grid.  `clade_hot[c]` is
 // the clade's row in that LDS table (0xFFFF: none), `hot_clades[h]` the reverse map.
-__global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ pairs, uint64_t n_pairs,
+//
+// Input is the run-wide set G of the sparse-mode emulation where it lies (ku_sparse.hip: cells of (slot + 1) << 32 |
+// encoding, 0 = empty; no compacted copy is made).  An entry walks up its slot's chain of all-sparse clades, leaf first:
+//   * a clade with a single member holds exactly that slot's entries, which are distinct by construction: histogram
+//     only, no set;
+//   * else (clade, encoding) goes into the union set; an entry that is already there stops the walk -- whoever put it
+//     there carries it further up, and the chains of two slots are the same above their first common clade.
+// So the work is one insert per DISTINCT (clade, encoding) plus one failed probe per duplicate, not entries x depth.
+__global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells,
+                                                                const uint32_t *__restrict__ dense,
                                                                 const uint32_t *__restrict__ slot_off,
                                                                 const uint32_t *__restrict__ slot_clade,
+                                                                const uint8_t *__restrict__ clade_single,
                                                                 const uint16_t *__restrict__ clade_hot,
                                                                 const uint32_t *__restrict__ hot_clades, uint32_t n_hot,
-                                                                unsigned long long *__restrict__ set, uint64_t mask,
-                                                                uint32_t *__restrict__ hist, uint32_t *__restrict__ err) {
+                                                                unsigned long long *set, uint64_t mask,
+                                                                uint32_t *hist, uint32_t *err) {
   __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
   for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
   __syncthreads();
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long p = pairs[i];
-    const uint32_t slot = (uint32_t)(p >> 32), enc = (uint32_t)p;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < g_cells; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long p = g_key[i];
+    if (!p) continue;
+    const uint32_t slot = (uint32_t)(p >> 32) - 1, enc = (uint32_t)p;
+    if (dense[slot]) continue;
     uint32_t r = encoded_rank(enc);
     if (r > KU_ROLLUP_BINS - 1) r = KU_ROLLUP_BINS - 1;
     for (uint32_t j = slot_off[slot]; j < slot_off[slot + 1]; ++j) {
       const uint32_t c = slot_clade[j];
-      const unsigned long long key = ((unsigned long long)(c + 1) << 32) | enc;
-      uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 20;
-      bool done = false;
-      for (uint32_t probe = 0; probe < 4096 && !done; ++probe, ++h) {
-        const unsigned long long old = atomicCAS(&set[h & mask], 0ull, key);
-        if (old == 0ull) {
-          const uint32_t hi = clade_hot[c];
-          if (hi != 0xFFFFu) atomicAdd(&hot[hi * KU_ROLLUP_BINS + r], 1u);
-          else atomicAdd(&hist[(size_t)c * KU_ROLLUP_BINS + r], 1u);
-          done = true;
-        } else if (old == key) done = true;
+      bool fresh = true;
+      if (!clade_single[c]) {
+        const unsigned long long key = ((unsigned long long)(c + 1) << 32) | enc;
+        uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 20;
+        bool done = false;
+        for (uint32_t probe = 0; probe < 4096 && !done; ++probe, ++h) {
+          const unsigned long long old = atomicCAS(&set[h & mask], 0ull, key);
+          if (old == 0ull) done = true;
+          else if (old == key) { done = true; fresh = false; }
+        }
+        if (!done) { atomicOr(err, 1u); fresh = false; }
       }
-      if (!done) atomicOr(err, 1u);
+      if (!fresh) break;
+      const uint32_t hi = clade_hot[c];
+      if (hi != 0xFFFFu) atomicAdd(&hot[hi * KU_ROLLUP_BINS + r], 1u);
+      else atomicAdd(&hist[(size_t)c * KU_ROLLUP_BINS + r], 1u);
     }
   }
   __syncthreads();
@@ -101,10 +116,53 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
     if (hot[i]) atomicAdd(&hist[(size_t)hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
 }
 
-__global__ __launch_bounds__(256) void ku_count_pairs_kernel(const unsigned long long *__restrict__ pairs, uint64_t n_pairs,
-                                                              uint32_t *__restrict__ per_slot) {
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x)
-    atomicAdd(&per_slot[(uint32_t)(pairs[i] >> 32)], 1u);
+// entries of G per slot (slots that stayed sparse only): sizes the union set.  Counted in a per-block LDS table keyed by
+// slot (neighbouring cells of a hash table belong to unrelated slots, but a run has far fewer slots than cells)
+__global__ __launch_bounds__(256) void ku_count_g_slots_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells,
+                                                                const uint32_t *__restrict__ dense, unsigned long long *per_slot) {
+  constexpr int LOG2 = 11;
+  __shared__ uint32_t s_key[1 << LOG2], s_cnt[1 << LOG2];
+  __shared__ uint32_t s_used;
+  for (uint32_t i = threadIdx.x; i < (1u << LOG2); i += blockDim.x) { s_key[i] = 0; s_cnt[i] = 0; }
+  if (threadIdx.x == 0) s_used = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < g_cells; base += stride) {  // block-uniform trip count
+    const uint64_t i = base + threadIdx.x;
+    const unsigned long long p = i < g_cells ? g_key[i] : 0ull;
+    if (p) {
+      const uint32_t slot = (uint32_t)(p >> 32) - 1;
+      if (!dense[slot]) {
+        uint32_t h = (slot * 2654435761u) >> (32 - LOG2);
+        bool placed = false;
+        for (int probe = 0; probe < 16 && !placed; ++probe) {
+          uint32_t cur = s_key[h];
+          if (cur == 0) {
+            const uint32_t old = atomicCAS(&s_key[h], 0u, slot + 1);
+            if (old == 0) atomicAdd(&s_used, 1u);
+            cur = old == 0 ? slot + 1 : old;
+          }
+          if (cur == slot + 1) { atomicAdd(&s_cnt[h], 1u); placed = true; }
+          h = (h + 1) & ((1u << LOG2) - 1);
+        }
+        if (!placed) atomicAdd(&per_slot[slot], 1ull);
+      }
+    }
+    __syncthreads();
+    if (s_used > (1u << LOG2) / 2) {  // block-uniform (read behind the barrier)
+      for (uint32_t t = threadIdx.x; t < (1u << LOG2); t += blockDim.x) {
+        if (s_key[t]) atomicAdd(&per_slot[s_key[t] - 1], (unsigned long long)s_cnt[t]);
+        s_key[t] = 0;
+        s_cnt[t] = 0;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_used = 0;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < (1u << LOG2); t += blockDim.x)
+    if (s_key[t]) atomicAdd(&per_slot[s_key[t] - 1], (unsigned long long)s_cnt[t]);
 }
 
 }  // namespace
@@ -116,22 +174,23 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
-int ku_launch_rollup_sparse(const unsigned long long *d_pairs, uint64_t n_pairs, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, const uint16_t *d_clade_hot, const uint32_t *d_hot_clades,
-                            uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist, uint32_t *d_err,
-                            int n_cu, hipStream_t stream) {
-  if (!n_pairs) return KU_OK;
-  const uint64_t want = (n_pairs + 255) / 256;
+int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
+                            const uint32_t *d_slot_clade, const uint8_t *d_clade_single, const uint16_t *d_clade_hot,
+                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
+                            uint32_t *d_err, int n_cu, hipStream_t stream) {
+  if (!g_cells) return KU_OK;
+  const uint64_t want = (g_cells + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_pairs, n_pairs, d_slot_off, d_slot_clade, d_clade_hot, d_hot_clades, n_hot, d_set,
-                                                       mask, d_hist, d_err);
+  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_slot_off, d_slot_clade, d_clade_single, d_clade_hot,
+                                                       d_hot_clades, n_hot, d_set, mask, d_hist, d_err);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
-int ku_launch_count_pairs(const unsigned long long *d_pairs, uint64_t n_pairs, uint32_t *d_per_slot, int n_cu, hipStream_t stream) {
-  if (!n_pairs) return KU_OK;
-  const uint64_t want = (n_pairs + 255) / 256;
+int ku_launch_count_g_slots(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, unsigned long long *d_per_slot,
+                            int n_cu, hipStream_t stream) {
+  if (!g_cells) return KU_OK;
+  const uint64_t want = (g_cells + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-  ku_count_pairs_kernel<<<blocks, 256, 0, stream>>>(d_pairs, n_pairs, d_per_slot);
+  ku_count_g_slots_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_per_slot);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

@@ -263,6 +263,40 @@ __device__ __noinline__ uint32_t ks_spill_resolve(uint32_t *g_key, uint32_t *g_c
   return res;
 }
 
+// The fused kernel's inserts into the run-wide set G (sparse fast path): the first probe of all of a lane's items goes out
+// together (one compare-and-swap each, back to back: their round trips overlap), the rare collisions are finished one
+// by one.  Returns the wave's number of new entries (uniform).
+template <int ITEMS>
+__device__ __forceinline__ uint32_t ks_g_insert_items(unsigned long long *g_key, uint64_t g_mask, const uint32_t (&slot)[ITEMS],
+                                                      const uint64_t (&hash)[ITEMS], const bool (&want)[ITEMS], uint32_t *err) {
+  unsigned long long key[ITEMS], old[ITEMS];
+  uint64_t h[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    key[j] = ((unsigned long long)(slot[j] + 1) << 32) | ks_encode(hash[j]);
+    h[j] = ks_mix(key[j]) & g_mask;
+  }
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) old[j] = want[j] ? atomicCAS(&g_key[h[j]], 0ull, key[j]) : key[j];
+  uint32_t fresh_n = 0;
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    bool fresh = want[j] && old[j] == 0ull;
+    if (want[j] && old[j] != 0ull && old[j] != key[j]) {  // the cell holds another entry: go on from the next one
+      bool placed = false;
+      for (uint32_t probe = 1; probe < 4096 && !placed; ++probe) {
+        h[j] = (h[j] + 1) & g_mask;
+        const unsigned long long o = atomicCAS(&g_key[h[j]], 0ull, key[j]);
+        fresh = o == 0ull;
+        placed = o == 0ull || o == key[j];
+      }
+      if (!placed) atomicOr(err, 4u);
+    }
+    fresh_n += (uint32_t)__popcll(__ballot(fresh));
+  }
+  return fresh_n;
+}
+
 // waves per SIMD the variant is compiled for: 2 k-mers per lane fit 80 VGPRs (6 waves, 8 B of scratch; LDS allows 6
 // blocks per CU), 3 per lane need 128 (4 waves)
 #ifndef KS_OCC2
@@ -774,25 +808,20 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         }
         const bool d_hit = n_hit == 0 || sf.dense[uni_slot] != 0, d_miss = n_miss == 0 || sf.dense[0] != 0;  // uniform
         if (!(d_hit && d_miss)) {
+          bool want[ITEMS];
 #pragma unroll
-          for (int j = 0; j < ITEMS; ++j) {
-            const bool okc = j * 64 + lane < n && !amb_k[j];
-            bool fresh = false;
-            if (okc && !(v[j] ? d_hit : d_miss)) fresh = ks_g_insert(sf.g_key, sf.g_mask, v[j], ks_encode(hh[j]), sf.err);
-            sp_fresh += (uint32_t)__popcll(__ballot(fresh));
-          }
+          for (int j = 0; j < ITEMS; ++j) want[j] = j * 64 + lane < n && !amb_k[j] && !(v[j] ? d_hit : d_miss);
+          sp_fresh += ks_g_insert_items<ITEMS>(sf.g_key, sf.g_mask, v, hh, want, sf.err);
         }
       } else {
+        bool want[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
           const bool okc = j * 64 + lane < n && !amb_k[j];
-          bool fresh = false;
-          if (okc) {
-            atomicAdd(&urow[v[j]], 1u);
-            if (!sf.dense[v[j]]) fresh = ks_g_insert(sf.g_key, sf.g_mask, v[j], ks_encode(hh[j]), sf.err);
-          }
-          sp_fresh += (uint32_t)__popcll(__ballot(fresh));
+          if (okc) atomicAdd(&urow[v[j]], 1u);
+          want[j] = okc && !sf.dense[v[j]];
         }
+        sp_fresh += ks_g_insert_items<ITEMS>(sf.g_key, sf.g_mask, v, hh, want, sf.err);
       }
     }
 
