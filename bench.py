@@ -239,7 +239,8 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
             pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory().numpy()
             obuf = {"calls": pin(n_dp, torch.int32).view(np.uint32), "hits": pin(n_dp, torch.int32).view(np.uint32),
                     "run_cnt": pin(n_dp, torch.int32).view(np.uint32), "run_off": pin(n_dp, torch.int64).view(np.uint64),
-                    "runs": pin((len(r["runs"]) + 1024, 2), torch.int32).view(np.uint32)}
+                    # (the extent of the run array varies a little from call to call: the waves claim it in chunks)
+                    "runs": pin((2 * len(r["runs"]) + (1 << 20), 2), torch.int32).view(np.uint32)}
             off, lens = pin(n_dp, torch.int64).view(np.uint64), pin(n_dp, torch.int32).view(np.uint32)
             off[:] = np.arange(n_dp, dtype=np.uint64) * stride
             lens[:] = read_len
@@ -313,19 +314,19 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
     return out
 
 
-def shard_bounds(synth_torch, kdist, dev, a, k, n_shards):
+def shard_bounds(synth_torch, dev, a, k, n_shards):
     """every rank derives the same shard plan from the same deterministic sample of the DB's bin keys"""
     probe = synth_torch.BenchDb(dev, n_species=min(a.species, 32), genome_len=min(a.genome_len, 50_000), k=k,
                                 nt=a.nt, seed=7)
     bins = synth_torch.bin_key(probe.kmers[torch.randperm(probe.n_pairs, device=dev)[:1_000_000]], k, a.nt)
-    return kdist.quantile_bin_bounds(bins, 4 ** a.nt, n_shards)
+    return synth_torch.quantile_bin_bounds(bins, 4 ** a.nt, n_shards)
 
 
-def sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, steps, warmup, stream):
+def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, warmup, stream):
     """the sharded step through ku_mgpu_step_device; returns a dict: elapsed seconds over `steps`, the group, the shard,
     whether every read was resolved exactly once, and the rank's own kernel measurements"""
     n_shards = max(a.db_shards or ws, ws)
-    bounds = shard_bounds(synth_torch, kdist, dev, a, k, n_shards)
+    bounds = shard_bounds(synth_torch, dev, a, k, n_shards)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     db = synth_torch.BenchDb(dev, n_species=a.species, genome_len=a.genome_len, k=k, nt=a.nt, seed=7, bin_lo=lo, bin_hi=hi)
     db.kmers = db.vals = None
@@ -434,7 +435,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    from krakenuniq_amd import capi, dist as kdist, synth_torch
+    from krakenuniq_amd import capi, synth_torch
     def fresh_uid():
         """id of one RCCL communicator of the C++ driver: rank 0 makes it, everybody gets it (an id serves one init)"""
         if ws <= 1:
@@ -460,7 +461,7 @@ def main():
 
     if sharded:
         t_build = time.time()
-        sr = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, uid, k, a.steps, a.warmup, stream)
+        sr = sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, a.steps, a.warmup, stream)
         elapsed, mg, db, L = sr["elapsed"], sr["mg"], sr["db"], sr["read_len"]
         value = a.reads * a.steps / elapsed / 1e6
         ctx = mg.ctx(0)
@@ -653,7 +654,7 @@ def main():
             del db
             torch.cuda.empty_cache()
             s_steps = max(2, min(a.steps, 4))
-            sr = sharded_run(a, capi, synth_torch, kdist, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, 1, stream)
+            sr = sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, 1, stream)
             el = sr["elapsed"]
             result["sharded"] = {"value": round(a.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
                                  "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sr["db"].n_pairs,

@@ -327,6 +327,32 @@ int ku_ctx_synchronize(ku_ctx *ctx);
  * B(q) = 16 + 12 * ceil(log2(n_bin + 1)) + 4.  Blocking. */
 int ku_lookup_stats_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint64_t *stats_out, void *stream);
 
+/* ------------------------------------------------------------------ UID databases (classify -I)
+ * A UID database (set_lcas -I, scripts/krakenuniq --uid-mapping) stores, instead of an LCA taxid, the id of the SET of
+ * taxids whose library sequences hold the k-mer; uid_to_taxid.map lists the sets as {taxid, parent uid} blocks
+ * (src/uid_mapping.cpp:32-91,279-302).  classify -I resolves a read from its per-UID hit counts with resolve_uids3
+ * (src/uid_mapping.cpp:212-274; src/classify.cpp:953-960): the taxid with the most hits, ties by the larger sum of
+ * count / |set| (double), then the LCA of the tied taxids -- summed and compared in the iteration order of the
+ * std::unordered_maps the reference walks.  Lookup, per-k-mer codes (the UIDs), HLL / n_kmers accounting run on the GPU
+ * as for any database (the values are just numbers); the resolve step is host code here: it uses the same container in
+ * the same insertion order as the reference, which is what makes the result identical to a reference built with the
+ * same C++ library.  ku_resolve_uids takes a batch's run-length encoded codes (ku_classify_batch_rle + ku_fetch_runs)
+ * and returns the calls; ku_ctx_replace_calls then moves the device's read counts of the last batch from the calls
+ * resolve_tree made to these (classify.cpp:968 counts the read under the UID call). */
+typedef struct ku_uid_map ku_uid_map;
+int ku_uid_map_open(const char *path, ku_uid_map **out);
+/* blocks: n * 2 uint32 {taxid, parent uid} */
+int ku_uid_map_from_blocks(const uint32_t *blocks, uint64_t n, ku_uid_map **out);
+void ku_uid_map_close(ku_uid_map *m);
+uint64_t ku_uid_map_size(const ku_uid_map *m);
+/* seq_len: the reads' lengths (the last run of a read ends at its k-mer count); n_threads host threads (0 = 1).
+ * KU_EDATA when a code is not a uid of the map. */
+int ku_resolve_uids(const ku_tax *tax, const ku_uid_map *map, const ku_run *runs, const uint64_t *run_off, const uint32_t *run_cnt,
+                    const uint32_t *seq_len, uint64_t n_reads, uint32_t k, uint32_t n_threads, uint32_t *calls);
+/* the calls of the batch classified last on this context are replaced by new_calls[n_reads]: n_reads of the per-taxon
+ * state moves accordingly (a call that is neither a taxDB id nor a database value cannot be counted: *n_dropped) */
+int ku_ctx_replace_calls(ku_ctx *ctx, const uint32_t *new_calls, uint64_t n_reads, uint64_t *n_dropped);
+
 /* ------------------------------------------------------------------ per-taxon state
  * Export of the run's `taxon_counts` (classify.cpp:78): one row per slot
  * (slot 0 = taxid 0 = "no hit") with its k-mer count and dense p=12 registers,

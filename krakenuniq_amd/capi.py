@@ -152,6 +152,12 @@ SIGNATURES = {
     "ku_mgpu_step_device": (C.c_int, [C.c_void_p, C.POINTER(DevBatch), C.c_uint64, C.c_uint64, u64p, u64p, C.POINTER(Opts)]),
     "ku_mgpu_reduce_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "ku_mgpu_count_taxons": (C.c_int, [C.c_void_p, u32p, u64p, u64p]),
+    "ku_uid_map_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ku_uid_map_from_blocks": (C.c_int, [u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ku_uid_map_close": (None, [C.c_void_p]),
+    "ku_uid_map_size": (C.c_uint64, [C.c_void_p]),
+    "ku_resolve_uids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64p, u32p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, u32p]),
+    "ku_ctx_replace_calls": (C.c_int, [C.c_void_p, u32p, C.c_uint64, u64p]),
     "ku_free": (None, [C.c_void_p]),
     "ku_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "ku_host_free": (None, [C.c_void_p]),
@@ -274,6 +280,44 @@ class Tax:
 
     def __len__(self):
         return lib().ku_tax_size(self.h)
+
+
+class UidMap:
+    """UID-to-taxid map of a UID database (set_lcas -I): {taxid, parent uid} blocks"""
+
+    def __init__(self, path=None, blocks=None):
+        self.h = C.c_void_p()
+        if path is not None:
+            _chk(lib().ku_uid_map_open(path.encode(), C.byref(self.h)), "ku_uid_map_open")
+        else:
+            b = np.ascontiguousarray(blocks, dtype=np.uint32).reshape(-1)
+            _chk(lib().ku_uid_map_from_blocks(_p(b, u32p), len(b) // 2, C.byref(self.h)), "ku_uid_map_from_blocks")
+
+    def __len__(self):
+        return int(lib().ku_uid_map_size(self.h))
+
+    def close(self):
+        if self.h:
+            lib().ku_uid_map_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resolve_uids(tax, uid_map, rle, lens, k, n_threads=1):
+    """resolve_uids3 for a batch from its run-length encoded codes (ku_resolve_uids); rle as classify_batch_rle returns"""
+    runs = np.ascontiguousarray(rle["runs"], dtype=np.uint32)
+    roff = np.ascontiguousarray(rle["run_off"], dtype=np.uint64)
+    rcnt = np.ascontiguousarray(rle["run_cnt"], dtype=np.uint32)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    calls = np.zeros(max(len(lens), 1), dtype=np.uint32)
+    _chk(lib().ku_resolve_uids(tax.h, uid_map.h, runs.ctypes.data, _p(roff, u64p), _p(rcnt, u32p), _p(lens, u32p), len(lens), k,
+                               n_threads, _p(calls, u32p)), "ku_resolve_uids")
+    return calls[:len(lens)]
 
 
 class Ctx:
@@ -436,6 +480,13 @@ class Ctx:
             runs = np.zeros((max(total.value, 1), 2), dtype=np.uint32)
         _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
         return {"calls": calls[:n], "hits": hits[:n], "runs": runs[:total.value], "run_off": roff[:n], "run_cnt": rcnt[:n]}
+
+    def replace_calls(self, new_calls):
+        """the last batch's reads are counted under new_calls (ku_ctx_replace_calls); returns the calls that could not be"""
+        nc = np.ascontiguousarray(new_calls, dtype=np.uint32)
+        dropped = C.c_uint64()
+        _chk(lib().ku_ctx_replace_calls(self.h, _p(nc, u32p), len(nc), C.byref(dropped)), "ku_ctx_replace_calls")
+        return int(dropped.value)
 
     def lookup_device(self, d_seqs, n_bytes, d_taxa, flags=0, stream=None):
         o = Opts(flags, 1, 0, 0)

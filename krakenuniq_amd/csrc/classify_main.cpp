@@ -20,7 +20,10 @@
 //   -x SIZE                             the database is streamed through HBM in minimizer-range chunks of at most SIZE
 //                                       bytes (src/krakendb.cpp:463-522) when that yields more than one chunk
 //   -p N                                accepted and ignored exactly like the reference
-//   -I file                             UID mapping: not built here -> exit 70 with a message
+//   -I file                             UID database (set_lcas -I / --uid-mapping): the values of the (single) database are
+//                                       UIDs, reads are resolved with resolve_uids3 on the host from the device's
+//                                       run-length encoded codes (src/classify.cpp:953-960, src/uid_mapping.cpp:212-274); no
+//                                       quick mode (the reference exits there too), one GPU, database resident
 // Extensions: -P (mate pairs merged on the fly); env KU_DEVICE selects the GPU (default 0); env KU_DEVICES=0,1,...
 // runs on several GPUs through the multi-GPU driver (ku_mgpu: database sharded by minimizer range, read batches
 // broadcast, per-k-mer slots reduce-scattered, per-taxon state reduced at the end; KU_MGPU_MODE=replicas keeps the
@@ -183,8 +186,8 @@ static double seconds_between(const timeval &a, const timeval &b) {
 
 int main(int argc, char **argv) {
   std::vector<std::string> dbs, idxs;
-  std::string kraken_out, report_out, taxdb, cls_out, ucls_out;
-  bool paired = false, warned_pairs = false;
+  std::string kraken_out, report_out, taxdb, cls_out, ucls_out, uid_map_file;
+  bool paired = false, warned_pairs = false, warned_uid_calls = false;
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
   uint64_t unit_nt = 64ull << 20;    // GPU batch size in nt (KU_BATCH_NT)
@@ -232,7 +235,7 @@ int main(int argc, char **argv) {
         chunk_bytes = parse_size(optarg);
         if (chunk_bytes == 0) die(EX_USAGE, "can't parse preload size %s", optarg);
         break;
-      case 'I': die(EX_SOFTWARE, "UID mapping (-I) is not built into the MI355X classify (see DESIGN.md)");
+      case 'I': uid_map_file = optarg; break;
       case 'n': break;
       case 'P': paired = true; break;  // extension: the input files are mate pairs, merged on the fly (scripts/read_merger.pl)
       default: usage(EX_USAGE);
@@ -251,6 +254,9 @@ int main(int argc, char **argv) {
   const char *base = strrchr(argv[0], '/');
   const bool exact = strcmp(base ? base + 1 : argv[0], "classifyExact") == 0 || getenv("KU_EXACT") != nullptr;
   if (exact && quick) die(EX_SOFTWARE, "exact counting with quick mode is not built into the MI355X classifyExact");
+  const bool map_uids = !uid_map_file.empty();
+  if (map_uids && dbs.size() > 1) { fprintf(stderr, "Cannot use more than one database with UID mapping!\n"); return 1; }  // src/classify.cpp:158-160
+  if (map_uids && quick) { fprintf(stderr, "Quick mode not available when mapping UIDs\n"); return 1; }                  // :954-956
   if (optind == argc && !populate) fprintf(stderr, "No sequence data files specified\n");
   if (paired && (argc - optind) % 2) die(EX_USAGE, "-P needs the input files in pairs (mate 1, mate 2)");
   if (taxdb.empty()) { fprintf(stderr, "TaxDB argument is required!\n"); return 1; }  // src/classify.cpp:221-222
@@ -273,6 +279,11 @@ int main(int argc, char **argv) {
   ku_db *db = db_handles[0];
   ku_tax *tax = nullptr;
   KU_CHECK(ku_tax_open(taxdb.c_str(), &tax));
+  ku_uid_map *uid_map = nullptr;
+  if (map_uids) {
+    fprintf(stderr, "Reading UID mapping file %s\n", uid_map_file.c_str());  // src/classify.cpp:163
+    KU_CHECK(ku_uid_map_open(uid_map_file.c_str(), &uid_map));
+  }
   ku_ctx *ctx = nullptr;
   ku_mgpu *mg = nullptr;  // KU_DEVICES=0,1,...: several GPUs through the multi-GPU driver
   std::vector<int> devices;
@@ -329,6 +340,7 @@ int main(int argc, char **argv) {
     if (n_chunks <= 1) chunk_bounds.clear();
   }
   const bool chunked = !chunk_bounds.empty();
+  if (map_uids && (mg || chunked)) die(EX_SOFTWARE, "UID mapping (-I) runs on one GPU with the database resident (no KU_DEVICES, no -x chunks)");
   if (mg && exact) die(EX_SOFTWARE, "exact counting on several GPUs is not built into the MI355X classifyExact");
   if (chunked && exact) die(EX_SOFTWARE, "exact counting with -x chunks is not built into the MI355X classifyExact");
   // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
@@ -753,10 +765,20 @@ int main(int argc, char **argv) {
     else
       KU_CHECK(ku_classify_batch_rle(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
                                      bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
-    if (print_kraken && !quick) {  // the runs only feed the Kraken lines
+    if ((print_kraken && !quick) || map_uids) {  // the runs feed the Kraken lines -- and the UID resolution
       bt->reserve_runs(n_runs);
       if (mg) KU_CHECK(ku_mgpu_fetch_runs(mg, bt->runs, n_runs));
       else KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
+    }
+    if (map_uids) {  // the calls of resolve_tree give way to resolve_uids3's; the read counts on the device follow
+      KU_CHECK(ku_resolve_uids(tax, uid_map, bt->runs, bt->run_off.data(), bt->run_cnt.data(), bt->len.data(), n, info.k,
+                               (uint32_t)fmt_threads, bt->calls.data()));
+      uint64_t dropped = 0;
+      KU_CHECK(ku_ctx_replace_calls(ctx, bt->calls.data(), n, &dropped));
+      if (dropped && !warned_uid_calls) {
+        fprintf(stderr, "\rclassify: reads were called with taxids that are neither in taxDB nor values of the database: they are missing from the report\n");
+        warned_uid_calls = true;
+      }
     }
     busy_gpu += now_s() - t_gpu;
     done_q.push(bt);
@@ -832,6 +854,7 @@ int main(int argc, char **argv) {
   if (mg) ku_mgpu_destroy(mg);
   else ku_ctx_destroy(ctx);
   ku_tax_close(tax);
+  ku_uid_map_close(uid_map);
   for (ku_db *h : db_handles) ku_db_close(h);
   return 0;
 }

@@ -473,7 +473,7 @@ extern "C" int ku_ctx_create(int device, ku_ctx **out) {
   ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc((void **)&ctx->d_scalar, 64));
+  HIP_TRY(hipMalloc((void **)&ctx->d_scalar, 128));
   if (const char *e = getenv("KU_LAYOUT")) ctx->hash_layout = strcmp(e, "sorted") != 0;
   if (const char *e = getenv("KU_LOAD_FACTOR")) {
     double f = atof(e);
@@ -1670,6 +1670,27 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
                               (uint32_t *)ctx->b_hits.p, s, seq_off, seq_len));
   return rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p, n_reads,
                        runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits, run_off, run_cnt, n_runs);
+}
+
+extern "C" int ku_ctx_replace_calls(ku_ctx *ctx, const uint32_t *new_calls, uint64_t n_reads, uint64_t *n_dropped) {
+  KU_TRY(check_ready(ctx));
+  if (n_dropped) *n_dropped = 0;
+  if (n_reads == 0) return KU_OK;
+  if (!new_calls) return fail(KU_EINVAL, "ku_ctx_replace_calls: null argument");
+  if (ctx->b_calls.cap < n_reads * 4) return fail(KU_ESTATE, "ku_ctx_replace_calls: the context holds no batch of that many reads");
+  if (ctx->b_hits.reserve(n_reads * 4) != KU_OK) return fail(KU_ENOMEM, "device batch buffers");
+  hipStream_t s = ctx->stream;
+  unsigned long long *d_dropped = (unsigned long long *)(ctx->d_scalar + 16);
+  HIP_TRY(hipMemsetAsync(d_dropped, 0, 8, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_hits.p, new_calls, n_reads * 4, hipMemcpyHostToDevice, s));
+  KU_TRY(ku_launch_replace_calls((const uint32_t *)ctx->b_calls.p, (const uint32_t *)ctx->b_hits.p, n_reads, ctx->d_node_taxid, ctx->tax.n_nodes,
+                                 ctx->cnt.n_reads, d_dropped, s));
+  HIP_TRY(hipMemcpyAsync(ctx->b_calls.p, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToDevice, s));  // a second replacement starts from these
+  unsigned long long dropped = 0;
+  HIP_TRY(hipMemcpyAsync(&dropped, d_dropped, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n_dropped) *n_dropped = dropped;
+  return KU_OK;
 }
 
 extern "C" int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs) {

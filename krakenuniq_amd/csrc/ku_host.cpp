@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 // ---------------------------------------------------------------------------- HLL estimator
 // sigma / tau series of Ertl's improved estimator (hyperloglogplus.cpp:373-387,408-422)
@@ -78,6 +79,134 @@ extern "C" uint64_t ku_hll_cardinality_sparse(const uint32_t *encoded, uint64_t 
   }
   C[0] = (int)m;
   return ertl_from_histogram(C, q, double(1 << pp), n_observed);
+}
+
+// ---------------------------------------------------------------------------- UID databases (classify -I)
+struct ku_uid_map {
+  std::vector<uint32_t> blocks;  // {taxid, parent uid} of uid i + 1 at 2 * i
+};
+extern "C" int ku_uid_map_from_blocks(const uint32_t *blocks, uint64_t n, ku_uid_map **out) {
+  if (!out || (n && !blocks)) { ku_set_error("ku_uid_map_from_blocks: null argument"); return KU_EINVAL; }
+  ku_uid_map *m = new ku_uid_map();
+  m->blocks.assign(blocks, blocks + 2 * n);
+  *out = m;
+  return KU_OK;
+}
+extern "C" int ku_uid_map_open(const char *path, ku_uid_map **out) {
+  if (!path || !out) { ku_set_error("ku_uid_map_open: null argument"); return KU_EINVAL; }
+  *out = nullptr;
+  FILE *f = fopen(path, "rb");
+  if (!f) { ku_set_error(std::string("can't open ") + path); return KU_ENOINPUT; }
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (sz < 0 || sz % 8) { fclose(f); ku_set_error("UID map: the file is not a sequence of {taxid, parent uid} blocks"); return KU_EDATA; }
+  ku_uid_map *m = new ku_uid_map();
+  m->blocks.resize((size_t)sz / 4);
+  const size_t got = sz ? fread(m->blocks.data(), 4, (size_t)sz / 4, f) : 0;
+  fclose(f);
+  if (got != (size_t)sz / 4) { delete m; ku_set_error("UID map: short read"); return KU_EDATA; }
+  *out = m;
+  return KU_OK;
+}
+extern "C" void ku_uid_map_close(ku_uid_map *m) { delete m; }
+extern "C" uint64_t ku_uid_map_size(const ku_uid_map *m) { return m ? m->blocks.size() / 2 : 0; }
+
+// lca (krakenutil.cpp:90-118) on the host Parent_map: a taxid without an entry ends the walk ("No parent for ...")
+static uint32_t host_lca(const ku_tax *t, uint32_t a, uint32_t b) {
+  if (a == 0 || b == 0) return a ? a : b;
+  std::vector<uint32_t> a_path;
+  for (uint32_t guard = 0; a > 1 && guard < 4096; ++guard) {
+    a_path.push_back(a);
+    auto it = t->row.find(a);
+    if (it == t->row.end() || a == 0) break;
+    a = t->parent_map[it->second];
+  }
+  for (uint32_t guard = 0; b > 1 && guard < 4096; ++guard) {
+    if (std::find(a_path.begin(), a_path.end(), b) != a_path.end()) return b;
+    auto it = t->row.find(b);
+    if (it == t->row.end()) break;
+    b = t->parent_map[it->second];
+  }
+  return 1;
+}
+
+// resolve_uids3 (uid_mapping.cpp:212-274) for one read; `hits` was filled by hit_counts[uid]++ in k-mer order like
+// classify_sequence does (classify.cpp:941): the containers and their insertion order are the reference's, so is the
+// order the sums and the ties are formed in
+static int resolve_uids_one(const ku_tax *tax, const ku_uid_map *map, const std::unordered_map<uint32_t, uint32_t> &hits, uint32_t *call) {
+  *call = 0;
+  if (hits.empty()) return KU_OK;
+  const uint64_t n_uid = map->blocks.size() / 2;
+  std::unordered_map<uint32_t, uint32_t> taxid_counts;
+  std::unordered_map<uint32_t, double> frac_taxid_counts;
+  std::vector<uint32_t> taxids;
+  for (auto it = hits.begin(); it != hits.end(); ++it) {
+    if (it->first == 0) continue;
+    taxids.clear();
+    for (uint32_t u = it->first; u != 0;) {  // get_taxids_for_uid (uid_mapping.cpp:279-302)
+      if (u > n_uid || taxids.size() > n_uid) { ku_set_error("UID " + std::to_string(u) + " is not in the UID map"); return KU_EDATA; }
+      taxids.push_back(map->blocks[2 * (size_t)(u - 1)]);
+      u = map->blocks[2 * (size_t)(u - 1) + 1];
+    }
+    const double frac_count = (double)it->second / (double)taxids.size();
+    for (size_t i = 0; i < taxids.size(); ++i) {
+      frac_taxid_counts[taxids[i]] += frac_count;
+      taxid_counts[taxids[i]] += it->second;
+    }
+  }
+  if (taxid_counts.empty()) return KU_OK;
+  std::vector<uint32_t> max_taxids;
+  uint32_t max_count = 0;
+  double max_frac_count = 0;
+  for (auto it = taxid_counts.begin(); it != taxid_counts.end(); ++it) {
+    if (it->second == max_count) {
+      const double f = frac_taxid_counts[it->first];
+      if (f == max_frac_count) max_taxids.push_back(it->first);
+      else if (f > max_frac_count) { max_frac_count = f; max_taxids.assign(1, it->first); }
+    } else if (it->second > max_count) {
+      max_taxids.assign(1, it->first);
+      max_count = it->second;
+      max_frac_count = frac_taxid_counts[it->first];
+    }
+  }
+  uint32_t max_taxon = max_taxids[0];
+  for (size_t i = 1; i < max_taxids.size(); ++i) max_taxon = host_lca(tax, max_taxon, max_taxids[i]);
+  *call = max_taxon;
+  return KU_OK;
+}
+
+extern "C" int ku_resolve_uids(const ku_tax *tax, const ku_uid_map *map, const ku_run *runs, const uint64_t *run_off, const uint32_t *run_cnt,
+                               const uint32_t *seq_len, uint64_t n_reads, uint32_t k, uint32_t n_threads, uint32_t *calls) {
+  if (!tax || !map || (n_reads && (!run_off || !run_cnt || !seq_len || !calls))) { ku_set_error("ku_resolve_uids: null argument"); return KU_EINVAL; }
+  if (n_threads == 0) n_threads = 1;
+  if (n_reads < 4096) n_threads = 1;
+  std::vector<int> status(n_threads, KU_OK);
+  std::vector<std::string> msg(n_threads);
+  auto work = [&](uint32_t t) {
+    std::unordered_map<uint32_t, uint32_t> hits;
+    for (uint64_t i = n_reads * t / n_threads; i < n_reads * (t + 1) / n_threads; ++i) {
+      hits = std::unordered_map<uint32_t, uint32_t>();  // a fresh container per read, as in classify_sequence (:902)
+      const uint32_t n = seq_len[i] >= k ? seq_len[i] - k + 1 : 0, c = run_cnt[i];
+      for (uint32_t j = 0; j < c; ++j) {
+        const ku_run &r = runs[run_off[i] + j];
+        if (r.code == 0 || r.code == KU_AMBIG) continue;
+        const uint32_t end = j + 1 < c ? runs[run_off[i] + j + 1].start : n;
+        hits[r.code] += end - r.start;
+      }
+      const int st = resolve_uids_one(tax, map, hits, &calls[i]);
+      if (st != KU_OK) { status[t] = st; msg[t] = "read " + std::to_string(i) + ": a code of the batch is not a UID of the map"; return; }
+    }
+  };
+  if (n_threads == 1) work(0);
+  else {
+    std::vector<std::thread> team;
+    for (uint32_t t = 0; t < n_threads; ++t) team.emplace_back(work, t);
+    for (auto &th : team) th.join();
+  }
+  for (uint32_t t = 0; t < n_threads; ++t)
+    if (status[t] != KU_OK) { ku_set_error(msg[t]); return status[t]; }
+  return KU_OK;
 }
 
 // ---------------------------------------------------------------------------- Kraken lines

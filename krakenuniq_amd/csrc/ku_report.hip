@@ -165,7 +165,38 @@ __global__ __launch_bounds__(256) void ku_count_g_slots_kernel(const unsigned lo
     if (s_key[t]) atomicAdd(&per_slot[s_key[t] - 1], (unsigned long long)s_cnt[t]);
 }
 
+// classify -I: the reads of the last batch are counted under new calls (ku_ctx_replace_calls).  node_taxid is ascending:
+// a binary search maps a taxid to its node; a taxid outside the node universe cannot be counted.
+__device__ __forceinline__ uint32_t node_of_taxid(const uint32_t *__restrict__ node_taxid, uint32_t n_nodes, uint32_t taxid) {
+  uint32_t lo = 0, hi = n_nodes;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (node_taxid[mid] < taxid) lo = mid + 1; else hi = mid;
+  }
+  return lo < n_nodes && node_taxid[lo] == taxid ? lo : 0xFFFFFFFFu;
+}
+__global__ void ku_replace_calls_kernel(const uint32_t *__restrict__ old_calls, const uint32_t *__restrict__ new_calls, uint64_t n,
+                                        const uint32_t *__restrict__ node_taxid, uint32_t n_nodes, unsigned long long *n_reads,
+                                        unsigned long long *n_dropped) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t o = old_calls[i], c = new_calls[i];
+    if (o == c) continue;
+    const uint32_t no = node_of_taxid(node_taxid, n_nodes, o), nc = node_of_taxid(node_taxid, n_nodes, c);
+    if (no != 0xFFFFFFFFu) atomicAdd(&n_reads[no], ~0ull);  // - 1
+    if (nc != 0xFFFFFFFFu) atomicAdd(&n_reads[nc], 1ull);
+    else atomicAdd(n_dropped, 1ull);
+  }
+}
+
 }  // namespace
+
+int ku_launch_replace_calls(const uint32_t *d_old, const uint32_t *d_new, uint64_t n, const uint32_t *d_node_taxid, uint32_t n_nodes,
+                            unsigned long long *d_n_reads, unsigned long long *d_dropped, hipStream_t stream) {
+  if (!n) return KU_OK;
+  const uint64_t want = (n + 255) / 256;
+  ku_replace_calls_kernel<<<(unsigned)(want < 4096 ? want : 4096), 256, 0, stream>>>(d_old, d_new, n, d_node_taxid, n_nodes, d_n_reads, d_dropped);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
 
 int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_off, const uint32_t *d_member_slot,
                            const uint8_t *d_clade_dense, uint32_t n_clades, uint32_t *d_hist, hipStream_t stream) {

@@ -74,6 +74,17 @@ def kmers_of_rows(codes: torch.Tensor, k: int) -> torch.Tensor:
     return out
 
 
+def quantile_bin_bounds(sample_bins: torch.Tensor, n_bins: int, world_size: int) -> np.ndarray:
+    """shard bounds from a sample of bin keys (every rank draws the same sample -> same plan)"""
+    b = np.zeros(world_size + 1, dtype=np.uint64)
+    b[-1] = n_bins
+    if world_size > 1:
+        q = torch.quantile(sample_bins.to(torch.float64), torch.linspace(0, 1, world_size + 1,
+                                                                         dtype=torch.float64)[1:-1].to(sample_bins.device))
+        b[1:-1] = np.ceil(q.cpu().numpy()).astype(np.uint64)
+    return b
+
+
 class BenchDb:
     """Synthetic taxonomy + genomes + (optionally sharded) database resident in HBM."""
 

@@ -735,13 +735,181 @@ static void cmap_merge(ko_cmap *dst, const ko_cmap *src) {
 
 /* one read; counts may be NULL (pure lookup) */
 #define KO_MAX_DBS 8
+
+/* ======================================================================== */
+/* UID mapping (classify -I): resolve_uids3, uid_mapping.cpp:212-274
+ *
+ * With a UID database the values are UIDs: uid u names the taxid set found by
+ * walking the {taxid, parent uid} blocks of the map file from block u - 1
+ * (get_taxids_for_uid, uid_mapping.cpp:279-302).  A read's call is the taxid with
+ * the most hits; ties go to the larger sum of count / |set| (double), then to
+ * the LCA of the tied taxids.  The sums are accumulated, and ties are found, in
+ * the ITERATION ORDER of std::unordered_map<uint32_t, ...> -- so this restates
+ * that order too: libstdc++'s _Hashtable with the identity hash, buckets =
+ * key % bucket_count, a singly linked node list in which a node enters at the
+ * head of its bucket or, for an empty bucket, at the head of the whole list,
+ * and the prime rehash policy (bucket counts 1, 13, 29, 59, 127, ...; checked
+ * against the real container through oracle/ref_kat.cpp UMORDER).              */
+/* ======================================================================== */
+static const uint32_t ko_um_primes[] = { /* std::__detail::__prime_list (libstdc++), the part a read can reach */
+  2,3,5,7,11,13,17,19,23,29,31,37,41,43,47,53,59,61,67,71,73,79,83,89,97,103,109,113,127,137,139,149,157,167,179,193,
+  199,211,227,241,257,277,293,313,337,359,383,409,439,467,503,541,577,619,661,709,761,823,887,953,1031,1109,1193,1289,
+  1381,1493,1613,1741,1879,2029,2179,2357,2549,2753,2971,3209,3469,3739,4027,4349,4703,5087,5503,5953,6427,6949,7517,
+  8123,8783,9497,10273,11113,12011,12983,14033,15173,16411,17749,19183,20753,22447,24281,26267,28411,30727,33223,35933,
+  38873,42043,45481,49201,53201,57557,62233,67307,72817,78779,85229,92203,99733,107897,116731,126271,136607,147793,
+  159871,172933,187091,202409,218971,236897,256279,277261,299951,324503,351061,379787,410857,444487,480881,520241,
+  562841,608903,658753,712697,771049,834181,902483,976369,1056323,1142821,1236397,1337629,1447153,1565659,1693859 };
+#define KO_UM_NONE (-1)
+#define KO_UM_BB (-2) /* &_M_before_begin */
+typedef struct {
+  uint32_t *key, *cnt; double *frac; int32_t *next;
+  int32_t *bkt; size_t n, cap, n_bkt, next_resize; int32_t head;
+} ko_um;
+static void um_init(ko_um *m) {
+  memset(m, 0, sizeof(*m));
+  m->n_bkt = 1; m->bkt = (int32_t *)malloc(sizeof(int32_t)); m->bkt[0] = KO_UM_NONE; m->head = KO_UM_NONE;
+}
+static void um_free(ko_um *m) { free(m->key); free(m->cnt); free(m->frac); free(m->next); free(m->bkt); }
+static int32_t um_next_of(const ko_um *m, int32_t node) { return node == KO_UM_BB ? m->head : m->next[node]; }
+static void um_set_next(ko_um *m, int32_t node, int32_t v) { if (node == KO_UM_BB) m->head = v; else m->next[node] = v; }
+static size_t um_next_bkt(ko_um *m, size_t n) { /* _Prime_rehash_policy::_M_next_bkt */
+  static const unsigned char fast[] = { 2, 2, 2, 3, 5, 5, 7, 7, 11, 11, 11, 11, 13, 13 };
+  if (n < sizeof(fast)) { if (n == 0) return 1; m->next_resize = fast[n]; return fast[n]; }
+  size_t lo = 6, hi = sizeof(ko_um_primes) / sizeof(ko_um_primes[0]);
+  while (lo < hi) { size_t mid = (lo + hi) / 2; if (ko_um_primes[mid] < n) lo = mid + 1; else hi = mid; }
+  m->next_resize = ko_um_primes[lo];
+  return ko_um_primes[lo];
+}
+static void um_rehash(ko_um *m, size_t n_new) { /* _M_rehash_aux(n, true_type) */
+  int32_t *nb = (int32_t *)malloc(n_new * sizeof(int32_t));
+  for (size_t i = 0; i < n_new; ++i) nb[i] = KO_UM_NONE;
+  int32_t p = m->head; m->head = KO_UM_NONE;
+  size_t bbegin_bkt = 0;
+  while (p != KO_UM_NONE) {
+    int32_t nx = m->next[p];
+    size_t b = m->key[p] % n_new;
+    if (nb[b] == KO_UM_NONE) {
+      m->next[p] = m->head; m->head = p; nb[b] = KO_UM_BB;
+      if (m->next[p] != KO_UM_NONE) nb[bbegin_bkt] = p;
+      bbegin_bkt = b;
+    } else {
+      m->next[p] = um_next_of(m, nb[b]);
+      um_set_next(m, nb[b], p);
+    }
+    p = nx;
+  }
+  free(m->bkt); m->bkt = nb; m->n_bkt = n_new;
+}
+static int32_t um_find(const ko_um *m, uint32_t k) {
+  size_t b = k % m->n_bkt;
+  int32_t prev = m->bkt[b];
+  if (prev == KO_UM_NONE) return -1;
+  int32_t p = um_next_of(m, prev);
+  for (;;) {
+    if (m->key[p] == k) return p;
+    int32_t nx = m->next[p];
+    if (nx == KO_UM_NONE || m->key[nx] % m->n_bkt != b) return -1;
+    p = nx;
+  }
+}
+static int32_t um_get(ko_um *m, uint32_t k) { /* operator[]: find or insert a zero-initialised value */
+  int32_t f = um_find(m, k);
+  if (f >= 0) return f;
+  if (m->n + 1 > m->next_resize) { /* _M_need_rehash(n_bkt, n_elt, 1), max_load_factor 1 */
+    size_t min_bkts = m->n + 1;
+    if (!m->next_resize && min_bkts < 11) min_bkts = 11;
+    if (min_bkts >= m->n_bkt) {
+      size_t want = min_bkts + 1 > m->n_bkt * 2 ? min_bkts + 1 : m->n_bkt * 2;
+      um_rehash(m, um_next_bkt(m, want));
+    } else m->next_resize = m->n_bkt;
+  }
+  if (m->n == m->cap) {
+    m->cap = m->cap ? 2 * m->cap : 64;
+    m->key = (uint32_t *)realloc(m->key, m->cap * 4); m->cnt = (uint32_t *)realloc(m->cnt, m->cap * 4);
+    m->frac = (double *)realloc(m->frac, m->cap * 8); m->next = (int32_t *)realloc(m->next, m->cap * 4);
+  }
+  int32_t node = (int32_t)m->n++;
+  m->key[node] = k; m->cnt[node] = 0; m->frac[node] = 0.0;
+  size_t b = k % m->n_bkt;
+  if (m->bkt[b] != KO_UM_NONE) { /* _M_insert_bucket_begin */
+    m->next[node] = um_next_of(m, m->bkt[b]);
+    um_set_next(m, m->bkt[b], node);
+  } else {
+    m->next[node] = m->head; m->head = node;
+    if (m->next[node] != KO_UM_NONE) m->bkt[m->key[m->next[node]] % m->n_bkt] = node;
+    m->bkt[b] = KO_UM_BB;
+  }
+  return node;
+}
+/* iteration order of an unordered_map<uint32_t, T> after operator[] on keys[0..n) in that order */
+size_t ko_umap_order(const uint32_t *keys, size_t n, uint32_t *out) {
+  ko_um m; um_init(&m);
+  for (size_t i = 0; i < n; ++i) um_get(&m, keys[i]);
+  size_t j = 0;
+  for (int32_t p = m.head; p != KO_UM_NONE; p = m.next[p]) out[j++] = m.key[p];
+  um_free(&m);
+  return j;
+}
+
+/* uids: the DB values of the read's unambiguous k-mers in k-mer order (zeros are skipped: classify.cpp:941
+ * only counts hits); map: n_uid blocks {taxid, parent uid}.  A uid or parent beyond the map ends the walk
+ * (the reference reads past its file there). */
+uint32_t ko_resolve_uids3(const ko_tax *t, const uint32_t *uids, size_t n, const uint32_t *map, size_t n_uid) {
+  ko_um hits; um_init(&hits);
+  for (size_t i = 0; i < n; ++i)
+    if (uids[i]) { const int32_t q = um_get(&hits, uids[i]); ++hits.cnt[q]; } /* (um_get may move the arrays) */
+  if (hits.n == 0) { um_free(&hits); return 0; }
+  ko_um tc; um_init(&tc);
+  uint32_t *chain = NULL; size_t chain_cap = 0;
+  for (int32_t p = hits.head; p != KO_UM_NONE; p = hits.next[p]) {
+    size_t len = 0;
+    for (uint32_t u = hits.key[p]; u != 0 && u <= n_uid;) {
+      if (len == chain_cap) { chain_cap = chain_cap ? 2 * chain_cap : 16; chain = (uint32_t *)realloc(chain, chain_cap * 4); }
+      chain[len++] = map[2 * (size_t)(u - 1)];
+      u = map[2 * (size_t)(u - 1) + 1];
+      if (len > n_uid) break; /* a cycle in a corrupt map */
+    }
+    if (!len) continue;
+    const double frac = (double)hits.cnt[p] / (double)len;
+    for (size_t i = 0; i < len; ++i) {
+      int32_t q = um_get(&tc, chain[i]);
+      tc.frac[q] += frac;
+      tc.cnt[q] += hits.cnt[p];
+    }
+  }
+  free(chain);
+  uint32_t res = 0;
+  if (tc.n) {
+    uint32_t *best = (uint32_t *)calloc(tc.n, 4); size_t nb = 0;
+    uint32_t max_count = 0; double max_frac = 0;
+    for (int32_t p = tc.head; p != KO_UM_NONE; p = tc.next[p]) {
+      if (tc.cnt[p] == max_count) {
+        if (tc.frac[p] == max_frac) best[nb++] = tc.key[p];
+        else if (tc.frac[p] > max_frac) { max_frac = tc.frac[p]; nb = 0; best[nb++] = tc.key[p]; }
+      } else if (tc.cnt[p] > max_count) {
+        nb = 0; best[nb++] = tc.key[p]; max_count = tc.cnt[p]; max_frac = tc.frac[p];
+      }
+    }
+    res = best[0];
+    for (size_t i = 1; i < nb; ++i) res = ko_lca(t, res, best[i]);
+    free(best);
+  }
+  um_free(&hits); um_free(&tc);
+  return res;
+}
+
+/* the run's UID map (ko_run_set_uid_map): NULL = plain taxid database */
+typedef struct { const uint32_t *map; size_t n_uid; } ko_uidmap;
+
 static uint32_t classify_one(const ko_db *const *dbs, int n_dbs, const ko_tax *tax, const char *seq, size_t len,
                              int quick, uint32_t min_hits, uint32_t *taxa_out, uint8_t *ambig_out, size_t *n_out,
-                             uint32_t *hits_out, ko_cmap *counts, u32map *hit_counts) {
+                             uint32_t *hits_out, ko_cmap *counts, u32map *hit_counts, const ko_uidmap *um) {
   const int k = dbs[0]->k; /* classify.cpp:913: KrakenDatabases[0]->get_k(), all k equal (:199-208) */
   size_t n = 0;
   uint32_t taxon = 0, hits = 0;
   u32map_clear(hit_counts);
+  uint32_t *hit_seq = NULL; size_t n_hit_seq = 0; /* UID mode: the hits in k-mer order (insertion order of hit_counts) */
+  if (um && um->map && len >= (size_t)k) hit_seq = (uint32_t *)malloc((len - k + 1) * 4);
   if (len >= (size_t)k) { /* classify.cpp:913 */
     const uint64_t kmer_mask = ~0ULL >> (64 - 2 * k);
     const uint32_t mini_mask = ~0U >> (32 - k);
@@ -777,6 +945,7 @@ static uint32_t classify_one(const ko_db *const *dbs, int n_dbs, const ko_tax *t
         }
         if (taxon) {
           ++*u32map_get(hit_counts, taxon, NULL);
+          if (hit_seq) hit_seq[n_hit_seq++] = taxon;
           if (quick && ++hits >= min_hits) stop = 1; /* classify.cpp:943-944: break before push */
         }
       }
@@ -786,7 +955,10 @@ static uint32_t classify_one(const ko_db *const *dbs, int n_dbs, const ko_tax *t
     }
   }
   uint32_t call;
-  if (quick) call = hits >= min_hits ? taxon : 0; /* classify.cpp:962-963 */
+  if (um && um->map) { /* classify.cpp:953-960 (quick mode exits there) */
+    call = ko_resolve_uids3(tax, hit_seq, n_hit_seq, um->map, um->n_uid);
+    free(hit_seq);
+  } else if (quick) call = hits >= min_hits ? taxon : 0; /* classify.cpp:962-963 */
   else {
     size_t nh = hit_counts->n;
     uint32_t *ts = (uint32_t *)malloc((nh + 1) * 4), *cs = (uint32_t *)malloc((nh + 1) * 4);
@@ -807,7 +979,7 @@ uint32_t ko_classify_read(const ko_db *db, const ko_tax *tax, const char *seq, s
                           uint32_t *hits_out) {
   u32map hc; u32map_init(&hc, 64);
   uint32_t call = classify_one(&db, 1, tax, seq, len, quick, min_hits, taxa_out, ambig_out, n_out, hits_out,
-                               NULL, &hc);
+                               NULL, &hc, NULL);
   u32map_free(&hc);
   return call;
 }
@@ -834,6 +1006,7 @@ struct ko_run {
   uint64_t total_sequences, total_classified;
   /* sorted view */
   uint32_t *order; size_t order_n;
+  ko_uidmap uid; /* classify -I */
 };
 
 ko_run *ko_run_new(const ko_db *db, const ko_tax *tax, uint64_t work_unit_nt, int quick, uint32_t min_hits,
@@ -849,6 +1022,8 @@ int ko_run_add_db(ko_run *r, const ko_db *db) { /* a further -d/-i pair, searche
   r->dbs[r->n_dbs++] = db;
   return 0;
 }
+/* classify -I: the values of the (single) database are UIDs; map = the file's {taxid, parent uid} blocks */
+void ko_run_set_uid_map(ko_run *r, const uint32_t *map, size_t n_uid) { r->uid.map = map; r->uid.n_uid = n_uid; }
 void ko_run_free(ko_run *r) { if (!r) return; cmap_free(&r->global); free(r->order); free(r); }
 
 void ko_run_classify(ko_run *r, const char *seqs, const uint64_t *off, const uint32_t *len, size_t n_reads,
@@ -882,7 +1057,7 @@ void ko_run_classify(ko_run *r, const char *seqs, const uint64_t *off, const uin
         size_t n = 0; uint32_t h = 0;
         uint32_t call = classify_one(r->dbs, r->n_dbs, r->tax, seqs + off[j], len[j], r->quick, r->min_hits,
                                      taxa_flat ? taxa_flat + taxa_off[j] : NULL,
-                                     ambig_flat ? ambig_flat + taxa_off[j] : NULL, &n, &h, &local, &hc);
+                                     ambig_flat ? ambig_flat + taxa_off[j] : NULL, &n, &h, &local, &hc, &r->uid);
         if (calls) calls[j] = call;
         if (n_slots) n_slots[j] = (uint32_t)n;
         if (hits) hits[j] = h;

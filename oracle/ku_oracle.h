@@ -60,6 +60,11 @@ uint32_t ko_lca(const ko_tax *t, uint32_t a, uint32_t b);                  /* kr
 uint32_t ko_resolve_tree(const ko_tax *t, const uint32_t *taxa, const uint32_t *counts,
                          size_t n);                                         /* krakenutil.cpp:149-200 */
 
+/* ---- UID mapping (classify -I): resolve_uids3, uid_mapping.cpp:212-274, including the iteration order of the
+ * std::unordered_maps it walks (libstdc++).  uids = the read's non-zero DB values in k-mer order. */
+uint32_t ko_resolve_uids3(const ko_tax *t, const uint32_t *uids, size_t n, const uint32_t *map, size_t n_uid);
+size_t ko_umap_order(const uint32_t *keys, size_t n, uint32_t *out);
+
 /* ---- A13/A14/A15: HyperLogLog++ (p = 12 in classify) -------- */
 typedef struct ko_hll ko_hll;
 ko_hll *ko_hll_new(int p, int sparse);
@@ -94,6 +99,7 @@ typedef struct ko_run ko_run;
 ko_run *ko_run_new(const ko_db *db, const ko_tax *tax, uint64_t work_unit_nt, int quick,
                    uint32_t min_hits, int threads);
 int ko_run_add_db(ko_run *r, const ko_db *db); /* hierarchical multi-DB (classify.cpp:928-936); -1: k differs / too many */
+void ko_run_set_uid_map(ko_run *r, const uint32_t *map, size_t n_uid); /* classify -I (one database, no quick mode) */
 void ko_run_free(ko_run *r);
 /* Classify n_reads reads (read i = seqs[off[i] .. off[i]+len[i])) emulating
  * process_file's work-unit partition (classify.cpp:487-564).  Optional flat

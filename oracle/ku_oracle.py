@@ -83,6 +83,9 @@ def lib():
         "ko_run_report": (C.c_void_p, [C.c_void_p, C.c_char_p, C.c_char_p]),
         "ko_free": (None, [C.c_void_p]),
         "ko_set_hll_sparse": (None, [C.c_int]),
+        "ko_resolve_uids3": (C.c_uint32, [C.c_void_p, u32p, C.c_size_t, u32p, C.c_size_t]),
+        "ko_umap_order": (C.c_size_t, [u32p, C.c_size_t, u32p]),
+        "ko_run_set_uid_map": (None, [C.c_void_p, u32p, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -173,6 +176,13 @@ class Tax:
     def lca(self, a, b):
         return lib().ko_lca(self.h, a, b)
 
+    def resolve_uids(self, uids, uid_map):
+        """resolve_uids3 (uid_mapping.cpp:212-274): uids = a read's non-zero DB values in k-mer order, uid_map = uint32
+        [n, 2] {taxid, parent uid} blocks"""
+        u = np.ascontiguousarray(uids, dtype=np.uint32)
+        m = np.ascontiguousarray(uid_map, dtype=np.uint32).reshape(-1)
+        return lib().ko_resolve_uids3(self.h, _p(u, u32p), len(u), _p(m, u32p), len(m) // 2)
+
     def resolve(self, hits: dict):
         t = np.array(list(hits.keys()), dtype=np.uint32)
         c = np.array(list(hits.values()), dtype=np.uint32)
@@ -237,6 +247,11 @@ class Run:
             _lib.ko_run_free(self.h)
             self.h = None
 
+    def set_uid_map(self, uid_map):
+        """classify -I: the database's values are UIDs; uid_map = uint32 [n, 2] {taxid, parent uid} (the map file)"""
+        self._uid_map = np.ascontiguousarray(uid_map, dtype=np.uint32).reshape(-1)
+        lib().ko_run_set_uid_map(self.h, _p(self._uid_map, u32p), len(self._uid_map) // 2)
+
     def classify(self, seqs, want_taxa=True):
         buf, off, lens = pack_reads(seqs)
         return self.classify_packed(buf, off, lens, want_taxa)
@@ -272,6 +287,14 @@ class Run:
         s = C.string_at(p).decode()
         lib().ko_free(p)
         return s
+
+
+def umap_order(keys):
+    """iteration order of a libstdc++ std::unordered_map<uint32_t, T> after operator[] on `keys` in that order"""
+    k = np.ascontiguousarray(keys, dtype=np.uint32)
+    out = np.zeros(max(len(k), 1), dtype=np.uint32)
+    n = lib().ko_umap_order(_p(k, u32p), len(k), _p(out, u32p))
+    return out[:n]
 
 
 def set_hll_sparse(sparse: bool):

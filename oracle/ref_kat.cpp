@@ -16,6 +16,7 @@
 //   kraken::lca / resolve_tree                  krakenutil.cpp:90-118,149-200
 //   murmurhash3_finalizer                       hyperloglogplus.cpp:830-838
 //   HyperLogLogPlusMinus<uint64_t>              hyperloglogplus.cpp:485-801
+//   kraken::resolve_uids3 / get_taxids_for_uid  uid_mapping.cpp:212-311
 //
 // Protocol (one command per line, answers on one line each unless noted):
 //   K <k>                      set k (once); builds an in-memory JFLISTDN header
@@ -38,12 +39,20 @@
 //   HMERGE <dst> <src>
 //   HCARD <id>                 -> "ertl heule flajolet nobs sparse listsize"
 //   HDUMP <id>                 -> "S v v v ..." sorted encoded list, or "D r r r ..." registers
+//   UIDMAP t:p t:p ...         the UID-to-taxid map file as set_lcas -I writes it: block i = {taxid, parent uid} of uid i+1
+//   UMORDER k k k ...          -> the keys in the iteration order of a std::unordered_map<uint32_t, uint32_t> they were
+//                              put into (operator[]) in the order given
+//   UIDTAXIDS <uid>            -> the taxids of the uid (get_taxids_for_uid)
+//   UIDRESOLVE u u u ...       the non-zero DB values (UIDs) of a read's k-mers in k-mer order: hit_counts[u]++ in that
+//                              order into a std::unordered_map as classify_sequence does (classify.cpp:939-942), then
+//                              resolve_uids3 with the PARENT map -> taxid
 #define private public   // harness only: dump sketch state (M / sparseList)
 #include "hyperloglogplus.hpp"
 #undef private
 #include "krakendb.hpp"
 #include "krakenutil.hpp"
 #include "quickfile.hpp"
+#include "uid_mapping.hpp"
 #include <algorithm>
 #include <cinttypes>
 #include <iostream>
@@ -62,6 +71,7 @@ static KrakenDBIndex *real_idx = NULL;
 static QuickFile kdb_file, idx_file;
 static unordered_map<uint32_t, uint32_t> parent_map;
 static map<int, HyperLogLogPlusMinus<uint64_t> *> sketches;
+static vector<uint32_t> uid_blob;  // {taxid, parent uid} pairs
 
 static uint64_t hex64(const string &s) { return strtoull(s.c_str(), NULL, 16); }
 
@@ -194,6 +204,33 @@ int main() {
         for (auto x : h->M) cout << " " << (int)x;
         cout << "\n";
       }
+    } else if (cmd == "UIDMAP") {
+      uid_blob.clear();
+      string tok;
+      while (ss >> tok) {
+        size_t c = tok.find(':');
+        uid_blob.push_back((uint32_t)strtoul(tok.substr(0, c).c_str(), NULL, 10));
+        uid_blob.push_back((uint32_t)strtoul(tok.substr(c + 1).c_str(), NULL, 10));
+      }
+      cout << "ok\n";
+    } else if (cmd == "UMORDER") {
+      unordered_map<uint32_t, uint32_t> m;
+      uint32_t u;
+      while (ss >> u) m[u]++;
+      bool first = true;
+      for (auto it = m.begin(); it != m.end(); ++it) { cout << (first ? "" : " ") << it->first; first = false; }
+      cout << "\n";
+    } else if (cmd == "UIDTAXIDS") {
+      uint32_t u; ss >> u;
+      vector<uint32_t> t = get_taxids_for_uid(u, (const char *)uid_blob.data());
+      for (size_t i = 0; i < t.size(); ++i) cout << (i ? " " : "") << t[i];
+      cout << "\n";
+    } else if (cmd == "UIDRESOLVE") {
+      unordered_map<uint32_t, uint32_t> hits;
+      unordered_map<uint32_t, vector<uint32_t> > dict;
+      uint32_t u;
+      while (ss >> u) hits[u]++;
+      cout << resolve_uids3(hits, parent_map, dict, (const char *)uid_blob.data(), uid_blob.size() * 4) << "\n";
     } else {
       cout << "ERR unknown command " << cmd << "\n";
     }

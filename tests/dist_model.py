@@ -1,9 +1,10 @@
 """torch.distributed model of the multi-GPU exchange (backend "gloo" in the CPU tests).
 
-The product path is the C++ driver krakenuniq_amd/csrc/ku_mgpu.cpp (RCCL through the C ABI: ku_mgpu_*), which bench.py
-and the classify executable use.  This module states the same exchange protocol on plain torch tensors so that the
-world-size-2 CPU tests (tests/test_dist_gloo.py) can check it -- slice plan, "non-zero wins" max-merge, owner-computes
-accounting, end-of-run state merge -- without a GPU; bench.py also takes its shard-bound helper from here.
+TEST INFRASTRUCTURE (it lives under tests/ for that reason).  The product path is the C++ driver
+krakenuniq_amd/csrc/ku_mgpu.cpp (RCCL through the C ABI: ku_mgpu_*), which bench.py and the classify executable use.
+This module states the same exchange protocol on plain torch tensors so that the world-size-2 CPU tests
+(tests/test_dist_gloo.py) can check it -- slice plan, "non-zero wins" max-merge, owner-computes accounting, end-of-run
+state merge -- without a GPU.
 
 The reference shards its database only *in time* (--preload-size chunk mode,
 src/krakendb.cpp:411-526, src/classify.cpp:566-791) and merges per-k-mer taxa with
@@ -109,14 +110,3 @@ def reduce_state(registers_u8: torch.Tensor, n_kmers_i64: torch.Tensor, n_reads_
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return r, k, n
-
-
-def quantile_bin_bounds(sample_bins: torch.Tensor, n_bins: int, world_size: int) -> np.ndarray:
-    """shard bounds from a sample of bin keys (every rank draws the same sample -> same plan)"""
-    b = np.zeros(world_size + 1, dtype=np.uint64)
-    b[-1] = n_bins
-    if world_size > 1:
-        q = torch.quantile(sample_bins.to(torch.float64), torch.linspace(0, 1, world_size + 1,
-                                                                         dtype=torch.float64)[1:-1].to(sample_bins.device))
-        b[1:-1] = np.ceil(q.cpu().numpy()).astype(np.uint64)
-    return b

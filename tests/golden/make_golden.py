@@ -22,6 +22,8 @@ Fixtures:
   f4/   paired FASTQs -> read_merger.pl -> merged.fa + outputs
   f7/   legacy KRAKIDX (type 1) index variant of f1 + outputs
   f9/   set_lcas: library FASTA + seqid map -> the reference's database.kdb / counts
+  f11/  UID mapping: the reference's set_lcas -I database + map, its classify -I output and report; kat_uid.json:
+        known answers of resolve_uids3 and of std::unordered_map's iteration order
   f8/   second database + reads for hierarchical multi-database runs (both orders, quick mode)
   f10/  CRLF inputs (FASTQ, one-line-per-sequence FASTA, multi-line FASTA) of f1 reads + outputs
   kat.json  per-function known-answer vectors from ref_kat
@@ -431,9 +433,106 @@ def make_kat(f1):
         json.dump(kat, f, separators=(",", ":"))
 
 
+def make_f11(f1, genomes):
+    """UID mapping (classify -I): the reference's set_lcas -I turns f1's k-mers (values zeroed) into a UID
+    database -- every k-mer's value names the SET of taxids whose library sequences hold it, uid_to_taxid.map stores the
+    sets as {taxid, parent uid} blocks (src/uid_mapping.cpp:32-91) -- and the reference's classify -I resolves reads on it
+    (resolve_uids3, :212-274).  The library makes sets of one, two and three taxids."""
+    d = os.path.join(HERE, "f11")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    kmers, vals, off, k, nt, _ = synth.read_db(f1)
+    synth.write_db(d, kmers, np.zeros_like(vals), off, k, nt)
+    os.rename(f"{d}/database.kdb", f"{d}/database0.kdb")
+    os.remove(f"{d}/database.idx")
+    a = synth.codes_to_ascii
+    g4, g5, g6, gp = a(genomes[4]), a(genomes[5]), a(genomes[6]), a(genomes[1000000001])
+    recs = [(b"seqA", g4), (b"seqB", g5), (b"seqC", g6), (b"seqP", gp), (b"seqD part of the first genome under another taxid", g4[500:1500]),
+            (b"seqE part of the second genome under the genus", g5[1200:2200])]
+    with open(f"{d}/library.fa", "wb") as f:
+        for h, sq in recs:
+            f.write(b">" + h + b"\n")
+            for i in range(0, len(sq), 70):
+                f.write(sq[i:i + 70] + b"\n")
+    with open(f"{d}/seqid2taxid.map", "w") as f:
+        f.write("seqA\t4\nseqB\t5\nseqC\t6\nseqP\t1000000001\nseqD\t6\nseqE\t2\n")
+    run([os.path.join(REF, "set_lcas"), "-M", "-x", "-d", f"{d}/database0.kdb", "-I", f"{d}/uid_to_taxid.map",
+         "-o", f"{d}/uid_database.kdb", "-i", f"{f1}/database.idx", "-b", f"{f1}/taxDB", "-m", f"{d}/seqid2taxid.map",
+         "-F", f"{d}/library.fa", "-c", f"{d}/uid_database.kdb.counts"])
+    os.remove(f"{d}/database0.kdb")
+    for fn in ("library.fa", "seqid2taxid.map"):
+        os.remove(f"{d}/{fn}")  # inputs of the reference's build step only
+    db = ["-d", f"{d}/uid_database.kdb", "-i", f"{f1}/database.idx", "-a", f"{f1}/taxDB", "-I", f"{d}/uid_to_taxid.map"]
+    for tag, extra in (("", []), ("_u1000", ["-u", "1000"])):
+        rep = f"{d}/report_uid{tag}.tsv"
+        if os.path.exists(rep):
+            os.remove(rep)
+        run([os.path.join(REF, "classify")] + db + extra + ["-o", f"{d}/out_uid{tag}.tsv", "-r", rep, f"{f1}/reads.fq"])
+    if os.path.exists(f"{d}/out_uid_u1000.tsv"):
+        assert open(f"{d}/out_uid_u1000.tsv").read() == open(f"{d}/out_uid.tsv").read()
+        os.remove(f"{d}/out_uid_u1000.tsv")
+    m = np.fromfile(f"{d}/uid_to_taxid.map", dtype="<u4").reshape(-1, 2)
+    assert len(m) > 4 and (m[:, 1] != 0).any(), "the fixture must hold UIDs of several taxids"
+    return d
+
+
+def make_kat_uid():
+    """known answers of resolve_uids3 and of the container order it depends on (oracle/ref_kat.cpp UIDRESOLVE / UMORDER)"""
+    rng = np.random.default_rng(11)
+    h = Kat()
+    h.cmd(f"K {K}")
+    ids = sorted(set(int(x) for x in rng.integers(2, 3000, 50)))
+    parent = {1: 1}
+    for i, t in enumerate(ids):
+        parent[t] = 1 if i < 3 else ids[int(rng.integers(0, i))]
+    parent[1000000005] = ids[7]
+    parent[7001] = 9999  # orphan
+    pm = {t: (0 if (p == t or p not in parent) else p) for t, p in parent.items()}
+    h.cmd("PARENT " + " ".join(f"{a}:{b}" for a, b in pm.items()))
+    allids = list(pm.keys()) + [4242]  # one taxid the taxonomy does not know
+    kat = {"parent_map": {str(a): b for a, b in pm.items()}, "order": [], "maps": []}
+    for n in (1, 5, 13, 14, 29, 30, 59, 60, 127, 128, 300, 1200):
+        for mode in range(3):
+            if mode == 0:
+                keys = rng.integers(1, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+            elif mode == 1:
+                keys = rng.integers(1, max(n // 2, 3), size=n).astype(np.uint32)
+            else:
+                keys = (rng.integers(1, 200, size=n) * 13).astype(np.uint32)
+            out = h.cmd("UMORDER " + " ".join(map(str, keys.tolist())))[0]
+            kat["order"].append({"keys": keys.tolist(), "order": [int(x) for x in out.split()]})
+    for n_uid in (6, 40, 400):
+        blocks = []
+        for u in range(1, n_uid + 1):
+            par = 0 if (u == 1 or rng.random() < 0.3) else int(rng.integers(1, u))
+            blocks.append([allids[int(rng.integers(0, len(allids)))], par])
+        h.cmd("UIDMAP " + " ".join(f"{t}:{p}" for t, p in blocks))
+        cases = []
+        for c in range(120):
+            n = int(rng.choice([1, 2, 3, 4, 6, 10, 30, 120, 400]))
+            pool = rng.integers(1, n_uid + 1, size=int(rng.integers(1, min(n, n_uid) + 1)))
+            uids = pool[rng.integers(0, len(pool), size=n)].astype(np.uint32)
+            call = int(h.cmd("UIDRESOLVE " + " ".join(map(str, uids.tolist())))[0])
+            cases.append({"uids": uids.tolist(), "call": call})
+        chains = {str(u): [int(x) for x in h.cmd(f"UIDTAXIDS {u}")[0].split()] for u in range(1, min(n_uid, 40) + 1)}
+        kat["maps"].append({"blocks": blocks, "chains": chains, "cases": cases})
+    h.p.stdin.close()
+    with open(os.path.join(HERE, "kat_uid.json"), "w") as f:
+        json.dump(kat, f, separators=(",", ":"))
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "classify")):
         raise SystemExit("build the reference first: make -C oracle ref")
+    if sys.argv[1:] == ["f11"]:  # the UID-mapping fixture and known answers without regenerating the others
+        rng = np.random.default_rng(7)
+        g4 = synth.procedural_genome(7, 4, 3000)
+        g5 = synth.mutate(g4, 0.03, rng)
+        g6 = synth.procedural_genome(7, 6, 3000)
+        gp = np.concatenate([g6[2000:2300], synth.procedural_genome(7, 99, 300)])
+        make_f11(os.path.join(HERE, "f1"), {4: g4, 5: g5, 6: g6, 1000000001: gp})
+        make_kat_uid()
+        return
     if sys.argv[1:] == ["f9"]:  # add the set_lcas fixture without regenerating the others
         rng = np.random.default_rng(7)
         g4 = synth.procedural_genome(7, 4, 3000)
@@ -456,7 +555,9 @@ def main():
     make_f4(f1, genomes)
     make_f7(f1)
     make_f10(f1)
+    make_f11(f1, genomes)
     make_kat(f1)
+    make_kat_uid()
     # count_unique known answer (HLL p=12 on the reads' k-mers)
     r = run([os.path.join(REF, "count_unique"), "-k", "31", "-p", "12"], stdin=open(f"{HERE}/f2/edge.fa", "rb"))
     open(os.path.join(HERE, "count_unique_edge.txt"), "wb").write(r.stdout)

@@ -395,3 +395,41 @@ def test_report_rows_formats_caller_side_roll_ups(golden, f1):
     assert got == open(f"{d}/report.tsv").read()
     with pytest.raises(capi.KuError):  # one element per entry
         capi.report_rows(tax, present[:-1], c_reads[:-1], t_reads[:-1], c_kmers[:-1], c_uniq[:-1])
+
+
+def test_resolve_uids_matches_the_reference_known_answers(golden):
+    """ku_resolve_uids (host C++: resolve_uids3 with the reference's containers) on the known answers of the reference's
+    own function (tests/golden/kat_uid.json), from run-length encoded codes as the device delivers them; one thread and a
+    team"""
+    import json
+    kat = json.load(open(os.path.join(golden, "kat_uid.json")))
+    pm = {int(a): b for a, b in kat["parent_map"].items()}
+    ids = np.array(sorted(pm), dtype=np.uint32)
+    par = np.array([pm[int(t)] if pm[int(t)] else int(t) for t in ids], dtype=np.uint32)
+    par[ids == 1] = 1
+    tax = capi.Tax(ids=ids, parents=par)
+    K = 31
+    for m in kat["maps"]:
+        umap = capi.UidMap(blocks=np.array(m["blocks"], dtype=np.uint32))
+        assert len(umap) == len(m["blocks"])
+        runs, roff, rcnt, lens, want = [], [], [], [], []
+        for rep in range(40):  # 4800 reads: the threaded path
+            for case in m["cases"]:
+                u = case["uids"] if rep % 2 == 0 else [0] + case["uids"] + [0xFFFFFFFF, 0]  # misses / ambiguous k-mers around
+                roff.append(len(runs))
+                n = 0
+                for i, x in enumerate(u):
+                    if i == 0 or x != u[i - 1]:
+                        runs.append((x, i))
+                        n += 1
+                rcnt.append(n)
+                lens.append(len(u) + K - 1)
+                want.append(case["call"])
+        rle = {"runs": np.array(runs, dtype=np.uint32), "run_off": np.array(roff, dtype=np.uint64), "run_cnt": np.array(rcnt, dtype=np.uint32)}
+        for thr in (1, 4):
+            got = capi.resolve_uids(tax, umap, rle, lens, K, n_threads=thr)
+            assert got.tolist() == want
+        bad = {"runs": np.array([(len(m["blocks"]) + 5, 0)], dtype=np.uint32), "run_off": np.zeros(1, np.uint64), "run_cnt": np.ones(1, np.uint32)}
+        with pytest.raises(capi.KuError) as e:
+            capi.resolve_uids(tax, umap, bad, [K], K)
+        assert e.value.status == -2

@@ -9,6 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "krakenuniq_amd", "bin", "classify")
 F1 = os.path.join(ROOT, "tests", "golden", "f1")
+F11 = os.path.join(ROOT, "tests", "golden", "f11")
 DB = ["-d", f"{F1}/database.kdb", "-i", f"{F1}/database.idx", "-a", f"{F1}/taxDB"]
 
 
@@ -34,7 +35,11 @@ def test_usage_and_exit_codes():
     assert r.returncode == 66  # EX_NOINPUT
     r = run(["-d", f"{F1}/taxDB", "-i", f"{F1}/database.idx", "-a", f"{F1}/taxDB", "r.fq"])
     assert r.returncode == 65  # EX_DATAERR: not a JFLISTDN file
-    assert run(DB + ["-I", "uid.map", "r.fq"]).returncode == 70
+    assert run(DB + ["-I", "/nonexistent/uid.map", "r.fq"]).returncode == 66  # UID map: EX_NOINPUT
+    r = run(DB + ["-I", f"{F11}/uid_to_taxid.map", "-q", "r.fq"])
+    assert r.returncode == 1 and b"Quick mode not available when mapping UIDs" in r.stderr  # classify.cpp:954-956
+    r = run(DB + ["-d", f"{F1}/database.kdb", "-i", f"{F1}/database.idx", "-I", f"{F11}/uid_to_taxid.map", "r.fq"])
+    assert r.returncode == 1 and b"Cannot use more than one database with UID mapping" in r.stderr  # classify.cpp:158-160
     assert run(DB + ["-d", "second.kdb", "r.fq"]).returncode == 64  # a -d without its -i
 
 
@@ -233,3 +238,22 @@ def test_pipe_inputs(tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     want = open(f"{F1}/out.tsv", "rb").read()
     assert r.stdout == want + want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unit,rep", [(None, "report_uid.tsv"), ("1000", "report_uid_u1000.tsv")])
+def test_uid_mapping_matches_reference(tmp_path, unit, rep):
+    """classify -I on the UID database the reference's set_lcas -I built (tests/golden/f11): the Kraken file (per-k-mer
+    codes are UIDs, calls come from resolve_uids3) and the report of the reference's classify -I, row for row"""
+    d = tmp_path / "db"
+    d.mkdir()
+    for fn, src in (("uid_database.kdb", F11), ("uid_database.kdb.counts", F11), ("uid_to_taxid.map", F11), ("database.idx", F1), ("taxDB", F1)):
+        (d / fn).write_bytes(open(f"{src}/{fn}", "rb").read())
+    out, report = tmp_path / "out.tsv", tmp_path / "report.tsv"
+    args = ["-d", f"{d}/uid_database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB", "-I", f"{d}/uid_to_taxid.map", "-t", "4",
+            "-o", str(out), "-r", str(report)] + (["-u", unit] if unit else []) + [f"{F1}/reads.fq"]
+    r = run(args, env=dict(os.environ, KU_BATCH_NT="65536"))  # several device batches
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == open(f"{F11}/out_uid.tsv", "rb").read()
+    assert rows(report.read_text()) == rows(open(f"{F11}/{rep}").read())
+    assert b"Reading UID mapping file" in r.stderr

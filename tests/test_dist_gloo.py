@@ -1,4 +1,4 @@
-"""world_size-2 `gloo` test of the multi-GPU orchestration (krakenuniq_amd/dist.py) on CPU.
+"""world_size-2 `gloo` test of the multi-GPU orchestration (tests/dist_model.py) on CPU.
 
 The collectives are exercised with the CPU oracle standing in for the kernels: rank r produces exactly what
 ku_lookup_device would produce for minimizer shard r (slots of the k-mers whose bin it owns, 0 elsewhere, -1
@@ -13,8 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from krakenuniq_amd import capi, synth
-from krakenuniq_amd import dist as kdist
+from krakenuniq_amd import capi, synth, synth_torch
+import dist_model as kdist
 from oracle import ku_oracle as ko
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f1")
@@ -149,5 +149,5 @@ def test_read_slice_and_bounds():
             lo, hi = kdist.read_slice(n, r, ws)
             cover += list(range(lo, hi))
         assert cover == list(range(n))
-    b = kdist.quantile_bin_bounds(torch.arange(0, 1000), 4 ** 7, 4)
+    b = synth_torch.quantile_bin_bounds(torch.arange(0, 1000), 4 ** 7, 4)
     assert b[0] == 0 and b[-1] == 4 ** 7 and (np.diff(b.astype(np.int64)) > 0).all()
