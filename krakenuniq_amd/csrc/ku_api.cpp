@@ -6,6 +6,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -419,6 +420,10 @@ struct ku_ctx {
   hipStream_t h2d_stream = nullptr;
   std::vector<hipEvent_t> seg_events;
   uint32_t *d_scalar = nullptr;
+  // ku_ctx_count_taxons of the store it was computed for (identified by its buffers)
+  std::vector<unsigned long long> count_cache;
+  const void *count_cache_store = nullptr, *count_cache_pairs = nullptr;
+  uint64_t count_cache_lines = 0;
   uint64_t n_runs = 0;  // runs of the last ku_classify_batch_rle, still in b_runs
   // exact distinct counting (classifyExact): one global set of canonical k-mers + first-insertion counters per slot
   unsigned long long *d_exact_set = nullptr, *d_exact_unique = nullptr;
@@ -483,13 +488,19 @@ extern "C" int ku_ctx_create(int device, ku_ctx **out) {
   return KU_OK;
 }
 
-static void store_free(DbStore &d) {
+static void store_free(DbStore &d) {  // (callers that free a context's store also drop its count_taxons cache: ctx_drop_count_cache)
   if (d.d_table) (void)hipFree(d.d_table);
   if (d.db_owned && d.d_pairs) (void)hipFree(d.d_pairs);
   if (d.offsets_owned && d.d_offsets) (void)hipFree(d.d_offsets);
   d = DbStore{};
 }
+static void ctx_drop_count_cache(ku_ctx *ctx) {
+  ctx->count_cache.clear();
+  ctx->count_cache_store = ctx->count_cache_pairs = nullptr;
+  ctx->count_cache_lines = 0;
+}
 static void ctx_free_db(ku_ctx *ctx) {
+  ctx_drop_count_cache(ctx);
   if (ctx->pf.valid) store_free(ctx->pf.store);
   ctx->pf.valid = false;
   store_free(ctx->m);
@@ -912,6 +923,20 @@ extern "C" int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *
   const DbStore &d = db_index ? ctx->extra[db_index - 1] : ctx->m;
   KU_TRY(ctx_activate(ctx));
   const uint32_t ns = ctx->tax.n_slots;
+  // callers ask twice (sizes, then values): the table is scanned once per resident store
+  if (ctx->count_cache_store == (const void *)d.d_table && ctx->count_cache_pairs == (const void *)d.d_pairs && ctx->count_cache.size() == ns &&
+      ctx->count_cache_lines == d.db.n_lines && d.db.n_lines + d.db.n_pairs) {
+    const std::vector<unsigned long long> &h = ctx->count_cache;
+    uint64_t m = 0;
+    for (uint32_t s = 0; s < ns; ++s) if (h[s]) ++m;
+    if (taxids && counts) {
+      if (*n < m) return fail(KU_EINVAL, "output arrays too small");
+      uint64_t j = 0;
+      for (uint32_t s = 0; s < ns; ++s) if (h[s]) { taxids[j] = ctx->h_slot_taxid[s]; counts[j] = h[s]; ++j; }
+    }
+    *n = m;
+    return KU_OK;
+  }
   unsigned long long *d_c = nullptr;
   HIP_TRY(hipMalloc((void **)&d_c, (size_t)ns * 8));
   std::vector<unsigned long long> h(ns);
@@ -924,6 +949,10 @@ extern "C" int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *
   if (st == KU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = KU_EHIP;
   (void)hipFree(d_c);
   if (st != KU_OK) return fail(st, "count_taxons kernel failed");
+  ctx->count_cache = h;
+  ctx->count_cache_store = d.d_table;
+  ctx->count_cache_pairs = d.d_pairs;
+  ctx->count_cache_lines = d.db.n_lines;
   uint64_t m = 0;
   for (uint32_t s = 0; s < ns; ++s) if (h[s]) ++m;
   if (taxids && counts) {
@@ -1739,6 +1768,7 @@ extern "C" int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, 
   if (!ctx->extra.empty()) return fail(KU_EUNSUP, "chunked runs use one database (as the reference's: classify.cpp:639)");
   if (db->info.k != ctx->m.db.k) return fail(KU_EINVAL, "ku_ctx_swap_shard: k differs from the resident shard's");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx_drop_count_cache(ctx);
   if (ctx->pf.valid && ctx->pf.db == db && ctx->pf.bin_lo == bin_lo && ctx->pf.bin_hi == bin_hi) {
     // the chunk was prefetched (ku_ctx_prefetch_shard): it only has to change places with the resident one
     store_free(ctx->m);
@@ -1929,6 +1959,17 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
   KU_TRY(ctx_activate(ctx));
   const size_t ns = ctx->tax.n_slots, nn = ctx->tax.n_nodes, nt = tax->ids.size();
   const bool exact = ctx->d_exact_unique != nullptr, sparse = ctx->sp.on && !exact;
+  // KU_REPORT_TIMES=1: where the call spends its time, on stderr
+  const bool times = getenv("KU_REPORT_TIMES") != nullptr;
+  auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+  double t_last = now();
+  auto lap = [&](const char *what) {
+    if (!times) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    const double t = now();
+    fprintf(stderr, "ku_ctx_report: %-28s %8.1f ms\n", what, (t - t_last) * 1e3);
+    t_last = t;
+  };
   // the run-wide (slot, encoding) set of the sparse sketches is read where it lies (no compacted copy): the end of the run
   // closes the last, partial work unit (classify.cpp:522-523)
   uint64_t n_pairs = 0;
@@ -1945,6 +1986,7 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
     if (err) return fail(KU_ENOMEM, "sparse-mode emulation: a device table overflowed");
     for (size_t i = 0; i < ns; ++i) slot_sparse[i] = dense[i] ? 0 : 1;
     n_pairs = total;  // entries of the set (an upper bound of the sparse slots' entries)
+    lap("close the last work unit");
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   std::vector<uint64_t> nk(ns), nr(nn), uq;
@@ -2008,7 +2050,9 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
     if (st == KU_OK) st = tmp.put(&d_dense, clade_dense);
     if (st == KU_OK) st = tmp.zeros(&d_hist, (size_t)n_clades * KU_ROLLUP_BINS);
     if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the clade roll-up");
+    lap("clade lists (host)");
     KU_TRY(ku_launch_rollup_dense(ctx->cnt.registers, d_moff, d_mslot, d_dense, n_clades, d_hist, ctx->stream));
+    lap("dense roll-up");
     if (sparse && n_pairs) {
       // all-sparse clades per slot (its root path up to the first clade with a dense member: density is inherited upwards)
       std::vector<uint32_t> s_off(ns + 1, 0), s_clade;
@@ -2028,17 +2072,19 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       std::vector<unsigned long long> per_slot(ns);
       HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 8, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      lap("entries per slot");
       // a clade with one member is that member's own set (distinct already): no union set, histogram only
       std::vector<uint8_t> clade_single(n_clades, 0);
       for (uint32_t c = 0; c < n_clades; ++c) clade_single[c] = m_off[c + 1] - m_off[c] == 1 ? 1 : 0;
-      uint64_t inserts = 0;  // upper bound of the union sets' entries: every entry in every clade with several members
       std::vector<uint64_t> clade_pairs(n_clades, 0);  // entries each clade's histogram may receive
-      for (size_t s = 0; s < ns; ++s) {
-        for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) {
-          clade_pairs[s_clade[j]] += per_slot[s];
-          if (!clade_single[s_clade[j]]) inserts += per_slot[s];
-        }
-      }
+      for (size_t s = 0; s < ns; ++s)
+        for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) clade_pairs[s_clade[j]] += per_slot[s];
+      // upper bound of the union sets' entries: a clade with several members holds at most what its members offer, and at
+      // most every encoding there is (2^25 indices; the 2^12 of them whose low 13 bits are zero come with up to 40 ranks)
+      const uint64_t enc_space = (1ull << 25) + (1ull << 12) * 40;
+      uint64_t inserts = 0;
+      for (uint32_t c = 0; c < n_clades; ++c)
+        if (!clade_single[c]) inserts += std::min(clade_pairs[c], enc_space);
       // the busiest clades (the ones near the root) count in LDS
       std::vector<uint32_t> hot_clades(n_clades);
       for (uint32_t c = 0; c < n_clades; ++c) hot_clades[c] = c;
@@ -2050,22 +2096,24 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       for (uint32_t h = 0; h < n_hot; ++h) clade_hot[hot_clades[h]] = (uint16_t)h;
       uint16_t *d_chot = nullptr;
       uint32_t *d_hotc = nullptr;
-      uint64_t cells = 1024;
-      while (cells < 2 * inserts) cells <<= 1;
+      const uint64_t cells = std::max<uint64_t>(1024, inserts + inserts / 2);  // load <= 2/3
       st = tmp.put(&d_soff, s_off);
       if (st == KU_OK) st = tmp.put(&d_sclade, s_clade);
       if (st == KU_OK) st = tmp.zeros(&d_err, 1);
       if (st == KU_OK) st = tmp.put(&d_chot, clade_hot);
       if (st == KU_OK) st = tmp.put(&d_hotc, hot_clades);
       if (st == KU_OK) st = tmp.put(&d_single, clade_single);
+      lap("union plan (host)");
       if (st == KU_OK) st = tmp.zeros(&d_set, cells);
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
-      KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_single, d_chot, d_hotc, n_hot, d_set, cells - 1,
+      lap("union set allocated + cleared");
+      KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_single, d_chot, d_hotc, n_hot, d_set, cells,
                                      d_hist, d_err, ctx->n_cu, ctx->stream));
       uint32_t err = 0;
       HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       if (err) return fail(KU_EHIP, "ku_ctx_report: the sparse-union set overflowed");
+      lap("sparse roll-up");
     }
     std::vector<uint32_t> hist((size_t)n_clades * KU_ROLLUP_BINS);
     HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2078,8 +2126,11 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       c_uniq[row] = has_members ? ku_hll_estimate_hist(hist.data() + (size_t)c * KU_ROLLUP_BINS, sparse && !clade_dense[c], c_kmers[row]) : 0;
     }
   }
-  return ku_report_rows(tax, counts_paths, n_paths, present.data(), c_reads.data(), t_reads.data(), c_kmers.data(), c_uniq.data(), nt,
-                        out, out_len);
+  lap("estimates (host)");
+  const int rst = ku_report_rows(tax, counts_paths, n_paths, present.data(), c_reads.data(), t_reads.data(), c_kmers.data(), c_uniq.data(), nt,
+                                 out, out_len);
+  lap("report text");
+  return rst;
 }
 
 extern "C" int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_register_bytes,

@@ -94,7 +94,7 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 #define KU_ROLLUP_HOT 48  // clades whose histogram is pre-aggregated in LDS
 int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
                             const uint32_t *d_slot_clade, const uint8_t *d_clade_single, const uint16_t *d_clade_hot,
-                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
+                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t set_cells, uint32_t *d_hist,
                             uint32_t *d_err, int n_cu, hipStream_t stream);
 int ku_launch_replace_calls(const uint32_t *d_old, const uint32_t *d_new, uint64_t n, const uint32_t *d_node_taxid, uint32_t n_nodes,
                             unsigned long long *d_n_reads, unsigned long long *d_dropped, hipStream_t stream);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
                                                                 const uint8_t *__restrict__ clade_single,
                                                                 const uint16_t *__restrict__ clade_hot,
                                                                 const uint32_t *__restrict__ hot_clades, uint32_t n_hot,
-                                                                unsigned long long *set, uint64_t mask,
+                                                                unsigned long long *set, uint64_t set_cells,
                                                                 uint32_t *hist, uint32_t *err) {
   __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
   for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
@@ -96,12 +96,15 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
       bool fresh = true;
       if (!clade_single[c]) {
         const unsigned long long key = ((unsigned long long)(c + 1) << 32) | enc;
-        uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 20;
+        // any table size (not only powers of two: the set is sized for a load of 0.7, it can take tens of GB): the
+        // hash's high half scaled to [0, set_cells)
+        uint64_t h = __umul64hi(key * 0x9E3779B97F4A7C15ull, set_cells);
         bool done = false;
-        for (uint32_t probe = 0; probe < 4096 && !done; ++probe, ++h) {
-          const unsigned long long old = atomicCAS(&set[h & mask], 0ull, key);
+        for (uint32_t probe = 0; probe < 8192 && !done; ++probe) {
+          const unsigned long long old = atomicCAS(&set[h], 0ull, key);
           if (old == 0ull) done = true;
           else if (old == key) { done = true; fresh = false; }
+          h = h + 1 == set_cells ? 0 : h + 1;
         }
         if (!done) { atomicOr(err, 1u); fresh = false; }
       }
@@ -207,13 +210,13 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 
 int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
                             const uint32_t *d_slot_clade, const uint8_t *d_clade_single, const uint16_t *d_clade_hot,
-                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t mask, uint32_t *d_hist,
+                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t set_cells, uint32_t *d_hist,
                             uint32_t *d_err, int n_cu, hipStream_t stream) {
   if (!g_cells) return KU_OK;
   const uint64_t want = (g_cells + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
   ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_slot_off, d_slot_clade, d_clade_single, d_clade_hot,
-                                                       d_hot_clades, n_hot, d_set, mask, d_hist, d_err);
+                                                       d_hot_clades, n_hot, d_set, set_cells, d_hist, d_err);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
