@@ -405,6 +405,22 @@ int ku_mgpu_uses_rccl(const ku_mgpu *m);
 /* shard plan (ku_db_shard_plan over the world) + upload of every local rank's range + taxonomy with the slot table of
  * the whole database (the ranks' distinct values are all-gathered); KU_MGPU_REPLICAS: the whole database everywhere */
 int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax);
+/* several databases searched in order per k-mer (classify -d A -d B, classify.cpp:928-936): replicas only -- with the
+ * first database in shards a later one could not tell that another rank had found the k-mer (the reference's own chunk
+ * mode searches the first database only, classify.cpp:639); KU_EUNSUP otherwise */
+int ku_mgpu_load_dbs(ku_mgpu *m, const ku_db *const *dbs, uint32_t n_dbs, const ku_tax *tax);
+/* The report modes of one context, over the group (single-process groups; call after the load):
+ *  - HyperLogLog++ sparse-mode emulation (ku_ctx_enable_sparse): host batches are cut at WORK UNIT boundaries, every rank
+ *    runs the emulation on whole units (replicas: the fused kernel's fast path; shards: on the merged per-k-mer slots of
+ *    its slice), the unit that is still open when a batch ends continues on rank 0 with the next batch;
+ *    ku_mgpu_reduce_state folds the ranks' states into rank 0's context (dense if any rank says so, else the union of the
+ *    ranks' sets), whose ku_ctx_report then equals the single-GPU report.  ku_mgpu_sparse_close_unit between input files.
+ *  - exact distinct counts (classifyExact; sharded mode): a k-mer is put into the set of the rank that owns its bin, the
+ *    per-slot counts add up in ku_mgpu_reduce_state. */
+int ku_mgpu_enable_sparse(ku_mgpu *m, uint64_t work_unit_nt, uint32_t global_log2);
+int ku_mgpu_sparse_close_unit(ku_mgpu *m);
+int ku_mgpu_sparse_state(const ku_mgpu *m); /* as ku_ctx_sparse_state; 2 as soon as one rank gave up */
+int ku_mgpu_enable_exact(ku_mgpu *m, uint32_t capacity_log2);
 /* the same last step alone, after the local shards were adopted through ku_mgpu_ctx() + ku_ctx_adopt_db */
 int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax);
 /* One batch on host buffers, arguments and results as ku_classify_batch_rle (+ ku_mgpu_fetch_runs for the runs).

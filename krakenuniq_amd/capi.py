@@ -145,6 +145,11 @@ SIGNATURES = {
     "ku_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "ku_mgpu_uses_rccl": (C.c_int, [C.c_void_p]),
     "ku_mgpu_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ku_mgpu_load_dbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]),
+    "ku_mgpu_enable_sparse": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "ku_mgpu_sparse_close_unit": (C.c_int, [C.c_void_p]),
+    "ku_mgpu_sparse_state": (C.c_int, [C.c_void_p]),
+    "ku_mgpu_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
     "ku_mgpu_set_taxonomy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ku_mgpu_classify_batch_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p,
                                              u32p, u64p, u32p, u64p]),

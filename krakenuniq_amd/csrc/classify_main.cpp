@@ -20,6 +20,9 @@
 //   -x SIZE                             the database is streamed through HBM in minimizer-range chunks of at most SIZE
 //                                       bytes (src/krakendb.cpp:463-522) when that yields more than one chunk
 //   -p N                                accepted and ignored exactly like the reference
+//   KU_DEVICES=0,1,...                  several GPUs (see the end of this comment): every flag keeps its meaning -- -r reports
+//                                       with the reference's sparse sketches (each GPU takes whole work units), several
+//                                       -d run as replicas, classifyExact on the sharded database; not with -x / -I
 //   -I file                             UID database (set_lcas -I / --uid-mapping): the values of the (single) database are
 //                                       UIDs, reads are resolved with resolve_uids3 on the host from the device's
 //                                       run-length encoded codes (src/classify.cpp:953-960, src/uid_mapping.cpp:212-274); no
@@ -298,10 +301,15 @@ int main(int argc, char **argv) {
     }
   }
   if (devices.size() > 1) {
-    if (db_handles.size() > 1) die(EX_SOFTWARE, "KU_DEVICES with several databases is not supported");
     if (chunk_bytes) die(EX_SOFTWARE, "KU_DEVICES with -x is not supported: the shards are resident on the GPUs");
     const char *mode = getenv("KU_MGPU_MODE");
-    const uint32_t mflags = (mode && strcmp(mode, "replicas") == 0) ? KU_MGPU_REPLICAS : 0u;
+    uint32_t mflags = (mode && strcmp(mode, "replicas") == 0) ? KU_MGPU_REPLICAS : 0u;
+    if (db_handles.size() > 1 && !mflags) {
+      // "the first database that holds the k-mer wins" (src/classify.cpp:928-936) needs every database whole on a rank
+      fprintf(stderr, "classify: several databases on several GPUs: every GPU holds all of them (replicas), the reads are split\n");
+      mflags = KU_MGPU_REPLICAS;
+    }
+    if (exact && mflags) die(EX_SOFTWARE, "exact counting on several GPUs needs the database sharded by minimizer range (not KU_MGPU_MODE=replicas / several databases)");
     KU_CHECK(ku_mgpu_create(devices.data(), (uint32_t)devices.size(), 0, (uint32_t)devices.size(), nullptr, mflags, &mg));
     fprintf(stderr, "Running on %zu GPU ranks (%s, %s exchange)\n", devices.size(), mflags ? "replicas" : "database sharded by minimizer range",
             ku_mgpu_uses_rccl(mg) ? "RCCL" : "same-process");
@@ -341,7 +349,6 @@ int main(int argc, char **argv) {
   }
   const bool chunked = !chunk_bounds.empty();
   if (map_uids && (mg || chunked)) die(EX_SOFTWARE, "UID mapping (-I) runs on one GPU with the database resident (no KU_DEVICES, no -x chunks)");
-  if (mg && exact) die(EX_SOFTWARE, "exact counting on several GPUs is not built into the MI355X classifyExact");
   if (chunked && exact) die(EX_SOFTWARE, "exact counting with -x chunks is not built into the MI355X classifyExact");
   // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
   auto counts_file_good = [](const std::string &name, bool say) {
@@ -377,7 +384,7 @@ int main(int argc, char **argv) {
     KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, values.data(), cap));
     add_chunk_counts();
   } else if (mg) {
-    KU_CHECK(ku_mgpu_load(mg, db, tax));
+    KU_CHECK(ku_mgpu_load_dbs(mg, db_handles.data(), (uint32_t)db_handles.size(), tax));
   } else {
     KU_CHECK(ku_ctx_load_db(ctx, db, 0, info.n_bins));
     for (size_t i = 1; i < db_handles.size(); ++i) KU_CHECK(ku_ctx_add_db(ctx, db_handles[i]));
@@ -387,19 +394,18 @@ int main(int argc, char **argv) {
   // was asked for; the emulation keeps every distinct k-mer of the taxa whose sketches stay sparse and is by far the most
   // expensive part of a run with many low-abundance taxa.  -x runs insert into the global sketches directly
   // (src/classify.cpp:719): one unit for the whole run.
-  bool sparse = want_report && !exact && !mg && !getenv("KU_NO_SPARSE");
-  if (want_report && !exact && mg)
-    fprintf(stderr, "classify: several GPUs: the report's kmers / dup / cov columns are dense HyperLogLog estimates (the reference's sparse "
-                    "sketches are reproduced on one GPU only)\n");
+  bool sparse = want_report && !exact && !getenv("KU_NO_SPARSE");
   if (sparse) {
     const char *e = getenv("KU_SPARSE_LOG2");
-    int st = ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, e ? (uint32_t)atoi(e) : 0u);
+    int st = mg ? ku_mgpu_enable_sparse(mg, work_unit_nt, e ? (uint32_t)atoi(e) : 0u)
+                : ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, e ? (uint32_t)atoi(e) : 0u);
     if (st == KU_EUNSUP) { fprintf(stderr, "classify: %s -- the report will carry dense estimates\n", ku_last_error()); sparse = false; }
     else KU_CHECK(st);
   }
-  if (exact) {  // 2^30 cells = 8 GiB hold ~750 M distinct k-mers; KU_EXACT_LOG2 sizes it for larger runs
+  if (exact) {  // 2^30 cells = 8 GiB hold ~750 M distinct k-mers (per GPU); KU_EXACT_LOG2 sizes it for larger runs
     const char *e = getenv("KU_EXACT_LOG2");
-    KU_CHECK(ku_ctx_enable_exact(ctx, e ? (uint32_t)atoi(e) : 30u));
+    if (mg) KU_CHECK(ku_mgpu_enable_exact(mg, e ? (uint32_t)atoi(e) : 30u));
+    else KU_CHECK(ku_ctx_enable_exact(ctx, e ? (uint32_t)atoi(e) : 30u));
   }
 
   Sink s_kraken, s_cls, s_ucls;
@@ -758,7 +764,10 @@ int main(int argc, char **argv) {
     bt->run_cnt.resize(n);
     ku_opts opts = base_opts;
     uint64_t n_runs = 0;
-    if (sparse && bt->first_of_file && ku_ctx_sparse_state(ctx) == 1) KU_CHECK(ku_sparse_close_unit(ctx));  // work units do not span input files
+    if (sparse && bt->first_of_file) {  // work units do not span input files
+      if (mg) KU_CHECK(ku_mgpu_sparse_close_unit(mg));
+      else if (ku_ctx_sparse_state(ctx) == 1) KU_CHECK(ku_sparse_close_unit(ctx));
+    }
     if (mg)
       KU_CHECK(ku_mgpu_classify_batch_rle(mg, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
                                           bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
@@ -819,11 +828,12 @@ int main(int argc, char **argv) {
       } else if (!good) {
         fprintf(stderr, "Writing kmer counts to %s... [only once for this database, may take a while] \n", cname.c_str());
         uint64_t nc = 0;
-        if (mg) KU_CHECK(ku_mgpu_count_taxons(mg, nullptr, nullptr, &nc));
+        const bool group_counts = mg && dbs.size() == 1;  // shards: summed over the ranks; several databases: replicas, rank 0 holds them all
+        if (group_counts) KU_CHECK(ku_mgpu_count_taxons(mg, nullptr, nullptr, &nc));
         else KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, nullptr, nullptr, &nc));
         std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
         uint64_t cap = nc;
-        if (mg) KU_CHECK(ku_mgpu_count_taxons(mg, ct.data(), cc.data(), &cap));
+        if (group_counts) KU_CHECK(ku_mgpu_count_taxons(mg, ct.data(), cc.data(), &cap));
         else KU_CHECK(ku_ctx_count_taxons_db(ctx, (uint32_t)di, ct.data(), cc.data(), &cap));
         FILE *cf = fopen(cname.c_str(), "w");
         if (!cf) die(EX_OSERR, "can't write %s", cname.c_str());
@@ -833,8 +843,9 @@ int main(int argc, char **argv) {
     }
     std::vector<const char *> cpaths;
     for (const std::string &c : cnames) cpaths.push_back(c.c_str());
-    if (mg) KU_CHECK(ku_mgpu_reduce_state(mg, nullptr));  // every rank's registers / counters into rank 0's context
-    if (sparse && ku_ctx_sparse_state(ctx) == 2)
+    const bool sparse_gave_up = sparse && (mg ? ku_mgpu_sparse_state(mg) : ku_ctx_sparse_state(ctx)) == 2;
+    if (mg) KU_CHECK(ku_mgpu_reduce_state(mg, nullptr));  // every rank's registers / counters / sparse sets into rank 0's context
+    if (sparse_gave_up)
       fprintf(stderr, "classify: warning: the sparse-sketch emulation ran out of device memory during the run -- the report's kmers / dup / "
                       "cov columns are dense-register estimates (within 3 sigma = 4.9 %% of the reference's)\n");
     // clade roll-up on the device, from the registers / counters / sparse sets where they lie (ku_ctx_report); in a

@@ -454,6 +454,7 @@ struct ku_ctx {
 };
 
 hipStream_t ku_ctx_stream_of(ku_ctx *ctx) { return ctx->stream; }
+unsigned long long *ku_ctx_exact_unique_of(ku_ctx *ctx) { return ctx->d_exact_unique; }
 int ku_ctx_device_of(const ku_ctx *ctx) { return ctx->device; }
 int ku_ctx_cus_of(const ku_ctx *ctx) { return ctx->n_cu; }
 uint32_t ku_ctx_k_of(const ku_ctx *ctx) { return ctx->m.db.k; }
@@ -1194,6 +1195,96 @@ extern "C" int ku_sparse_export(ku_ctx *ctx, uint8_t *slot_is_sparse, uint64_t *
   return KU_OK;
 }
 
+// ---- the emulation over several GPUs (ku_mgpu.cpp): every rank runs it on whole work units of the read stream, the open
+// unit travels to the rank that classifies the next reads, and the ranks' states are folded into one at the end of the run
+// (a taxon's global sketch is dense iff some unit made it dense, on whichever rank; else it holds every encoding of the
+// run: the union of the ranks' sets)
+int ku_ctx_sparse_on(const ku_ctx *ctx) { return ctx && ctx->sp.on ? 1 : 0; }
+uint64_t ku_ctx_sparse_unit_nt(const ku_ctx *ctx) { return ctx ? ctx->sp.unit_nt : 0; }
+// one pass of the emulation over reads whose per-k-mer array holds slot ids (the sharded path, between the exchange and
+// the resolve stage); KU_ENOMEM switches the emulation off on this context like the single-GPU path does
+int ku_ctx_sparse_pass_slots(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
+                             const uint32_t *h_len, uint64_t n_reads, uint64_t n_bytes, const uint32_t *d_taxa, uint32_t quick_min_hits,
+                             hipStream_t s) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->sp.on || n_reads == 0) return KU_OK;
+  int st = sparse_pass(ctx, d_seqs, d_off, d_len, h_off, h_len, n_reads, n_bytes, d_taxa, quick_min_hits, s);
+  if (st == KU_ENOMEM) {
+    (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
+    ctx_free_sparse(ctx);
+    ctx->sp.gave_up = true;
+    return KU_OK;
+  }
+  return st;
+}
+// the unit that is still open on `src` continues on `dst` (same process; the contexts may sit on different devices)
+int ku_ctx_sparse_move_open_unit(ku_ctx *src, ku_ctx *dst) {
+  if (!src || !dst || !src->sp.on || !dst->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled on both contexts");
+  if (src == dst || !src->sp.open) return KU_OK;
+  if (dst->sp.open) return fail(KU_ESTATE, "the destination context holds an open work unit of its own");
+  KU_TRY(ctx_activate(src));
+  HIP_TRY(hipStreamSynchronize(src->stream));
+  KU_TRY(ctx_activate(dst));
+  HIP_TRY(hipStreamSynchronize(dst->stream));
+  if (src->sp.n_carry_l > dst->sp.cap_carry_l || src->sp.n_carry_u > dst->sp.cap_carry_u) return fail(KU_ESTATE, "carry buffers differ between the contexts");
+  if (src->sp.n_carry_l) HIP_TRY(hipMemcpy(dst->sp.carry_l.p, src->sp.carry_l.p, src->sp.n_carry_l * 8, hipMemcpyDefault));
+  if (src->sp.n_carry_u) HIP_TRY(hipMemcpy(dst->sp.carry_u.p, src->sp.carry_u.p, src->sp.n_carry_u * 12, hipMemcpyDefault));
+  dst->sp.n_carry_l = src->sp.n_carry_l;
+  dst->sp.n_carry_u = src->sp.n_carry_u;
+  dst->sp.open = true;
+  dst->sp.acc_nt = src->sp.acc_nt;
+  src->sp.open = false;
+  src->sp.acc_nt = 0;
+  src->sp.n_carry_l = src->sp.n_carry_u = 0;
+  return KU_OK;
+}
+// end of the run on this rank: the last, partial unit closes; dense flags out (host, one per slot)
+int ku_ctx_sparse_finish(ku_ctx *ctx, uint32_t *h_dense) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled");
+  KU_TRY(sparse_close_open_unit(ctx));
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, ctx->sp.dev.err, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(h_dense, ctx->sp.dev.dense, (size_t)ctx->tax.n_slots * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (err) return fail(KU_ENOMEM, "sparse-mode emulation: a device table overflowed");
+  return KU_OK;
+}
+int ku_ctx_sparse_set_dense(ku_ctx *ctx, const uint32_t *h_dense) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled");
+  HIP_TRY(hipMemcpyAsync(ctx->sp.dev.dense, h_dense, (size_t)ctx->tax.n_slots * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return KU_OK;
+}
+// the run-wide set of `src` joins that of `dst` (entries of slots that are dense by now are dropped on the way)
+int ku_ctx_sparse_absorb(ku_ctx *dst, ku_ctx *src) {
+  if (!dst || !src || !dst->sp.on || !src->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled on both contexts");
+  KU_TRY(ctx_activate(src));
+  HIP_TRY(hipStreamSynchronize(src->stream));
+  unsigned long long n_src = 0;
+  HIP_TRY(hipMemcpy(&n_src, src->sp.dev.g_count, 8, hipMemcpyDeviceToHost));
+  KU_TRY(ctx_activate(dst));
+  hipStream_t s = dst->stream;
+  KU_TRY(sparse_reserve_global(dst, n_src, s));
+  const uint64_t cells = src->sp.dev.g_mask + 1, step = 1ull << 23;  // 64 MB of cells at a time
+  if (dst->sp.out.reserve(std::min(cells, step) * 8) != KU_OK) return fail(KU_ENOMEM, "device memory for the merge of the sparse sets");
+  for (uint64_t c0 = 0; c0 < cells; c0 += step) {
+    const uint64_t n = std::min(step, cells - c0);
+    HIP_TRY(hipMemcpyAsync(dst->sp.out.p, src->sp.dev.g_key + c0, n * 8, hipMemcpyDefault, s));
+    KU_TRY(ku_launch_sparse_absorb(dst->sp.dev, (const unsigned long long *)dst->sp.out.p, n, s));
+  }
+  unsigned long long c = 0;
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&c, dst->sp.dev.g_count, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&err, dst->sp.dev.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  dst->sp.g_count = c;
+  if (err) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set is full");
+  return KU_OK;
+}
+
 // ---------------------------------------------------------------------------- classification
 static int check_ready(ku_ctx *ctx) {
   if (!ctx) return fail(KU_EINVAL, "null context");
@@ -1220,6 +1311,22 @@ extern "C" int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
     if (st != KU_OK) return fail(st, "lookup kernel launch failed");
   }
   return KU_OK;
+}
+
+int ku_exact_owned_step(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads, uint64_t n_bytes,
+                        const ku_opts *opts, uint32_t *d_taxa, hipStream_t s) {
+  KU_TRY(check_ready(ctx));
+  if (!ctx->d_exact_set) return fail(KU_ESTATE, "exact counting is not enabled on this context");
+  if (!ctx->extra.empty()) return fail(KU_EUNSUP, "exact counting on a shard goes with one database");
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  if (o.flags & (KU_F_QUICK | KU_F_NO_COUNTS)) return fail(KU_EUNSUP, "exact counting goes with the plain classification only");
+  o.flags |= KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK;
+  HIP_TRY(hipMemsetAsync(d_taxa, 0xFE, n_bytes * 4, s));
+  KU_TRY(ku_lookup_device(ctx, d_seqs, n_bytes, &o, d_taxa, s));
+  int st = ku_launch_exact(ctx->m.db.k, (const uint8_t *)d_seqs, d_off, d_len, n_reads, d_taxa, ctx->d_exact_set, ctx->exact_mask,
+                           ctx->d_exact_unique, ctx->d_scalar + 6, ctx->n_cu, s);
+  if (st != KU_OK) return fail(st, "exact counting kernel launch failed");
+  return ku_launch_replace_u32(d_taxa, n_bytes, KU_FOREIGN_MARK, 0u, s);
 }
 
 extern "C" int ku_lookup_stats_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint64_t *stats_out,
@@ -1271,6 +1378,7 @@ static int classify_device_impl(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
   const uint32_t flags = opts ? opts->flags : 0;
   // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
   const bool exact = ctx->d_exact_set != nullptr;
+  if (exact && !store_whole(ctx->m)) return fail(KU_EUNSUP, "exact counting on a shard runs through the multi-GPU driver (ku_mgpu_enable_exact)");
   if (exact && (flags & (KU_F_QUICK | KU_F_KEEP_SLOTS | KU_F_NO_COUNTS)))
     return fail(KU_EUNSUP, "exact counting goes with the plain classification only (no quick mode / slot output / count-less runs)");
   const bool sparse = ctx->sp.on && !(flags & KU_F_NO_COUNTS);
@@ -2062,9 +2170,8 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
         walk(ctx->h_slot_taxid[s], [&](size_t row) { if (!clade_dense[clade_of[row]]) s_clade.push_back((uint32_t)clade_of[row]); });
       }
       s_off[ns] = (uint32_t)s_clade.size();
-      uint32_t *d_soff = nullptr, *d_sclade = nullptr, *d_err = nullptr;
-      unsigned long long *d_set = nullptr, *d_per_slot = nullptr;
-      uint8_t *d_single = nullptr;
+      uint32_t *d_soff = nullptr, *d_sclade = nullptr, *d_err = nullptr, *d_set = nullptr, *d_setcells = nullptr;
+      unsigned long long *d_per_slot = nullptr, *d_setoff = nullptr;
       const KuSparseDev &sd = ctx->sp.dev;
       st = tmp.zeros(&d_per_slot, ns);
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the clade roll-up");
@@ -2073,18 +2180,23 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 8, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       lap("entries per slot");
-      // a clade with one member is that member's own set (distinct already): no union set, histogram only
-      std::vector<uint8_t> clade_single(n_clades, 0);
-      for (uint32_t c = 0; c < n_clades; ++c) clade_single[c] = m_off[c + 1] - m_off[c] == 1 ? 1 : 0;
       std::vector<uint64_t> clade_pairs(n_clades, 0);  // entries each clade's histogram may receive
       for (size_t s = 0; s < ns; ++s)
         for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) clade_pairs[s_clade[j]] += per_slot[s];
-      // upper bound of the union sets' entries: a clade with several members holds at most what its members offer, and at
-      // most every encoding there is (2^25 indices; the 2^12 of them whose low 13 bits are zero come with up to 40 ranks)
+      // union sets, one table of 4-byte cells per clade with several members (a clade with one member is that member's
+      // own set, distinct already: histogram only): room for what its members offer -- at most every encoding there is
+      // (2^25 indices; the 2^12 of them whose low 13 bits are zero come with up to 40 ranks) -- at a load of 2/3
       const uint64_t enc_space = (1ull << 25) + (1ull << 12) * 40;
-      uint64_t inserts = 0;
-      for (uint32_t c = 0; c < n_clades; ++c)
-        if (!clade_single[c]) inserts += std::min(clade_pairs[c], enc_space);
+      std::vector<unsigned long long> set_off(n_clades, 0);
+      std::vector<uint32_t> set_cells(n_clades, 0);
+      uint64_t cells = 0;
+      for (uint32_t c = 0; c < n_clades; ++c) {
+        if (m_off[c + 1] - m_off[c] <= 1 || !clade_pairs[c]) continue;
+        const uint64_t bound = std::min(clade_pairs[c], enc_space);
+        set_off[c] = cells;
+        set_cells[c] = (uint32_t)(bound + bound / 2 + 16);
+        cells += set_cells[c];
+      }
       // the busiest clades (the ones near the root) count in LDS
       std::vector<uint32_t> hot_clades(n_clades);
       for (uint32_t c = 0; c < n_clades; ++c) hot_clades[c] = c;
@@ -2096,18 +2208,18 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       for (uint32_t h = 0; h < n_hot; ++h) clade_hot[hot_clades[h]] = (uint16_t)h;
       uint16_t *d_chot = nullptr;
       uint32_t *d_hotc = nullptr;
-      const uint64_t cells = std::max<uint64_t>(1024, inserts + inserts / 2);  // load <= 2/3
       st = tmp.put(&d_soff, s_off);
       if (st == KU_OK) st = tmp.put(&d_sclade, s_clade);
       if (st == KU_OK) st = tmp.zeros(&d_err, 1);
       if (st == KU_OK) st = tmp.put(&d_chot, clade_hot);
       if (st == KU_OK) st = tmp.put(&d_hotc, hot_clades);
-      if (st == KU_OK) st = tmp.put(&d_single, clade_single);
+      if (st == KU_OK) st = tmp.put(&d_setoff, set_off);
+      if (st == KU_OK) st = tmp.put(&d_setcells, set_cells);
       lap("union plan (host)");
       if (st == KU_OK) st = tmp.zeros(&d_set, cells);
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
       lap("union set allocated + cleared");
-      KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_single, d_chot, d_hotc, n_hot, d_set, cells,
+      KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_setoff, d_setcells, d_chot, d_hotc, n_hot, d_set,
                                      d_hist, d_err, ctx->n_cu, ctx->stream));
       uint32_t err = 0;
       HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -93,8 +93,8 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
                            const uint8_t *d_clade_dense, uint32_t n_clades, uint32_t *d_hist, hipStream_t stream);
 #define KU_ROLLUP_HOT 48  // clades whose histogram is pre-aggregated in LDS
 int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, const uint8_t *d_clade_single, const uint16_t *d_clade_hot,
-                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t set_cells, uint32_t *d_hist,
+                            const uint32_t *d_slot_clade, const unsigned long long *d_set_off, const uint32_t *d_set_cells,
+                            const uint16_t *d_clade_hot, const uint32_t *d_hot_clades, uint32_t n_hot, uint32_t *d_set, uint32_t *d_hist,
                             uint32_t *d_err, int n_cu, hipStream_t stream);
 int ku_launch_replace_calls(const uint32_t *d_old, const uint32_t *d_new, uint64_t n, const uint32_t *d_node_taxid, uint32_t n_nodes,
                             unsigned long long *d_n_reads, unsigned long long *d_dropped, hipStream_t stream);
@@ -105,9 +105,23 @@ int ku_launch_count_g_slots(const unsigned long long *d_g_key, uint64_t g_cells,
 struct ku_db;
 int ku_db_raw(const ku_db *db, const uint8_t **pairs, const uint64_t **offsets);
 
+// the sparse-mode emulation over several GPUs (ku_api.cpp; used by ku_mgpu.cpp)
+struct ku_ctx;
+int ku_ctx_sparse_on(const ku_ctx *ctx);
+uint64_t ku_ctx_sparse_unit_nt(const ku_ctx *ctx);
+int ku_ctx_sparse_pass_slots(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
+                             const uint32_t *h_len, uint64_t n_reads, uint64_t n_bytes, const uint32_t *d_taxa, uint32_t quick_min_hits,
+                             hipStream_t s);
+int ku_ctx_sparse_move_open_unit(ku_ctx *src, ku_ctx *dst);
+int ku_ctx_sparse_finish(ku_ctx *ctx, uint32_t *h_dense);
+int ku_ctx_sparse_set_dense(ku_ctx *ctx, const uint32_t *h_dense);
+int ku_ctx_sparse_absorb(ku_ctx *dst, ku_ctx *src);
+int ku_launch_sparse_absorb(const KuSparseDev &s, const unsigned long long *d_keys, uint64_t n, hipStream_t stream);
+
 // context internals the multi-GPU driver (ku_mgpu.cpp) needs
 struct ku_ctx;
 hipStream_t ku_ctx_stream_of(ku_ctx *ctx);
+unsigned long long *ku_ctx_exact_unique_of(ku_ctx *ctx);  // first-insertion counters per slot (nullptr: exact counting is off)
 int ku_ctx_device_of(const ku_ctx *ctx);
 int ku_ctx_cus_of(const ku_ctx *ctx);
 uint32_t ku_ctx_k_of(const ku_ctx *ctx);
@@ -178,6 +192,12 @@ int ku_launch_quick_chunked(const KuTaxDev &tax, const KuCountsDev &cnt, uint32_
 // element-wise merges of the multi-GPU driver's same-process exchange: dst = max(dst, src) / dst += src
 int ku_launch_merge_max_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream);
 int ku_launch_merge_max_u8(uint8_t *dst, const uint8_t *src, uint64_t n, hipStream_t stream);
+int ku_launch_replace_u32(uint32_t *p, uint64_t n, uint32_t from, uint32_t to, hipStream_t stream);
+// per-k-mer array preset of a sharded exact-counting pass: positions another rank owns keep it (never a slot id: 0xFE bytes)
+#define KU_FOREIGN_MARK 0xFEFEFEFEu
+// classifyExact on a shard (ku_mgpu.cpp): lookup of the owned k-mers + their insertion into this rank's k-mer set
+int ku_exact_owned_step(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads, uint64_t n_bytes,
+                        const ku_opts *opts, uint32_t *d_taxa, hipStream_t s);
 int ku_launch_merge_add_u64(unsigned long long *dst, const unsigned long long *src, uint64_t n, hipStream_t stream);
 // DB preparation
 int ku_launch_repack(const uint8_t *d_raw, uint64_t n_pairs, uint32_t key_len, uint32_t *d_pairs,

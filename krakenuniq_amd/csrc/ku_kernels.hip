@@ -867,7 +867,7 @@ __global__ __launch_bounds__(64) void ku_exact_kernel(uint32_t k, const uint8_t 
     const uint64_t off = seq_off[r];
     for (uint32_t i = tid; i < n; i += 64) {
       const uint32_t s = taxa[off + i];
-      if (s == KU_AMBIG) continue;
+      if (s == KU_AMBIG || s == KU_FOREIGN_MARK) continue;  // (several GPUs: a k-mer another rank owns is that rank's to count)
       const uint64_t canon = ku_canon_from_ascii(seqs + off + i, k);
       const unsigned long long key = canon + 1;  // 0 marks an empty cell
       uint64_t h = ku_fmix64(canon) & mask;
@@ -1237,6 +1237,17 @@ int ku_launch_merge_max_u8(uint8_t *dst, const uint8_t *src, uint64_t n, hipStre
 int ku_launch_merge_add_u64(unsigned long long *dst, const unsigned long long *src, uint64_t n, hipStream_t stream) {
   if (n == 0) return KU_OK;
   hipLaunchKernelGGL(ku_merge_add_u64_kernel, dim3(ku_merge_grid(n)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// every `from` in a uint32 array becomes `to` (the marks of positions other ranks own, before the exchange)
+__global__ void ku_replace_u32_kernel(uint32_t *p, uint64_t n, uint32_t from, uint32_t to) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    if (p[i] == from) p[i] = to;
+}
+int ku_launch_replace_u32(uint32_t *p, uint64_t n, uint32_t from, uint32_t to, hipStream_t stream) {
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_replace_u32_kernel, dim3(ku_merge_grid(n)), dim3(256), 0, stream, p, n, from, to);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

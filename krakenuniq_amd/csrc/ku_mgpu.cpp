@@ -152,6 +152,11 @@ struct ku_mgpu {
   Shared sh;
   bool loaded = false, tax_set = false;
   bool reduced = false;  // ku_mgpu_reduce_state ran and no batch was classified since: a second call would add the sums again
+  // HyperLogLog++ sparse-mode emulation over the group (ku_mgpu_enable_sparse): every rank runs it on whole work units
+  bool sparse = false;
+  uint64_t unit_nt = 0, acc_nt = 0;  // -u, and the nt of the unit that is still open (classify.cpp:510-521)
+  int open_rank = -1;                // the rank whose context holds that unit's state
+  bool exact = false;                // classifyExact on the sharded group (ku_mgpu_enable_exact)
 };
 
 namespace {
@@ -367,6 +372,46 @@ int comm_allreduce_state(ku_mgpu *m, ku_mgpu::Rank &r, hipStream_t s) {
   return gate_out(m, st);
 }
 
+// classifyExact over a sharded group: the ranks' k-mer sets are disjoint (a k-mer lives where its bin lives), the
+// first-insertion counters per slot add up
+int comm_allreduce_exact(ku_mgpu *m, ku_mgpu::Rank &r, hipStream_t s) {
+  if (comm_noop(m)) return KU_OK;
+  unsigned long long *uq = ku_ctx_exact_unique_of(r.ctx);
+  ku_counts_dims d{};
+  int st = uq ? ku_counts_dims_get(r.ctx, &d) : mfail(KU_ESTATE, "exact counting is not enabled on every rank");
+  if (m->use_rccl) {
+    st = rccl_gate(m, st);
+    if (st != KU_OK) return st;
+    M_NCCL(g_rccl.AllReduce(uq, uq, d.n_slots, ncclUint64, ncclSum, r.comm, s));
+    return KU_OK;
+  }
+  if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "stream synchronisation failed");
+  m->sh.ptr_a[r.local] = uq;
+  gate_in(m, st);
+  barrier(m);
+  if (r.local == 0 && !m->sh.failed.load()) {
+    for (uint32_t q = 1; q < m->n_local && st == KU_OK; ++q) {
+      const void *a = m->sh.ptr_a[q];
+      if (m->sh.dev[q] != r.device) {
+        st = r.scratch.reserve(d.n_slots * 8);
+        if (st == KU_OK) st = copy_from_peer(m, r, r.scratch.p, a, d.n_slots * 8, s);
+        a = r.scratch.p;
+      }
+      if (st == KU_OK) st = ku_launch_merge_add_u64(uq, (const unsigned long long *)a, d.n_slots, s);
+      if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "exact counter merge failed");
+    }
+  }
+  gate_in(m, st);
+  barrier(m);
+  if (r.local != 0 && st == KU_OK && !m->sh.failed.load()) {
+    st = copy_from_peer(m, r, uq, m->sh.ptr_a[0], d.n_slots * 8, s);
+    if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "exact counter copy failed");
+  }
+  gate_in(m, st);
+  barrier(m);
+  return gate_out(m, st);
+}
+
 // union of every rank's ascending value list
 int comm_allgather_values(ku_mgpu *m, ku_mgpu::Rank &r, int st, const std::vector<uint32_t> &mine, std::vector<uint32_t> &all) {
   all = mine;
@@ -510,6 +555,24 @@ extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
   return KU_OK;
 }
 
+extern "C" int ku_mgpu_load_dbs(ku_mgpu *m, const ku_db *const *dbs, uint32_t n_dbs, const ku_tax *tax) {
+  if (!m || !dbs || !n_dbs || !tax) return mfail(KU_EINVAL, "ku_mgpu_load_dbs: null argument");
+  if (n_dbs == 1) return ku_mgpu_load(m, dbs[0], tax);
+  // several databases are searched one after the other per k-mer, the first hit wins (classify.cpp:928-936): with the
+  // first database cut into shards a later one could not tell whether another rank had found the k-mer already -- the
+  // reference's own chunk mode only searches the first database (classify.cpp:639).  Replicas hold everything.
+  if (!(m->flags & KU_MGPU_REPLICAS)) return mfail(KU_EUNSUP, "several databases on several GPUs need the replicas mode (KU_MGPU_REPLICAS)");
+  ku_db_info info;
+  M_TRY(ku_db_get_info(dbs[0], &info));
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
+    M_TRY(ku_ctx_load_db(r.ctx, dbs[0], 0, info.n_bins));
+    for (uint32_t i = 1; i < n_dbs; ++i) M_TRY(ku_ctx_add_db(r.ctx, dbs[i]));
+    return KU_OK;
+  }));
+  m->loaded = true;
+  return ku_mgpu_set_taxonomy(m, tax);
+}
+
 extern "C" int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax) {
   if (!m || !db || !tax) return mfail(KU_EINVAL, "ku_mgpu_load: null argument");
   ku_db_info info;
@@ -524,24 +587,77 @@ extern "C" int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax) {
   return ku_mgpu_set_taxonomy(m, tax);
 }
 
+// ---------------------------------------------------------------------------- report modes over the group
+extern "C" int ku_mgpu_enable_sparse(ku_mgpu *m, uint64_t work_unit_nt, uint32_t global_log2) {
+  if (!m) return mfail(KU_EINVAL, "ku_mgpu_enable_sparse: null argument");
+  if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_enable_sparse: load the database and the taxonomy first");
+  if (!single_process(m)) return mfail(KU_EUNSUP, "the sparse-mode emulation over several GPUs needs the group in one process");
+  if (work_unit_nt == 0) return mfail(KU_EUNSUP, "ku_mgpu_enable_sparse: a work unit size is needed (the ranks take whole units)");
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int { return ku_ctx_enable_sparse(r.ctx, work_unit_nt, global_log2); }));
+  m->sparse = true;
+  m->unit_nt = work_unit_nt;
+  m->acc_nt = 0;
+  m->open_rank = -1;
+  return KU_OK;
+}
+extern "C" int ku_mgpu_sparse_close_unit(ku_mgpu *m) {
+  if (!m) return mfail(KU_EINVAL, "ku_mgpu_sparse_close_unit: null argument");
+  if (!m->sparse) return KU_OK;
+  if (m->open_rank >= 0) {
+    ku_mgpu::Rank &r = m->ranks[m->open_rank];
+    if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
+    M_TRY(ku_sparse_close_unit(r.ctx));
+  }
+  m->acc_nt = 0;
+  m->open_rank = -1;
+  return KU_OK;
+}
+extern "C" int ku_mgpu_sparse_state(const ku_mgpu *m) {
+  if (!m) return 0;
+  int worst = m->sparse ? 1 : 0;
+  for (const auto &r : m->ranks) {
+    const int s = ku_ctx_sparse_state(r.ctx);
+    if (s == 2) worst = 2;
+  }
+  return worst;
+}
+extern "C" int ku_mgpu_enable_exact(ku_mgpu *m, uint32_t capacity_log2) {
+  if (!m) return mfail(KU_EINVAL, "ku_mgpu_enable_exact: null argument");
+  if (!m->tax_set) return mfail(KU_ESTATE, "ku_mgpu_enable_exact: load the database and the taxonomy first");
+  // owner-computes: a k-mer is put into the set of the rank that owns its minimizer bin, so the ranks' sets are disjoint
+  // and the distinct counts add up.  Replicas would see the same k-mer on several ranks.
+  if (m->flags & KU_MGPU_REPLICAS) return mfail(KU_EUNSUP, "exact counting over several GPUs needs the sharded mode (the k-mer set is partitioned by owner)");
+  M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int { return ku_ctx_enable_exact(r.ctx, capacity_log2); }));
+  m->exact = true;
+  return KU_OK;
+}
+
 // ---------------------------------------------------------------------------- one batch
 namespace {
 // the sharded batch on one rank, everything on stream s: broadcast, lookup of the owned k-mers, slot merge, resolve
 int rank_step_sharded(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_t *d_off, uint32_t *d_len, uint32_t *d_calls,
                       uint32_t *d_taxa, uint32_t *d_hits, uint64_t n_bytes, uint64_t n_reads, const uint64_t *rb,
-                      const uint64_t *pos, const ku_opts &opts, hipStream_t s) {
+                      const uint64_t *pos, const ku_opts &opts, hipStream_t s, const uint64_t *h_off = nullptr,
+                      const uint32_t *h_len = nullptr) {
   st = comm_broadcast(m, r, st, d_seqs, n_bytes, s);
   st = comm_broadcast(m, r, st, d_off, n_reads * 8, s);
   st = comm_broadcast(m, r, st, d_len, n_reads * 4, s);
   ku_opts lo = opts;
   lo.flags = (opts.flags & ~KU_F_MERGE_CHUNK) | KU_F_KEEP_SLOTS;
-  if (st == KU_OK) st = ku_lookup_device(r.ctx, d_seqs, n_bytes, &lo, d_taxa, s);
+  if (st == KU_OK && m->exact) {
+    // classifyExact: the k-mers this rank OWNS go into its set.  The lookup runs as a chunk pass over an array preset with
+    // a mark (positions of other owners keep it), the set takes what is not marked, the marks become 0 for the exchange
+    st = ku_exact_owned_step(r.ctx, d_seqs, d_off, d_len, n_reads, n_bytes, &lo, d_taxa, s);
+  } else if (st == KU_OK) st = ku_lookup_device(r.ctx, d_seqs, n_bytes, &lo, d_taxa, s);
   st = comm_reduce_slices_max(m, r, st, d_taxa, pos, s);
   if (st != KU_OK) return st;
   const uint64_t r0 = rb[r.rank], nr = rb[r.rank + 1] - r0;
   ku_opts ro = opts;
   ro.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
   if (nr == 0) return KU_OK;
+  if (m->sparse && h_len && !(opts.flags & KU_F_NO_COUNTS))  // the rank's slice is whole work units: its merged slots feed the emulation
+    M_TRY(ku_ctx_sparse_pass_slots(r.ctx, d_seqs, d_off + r0, d_len + r0, h_off + r0, h_len + r0, nr, n_bytes, d_taxa,
+                                   (opts.flags & KU_F_QUICK) ? std::max(1u, opts.min_hits) : 0u, s));
   return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
 }
 }  // namespace
@@ -583,18 +699,47 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
   }
   o.max_read_len = max_len;
   const bool replicas = (m->flags & KU_MGPU_REPLICAS) != 0, quick = (o.flags & KU_F_QUICK) != 0;
-  // slices of the read dimension, balanced by bytes and cut at read boundaries
+  // slices of the read dimension, balanced by bytes and cut at read boundaries -- with the sparse-mode emulation on, at
+  // WORK UNIT boundaries (a unit closes behind the read that fills it, classify.cpp:510-521): every rank then runs the
+  // emulation on whole units; the unit that is still open when the batch ends continues on rank 0 with the next batch
   const uint32_t W = m->world;
   std::vector<uint64_t> rb(W + 1), pos(W + 1);
+  const bool sparse = m->sparse && !(o.flags & KU_F_NO_COUNTS);
   rb[0] = 0;
-  for (uint32_t q = 1; q < W; ++q) {
-    const uint64_t target = n_bytes / W * q;
-    rb[q] = std::max<uint64_t>(rb[q - 1], (uint64_t)(std::lower_bound(seq_off, seq_off + n_reads, target) - seq_off));
+  if (sparse) {
+    if (m->open_rank > 0) {  // the open unit's state moves to the rank that takes the first reads
+      M_TRY(ku_ctx_sparse_move_open_unit(m->ranks[m->open_rank].ctx, m->ranks[0].ctx));
+      m->open_rank = 0;
+    }
+    std::vector<uint64_t> unit_end;  // read indices behind which a unit closes
+    uint64_t acc = m->acc_nt;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+      acc += seq_len[i];
+      if (acc >= m->unit_nt) { unit_end.push_back(i + 1); acc = 0; }
+    }
+    for (uint32_t q = 1; q < W; ++q) {
+      const uint64_t target = n_bytes / W * q;
+      // the first unit boundary at or behind the target byte (none: the rest of the batch is one rank's)
+      auto it = std::lower_bound(unit_end.begin(), unit_end.end(), target, [&](uint64_t e, uint64_t t) { return (e < n_reads ? seq_off[e] : n_bytes) < t; });
+      rb[q] = std::max<uint64_t>(rb[q - 1], it == unit_end.end() ? n_reads : *it);
+    }
+    m->acc_nt = acc;
+  } else {
+    for (uint32_t q = 1; q < W; ++q) {
+      const uint64_t target = n_bytes / W * q;
+      rb[q] = std::max<uint64_t>(rb[q - 1], (uint64_t)(std::lower_bound(seq_off, seq_off + n_reads, target) - seq_off));
+    }
   }
   rb[W] = n_reads;
   for (uint32_t q = 0; q < W; ++q) pos[q] = rb[q] < n_reads ? seq_off[rb[q]] : n_bytes;
   pos[0] = 0;
   pos[W] = n_bytes;
+  if (sparse) {  // where the open unit (if any) ends up: the last rank that got reads
+    m->open_rank = -1;
+    if (m->acc_nt > 0)
+      for (uint32_t q = 0; q < W; ++q)
+        if (rb[q + 1] > rb[q]) m->open_rank = (int)q;
+  }
   std::vector<uint64_t> totals(W, 0);
   M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
     hipStream_t s = ku_ctx_stream_of(r.ctx);
@@ -604,24 +749,24 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
     const uint64_t nq = replicas ? nr : n_reads;
     const uint64_t runs_cap = (replicas ? nb : pos[r.rank + 1] - pos[r.rank]) + 1;
     int st = KU_OK;
-    if (r.seqs.reserve(nb + 16) || r.off.reserve(nq * 8 + 8) || r.len.reserve(nq * 4 + 4) || r.calls.reserve(nq * 4 + 4) ||
-        r.taxa.reserve((nb + 16) * 4) || r.hits.reserve(nq * 4 + 4) || r.runs.reserve(runs_cap * 8) ||
-        r.roff.reserve(nq * 8 + 8) || r.rcnt.reserve(nq * 4 + 4) || r.small.reserve(64))
+    if (!replicas && (r.seqs.reserve(nb + 16) || r.off.reserve(nq * 8 + 8) || r.len.reserve(nq * 4 + 4) || r.calls.reserve(nq * 4 + 4) ||
+                      r.taxa.reserve((nb + 16) * 4) || r.hits.reserve(nq * 4 + 4) || r.runs.reserve(runs_cap * 8) ||
+                      r.roff.reserve(nq * 8 + 8) || r.rcnt.reserve(nq * 4 + 4) || r.small.reserve(64)))
       st = mfail(KU_ENOMEM, "device memory for the batch");
     uint32_t *d_calls = (uint32_t *)r.calls.p, *d_hits = (uint32_t *)r.hits.p, *d_taxa = (uint32_t *)r.taxa.p;
     uint64_t *d_off = (uint64_t *)r.off.p;
     uint32_t *d_len = (uint32_t *)r.len.p;
     if (replicas) {
-      // slice offsets are relative to the slice's first byte
-      std::vector<uint64_t> rel(nr);
+      // a replica is a whole single-GPU pipeline on its slice: the context's own host-buffer entry point (fused kernel with
+      // run-length encoded output, the slice uploaded in segments under the kernels, the emulation's fast path)
+      if (nr == 0) return KU_OK;
+      std::vector<uint64_t> rel(nr);  // slice offsets are relative to the slice's first byte
       for (uint64_t i = 0; i < nr; ++i) rel[i] = seq_off[r0 + i] - b0;
-      if (st == KU_OK && nr) {
-        M_HIP(hipMemcpyAsync(r.seqs.p, seqs + b0, nb, hipMemcpyHostToDevice, s));
-        M_HIP(hipMemcpyAsync(d_off, rel.data(), nr * 8, hipMemcpyHostToDevice, s));
-        M_HIP(hipMemcpyAsync(d_len, seq_len + r0, nr * 4, hipMemcpyHostToDevice, s));
-        M_HIP(hipStreamSynchronize(s));  // `rel` goes out of scope
-        st = ku_classify_batch_device(r.ctx, r.seqs.p, nb, d_off, d_len, nr, &o, d_calls, d_taxa, d_hits, s);
-      }
+      uint64_t nruns = 0;
+      M_TRY(ku_classify_batch_rle(r.ctx, seqs + b0, nb, rel.data(), seq_len + r0, nr, &o, calls + r0, hits ? hits + r0 : nullptr, run_off + r0,
+                                  run_cnt + r0, &nruns));
+      totals[r.rank] = nruns;
+      return KU_OK;
     } else {
       if (st == KU_OK && r.rank == 0 &&
           (hipMemcpyAsync(r.seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -629,7 +774,7 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
            hipMemcpyAsync(d_len, seq_len, n_reads * 4, hipMemcpyHostToDevice, s) != hipSuccess))
         st = mfail(KU_EHIP, "upload of the batch failed");
       st = rank_step_sharded(m, r, st, r.seqs.p, d_off, d_len, d_calls, d_taxa, d_hits, n_bytes, n_reads, rb.data(),
-                             pos.data(), o, s);
+                             pos.data(), o, s, seq_off, seq_len);
     }
     if (st != KU_OK) return st;
     if (nr == 0) return KU_OK;
@@ -678,6 +823,7 @@ extern "C" int ku_mgpu_fetch_runs(ku_mgpu *m, ku_run *runs, uint64_t n_runs) {
   return run_all(m, [&](ku_mgpu::Rank &r) -> int {
     if (r.run_base >= n_runs || r.n_runs == 0) return KU_OK;
     const uint64_t n = std::min(r.n_runs, n_runs - r.run_base);
+    if (m->flags & KU_MGPU_REPLICAS) return ku_fetch_runs(r.ctx, runs + r.run_base, n);  // the runs lie in the rank's context
     hipStream_t s = ku_ctx_stream_of(r.ctx);
     M_HIP(hipMemcpyAsync(runs + r.run_base, r.runs.p, n * 8, hipMemcpyDeviceToHost, s));
     M_HIP(hipStreamSynchronize(s));
@@ -691,8 +837,36 @@ extern "C" int ku_mgpu_reduce_state(ku_mgpu *m, void *const *streams) {
   if (m->reduced) return mfail(KU_ESTATE, "ku_mgpu_reduce_state: the state is reduced already (another call would add the counters again)");
   M_TRY(run_all(m, [&](ku_mgpu::Rank &r) -> int {
     hipStream_t s = (streams && streams[r.local]) ? (hipStream_t)streams[r.local] : ku_ctx_stream_of(r.ctx);
-    return comm_allreduce_state(m, r, s);
+    int st = comm_allreduce_state(m, r, s);
+    if (st == KU_OK && m->exact) st = comm_allreduce_exact(m, r, s);
+    return st;
   }));
+  if (m->sparse && ku_mgpu_sparse_state(m) == 1) {
+    // the emulation's state of the whole run ends up in rank 0's context: the last unit closes where it is, a taxon is
+    // dense if any rank found it dense, the sparse taxa's sets are the union of the ranks' sets (hyperloglogplus.cpp:586-665)
+    const size_t ns = [&] { ku_counts_dims d{}; (void)ku_counts_dims_get(m->ranks[0].ctx, &d); return (size_t)d.n_slots; }();
+    std::vector<uint32_t> dense(ns, 0), one(ns);
+    for (auto &r : m->ranks) {
+      if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
+      M_TRY(ku_ctx_sparse_finish(r.ctx, one.data()));
+      for (size_t i = 0; i < ns; ++i) dense[i] |= one[i];
+    }
+    for (auto &r : m->ranks) {
+      if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
+      M_TRY(ku_ctx_sparse_set_dense(r.ctx, dense.data()));
+    }
+    for (uint32_t q = 1; q < m->n_local; ++q) M_TRY(ku_ctx_sparse_absorb(m->ranks[0].ctx, m->ranks[q].ctx));
+    m->acc_nt = 0;
+    m->open_rank = -1;
+  } else if (m->sparse) {
+    // a rank ran out of memory for its tables during the run: no rank's sets are the run's any more -- the report falls
+    // back to the dense registers everywhere (ku_mgpu_sparse_state said 2 before this call)
+    for (auto &r : m->ranks) {
+      if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
+      M_TRY(ku_ctx_disable_sparse(r.ctx));
+    }
+    m->sparse = false;
+  }
   m->reduced = true;
   return KU_OK;
 }

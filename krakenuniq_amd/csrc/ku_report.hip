@@ -72,15 +72,18 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
 //   * else (clade, encoding) goes into the union set; an entry that is already there stops the walk -- whoever put it
 //     there carries it further up, and the chains of two slots are the same above their first common clade.
 // So the work is one insert per DISTINCT (clade, encoding) plus one failed probe per duplicate, not entries x depth.
+// The union sets are one open-addressing table PER CLADE of 4-byte cells holding the encoding alone (0 never is one: index
+// 0 carries the rank flag), laid out back to back: set_off[c] / set_cells[c]; half the memory of (clade, encoding) keys --
+// and the time goes into getting that memory (tens of GB for a run of many sparse taxa), not into the kernel.
 __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells,
                                                                 const uint32_t *__restrict__ dense,
                                                                 const uint32_t *__restrict__ slot_off,
                                                                 const uint32_t *__restrict__ slot_clade,
-                                                                const uint8_t *__restrict__ clade_single,
+                                                                const unsigned long long *__restrict__ set_off,
+                                                                const uint32_t *__restrict__ set_cells,
                                                                 const uint16_t *__restrict__ clade_hot,
                                                                 const uint32_t *__restrict__ hot_clades, uint32_t n_hot,
-                                                                unsigned long long *set, uint64_t set_cells,
-                                                                uint32_t *hist, uint32_t *err) {
+                                                                uint32_t *set, uint32_t *hist, uint32_t *err) {
   __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
   for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
   __syncthreads();
@@ -91,20 +94,23 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
     if (dense[slot]) continue;
     uint32_t r = encoded_rank(enc);
     if (r > KU_ROLLUP_BINS - 1) r = KU_ROLLUP_BINS - 1;
+    uint32_t g = enc * 0x9E3779B1u;  // (the index sits in the high bits of an encoding: spread it)
+    g ^= g >> 15;
+    g *= 0x85EBCA77u;
+    g ^= g >> 13;
     for (uint32_t j = slot_off[slot]; j < slot_off[slot + 1]; ++j) {
       const uint32_t c = slot_clade[j];
       bool fresh = true;
-      if (!clade_single[c]) {
-        const unsigned long long key = ((unsigned long long)(c + 1) << 32) | enc;
-        // any table size (not only powers of two: the set is sized for a load of 0.7, it can take tens of GB): the
-        // hash's high half scaled to [0, set_cells)
-        uint64_t h = __umul64hi(key * 0x9E3779B97F4A7C15ull, set_cells);
+      const uint32_t cells = set_cells[c];  // 0: a clade with a single member (that member's own, distinct entries)
+      if (cells) {
+        uint32_t *tab = set + set_off[c];
+        uint32_t h = __umulhi(g, cells);
         bool done = false;
         for (uint32_t probe = 0; probe < 8192 && !done; ++probe) {
-          const unsigned long long old = atomicCAS(&set[h], 0ull, key);
-          if (old == 0ull) done = true;
-          else if (old == key) { done = true; fresh = false; }
-          h = h + 1 == set_cells ? 0 : h + 1;
+          const uint32_t old = atomicCAS(&tab[h], 0u, enc);
+          if (old == 0u) done = true;
+          else if (old == enc) { done = true; fresh = false; }
+          h = h + 1 == cells ? 0 : h + 1;
         }
         if (!done) { atomicOr(err, 1u); fresh = false; }
       }
@@ -209,14 +215,14 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 }
 
 int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, const uint8_t *d_clade_single, const uint16_t *d_clade_hot,
-                            const uint32_t *d_hot_clades, uint32_t n_hot, unsigned long long *d_set, uint64_t set_cells, uint32_t *d_hist,
+                            const uint32_t *d_slot_clade, const unsigned long long *d_set_off, const uint32_t *d_set_cells,
+                            const uint16_t *d_clade_hot, const uint32_t *d_hot_clades, uint32_t n_hot, uint32_t *d_set, uint32_t *d_hist,
                             uint32_t *d_err, int n_cu, hipStream_t stream) {
   if (!g_cells) return KU_OK;
   const uint64_t want = (g_cells + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_slot_off, d_slot_clade, d_clade_single, d_clade_hot,
-                                                       d_hot_clades, n_hot, d_set, set_cells, d_hist, d_err);
+  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_slot_off, d_slot_clade, d_set_off, d_set_cells, d_clade_hot,
+                                                       d_hot_clades, n_hot, d_set, d_hist, d_err);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

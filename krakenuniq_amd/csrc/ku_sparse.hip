@@ -306,6 +306,19 @@ __global__ void ku_sparse_rehash_kernel(KuSparseDev s, const unsigned long long 
   ks_count_add(s.g_count, n_new);
 }
 
+// another rank's run-wide set joins this one (several GPUs: the union of the ranks' sets; ku_ctx_sparse_absorb)
+__global__ void ku_sparse_absorb_kernel(KuSparseDev s, const unsigned long long *__restrict__ keys, uint64_t n) {
+  unsigned long long n_new = 0;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long gk = keys[i];
+    if (!gk) continue;
+    const uint32_t slot = (uint32_t)(gk >> 32) - 1;
+    if (s.dense[slot]) continue;
+    if (ks_g_insert(s.g_key, s.g_mask, slot, (uint32_t)gk, s.err)) ++n_new;
+  }
+  ks_count_add(s.g_count, n_new);
+}
+
 // run's end: (slot, encoding) of every slot that stayed sparse
 __global__ void ku_sparse_export_kernel(KuSparseDev s, unsigned long long *out, uint64_t cap, unsigned long long *counter) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.g_mask; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -383,5 +396,10 @@ int ku_launch_sparse_insert_runs(const KuSparseDev &s, uint32_t k, const uint8_t
   hipLaunchKernelGGL(ku_sparse_insert_runs_kernel, dim3((unsigned)(n_list < cap ? n_list : cap)), dim3(64), 0, stream, s, k, d_seqs, d_seq_off,
                      d_seq_len, d_list_read, d_list_unit, d_list_urow, n_list, (const uint2 *)d_runs, d_run_off, d_run_cnt, d_slot_taxid,
                      n_slots, d_u_cnt);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_absorb(const KuSparseDev &s, const unsigned long long *d_keys, uint64_t n, hipStream_t stream) {
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_sparse_absorb_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, s, d_keys, n);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

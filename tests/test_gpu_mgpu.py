@@ -114,27 +114,157 @@ def test_empty_and_tiny_batches(f1):
     mg.close()
 
 
+def rows(text):
+    return sorted(text.strip("\n").split("\n"))
+
+
+@pytest.mark.parametrize("unit,report", [(500000, "report.tsv"), (1000, "report_u1000.tsv")])
+@pytest.mark.parametrize("devices,flags", [([0, 0, 0], 0), ([0, 0], capi.KU_MGPU_REPLICAS), ([0, 0, 0, 0], capi.KU_MGPU_REPLICAS)])
+def test_group_report_equals_the_reference(f1, devices, flags, unit, report):
+    """the HyperLogLog++ sparse-mode emulation over a group: host batches are cut at work-unit boundaries, every rank runs
+    the emulation on whole units, the open unit moves on to rank 0, ku_mgpu_reduce_state folds the ranks' states: the
+    report of rank 0's context equals the reference's row for row -- like one GPU's"""
+    mg = capi.Mgpu(devices, flags=flags)
+    mg.load(f1["cdb"], f1["ctax"])
+    mg.enable_sparse(unit)
+    n = len(f1["lens"])
+    cuts = [0, n // 5, n // 5 + 3, n // 2, n]
+    text = ""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo = int(f1["off"][a])
+        hi = int(f1["off"][b]) if b < n else len(f1["buf"])
+        r = mg.classify_batch_rle(f1["buf"][lo:hi], f1["off"][a:b] - lo, f1["lens"][a:b])
+        text += capi.format_kraken_rle(f1["buf"][lo:hi], f1["off"][a:b] - lo, f1["lens"][a:b], f1["ids"][a:b], K, r)
+    assert text == f1["text"]
+    assert mg.sparse_state() == 1
+    mg.reduce_state()
+    assert same_counts(mg.ctx(0).counts(), f1["counts"])
+    assert rows(mg.ctx(0).report(f1["ctax"], [f"{F1}/database.kdb.counts"])) == rows(open(f"{F1}/{report}").read())
+    mg.close()
+
+
+def test_group_sparse_state_equals_the_oracle_on_a_random_database():
+    """taxa of very different abundance over three ranks, sharded and replicas: which sketches switch to dense and the exact
+    sets of the ones that do not (as tests/test_gpu_sparse.py checks for one GPU)"""
+    from test_gpu_sparse import assert_sparse_state_equals_oracle
+    rng = np.random.default_rng(4)
+    db = gc.random_db(rng, n_genomes=8, glen=6000, k=K, nt=9)
+    weights = np.array([200, 60, 20, 8, 3, 1, 1, 0.3])
+    weights = weights / weights.sum()
+    sp = list(db["genomes"])
+    seqs = []
+    for _ in range(5000):
+        g = db["genomes"][sp[int(rng.choice(len(sp), p=weights))]]
+        L = int(rng.integers(60, 260))
+        s0 = int(rng.integers(0, len(g) - L))
+        seqs.append(synth.codes_to_ascii(g[s0:s0 + L]))
+    buf, off, lens = ko.pack_reads(seqs)
+    ids, par = db["tax"].arrays()
+    raw = db["pairs"].view(np.uint8).reshape(-1)
+    odb = ko.Db(pairs=raw, key_ct=len(db["kmers"]), k=K, offsets=db["offsets"], nt=9)
+    otax = ko.Tax(ids=ids, parents=par)
+    unit = 30000
+    run = ko.Run(odb, otax, work_unit_nt=unit)
+    run.classify(seqs)
+    for flags in (0, capi.KU_MGPU_REPLICAS):
+        cdb = capi.Db(pairs=raw, key_ct=len(db["kmers"]), k=K, offsets=db["offsets"], nt=9)
+        ctax = capi.Tax(ids=ids, parents=par)
+        mg = capi.Mgpu([0, 0, 0], flags=flags)
+        mg.load(cdb, ctax)
+        mg.enable_sparse(unit)
+        n = len(seqs)
+        cuts = [0, 700, 2100, 2150, n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            lo = int(off[a])
+            hi = int(off[b]) if b < n else len(buf)
+            mg.classify_batch_rle(buf[lo:hi], off[a:b] - lo, lens[a:b])
+        mg.reduce_state()
+        counts, flg, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(mg.ctx(0), run)
+        gc.assert_same_counts(counts, run)
+        assert n_sparse > 0 and n_dense > 0
+        mg.close()
+
+
+def test_group_exact_counts_equal_the_reference(f1):
+    """classifyExact over a sharded group: a k-mer goes into the set of the rank that owns its minimizer bin, the distinct
+    counts add up: the reference's report_exact.tsv"""
+    mg = capi.Mgpu([0, 0, 0])
+    mg.load(f1["cdb"], f1["ctax"])
+    mg.enable_exact(20)
+    n = len(f1["lens"])
+    h = n // 3
+    cut = int(f1["off"][h])
+    mg.classify_batch_rle(f1["buf"][:cut], f1["off"][:h], f1["lens"][:h])
+    mg.classify_batch_rle(f1["buf"][cut:], f1["off"][h:] - cut, f1["lens"][h:])
+    mg.reduce_state()
+    assert same_counts(mg.ctx(0).counts(), f1["counts"])
+    assert rows(mg.ctx(0).report(f1["ctax"], [f"{F1}/database.kdb.counts"])) == rows(open(f"{F1}/report_exact.tsv").read())
+    mg.close()
+    with pytest.raises(capi.KuError):  # replicas would see a k-mer on several ranks
+        m2 = capi.Mgpu([0, 0], flags=capi.KU_MGPU_REPLICAS)
+        m2.load(f1["cdb"], f1["ctax"])
+        try:
+            m2.enable_exact(20)
+        finally:
+            m2.close()
+
+
+def test_group_of_replicas_with_two_databases(f1):
+    """-d A -d B on several GPUs: every rank holds both databases, the first one with the k-mer wins (classify.cpp:928-936)"""
+    g = os.path.join(ROOT, "tests", "golden")
+    d8 = os.path.join(g, "f8")
+    ids, seqs = synth.read_seqfile(f"{d8}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    for order, dirs in (("", [F1, d8]), ("_swapped", [d8, F1])):
+        cdbs = [capi.Db(f"{x}/database.kdb", f"{x}/database.idx") for x in dirs]
+        mg = capi.Mgpu([0, 0, 0], flags=capi.KU_MGPU_REPLICAS)
+        mg.load_dbs(cdbs, f1["ctax"])
+        mg.enable_sparse()
+        rle = mg.classify_batch_rle(buf, off, lens)
+        assert capi.format_kraken_rle(buf, off, lens, ids, K, rle) == open(f"{d8}/out{order}.tsv").read()
+        mg.reduce_state()
+        got = mg.ctx(0).report(f1["ctax"], [f"{x}/database.kdb.counts" for x in dirs])
+        assert rows(got) == rows(open(f"{d8}/report{order}.tsv").read())
+        mg.close()
+    with pytest.raises(capi.KuError) as e:  # shards: a later database could not know what another rank found
+        m2 = capi.Mgpu([0, 0])
+        try:
+            m2.load_dbs([capi.Db(f"{x}/database.kdb", f"{x}/database.idx") for x in (F1, d8)], f1["ctax"])
+        finally:
+            m2.close()
+    assert e.value.status == -7
+
+
 def test_cli_with_several_ranks(tmp_path):
+    """KU_DEVICES: the executable's outputs -- Kraken file AND report, sparse sketches included -- equal the one-GPU run's,
+    i.e. the reference's"""
     db = tmp_path / "db"
     db.mkdir()
     for fn in ("database.kdb", "database.idx", "taxDB"):
         (db / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
     args = ["-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB", "-t", "4"]
     outs = {}
-    # the groups report dense-register estimates (the sparse-mode emulation is a single-GPU feature): same baseline
-    for name, env in (("one", {"KU_NO_SPARSE": "1"}), ("sharded", {"KU_DEVICES": "0,0,0"}),
-                      ("replicas", {"KU_DEVICES": "0,0", "KU_MGPU_MODE": "replicas"})):
+    for name, env in (("one", {}), ("sharded", {"KU_DEVICES": "0,0,0"}), ("replicas", {"KU_DEVICES": "0,0", "KU_MGPU_MODE": "replicas"})):
         out, rep = tmp_path / f"{name}.tsv", tmp_path / f"{name}.report"
         r = subprocess.run([BIN] + args + ["-o", str(out), "-r", str(rep), f"{F1}/reads.fq"], stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, env={**os.environ, **env})
+                           stderr=subprocess.PIPE, env={**os.environ, "KU_BATCH_NT": "65536", **env})  # several batches
         assert r.returncode == 0, r.stderr.decode()
         if name != "one":
             assert b"GPU ranks" in r.stderr
-        outs[name] = (out.read_bytes(), rep.read_text())
+        outs[name] = (out.read_bytes(), rows(rep.read_text()))
         (db / "database.kdb.counts").unlink()  # regenerated by every run: the group sums it over the shards
     assert outs["one"][0] == open(f"{F1}/out.tsv", "rb").read()
+    assert outs["one"][1] == rows(open(f"{F1}/report.tsv").read())
     for name in ("sharded", "replicas"):
         assert outs[name] == outs["one"], name
+    # classifyExact on the sharded group
+    exact = os.path.join(ROOT, "krakenuniq_amd", "bin", "classifyExact")
+    out, rep = tmp_path / "exact.tsv", tmp_path / "exact.report"
+    r = subprocess.run([exact] + args + ["-o", str(out), "-r", str(rep), f"{F1}/reads.fq"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "KU_DEVICES": "0,0,0", "KU_EXACT_LOG2": "20"})
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+    assert rows(rep.read_text()) == rows(open(f"{F1}/report_exact.tsv").read())
 
 
 def test_device_step_matches_single_context():
