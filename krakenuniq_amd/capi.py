@@ -580,6 +580,24 @@ class Mgpu:
         self._keep += [db, tax]
         _chk(lib().ku_mgpu_load(self.h, db.h, tax.h), "ku_mgpu_load")
 
+    def load_dbs(self, dbs, tax: Tax):
+        """several databases searched in order per k-mer (replicas only)"""
+        arr = (C.c_void_p * len(dbs))(*[d.h for d in dbs])
+        self._keep += list(dbs) + [tax]
+        _chk(lib().ku_mgpu_load_dbs(self.h, arr, len(dbs), tax.h), "ku_mgpu_load_dbs")
+
+    def enable_sparse(self, work_unit_nt=500000, global_log2=0):
+        _chk(lib().ku_mgpu_enable_sparse(self.h, work_unit_nt, global_log2), "ku_mgpu_enable_sparse")
+
+    def sparse_close_unit(self):
+        _chk(lib().ku_mgpu_sparse_close_unit(self.h), "ku_mgpu_sparse_close_unit")
+
+    def sparse_state(self):
+        return lib().ku_mgpu_sparse_state(self.h)
+
+    def enable_exact(self, capacity_log2=20):
+        _chk(lib().ku_mgpu_enable_exact(self.h, capacity_log2), "ku_mgpu_enable_exact")
+
     def set_taxonomy(self, tax: Tax):
         self._keep.append(tax)
         _chk(lib().ku_mgpu_set_taxonomy(self.h, tax.h), "ku_mgpu_set_taxonomy")
