@@ -228,32 +228,42 @@ __global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed) {
 }
 
 // the open unit (index `unit`) moves on to the next batch: its encodings and its (unit, slot) statistics.  Places in
-// the carry arrays are claimed once per wave and round (one add per entry queued the whole grid on one address: 0.5 ms
-// per batch for a few hundred thousand entries)
-__device__ __forceinline__ unsigned long long ks_wave_claim(unsigned long long *counter, bool want, uint32_t lane) {
+// the carry arrays are claimed once per BLOCK and round: the entries of a block are counted through LDS (wave ballots,
+// then the four waves' totals), one thread adds to the global counter.  (One add per entry -- and still one per wave --
+// queued the grid on a single address: 0.5 ms per batch for a few hundred thousand entries.)
+__device__ __forceinline__ unsigned long long ks_block_claim(unsigned long long *counter, bool want, uint32_t *s_wave /* [5] */) {
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const unsigned long long bal = __ballot(want);
-  if (!bal) return 0;
-  const int leader = __ffsll((long long)bal) - 1;
-  unsigned long long base = 0;
-  if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(bal));
-  base = __shfl(base, leader, 64);
-  return base + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = run; run += c; }
+    const unsigned long long base = run ? atomicAdd(counter, (unsigned long long)run) : 0ull;
+    s_wave[4] = (uint32_t)base;
+    s_wave[5] = (uint32_t)(base >> 32);
+  }
+  __syncthreads();
+  const unsigned long long base = ((unsigned long long)s_wave[5] << 32) | s_wave[4];
+  const unsigned long long mine = base + s_wave[wv] + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();  // s_wave is reused by the next claim
+  return mine;
 }
-__global__ void ku_sparse_carry_out_kernel(KuSparseDev s, uint32_t unit, unsigned long long *carry_l, uint32_t *carry_u,
-                                           unsigned long long *counters, uint64_t cap_l, uint64_t cap_u) {
-  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;  // a power of two >= 4096: whole waves, same trip count
-  const uint32_t lane = threadIdx.x & 63u;
+__global__ __launch_bounds__(256) void ku_sparse_carry_out_kernel(KuSparseDev s, uint32_t unit, unsigned long long *carry_l, uint32_t *carry_u,
+                                                                  unsigned long long *counters, uint64_t cap_l, uint64_t cap_u) {
+  __shared__ uint32_t s_wave[6];
+  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;  // a power of two >= 4096: whole blocks, same trip count
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long lk = i <= s.l_mask ? s.l_key[i] : 0ull;
     const bool take_l = lk && (uint32_t)(lk >> 50) - 1 == unit && !s.dense[(uint32_t)(lk >> 32) & 0x3FFFFu];
-    const unsigned long long el = ks_wave_claim(&counters[0], take_l, lane);
+    const unsigned long long el = ks_block_claim(&counters[0], take_l, s_wave);
     if (take_l) {
       if (el < cap_l) carry_l[el] = lk & 0x3FFFFFFFFFFFFull;  // slot << 32 | encoding
       else atomicOr(s.err, 1u);
     }
     const unsigned long long uk = i <= s.u_mask ? s.u_key[i] : 0ull;
     const bool take_u = uk && (uint32_t)(uk >> 32) - 1 == unit && !s.dense[(uint32_t)uk];
-    const unsigned long long eu = ks_wave_claim(&counters[1], take_u, lane);
+    const unsigned long long eu = ks_block_claim(&counters[1], take_u, s_wave);
     if (take_u) {
       if (eu < cap_u) {
         carry_u[3 * eu] = (uint32_t)uk;
