@@ -418,10 +418,18 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
           "kernel_ms": round(lookup_ms, 3), "resolve_slice_ms": round(resolve_ms, 3), "owned_lookups_per_launch": int(st["lookups"]),
           "owned_fraction_of_kmers": round(st["lookups"] / max(1.0, a.reads * (L - k + 1.0)), 4),
           "algorithmic_bytes_per_launch": int(bytes_algo), "mean_ceil_log2_bin": round(st["sum_ceil_log2"] / max(st["lookups"], 1), 3)}
-    wire = {"broadcast_in_bytes_per_read": stride + 12 if ws > 1 else 0,
-            "exchange_out_bytes_per_read": round(4.0 * stride * (ws - 1) / ws, 1) if ws > 1 else 0.0,
-            "exchange_in_bytes_per_read": round(4.0 * stride * (ws - 1) / ws, 1) if ws > 1 else 0.0,
-            "note": "per rank; the exchange is an all-to-all of 4-byte slots per base position (ku_mgpu.cpp)"}
+    nk = L - k + 1.0
+    if mg.uses_routing():
+        wire = {"exchange": "owner routing", "scatter_in_bytes_per_read": round((stride + 12.0) / ws, 1),
+                "kmers_out_bytes_per_read": round(12.0 * nk * (ws - 1) / ws / ws, 1), "slots_in_bytes_per_read": round(4.0 * nk * (ws - 1) / ws / ws, 1),
+                "note": "per rank and per read OF THE BATCH: a rank scans 1/N of the reads and sends each k-mer (12 B) to the owner of its bin, "
+                        "a 4-B slot comes back; the position-wise exchange (KU_MGPU_EXCHANGE=slots) broadcasts every read to every rank and "
+                        f"moves {round(4.0 * stride * (ws - 1) / ws, 1)} B per read per rank"}
+    else:
+        wire = {"exchange": "position-wise" if ws > 1 else "none", "broadcast_in_bytes_per_read": stride + 12 if ws > 1 else 0,
+                "exchange_out_bytes_per_read": round(4.0 * stride * (ws - 1) / ws, 1) if ws > 1 else 0.0,
+                "exchange_in_bytes_per_read": round(4.0 * stride * (ws - 1) / ws, 1) if ws > 1 else 0.0,
+                "note": "per rank; an all-to-all of 4-byte slots per base position (ku_mgpu.cpp)"}
     return {"elapsed": elapsed, "mg": mg, "db": db, "ok": total_reads == a.reads * steps, "roofline": rf, "wire": wire,
             "n_shards": n_shards, "read_len": L}
 
@@ -664,7 +672,7 @@ def main():
             result["sharded"] = {"value": round(a.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
                                  "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sr["db"].n_pairs,
                                  "every_read_resolved_once": sr["ok"], "roofline": sr["roofline"], "wire": sr["wire"],
-                                 "path": "ku_mgpu_step_device: ncclBroadcast -> owner lookup -> all-to-all (grouped ncclSend/ncclRecv) + max-merge -> per-slice resolve"}
+                                 "path": "ku_mgpu_step_device: " + ("scatter of the read slices -> scan of the own slice -> k-mers to their owners (all-to-all) -> probe + accounting at the owner -> slots back -> per-slice resolve" if sr["wire"].get("exchange") == "owner routing" else "ncclBroadcast -> owner lookup -> all-to-all (grouped ncclSend/ncclRecv) + max-merge -> per-slice resolve")}
             sr["mg"].close()
         except Exception as e:
             result["sharded"] = {"value": None, "error": str(e)[:300]}

@@ -374,11 +374,14 @@ int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_regist
  * The database split into contiguous minimizer-bin ranges, one per GPU, all resident at the same time.  The reference
  * has this partitioning only in time (--preload-size chunk mode): ownership KrakenDB::prepare_chunking / upper_bound /
  * is_minimizer_in_chunk (krakendb.cpp:430-526), per-chunk lookup classify_sequence_with_db_chunk (classify.cpp:1014-1056),
- * "non-zero wins" merge (classify.cpp:445-452), final resolve pass (classify.cpp:676-785).  Here, per batch:
- *   broadcast of the read batch from rank 0 -> ku_lookup_device(KU_F_KEEP_SLOTS) on every rank (each searches and
- *   accounts -- HLL, n_kmers, misses under taxon 0 -- only the k-mers whose bin it owns) -> max-reduce of the per-k-mer
- *   slots, scattered over the read dimension (rank r receives the merged slots of its slice of the reads) ->
- *   ku_resolve_device + run-length encoding of that slice on rank r;
+ * "non-zero wins" merge (classify.cpp:445-452), final resolve pass (classify.cpp:676-785).  Here, per batch, either
+ *   OWNER ROUTING (default): rank r takes slice r of the reads, scans it once (k-mers, minimizers), sends every
+ *   unambiguous canonical k-mer to the rank that owns its bin (all-to-all), which probes its shard and accounts the k-mer
+ *   -- HLL, n_kmers, misses under taxon 0: owner-computes, nothing is counted twice -- and sends the slot back; or
+ *   POSITION-WISE (KU_MGPU_EXCHANGE=slots; shards in the sorted layout, several passes): broadcast of the read batch from
+ *   rank 0 -> ku_lookup_device(KU_F_KEEP_SLOTS) on every rank (each searches and accounts only the k-mers whose bin it
+ *   owns) -> max-reduce of the per-k-mer slots, scattered over the read dimension;
+ *   then ku_resolve_device + run-length encoding of the slice on rank r;
  * at the end of the run ku_mgpu_reduce_state merges the per-taxon state (registers MAX, n_kmers / n_reads SUM).
  * A ku_mgpu drives `n_local` ranks of a `world` of ranks from this process, one host thread per rank:
  *   - one process, all ranks (first_rank = 0, n_local = world, id = NULL): what the classify executable does for
@@ -402,6 +405,11 @@ void ku_mgpu_destroy(ku_mgpu *m);
 ku_ctx *ku_mgpu_ctx(ku_mgpu *m, uint32_t local_index);
 /* 1 when the ranks exchange through RCCL, 0 for the same-process copy + merge exchange */
 int ku_mgpu_uses_rccl(const ku_mgpu *m);
+/* 1 when sharded batches are owner-routed (valid after the load / ku_mgpu_set_taxonomy): a rank scans only its own slice of
+ * the reads and sends every k-mer to the rank that owns its minimizer bin (12 B out, a 4-B slot back) instead of every
+ * rank scanning every read and exchanging 4 B per base position.  The default for sharded groups whose ranks all hold a
+ * probe table of one database; KU_MGPU_EXCHANGE=slots keeps the position-wise exchange. */
+int ku_mgpu_uses_routing(const ku_mgpu *m);
 /* shard plan (ku_db_shard_plan over the world) + upload of every local rank's range + taxonomy with the slot table of
  * the whole database (the ranks' distinct values are all-gathered); KU_MGPU_REPLICAS: the whole database everywhere */
 int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax);

@@ -144,6 +144,7 @@ SIGNATURES = {
     "ku_mgpu_destroy": (None, [C.c_void_p]),
     "ku_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "ku_mgpu_uses_rccl": (C.c_int, [C.c_void_p]),
+    "ku_mgpu_uses_routing": (C.c_int, [C.c_void_p]),
     "ku_mgpu_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ku_mgpu_load_dbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]),
     "ku_mgpu_enable_sparse": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
@@ -575,6 +576,9 @@ class Mgpu:
 
     def uses_rccl(self):
         return bool(lib().ku_mgpu_uses_rccl(self.h))
+
+    def uses_routing(self):
+        return bool(lib().ku_mgpu_uses_routing(self.h))
 
     def load(self, db: Db, tax: Tax):
         self._keep += [db, tax]

@@ -1313,6 +1313,26 @@ extern "C" int ku_lookup_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
   return KU_OK;
 }
 
+// ---- owner routing (ku_mgpu.cpp): the context's database / counters behind the three kernels
+int ku_ctx_route_info(const ku_ctx *ctx, uint64_t *bin_lo, uint64_t *bin_hi, int *is_hash, int *single_db) {
+  if (!ctx || !ctx->db_loaded || !ctx->tax_set) return fail(KU_ESTATE, "no database / taxonomy on this context");
+  if (bin_lo) *bin_lo = ctx->m.db.bin_lo;
+  if (bin_hi) *bin_hi = ctx->m.db.bin_hi;
+  if (is_hash) *is_hash = ctx->m.db.table != nullptr;
+  if (single_db) *single_db = ctx->extra.empty();
+  return KU_OK;
+}
+int ku_ctx_route_scan(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, hipStream_t s) {
+  KU_TRY(check_ready(ctx));
+  int st = ku_launch_route_scan(ctx->m.db, (const uint8_t *)d_seqs, n_bytes, d_taxa, rt, ctx->n_cu, s);
+  return st == KU_OK ? KU_OK : fail(st, "route scan kernel launch failed");
+}
+int ku_ctx_route_probe(ku_ctx *ctx, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts, hipStream_t s) {
+  KU_TRY(check_ready(ctx));
+  int st = ku_launch_route_probe(ctx->m.db, ctx->cnt, d_ent, n, d_slots, do_counts, ctx->n_cu, s);
+  return st == KU_OK ? KU_OK : fail(st, "route probe kernel launch failed");
+}
+
 int ku_exact_owned_step(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads, uint64_t n_bytes,
                         const ku_opts *opts, uint32_t *d_taxa, hipStream_t s) {
   KU_TRY(check_ready(ctx));

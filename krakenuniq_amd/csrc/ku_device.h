@@ -341,14 +341,19 @@ __device__ __forceinline__ uint64_t ku_locus_key(uint64_t c, uint32_t k, uint32_
   bin = mn;
   return ku_locus_assemble(c, best, a, plus, k, m);
 }
-__device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lines) {
-  // 32-bit mixing (v_mul_lo/hi_u32 are quarter-rate on CDNA; 64-bit multiplies cost four of them each);
-  // n_lines < 2^32 is enforced at table construction (512 GiB of table per shard)
+// 32-bit mix of a locus key: everything of the bucket choice that does not depend on the table's size (a k-mer routed to
+// the GPU that owns its bin travels with this word; the owner scales it to its own table)
+__device__ __forceinline__ uint32_t ku_locus_prehash(uint64_t locus) {
+  // 32-bit mixing (v_mul_lo/hi_u32 are quarter-rate on CDNA; 64-bit multiplies cost four of them each)
   uint32_t g = (uint32_t)locus * 0x9E3779B1u ^ __builtin_rotateleft32((uint32_t)(locus >> 32) * 0x85EBCA77u, 15);
   g ^= g >> 15;
   g *= 0x2C1B3C6Du;
   g ^= g >> 13;
-  return __umulhi(g, (uint32_t)n_lines);  // (a 2-multiply variant filled the buckets unevenly: 43 ms instead of 20)
+  return g;
+}
+__device__ __forceinline__ uint64_t ku_locus_line(uint64_t locus, uint64_t n_lines) {
+  // n_lines < 2^32 is enforced at table construction (512 GiB of table per shard)
+  return __umulhi(ku_locus_prehash(locus), (uint32_t)n_lines);  // (a 2-multiply variant filled the buckets unevenly: 43 ms instead of 20)
 }
 
 // lca() in node space (krakenutil.cpp:90-118).  Nodes are ranks of taxids in a

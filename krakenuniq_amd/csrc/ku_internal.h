@@ -52,6 +52,21 @@ struct KuCountsDev {
   unsigned long long *n_reads;        // n_nodes
 };
 
+// Owner routing of the sharded multi-GPU path (ku_mgpu.cpp, ku_route.hip): a rank scans only its own slice of the reads and
+// sends every unambiguous canonical k-mer -- with the size-independent half of its bucket hash -- to the rank that owns its
+// minimizer bin; the owner probes, accounts (HLL, n_kmers) and sends the slot back.  ku_lookup_kernel<3,...> is the scan:
+// a counting pass (fill = 0: k-mers per owner) and a filling pass (fill = 1: the owners' queues, in slice order per block).
+struct KuRouteDev {
+  const uint64_t *own_lo, *own_hi;  // [world] the ranks' minimizer ranges
+  unsigned long long *counts;       // [world] k-mers per owner (counting pass)
+  unsigned long long *cursor;       // [world] next free entry of each owner's queue (filling pass)
+  const uint64_t *q_off;            // [world + 1] first entry of each owner's queue
+  uint32_t *q_ent;                  // 3 dwords per entry: k-mer low, k-mer high, bucket prehash
+  uint32_t *q_pos;                  // the entry's position in the per-k-mer array (where its slot goes)
+  uint64_t pos_base;                // position of the slice's first byte
+  uint32_t world;
+  uint32_t fill;
+};
 // HyperLogLog++ sparse-mode emulation (ku_sparse.hip): tables of one context
 struct KuSparseDev {
   unsigned long long *l_key;  // (unit + 1) << 50 | slot << 32 | encoding; 0 = empty
@@ -118,6 +133,9 @@ int ku_ctx_sparse_set_dense(ku_ctx *ctx, const uint32_t *h_dense);
 int ku_ctx_sparse_absorb(ku_ctx *dst, ku_ctx *src);
 int ku_launch_sparse_absorb(const KuSparseDev &s, const unsigned long long *d_keys, uint64_t n, hipStream_t stream);
 
+int ku_ctx_route_info(const ku_ctx *ctx, uint64_t *bin_lo, uint64_t *bin_hi, int *is_hash, int *single_db);
+int ku_ctx_route_scan(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, hipStream_t s);
+int ku_ctx_route_probe(ku_ctx *ctx, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts, hipStream_t s);
 // context internals the multi-GPU driver (ku_mgpu.cpp) needs
 struct ku_ctx;
 hipStream_t ku_ctx_stream_of(ku_ctx *ctx);
@@ -130,6 +148,12 @@ void ku_set_error(const std::string &s);
 // launch wrappers implemented in ku_kernels.hip (all asynchronous on `stream`)
 int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d_seqs, uint64_t n_bytes,
                      uint32_t *d_taxa, bool do_counts, bool prior, bool merge_chunk, int n_cu, hipStream_t stream);
+// owner routing (ku_route.hip; the scan is ku_lookup_kernel<3, 1, true, false> in ku_kernels.hip)
+int ku_launch_route_scan(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, int n_cu,
+                         hipStream_t stream);
+int ku_launch_route_probe(const KuDbDev &db, const KuCountsDev &cnt, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts,
+                          int n_cu, hipStream_t stream);
+int ku_launch_route_scatter(const uint32_t *d_pos, const uint32_t *d_slots, uint64_t n, uint32_t *d_taxa, hipStream_t stream);
 int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
                            int n_cu, hipStream_t stream);
 int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,

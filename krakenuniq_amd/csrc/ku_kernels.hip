@@ -43,7 +43,9 @@
 // MODE 0: lookup only; MODE 1: lookup + per-taxon accounting; MODE 2: measurement
 // only -- no search, accumulates {queries, sum ceil(log2(n_b+1)), queries into
 // non-empty bins, sum n_b} into stats[4] (the algorithmic-bytes model of
-// SURVEY.md 8(d), DESIGN.md "Roofline").
+// SURVEY.md 8(d), DESIGN.md "Roofline").  MODE 3: the scan of the owner-routed multi-GPU path (KuRouteDev): stages 1-3
+// only, every unambiguous k-mer goes -- canonical form + bucket prehash -- into the queue of the rank that owns its
+// minimizer bin (counting pass, then filling pass); taxa[] gets KU_AMBIG / 0 placeholders.
 // LAYOUT 0: sorted bins + binary search (the on-disk order); LAYOUT 1: hash table.
 // SHARDED: the context owns a strict sub-range of the minimizer bins, so the minimizer of
 // every k-mer is needed for the ownership test (always needed by LAYOUT 0 and MODE 2).
@@ -54,7 +56,7 @@ template <int MODE, int LAYOUT, bool SHARDED, bool PRIOR>
 __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
                                                                const uint8_t *__restrict__ seqs,
                                                                uint64_t n_bytes, uint32_t *__restrict__ taxa,
-                                                               unsigned long long *stats, uint32_t ablate) {
+                                                               unsigned long long *stats, uint32_t ablate, KuRouteDev rt) {
   // bit 4 of `ablate` (KU_CTL_MERGE) is a production flag: chunk pass of an out-of-core run -- positions owned by
   // another chunk keep what that chunk's pass wrote ("non-zero wins" merge, classify.cpp:445-452).  The other
   // bits are a measurement knob (env KU_ABLATE, scripts/ablate_lookup.py): bit0 skip the table/bin probe,
@@ -70,6 +72,10 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   // hash layout: packed window elements (key, offset, strand bit; ku_device.h) of the anchor search, two buffers so
   // that a doubling step reads one and writes the other (one barrier per step)
   constexpr bool PK = LAYOUT == 1 && MODE != 2;
+  constexpr bool ROUTE = MODE == 3;
+  __shared__ uint32_t s_rcnt[ROUTE ? 64 : 1];   // ROUTE: k-mers of the tile (filling pass) / of the block (counting pass) per owner
+  __shared__ unsigned long long s_rbase[ROUTE ? 64 : 1];
+  if (ROUTE) { if (threadIdx.x < 64) s_rcnt[threadIdx.x] = 0; }
   __shared__ uint32_t s_pa[PK ? KU_TILE + 64 : 1];
   __shared__ uint32_t s_pb[PK ? KU_TILE + 64 : 1];
   __shared__ uint32_t s_tie;
@@ -247,6 +253,11 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
             for (uint32_t i = 0; i < w; ++i) mn = min(mn, s_mm[p + i]);
           }
           uint64_t bin = mn;
+          if (ROUTE) {
+            n_b[j] = 0xFFu;  // the owner: the rank whose minimizer range holds the bin (none: the k-mer is nobody's, a miss)
+            for (uint32_t q = 0; q < rt.world; ++q)
+              if (bin >= rt.own_lo[q] && bin < rt.own_hi[q]) n_b[j] = q;
+          } else
           if (!SHARDED || (bin >= db.bin_lo && bin < db.bin_hi)) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
             if (LAYOUT == 0 || MODE == 2) {
               const uint64_t *o = db.offsets + (bin - db.bin_lo);
@@ -262,6 +273,40 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       }
     }
 
+    if (ROUTE) {
+      // (n_b[j] = owner, 0xFF none.)  Counting pass: per-owner totals of the block in LDS.  Filling pass: the tile's
+      // entries get consecutive places in their owners' queues -- local index from the LDS counter, one claim per owner
+      // and tile from the global cursor -- so the k-mers of a read stay together and in slice order per block, which
+      // is what keeps the owner's bucket probes on few lines per wave
+      uint32_t idx[KU_ITEMS];
+#pragma unroll
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        const bool go = ok[j] && n_b[j] != 0xFFu;
+        idx[j] = go ? atomicAdd(&s_rcnt[n_b[j]], 1u) : 0u;
+        if (rt.fill) {
+          const uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
+          if (pos < n_bytes) taxa[pos] = ok[j] ? 0u : KU_AMBIG;
+        }
+      }
+      if (rt.fill) {
+        __syncthreads();
+        if (tid < rt.world) s_rbase[tid] = s_rcnt[tid] ? atomicAdd(&rt.cursor[tid], (unsigned long long)s_rcnt[tid]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KU_ITEMS; ++j) {
+          if (ok[j] && n_b[j] != 0xFFu) {
+            const unsigned long long e = rt.q_off[n_b[j]] + s_rbase[n_b[j]] + idx[j];
+            rt.q_ent[3 * e] = (uint32_t)canon[j];
+            rt.q_ent[3 * e + 1] = (uint32_t)(canon[j] >> 32);
+            rt.q_ent[3 * e + 2] = ku_locus_prehash(locus[j]);
+            rt.q_pos[e] = (uint32_t)(rt.pos_base + tile0 + (uint64_t)j * KU_THREADS + tid);
+          }
+        }
+        __syncthreads();
+        if (tid < 64) s_rcnt[tid] = 0;
+      }
+      continue;
+    }
     if (MODE == 2) {
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j)
@@ -428,6 +473,10 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     __syncthreads();
     ku_ct_flush(s_ctk, s_ctc, cnt.n_kmers);
   }
+  if (ROUTE && !rt.fill) {
+    __syncthreads();
+    if (tid < rt.world && s_rcnt[tid]) atomicAdd(&rt.counts[tid], (unsigned long long)s_rcnt[tid]);
+  }
   if (MODE == 2) {
     unsigned long long v[4] = {st_q, st_lg, st_ne, st_nb};
 #pragma unroll
@@ -454,7 +503,7 @@ int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d
   const char *ab = getenv("KU_ABLATE");
   const uint32_t ablate = ((ab ? (uint32_t)atoi(ab) : 0u) & ~KU_CTL_MERGE) | (merge_chunk ? KU_CTL_MERGE : 0u);
   if (prior && sharded) return KU_EUNSUP;
-#define KU_LAUNCH(M, L, S, P) hipLaunchKernelGGL((ku_lookup_kernel<M, L, S, P>), grid, block, 0, stream, db, cnt, d_seqs, n_bytes, d_taxa, ns, ablate)
+#define KU_LAUNCH(M, L, S, P) hipLaunchKernelGGL((ku_lookup_kernel<M, L, S, P>), grid, block, 0, stream, db, cnt, d_seqs, n_bytes, d_taxa, ns, ablate, KuRouteDev{})
   if (prior) {
     if (db.table) { if (do_counts) KU_LAUNCH(1, 1, false, true); else KU_LAUNCH(0, 1, false, true); }
     else { if (do_counts) KU_LAUNCH(1, 0, true, true); else KU_LAUNCH(0, 0, true, true); }
@@ -472,7 +521,17 @@ int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_
                            int n_cu, hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
   hipLaunchKernelGGL((ku_lookup_kernel<2, 0, true, false>), dim3(ku_lookup_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream,
-                     db, KuCountsDev{}, d_seqs, n_bytes, (uint32_t *)nullptr, d_stats, 0u);
+                     db, KuCountsDev{}, d_seqs, n_bytes, (uint32_t *)nullptr, d_stats, 0u, KuRouteDev{});
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// the scan of the owner-routed path over one rank's slice of the reads (counting or filling pass, rt.fill)
+int ku_launch_route_scan(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, int n_cu,
+                         hipStream_t stream) {
+  if (n_bytes == 0) return KU_OK;
+  if (!db.table || rt.world == 0 || rt.world > 64) return KU_EINVAL;
+  hipLaunchKernelGGL((ku_lookup_kernel<3, 1, true, false>), dim3(ku_lookup_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream, db,
+                     KuCountsDev{}, d_seqs, n_bytes, d_taxa, (unsigned long long *)nullptr, 0u, rt);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

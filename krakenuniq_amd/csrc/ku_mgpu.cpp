@@ -131,6 +131,8 @@ struct Shared {
   bool bar_init = false;
   std::vector<const void *> ptr_a, ptr_b, ptr_c;  // published per local rank
   std::vector<std::vector<uint32_t>> vals;
+  std::vector<std::vector<uint64_t>> u64s;
+  std::vector<const uint64_t *> offs;  // host offset tables published next to ptr_a
   std::vector<int> dev;
   std::atomic<int> failed{0};
 };
@@ -145,6 +147,7 @@ struct ku_mgpu {
     ku_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     DBuf seqs, off, len, taxa, calls, hits, runs, roff, rcnt, scratch, small;
+    DBuf q_ent, q_pos, r_ent, r_slots, ret_slots, rt_dev;  // owner routing: send queues, what this rank received, what came back
     uint64_t n_runs = 0;   // runs of the last host batch still in `runs`
     uint64_t run_base = 0; // where they start in the caller's array
   };
@@ -157,6 +160,9 @@ struct ku_mgpu {
   uint64_t unit_nt = 0, acc_nt = 0;  // -u, and the nt of the unit that is still open (classify.cpp:510-521)
   int open_rank = -1;                // the rank whose context holds that unit's state
   bool exact = false;                // classifyExact on the sharded group (ku_mgpu_enable_exact)
+  // owner routing of the sharded path (set up with the taxonomy): every rank's minimizer range
+  bool route = false;
+  std::vector<uint64_t> own_lo, own_hi;
 };
 
 namespace {
@@ -453,6 +459,110 @@ int comm_allgather_values(ku_mgpu *m, ku_mgpu::Rank &r, int st, const std::vecto
   return st;
 }
 
+// every rank's `n` numbers, rank-major, on every rank
+int comm_allgather_u64(ku_mgpu *m, ku_mgpu::Rank &r, int st, const uint64_t *mine, uint32_t n, std::vector<uint64_t> &all, hipStream_t s) {
+  all.assign((size_t)m->world * n, 0);
+  if (comm_noop(m)) { std::copy(mine, mine + n, all.begin()); return st; }
+  if (m->use_rccl) {
+    st = rccl_gate(m, st);
+    if (st != KU_OK) return st;
+    M_TRY(r.small.reserve(8ull * n * (m->world + 1) + 64));
+    unsigned long long *d_all = (unsigned long long *)r.small.p, *d_mine = d_all + (size_t)n * m->world;
+    M_HIP(hipMemcpyAsync(d_mine, mine, 8ull * n, hipMemcpyHostToDevice, s));
+    M_NCCL(g_rccl.AllGather(d_mine, d_all, n, ncclUint64, r.comm, s));
+    M_HIP(hipMemcpyAsync(all.data(), d_all, 8ull * n * m->world, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    return KU_OK;
+  }
+  m->sh.u64s[r.local].assign(mine, mine + n);
+  gate_in(m, st);
+  barrier(m);
+  for (uint32_t q = 0; q < m->n_local; ++q) std::copy(m->sh.u64s[q].begin(), m->sh.u64s[q].end(), all.begin() + (size_t)q * n);
+  barrier(m);
+  return gate_out(m, st);
+}
+
+// all-to-all of variable-size segments: rank r sends send[send_off[q] .. send_off[q + 1]) (elements of `elem` bytes) to rank
+// q and receives rank p's segment for it at recv[recv_off[p] ..).  Over xGMI every pair of GPUs has its own link: the
+// world - 1 transfers of a rank run side by side (grouped ncclSend / ncclRecv).
+int comm_alltoallv(ku_mgpu *m, ku_mgpu::Rank &r, int st, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off,
+                   size_t elem, hipStream_t s) {
+  if (comm_noop(m)) {
+    const uint64_t n = send_off[1] - send_off[0];
+    if (st == KU_OK && n && hipMemcpyAsync((char *)recv + recv_off[0] * elem, (const char *)send + send_off[0] * elem, n * elem, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      st = mfail(KU_EHIP, "local copy failed");
+    return st;
+  }
+  if (m->use_rccl) {
+    st = rccl_gate(m, st);
+    if (st != KU_OK) return st;
+    M_NCCL(g_rccl.GroupStart());
+    ncclResult_t e = ncclSuccess;
+    for (uint32_t q = 0; q < m->world && e == ncclSuccess; ++q) {
+      const uint64_t ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
+      if (ns) e = g_rccl.Send((const char *)send + send_off[q] * elem, ns * elem, ncclUint8, (int)q, r.comm, s);
+      if (e == ncclSuccess && nr) e = g_rccl.Recv((char *)recv + recv_off[q] * elem, nr * elem, ncclUint8, (int)q, r.comm, s);
+    }
+    if (e != ncclSuccess) {
+      (void)g_rccl.GroupEnd();
+      return mfail(KU_EHIP, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(e));
+    }
+    M_NCCL(g_rccl.GroupEnd());
+    return KU_OK;
+  }
+  if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "stream synchronisation failed");
+  m->sh.ptr_a[r.local] = send;
+  m->sh.offs[r.local] = send_off;
+  gate_in(m, st);
+  barrier(m);
+  if (!m->sh.failed.load()) {
+    for (uint32_t p = 0; p < m->n_local && st == KU_OK; ++p) {  // pull: rank p's segment for this rank
+      const uint64_t *po = m->sh.offs[p];
+      const uint64_t n = po[r.rank + 1] - po[r.rank];
+      if (n) st = copy_from_peer(m, r, (char *)recv + recv_off[p] * elem, (const char *)m->sh.ptr_a[p] + po[r.rank] * elem, n * elem, s);
+    }
+    if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "all-to-all copy failed");
+  }
+  gate_in(m, st);
+  barrier(m);  // the peers may reuse their send buffers
+  return gate_out(m, st);
+}
+
+// rank 0 holds buf[0 .. bounds[world]) (elements of `elem` bytes); rank q receives its slice [bounds[q], bounds[q + 1]) in place
+int comm_scatter_slices(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *buf, const uint64_t *bounds, size_t elem, hipStream_t s) {
+  if (comm_noop(m)) return st;
+  const uint64_t lo = bounds[r.rank], n = bounds[r.rank + 1] - lo;
+  if (m->use_rccl) {
+    st = rccl_gate(m, st);
+    if (st != KU_OK) return st;
+    M_NCCL(g_rccl.GroupStart());
+    ncclResult_t e = ncclSuccess;
+    if (r.rank == 0) {
+      for (uint32_t q = 1; q < m->world && e == ncclSuccess; ++q) {
+        const uint64_t nq = bounds[q + 1] - bounds[q];
+        if (nq) e = g_rccl.Send((const char *)buf + bounds[q] * elem, nq * elem, ncclUint8, (int)q, r.comm, s);
+      }
+    } else if (n) e = g_rccl.Recv((char *)buf + lo * elem, n * elem, ncclUint8, 0, r.comm, s);
+    if (e != ncclSuccess) {
+      (void)g_rccl.GroupEnd();
+      return mfail(KU_EHIP, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(e));
+    }
+    M_NCCL(g_rccl.GroupEnd());
+    return KU_OK;
+  }
+  if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "stream synchronisation failed");
+  m->sh.ptr_a[r.local] = buf;
+  gate_in(m, st);
+  barrier(m);
+  if (st == KU_OK && !m->sh.failed.load() && r.local != 0 && n) {
+    st = copy_from_peer(m, r, (char *)buf + lo * elem, (const char *)m->sh.ptr_a[0] + lo * elem, n * elem, s);
+    if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "scatter copy failed");
+  }
+  gate_in(m, st);
+  barrier(m);
+  return gate_out(m, st);
+}
+
 bool single_process(const ku_mgpu *m) { return m->first_rank == 0 && m->n_local == m->world; }
 }  // namespace
 
@@ -473,7 +583,9 @@ extern "C" void ku_mgpu_destroy(ku_mgpu *m) {
     (void)hipSetDevice(r.device);
     if (r.ctx) (void)ku_ctx_synchronize(r.ctx);
     if (r.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r.comm);
-    for (DBuf *b : {&r.seqs, &r.off, &r.len, &r.taxa, &r.calls, &r.hits, &r.runs, &r.roff, &r.rcnt, &r.scratch, &r.small}) b->release();
+    for (DBuf *b : {&r.seqs, &r.off, &r.len, &r.taxa, &r.calls, &r.hits, &r.runs, &r.roff, &r.rcnt, &r.scratch, &r.small, &r.q_ent, &r.q_pos,
+                    &r.r_ent, &r.r_slots, &r.ret_slots, &r.rt_dev})
+      b->release();
     if (r.ctx) ku_ctx_destroy(r.ctx);
   }
   if (m->sh.bar_init) pthread_barrier_destroy(&m->sh.bar);
@@ -498,6 +610,8 @@ extern "C" int ku_mgpu_create(const int *devices, uint32_t n_local, uint32_t fir
   m->sh.ptr_b.assign(n_local, nullptr);
   m->sh.ptr_c.assign(n_local, nullptr);
   m->sh.vals.resize(n_local);
+  m->sh.u64s.resize(n_local);
+  m->sh.offs.assign(n_local, nullptr);
   m->sh.dev.assign(devices, devices + n_local);
   std::set<int> distinct(devices, devices + n_local);
   // KU_MGPU_FORCE_RCCL=1 takes the RCCL calls even for a world of one rank (a way to exercise them on a 1-GPU box)
@@ -539,6 +653,7 @@ extern "C" ku_ctx *ku_mgpu_ctx(ku_mgpu *m, uint32_t local_index) {
   return (m && local_index < m->n_local) ? m->ranks[local_index].ctx : nullptr;
 }
 extern "C" int ku_mgpu_uses_rccl(const ku_mgpu *m) { return m && m->use_rccl ? 1 : 0; }
+extern "C" int ku_mgpu_uses_routing(const ku_mgpu *m) { return m && m->route && !m->exact ? 1 : 0; }
 
 extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
   if (!m || !tax) return mfail(KU_EINVAL, "ku_mgpu_set_taxonomy: null argument");
@@ -549,7 +664,23 @@ extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
     if (st == KU_OK && n) st = ku_ctx_db_values(r.ctx, mine.data(), &n);
     st = comm_allgather_values(m, r, st, mine, all);
     if (st != KU_OK) return st;
-    return ku_ctx_set_taxonomy(r.ctx, tax, all.data(), all.size());
+    st = ku_ctx_set_taxonomy(r.ctx, tax, all.data(), all.size());
+    // owner routing needs every rank's minimizer range and the probe table everywhere
+    uint64_t info[4] = {0, 0, 0, 0};
+    int is_hash = 0, single = 0;
+    if (st == KU_OK) st = ku_ctx_route_info(r.ctx, &info[0], &info[1], &is_hash, &single);
+    info[2] = (uint64_t)(is_hash && single);
+    std::vector<uint64_t> allinfo;
+    st = comm_allgather_u64(m, r, st, info, 4, allinfo, ku_ctx_stream_of(r.ctx));
+    if (st == KU_OK && r.local == 0) {
+      m->own_lo.assign(m->world, 0);
+      m->own_hi.assign(m->world, 0);
+      bool ok = true;
+      for (uint32_t q = 0; q < m->world; ++q) { m->own_lo[q] = allinfo[4 * q]; m->own_hi[q] = allinfo[4 * q + 1]; ok = ok && allinfo[4 * q + 2]; }
+      const char *ex = getenv("KU_MGPU_EXCHANGE");
+      m->route = ok && m->world > 1 && m->world <= 64 && !(m->flags & KU_MGPU_REPLICAS) && !(ex && (!strcmp(ex, "slots") || !strcmp(ex, "reduce")));
+    }
+    return st;
   }));
   m->tax_set = true;
   return KU_OK;
@@ -660,6 +791,81 @@ int rank_step_sharded(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64
                                    (opts.flags & KU_F_QUICK) ? std::max(1u, opts.min_hits) : 0u, s));
   return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
 }
+
+// The owner-routed sharded batch on one rank: the rank scans only ITS slice of the reads, every
+// unambiguous k-mer travels to the rank that owns its minimizer bin, the slot comes back.
+//   have_slice: the rank's slice of seqs / off / len is in place already (host batches: every rank uploads its own part);
+//   else rank 0 holds the whole batch and the slices are scattered first (device batches).
+int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_t *d_off, uint32_t *d_len, uint32_t *d_calls,
+                     uint32_t *d_taxa, uint32_t *d_hits, uint64_t n_bytes, uint64_t n_reads, const uint64_t *rb, const uint64_t *pos,
+                     const ku_opts &opts, hipStream_t s, const uint64_t *h_off, const uint32_t *h_len, bool have_slice) {
+  const uint32_t W = m->world;
+  const uint64_t r0 = rb[r.rank], nr = rb[r.rank + 1] - r0, p0 = pos[r.rank], nb = pos[r.rank + 1] - p0;
+  (void)n_reads;
+  if (!have_slice) {
+    st = comm_scatter_slices(m, r, st, d_seqs, pos, 1, s);
+    st = comm_scatter_slices(m, r, st, d_off, rb, 8, s);
+    st = comm_scatter_slices(m, r, st, d_len, rb, 4, s);
+  }
+  // ---- device-side tables of this step: ranges, counters, queue offsets
+  uint64_t *d_lo = nullptr, *d_hi = nullptr, *d_qoff = nullptr;
+  unsigned long long *d_counts = nullptr, *d_cursor = nullptr;
+  if (st == KU_OK) st = r.rt_dev.reserve((5ull * W + 1) * 8);
+  if (st == KU_OK) {
+    d_lo = (uint64_t *)r.rt_dev.p;
+    d_hi = d_lo + W;
+    d_counts = (unsigned long long *)(d_hi + W);
+    d_cursor = d_counts + W;
+    d_qoff = (uint64_t *)(d_cursor + W);
+    if (hipMemcpyAsync(d_lo, m->own_lo.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_hi, m->own_hi.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(d_counts, 0, 16ull * W, s) != hipSuccess)
+      st = mfail(KU_EHIP, "routing tables upload failed");
+  }
+  KuRouteDev rt{};
+  rt.own_lo = d_lo; rt.own_hi = d_hi; rt.counts = d_counts; rt.cursor = d_cursor; rt.q_off = d_qoff;
+  rt.pos_base = p0; rt.world = W; rt.fill = 0;
+  // ---- counting pass over the slice, then every rank learns how much it gets from whom
+  std::vector<uint64_t> cnt(W, 0), all;
+  if (st == KU_OK && nb) st = ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s);
+  if (st == KU_OK && (hipMemcpyAsync(cnt.data(), d_counts, 8ull * W, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+    st = mfail(KU_EHIP, "routing counts copy failed");
+  st = comm_allgather_u64(m, r, st, cnt.data(), W, all, s);
+  if (st != KU_OK) return st;
+  std::vector<uint64_t> send_off(W + 1, 0), recv_off(W + 1, 0);
+  for (uint32_t q = 0; q < W; ++q) {
+    send_off[q + 1] = send_off[q] + all[(size_t)r.rank * W + q];
+    recv_off[q + 1] = recv_off[q] + all[(size_t)q * W + r.rank];
+  }
+  const uint64_t n_send = send_off[W], n_recv = recv_off[W];
+  if (n_send >= (1ull << 32) || n_recv >= (1ull << 32)) st = mfail(KU_EUNSUP, "owner routing: more than 2^32 k-mers per rank and batch");
+  if (st == KU_OK && (r.q_ent.reserve(std::max<uint64_t>(n_send, 1) * 12) || r.q_pos.reserve(std::max<uint64_t>(n_send, 1) * 4) ||
+                      r.ret_slots.reserve(std::max<uint64_t>(n_send, 1) * 4) || r.r_ent.reserve(std::max<uint64_t>(n_recv, 1) * 12) ||
+                      r.r_slots.reserve(std::max<uint64_t>(n_recv, 1) * 4)))
+    st = mfail(KU_ENOMEM, "device memory for the routing queues");
+  // ---- filling pass: the owners' queues (and KU_AMBIG / 0 placeholders in the per-k-mer array of the slice)
+  if (st == KU_OK && (hipMemcpyAsync(d_qoff, send_off.data(), 8ull * (W + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
+                      hipMemsetAsync(d_cursor, 0, 8ull * W, s) != hipSuccess))
+    st = mfail(KU_EHIP, "routing tables upload failed");
+  rt.fill = 1;
+  rt.q_ent = (uint32_t *)r.q_ent.p;
+  rt.q_pos = (uint32_t *)r.q_pos.p;
+  if (st == KU_OK && nb) st = ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s);
+  // ---- k-mers to their owners (12 B each), probe + accounting there, slots back (4 B each), into place
+  st = comm_alltoallv(m, r, st, r.q_ent.p, send_off.data(), r.r_ent.p, recv_off.data(), 12, s);
+  const bool counts = !(opts.flags & (KU_F_NO_COUNTS | KU_F_QUICK));  // quick mode books the scanned prefix in the resolve stage
+  if (st == KU_OK) st = ku_ctx_route_probe(r.ctx, (const uint32_t *)r.r_ent.p, n_recv, (uint32_t *)r.r_slots.p, counts, s);
+  st = comm_alltoallv(m, r, st, r.r_slots.p, recv_off.data(), r.ret_slots.p, send_off.data(), 4, s);
+  if (st == KU_OK) st = ku_launch_route_scatter((const uint32_t *)r.q_pos.p, (const uint32_t *)r.ret_slots.p, n_send, d_taxa, s);
+  if (st != KU_OK) return st;
+  if (nr == 0) return KU_OK;
+  ku_opts ro = opts;
+  ro.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
+  if (m->sparse && h_len && !(opts.flags & KU_F_NO_COUNTS))
+    M_TRY(ku_ctx_sparse_pass_slots(r.ctx, d_seqs, d_off + r0, d_len + r0, h_off + r0, h_len + r0, nr, n_bytes, d_taxa,
+                                   (opts.flags & KU_F_QUICK) ? std::max(1u, opts.min_hits) : 0u, s));
+  return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
+}
 }  // namespace
 
 extern "C" int ku_mgpu_step_device(ku_mgpu *m, const ku_mgpu_dev_batch *local, uint64_t n_bytes, uint64_t n_reads,
@@ -673,6 +879,9 @@ extern "C" int ku_mgpu_step_device(ku_mgpu *m, const ku_mgpu_dev_batch *local, u
     const ku_mgpu_dev_batch &b = local[r.local];
     if (n_bytes && (!b.d_seqs || !b.d_taxa)) return mfail(KU_EINVAL, "ku_mgpu_step_device: null buffer");
     hipStream_t s = b.stream ? (hipStream_t)b.stream : ku_ctx_stream_of(r.ctx);
+    if (m->route && !m->exact)
+      return rank_step_routed(m, r, KU_OK, b.d_seqs, b.d_seq_off, b.d_seq_len, b.d_calls, b.d_taxa, nullptr, n_bytes, n_reads, read_bounds,
+                              pos_bounds, o, s, nullptr, nullptr, false);
     return rank_step_sharded(m, r, KU_OK, b.d_seqs, b.d_seq_off, b.d_seq_len, b.d_calls, b.d_taxa, nullptr, n_bytes, n_reads,
                              read_bounds, pos_bounds, o, s);
   });
@@ -767,6 +976,15 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
                                   run_cnt + r0, &nruns));
       totals[r.rank] = nruns;
       return KU_OK;
+    } else if (m->route && !m->exact) {
+      // owner routing: every rank takes its own slice of the host batch over its own PCIe link (no broadcast at all)
+      const uint64_t p0 = pos[r.rank], pb = pos[r.rank + 1] - p0;
+      if (st == KU_OK && ((pb && hipMemcpyAsync((char *)r.seqs.p + p0, seqs + p0, pb, hipMemcpyHostToDevice, s) != hipSuccess) ||
+                          (nr && (hipMemcpyAsync(d_off + r0, seq_off + r0, nr * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+                                  hipMemcpyAsync(d_len + r0, seq_len + r0, nr * 4, hipMemcpyHostToDevice, s) != hipSuccess))))
+        st = mfail(KU_EHIP, "upload of the batch failed");
+      st = rank_step_routed(m, r, st, r.seqs.p, d_off, d_len, d_calls, d_taxa, d_hits, n_bytes, n_reads, rb.data(), pos.data(), o, s,
+                            seq_off, seq_len, true);
     } else {
       if (st == KU_OK && r.rank == 0 &&
           (hipMemcpyAsync(r.seqs.p, seqs, n_bytes, hipMemcpyHostToDevice, s) != hipSuccess ||

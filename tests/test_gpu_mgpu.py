@@ -46,10 +46,13 @@ def same_counts(a, b):
 
 
 @pytest.mark.parametrize("devices", device_lists())
-@pytest.mark.parametrize("flags", [0, capi.KU_MGPU_REPLICAS])
-def test_group_reproduces_reference_output_and_state(f1, devices, flags):
+@pytest.mark.parametrize("flags,exchange", [(0, "route"), (0, "slots"), (capi.KU_MGPU_REPLICAS, None)])
+def test_group_reproduces_reference_output_and_state(f1, devices, flags, exchange, monkeypatch):
+    if exchange == "slots":
+        monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
     mg = capi.Mgpu(devices, flags=flags)
     mg.load(f1["cdb"], f1["ctax"])
+    assert mg.uses_routing() == (exchange == "route")
     # two batches: the state accumulates in the ranks' contexts across batches
     n = len(f1["lens"])
     h = n // 3
@@ -119,8 +122,11 @@ def rows(text):
 
 
 @pytest.mark.parametrize("unit,report", [(500000, "report.tsv"), (1000, "report_u1000.tsv")])
-@pytest.mark.parametrize("devices,flags", [([0, 0, 0], 0), ([0, 0], capi.KU_MGPU_REPLICAS), ([0, 0, 0, 0], capi.KU_MGPU_REPLICAS)])
-def test_group_report_equals_the_reference(f1, devices, flags, unit, report):
+@pytest.mark.parametrize("devices,flags,exchange", [([0, 0, 0], 0, "route"), ([0, 0, 0], 0, "slots"), ([0, 0], capi.KU_MGPU_REPLICAS, None),
+                                                   ([0, 0, 0, 0], capi.KU_MGPU_REPLICAS, None)])
+def test_group_report_equals_the_reference(f1, devices, flags, exchange, unit, report, monkeypatch):
+    if exchange == "slots":
+        monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
     """the HyperLogLog++ sparse-mode emulation over a group: host batches are cut at work-unit boundaries, every rank runs
     the emulation on whole units, the open unit moves on to rank 0, ku_mgpu_reduce_state folds the ranks' states: the
     report of rank 0's context equals the reference's row for row -- like one GPU's"""
@@ -267,9 +273,13 @@ def test_cli_with_several_ranks(tmp_path):
     assert rows(rep.read_text()) == rows(open(f"{F1}/report_exact.tsv").read())
 
 
-def test_device_step_matches_single_context():
+@pytest.mark.parametrize("exchange", ["route", "slots"])
+def test_device_step_matches_single_context(exchange, monkeypatch):
     """ku_mgpu_step_device (the bench path) with three ranks on one device: shards adopted from device memory, batch
-    broadcast from rank 0, slices resolved per rank == one context holding the whole database"""
+    scattered (owner routing) or broadcast (position-wise exchange) from rank 0, slices resolved per rank == one context
+    holding the whole database"""
+    if exchange == "slots":
+        monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
     import torch
     dev = torch.device("cuda:0")
     NT, L, N, W = 11, 150, 300_000, 3
@@ -300,6 +310,7 @@ def test_device_step_matches_single_context():
         mg.ctx(r).adopt_db(sh.pairs.data_ptr(), sh.n_pairs, sh.offsets.data_ptr(), K, NT, 2, bounds[r], bounds[r + 1])
         shards.append(sh)
     mg.set_taxonomy(ctax)
+    assert mg.uses_routing() == (exchange == "route")
     stride = L + 1
     rb = [N * r // W for r in range(W + 1)]
     pb = [x * stride for x in rb]
