@@ -37,8 +37,9 @@ with open(f'profiles/{tag}_kernel_stats.csv', 'w', newline='') as f:
 for r in rows[1:]:
     if 'ku_' in r[0]: print(r[0][:44], 'calls', r[1], 'avg_ns', r[3])
 # the other read shapes (scripts/profile_configs.sh)
-for c in ("paired", "long", "nt15", "sharded8", "cli_report"):
-    fs = newest(f'gpurun_out/{tag}_{c}_stats/runc/*kernel_stats.csv') or newest(f'gpurun_out/{tag}_{c}/runc/*kernel_stats.csv')
+for c in ("paired", "long", "nt15", "sharded8", "cli_report", "route_route", "route_slots"):
+    fs = (newest(f'gpurun_out/{tag}_{c}_stats/runc/*kernel_stats.csv') or newest(f'gpurun_out/{tag}_{c}/runc/*kernel_stats.csv')
+          or newest(f'gpurun_out/prof_{tag}_{c}/runc/*kernel_stats.csv'))
     if c == "cli_report":  # the profiler follows the executable the script starts: the file with our kernels
         fs = [f for f in (glob.glob(f'gpurun_out/{tag}_{c}/runc/*kernel_stats.csv')) if 'ku_classify_short' in open(f).read()][-1:]
     if not fs:
