@@ -567,7 +567,7 @@ class Mgpu:
     def close(self):
         if getattr(self, "h", None) and _lib is not None:
             _lib.ku_mgpu_destroy(self.h)
-        self.h = C.c_void_p()
+        self.h = None  # (at interpreter exit the ctypes module may be gone already: no new objects here)
 
     __del__ = close
 

@@ -58,14 +58,12 @@ struct KuCountsDev {
 // a counting pass (fill = 0: k-mers per owner) and a filling pass (fill = 1: the owners' queues, in slice order per block).
 struct KuRouteDev {
   const uint64_t *own_lo, *own_hi;  // [world] the ranks' minimizer ranges
-  unsigned long long *counts;       // [world] k-mers per owner (counting pass)
-  unsigned long long *cursor;       // [world] next free entry of each owner's queue (filling pass)
-  const uint64_t *q_off;            // [world + 1] first entry of each owner's queue
+  unsigned long long *cursor;       // [world] entries claimed in each owner's queue (ends as the owner's total, also beyond cap)
+  const uint64_t *q_off;            // [world] first entry of each owner's queue
   uint32_t *q_ent;                  // 3 dwords per entry: k-mer low, k-mer high, bucket prehash
-  uint32_t *q_pos;                  // the entry's position in the per-k-mer array (where its slot goes)
-  uint64_t pos_base;                // position of the slice's first byte
+  uint32_t *q_pos;                  // the entry's position in the slice's per-k-mer array (where its slot goes)
+  uint64_t cap;                     // room per queue (0: the queues are exactly sized)
   uint32_t world;
-  uint32_t fill;
 };
 // HyperLogLog++ sparse-mode emulation (ku_sparse.hip): tables of one context
 struct KuSparseDev {

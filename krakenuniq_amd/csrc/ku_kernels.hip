@@ -45,7 +45,7 @@
 // non-empty bins, sum n_b} into stats[4] (the algorithmic-bytes model of
 // SURVEY.md 8(d), DESIGN.md "Roofline").  MODE 3: the scan of the owner-routed multi-GPU path (KuRouteDev): stages 1-3
 // only, every unambiguous k-mer goes -- canonical form + bucket prehash -- into the queue of the rank that owns its
-// minimizer bin (counting pass, then filling pass); taxa[] gets KU_AMBIG / 0 placeholders.
+// minimizer bin; taxa[] gets KU_AMBIG / 0 placeholders.
 // LAYOUT 0: sorted bins + binary search (the on-disk order); LAYOUT 1: hash table.
 // SHARDED: the context owns a strict sub-range of the minimizer bins, so the minimizer of
 // every k-mer is needed for the ownership test (always needed by LAYOUT 0 and MODE 2).
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   // that a doubling step reads one and writes the other (one barrier per step)
   constexpr bool PK = LAYOUT == 1 && MODE != 2;
   constexpr bool ROUTE = MODE == 3;
-  __shared__ uint32_t s_rcnt[ROUTE ? 64 : 1];   // ROUTE: k-mers of the tile (filling pass) / of the block (counting pass) per owner
+  __shared__ uint32_t s_rcnt[ROUTE ? 64 : 1];   // ROUTE: k-mers of the tile per owner
   __shared__ unsigned long long s_rbase[ROUTE ? 64 : 1];
   if (ROUTE) { if (threadIdx.x < 64) s_rcnt[threadIdx.x] = 0; }
   __shared__ uint32_t s_pa[PK ? KU_TILE + 64 : 1];
@@ -274,37 +274,52 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     }
 
     if (ROUTE) {
-      // (n_b[j] = owner, 0xFF none.)  Counting pass: per-owner totals of the block in LDS.  Filling pass: the tile's
-      // entries get consecutive places in their owners' queues -- local index from the LDS counter, one claim per owner
-      // and tile from the global cursor -- so the k-mers of a read stay together and in slice order per block, which
-      // is what keeps the owner's bucket probes on few lines per wave
+      // (n_b[j] = owner, 0xFF none.)  The tile's entries get consecutive places in their owners' queues: the lanes of a
+      // wave that share an owner take their local index with ONE LDS add (neighbouring k-mers share a minimizer, so a wave
+      // sees one to three owners), the block claims its room once per owner and tile from the queue's global cursor --
+      // the k-mers of a read stay together and in read order, which keeps the owner's bucket probes on few lines per
+      // wave.  A queue has room for rt.cap entries (0: exactly sized); claims beyond it are counted, not written, so
+      // the cursors always end as the true per-owner totals and the host can size an exact second pass.
       uint32_t idx[KU_ITEMS];
+      const uint32_t lane = tid & 63u;
+      const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         const bool go = ok[j] && n_b[j] != 0xFFu;
-        idx[j] = go ? atomicAdd(&s_rcnt[n_b[j]], 1u) : 0u;
-        if (rt.fill) {
-          const uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
-          if (pos < n_bytes) taxa[pos] = ok[j] ? 0u : KU_AMBIG;
+        idx[j] = 0;
+        unsigned long long todo = __ballot(go);
+        while (todo) {  // wave-uniform
+          const uint32_t lead = (uint32_t)__ffsll((long long)todo) - 1u;
+          const uint32_t o = ku_wave_bcast(n_b[j], lead);
+          const bool mine = go && n_b[j] == o;
+          const unsigned long long same = __ballot(mine);
+          uint32_t base = 0;
+          if (lane == lead) base = atomicAdd(&s_rcnt[o], (uint32_t)__popcll(same));
+          base = ku_wave_bcast(base, lead);
+          if (mine) idx[j] = base + (uint32_t)__popcll(same & below);
+          todo &= ~same;
         }
+        const uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
+        if (pos < n_bytes) taxa[pos] = ok[j] ? 0u : KU_AMBIG;
       }
-      if (rt.fill) {
-        __syncthreads();
-        if (tid < rt.world) s_rbase[tid] = s_rcnt[tid] ? atomicAdd(&rt.cursor[tid], (unsigned long long)s_rcnt[tid]) : 0ull;
-        __syncthreads();
+      __syncthreads();
+      if (tid < rt.world) s_rbase[tid] = s_rcnt[tid] ? atomicAdd(&rt.cursor[tid], (unsigned long long)s_rcnt[tid]) : 0ull;
+      __syncthreads();
 #pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
-          if (ok[j] && n_b[j] != 0xFFu) {
-            const unsigned long long e = rt.q_off[n_b[j]] + s_rbase[n_b[j]] + idx[j];
+      for (int j = 0; j < KU_ITEMS; ++j) {
+        if (ok[j] && n_b[j] != 0xFFu) {
+          const unsigned long long loc = s_rbase[n_b[j]] + idx[j];
+          if (rt.cap == 0 || loc < rt.cap) {
+            const unsigned long long e = rt.q_off[n_b[j]] + loc;
             rt.q_ent[3 * e] = (uint32_t)canon[j];
             rt.q_ent[3 * e + 1] = (uint32_t)(canon[j] >> 32);
             rt.q_ent[3 * e + 2] = ku_locus_prehash(locus[j]);
-            rt.q_pos[e] = (uint32_t)(rt.pos_base + tile0 + (uint64_t)j * KU_THREADS + tid);
+            rt.q_pos[e] = (uint32_t)(tile0 + (uint64_t)j * KU_THREADS + tid);
           }
         }
-        __syncthreads();
-        if (tid < 64) s_rcnt[tid] = 0;
       }
+      __syncthreads();
+      if (tid < 64) s_rcnt[tid] = 0;
       continue;
     }
     if (MODE == 2) {
@@ -473,10 +488,6 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     __syncthreads();
     ku_ct_flush(s_ctk, s_ctc, cnt.n_kmers);
   }
-  if (ROUTE && !rt.fill) {
-    __syncthreads();
-    if (tid < rt.world && s_rcnt[tid]) atomicAdd(&rt.counts[tid], (unsigned long long)s_rcnt[tid]);
-  }
   if (MODE == 2) {
     unsigned long long v[4] = {st_q, st_lg, st_ne, st_nb};
 #pragma unroll
@@ -525,7 +536,7 @@ int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
-// the scan of the owner-routed path over one rank's slice of the reads (counting or filling pass, rt.fill)
+// the scan of the owner-routed path over one rank's slice of the reads
 int ku_launch_route_scan(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, int n_cu,
                          hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;

@@ -485,11 +485,11 @@ int comm_allgather_u64(ku_mgpu *m, ku_mgpu::Rank &r, int st, const uint64_t *min
 // all-to-all of variable-size segments: rank r sends send[send_off[q] .. send_off[q + 1]) (elements of `elem` bytes) to rank
 // q and receives rank p's segment for it at recv[recv_off[p] ..).  Over xGMI every pair of GPUs has its own link: the
 // world - 1 transfers of a rank run side by side (grouped ncclSend / ncclRecv).
-int comm_alltoallv(ku_mgpu *m, ku_mgpu::Rank &r, int st, const void *send, const uint64_t *send_off, void *recv, const uint64_t *recv_off,
-                   size_t elem, hipStream_t s) {
+int comm_alltoallv(ku_mgpu *m, ku_mgpu::Rank &r, int st, const void *send, const uint64_t *send_at, const uint64_t *send_n, void *recv,
+                   const uint64_t *recv_at, const uint64_t *recv_n, size_t elem, hipStream_t s) {
   if (comm_noop(m)) {
-    const uint64_t n = send_off[1] - send_off[0];
-    if (st == KU_OK && n && hipMemcpyAsync((char *)recv + recv_off[0] * elem, (const char *)send + send_off[0] * elem, n * elem, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (st == KU_OK && send_n[0] &&
+        hipMemcpyAsync((char *)recv + recv_at[0] * elem, (const char *)send + send_at[0] * elem, send_n[0] * elem, hipMemcpyDeviceToDevice, s) != hipSuccess)
       st = mfail(KU_EHIP, "local copy failed");
     return st;
   }
@@ -499,9 +499,8 @@ int comm_alltoallv(ku_mgpu *m, ku_mgpu::Rank &r, int st, const void *send, const
     M_NCCL(g_rccl.GroupStart());
     ncclResult_t e = ncclSuccess;
     for (uint32_t q = 0; q < m->world && e == ncclSuccess; ++q) {
-      const uint64_t ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
-      if (ns) e = g_rccl.Send((const char *)send + send_off[q] * elem, ns * elem, ncclUint8, (int)q, r.comm, s);
-      if (e == ncclSuccess && nr) e = g_rccl.Recv((char *)recv + recv_off[q] * elem, nr * elem, ncclUint8, (int)q, r.comm, s);
+      if (send_n[q]) e = g_rccl.Send((const char *)send + send_at[q] * elem, send_n[q] * elem, ncclUint8, (int)q, r.comm, s);
+      if (e == ncclSuccess && recv_n[q]) e = g_rccl.Recv((char *)recv + recv_at[q] * elem, recv_n[q] * elem, ncclUint8, (int)q, r.comm, s);
     }
     if (e != ncclSuccess) {
       (void)g_rccl.GroupEnd();
@@ -512,15 +511,13 @@ int comm_alltoallv(ku_mgpu *m, ku_mgpu::Rank &r, int st, const void *send, const
   }
   if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "stream synchronisation failed");
   m->sh.ptr_a[r.local] = send;
-  m->sh.offs[r.local] = send_off;
+  m->sh.offs[r.local] = send_at;
   gate_in(m, st);
   barrier(m);
   if (!m->sh.failed.load()) {
-    for (uint32_t p = 0; p < m->n_local && st == KU_OK; ++p) {  // pull: rank p's segment for this rank
-      const uint64_t *po = m->sh.offs[p];
-      const uint64_t n = po[r.rank + 1] - po[r.rank];
-      if (n) st = copy_from_peer(m, r, (char *)recv + recv_off[p] * elem, (const char *)m->sh.ptr_a[p] + po[r.rank] * elem, n * elem, s);
-    }
+    for (uint32_t p = 0; p < m->n_local && st == KU_OK; ++p)  // pull: rank p's segment for this rank
+      if (recv_n[p])
+        st = copy_from_peer(m, r, (char *)recv + recv_at[p] * elem, (const char *)m->sh.ptr_a[p] + m->sh.offs[p][r.rank] * elem, recv_n[p] * elem, s);
     if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "all-to-all copy failed");
   }
   gate_in(m, st);
@@ -807,56 +804,69 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
     st = comm_scatter_slices(m, r, st, d_off, rb, 8, s);
     st = comm_scatter_slices(m, r, st, d_len, rb, 4, s);
   }
-  // ---- device-side tables of this step: ranges, counters, queue offsets
+  // ---- device-side tables of this step: ranges, cursors, queue offsets
   uint64_t *d_lo = nullptr, *d_hi = nullptr, *d_qoff = nullptr;
-  unsigned long long *d_counts = nullptr, *d_cursor = nullptr;
-  if (st == KU_OK) st = r.rt_dev.reserve((5ull * W + 1) * 8);
-  if (st == KU_OK) {
+  unsigned long long *d_cursor = nullptr;
+  if (st == KU_OK) st = r.rt_dev.reserve(4ull * W * 8);
+  // One scanning pass: every owner's queue gets room for twice its fair share of the slice's k-mers (the shard bounds are
+  // quantiles of the database, reads follow the database) and the cursors come back as the true totals; a queue that
+  // did not hold its total (a batch from one corner of the minimizer space) sends the scan through a second, exactly
+  // sized pass -- the results do not depend on which it was (KU_ROUTE_CAP: entries per queue, for the tests)
+  uint64_t cap = std::max<uint64_t>(2 * (nb / W) + 65536, 1);
+  if (const char *e = std::getenv("KU_ROUTE_CAP")) cap = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+  cap = std::min<uint64_t>(cap, std::max<uint64_t>(nb, 1));
+  std::vector<uint64_t> cnt(W, 0), send_at(W, 0), all;
+  for (uint32_t q = 0; q < W; ++q) send_at[q] = q * cap;
+  KuRouteDev rt{};
+  auto scan = [&](uint64_t room, uint64_t total) -> int {
+    if (r.q_ent.reserve(std::max<uint64_t>(total, 1) * 12) || r.q_pos.reserve(std::max<uint64_t>(total, 1) * 4) ||
+        r.ret_slots.reserve(std::max<uint64_t>(total, 1) * 4))
+      return mfail(KU_ENOMEM, "device memory for the routing queues");
     d_lo = (uint64_t *)r.rt_dev.p;
     d_hi = d_lo + W;
-    d_counts = (unsigned long long *)(d_hi + W);
-    d_cursor = d_counts + W;
+    d_cursor = (unsigned long long *)(d_hi + W);
     d_qoff = (uint64_t *)(d_cursor + W);
     if (hipMemcpyAsync(d_lo, m->own_lo.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(d_hi, m->own_hi.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemsetAsync(d_counts, 0, 16ull * W, s) != hipSuccess)
-      st = mfail(KU_EHIP, "routing tables upload failed");
+        hipMemcpyAsync(d_qoff, send_at.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(d_cursor, 0, 8ull * W, s) != hipSuccess)
+      return mfail(KU_EHIP, "routing tables upload failed");
+    rt.own_lo = d_lo; rt.own_hi = d_hi; rt.cursor = d_cursor; rt.q_off = d_qoff;
+    rt.q_ent = (uint32_t *)r.q_ent.p;
+    rt.q_pos = (uint32_t *)r.q_pos.p;
+    rt.world = W; rt.cap = room;
+    if (nb) M_TRY(ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s));
+    if (hipMemcpyAsync(cnt.data(), d_cursor, 8ull * W, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return mfail(KU_EHIP, "routing counts copy failed");
+    return KU_OK;
+  };
+  if (st == KU_OK) st = scan(cap, cap * W);
+  if (st == KU_OK && *std::max_element(cnt.begin(), cnt.end()) > cap) {
+    uint64_t total = 0;
+    for (uint32_t q = 0; q < W; ++q) { send_at[q] = total; total += cnt[q]; }
+    st = scan(0, total);
   }
-  KuRouteDev rt{};
-  rt.own_lo = d_lo; rt.own_hi = d_hi; rt.counts = d_counts; rt.cursor = d_cursor; rt.q_off = d_qoff;
-  rt.pos_base = p0; rt.world = W; rt.fill = 0;
-  // ---- counting pass over the slice, then every rank learns how much it gets from whom
-  std::vector<uint64_t> cnt(W, 0), all;
-  if (st == KU_OK && nb) st = ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s);
-  if (st == KU_OK && (hipMemcpyAsync(cnt.data(), d_counts, 8ull * W, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
-    st = mfail(KU_EHIP, "routing counts copy failed");
+  // ---- every rank learns how much it gets from whom
   st = comm_allgather_u64(m, r, st, cnt.data(), W, all, s);
   if (st != KU_OK) return st;
-  std::vector<uint64_t> send_off(W + 1, 0), recv_off(W + 1, 0);
+  std::vector<uint64_t> recv_at(W, 0), recv_n(W, 0);
+  uint64_t n_recv = 0, n_send = 0;
   for (uint32_t q = 0; q < W; ++q) {
-    send_off[q + 1] = send_off[q] + all[(size_t)r.rank * W + q];
-    recv_off[q + 1] = recv_off[q] + all[(size_t)q * W + r.rank];
+    recv_at[q] = n_recv;
+    recv_n[q] = all[(size_t)q * W + r.rank];
+    n_recv += recv_n[q];
+    n_send += cnt[q];
   }
-  const uint64_t n_send = send_off[W], n_recv = recv_off[W];
-  if (n_send >= (1ull << 32) || n_recv >= (1ull << 32)) st = mfail(KU_EUNSUP, "owner routing: more than 2^32 k-mers per rank and batch");
-  if (st == KU_OK && (r.q_ent.reserve(std::max<uint64_t>(n_send, 1) * 12) || r.q_pos.reserve(std::max<uint64_t>(n_send, 1) * 4) ||
-                      r.ret_slots.reserve(std::max<uint64_t>(n_send, 1) * 4) || r.r_ent.reserve(std::max<uint64_t>(n_recv, 1) * 12) ||
-                      r.r_slots.reserve(std::max<uint64_t>(n_recv, 1) * 4)))
+  if (n_send >= (1ull << 32) || n_recv >= (1ull << 32) || nb >= (1ull << 32)) st = mfail(KU_EUNSUP, "owner routing: more than 2^32 k-mers per rank and batch");
+  if (st == KU_OK && (r.r_ent.reserve(std::max<uint64_t>(n_recv, 1) * 12) || r.r_slots.reserve(std::max<uint64_t>(n_recv, 1) * 4)))
     st = mfail(KU_ENOMEM, "device memory for the routing queues");
-  // ---- filling pass: the owners' queues (and KU_AMBIG / 0 placeholders in the per-k-mer array of the slice)
-  if (st == KU_OK && (hipMemcpyAsync(d_qoff, send_off.data(), 8ull * (W + 1), hipMemcpyHostToDevice, s) != hipSuccess ||
-                      hipMemsetAsync(d_cursor, 0, 8ull * W, s) != hipSuccess))
-    st = mfail(KU_EHIP, "routing tables upload failed");
-  rt.fill = 1;
-  rt.q_ent = (uint32_t *)r.q_ent.p;
-  rt.q_pos = (uint32_t *)r.q_pos.p;
-  if (st == KU_OK && nb) st = ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s);
   // ---- k-mers to their owners (12 B each), probe + accounting there, slots back (4 B each), into place
-  st = comm_alltoallv(m, r, st, r.q_ent.p, send_off.data(), r.r_ent.p, recv_off.data(), 12, s);
+  st = comm_alltoallv(m, r, st, r.q_ent.p, send_at.data(), cnt.data(), r.r_ent.p, recv_at.data(), recv_n.data(), 12, s);
   const bool counts = !(opts.flags & (KU_F_NO_COUNTS | KU_F_QUICK));  // quick mode books the scanned prefix in the resolve stage
   if (st == KU_OK) st = ku_ctx_route_probe(r.ctx, (const uint32_t *)r.r_ent.p, n_recv, (uint32_t *)r.r_slots.p, counts, s);
-  st = comm_alltoallv(m, r, st, r.r_slots.p, recv_off.data(), r.ret_slots.p, send_off.data(), 4, s);
-  if (st == KU_OK) st = ku_launch_route_scatter((const uint32_t *)r.q_pos.p, (const uint32_t *)r.ret_slots.p, n_send, d_taxa, s);
+  st = comm_alltoallv(m, r, st, r.r_slots.p, recv_at.data(), recv_n.data(), r.ret_slots.p, send_at.data(), cnt.data(), 4, s);
+  for (uint32_t q = 0; q < W && st == KU_OK; ++q)
+    st = ku_launch_route_scatter((const uint32_t *)r.q_pos.p + send_at[q], (const uint32_t *)r.ret_slots.p + send_at[q], cnt[q], d_taxa + p0, s);
   if (st != KU_OK) return st;
   if (nr == 0) return KU_OK;
   ku_opts ro = opts;

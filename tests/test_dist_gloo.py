@@ -70,8 +70,7 @@ def _worker(rank, ws, port, ret):
         for s, h in sketches.items():
             regs[s] = h.registers()
         want_all = np.concatenate(full)
-        # n_reads: each rank resolves its own slice of the reads
-        r0, r1 = kdist.read_slice(len(seqs), rank, ws)
+        r0, r1 = kdist.read_slice(len(seqs), rank, ws)  # the reads this rank resolves (and, routed, the only ones it scans)
         # the exchange as the C++ driver does it: all-to-all of read-aligned slices + max-merge of the received ones
         starts = np.concatenate([[0], np.cumsum([len(x) for x in local])]).astype(np.int64)
         pos = [int(starts[kdist.read_slice(len(seqs), q, ws)[0]]) for q in range(ws)] + [int(starts[-1])]
@@ -80,6 +79,33 @@ def _worker(rank, ws, port, ret):
         # ... and as one all-reduce (round 1's form)
         merged = kdist.merge_taxa_max(torch.from_numpy(np.concatenate(local)))
         assert (merged.numpy() == want_all).all()
+        # ... and by owner routing (round 3): this rank scans only ITS reads, k-mers travel to their owners, slots return
+        table = {int(km): slot_of[int(v)] for km, v in zip(kmers[int(off[lo]):int(off[hi])], vals[int(off[lo]):int(off[hi])])}
+        r_regs, r_nk, r_sk = np.zeros_like(regs), np.zeros_like(n_kmers), {}
+
+        def probe(got):
+            out = torch.zeros(len(got), dtype=torch.int64)
+            for j, km in enumerate(got.numpy().view(np.uint64)):
+                s = table.get(int(km), 0)
+                out[j] = s
+                r_sk.setdefault(s, ko.Hll(12, False)).insert(int(km))
+                r_nk[s] += 1
+            return out
+
+        my_kmers, my_owner, my_want, my_amb = [], [], [], []
+        for i in range(r0, r1):
+            fwd, amb = ko.scan(seqs[i], K)
+            canon = synth.canonical(fwd, K)
+            bins = synth.bin_key(canon, K, NT)
+            my_kmers.append(canon[amb == 0])
+            my_owner.append(np.searchsorted(np.asarray(bounds, dtype=np.uint64), bins[amb == 0], side="right") - 1)
+            my_want.append(full[i][amb == 0])
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+        slots = kdist.route_lookup(torch.from_numpy(cat(my_kmers, np.uint64).view(np.int64)), torch.from_numpy(cat(my_owner, np.int64)), probe)
+        assert (slots.numpy() == cat(my_want, np.int64)).all()
+        for s, h in r_sk.items():
+            r_regs[s] = h.registers()
+        assert (r_regs == regs).all() and (r_nk == n_kmers).all()  # the owner booked exactly what the position-wise scan books
         node_ids = sorted({int(c) for c in res["calls"]})
         n_reads = np.zeros(len(node_ids), dtype=np.int64)
         for c in res["calls"][r0:r1]:
