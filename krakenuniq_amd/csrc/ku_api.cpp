@@ -977,7 +977,12 @@ extern "C" int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t
   }
   ku_ctx::Sparse &sp = ctx->sp;
   KuSparseDev &d = sp.dev;
-  const uint32_t l_log2 = 26, u_log2 = 22;
+  // One pass of the emulation covers at most 2^25 bases (sparse_pass), the carried open unit at most 2^25 entries more: L
+  // (distinct (unit, slot, encoding) of a pass) at 2^27 cells and U ((unit, slot) pairs: at most one per k-mer, and at
+  // most n_slots per unit) sized from the slot count never run above half full, whatever the sample looks like
+  const uint32_t l_log2 = 27;
+  uint32_t u_log2 = 22;
+  while (u_log2 < 27 && (1ull << u_log2) < 128ull * ctx->tax.n_slots) ++u_log2;
   d.l_mask = (1ull << l_log2) - 1;
   d.u_mask = (1ull << u_log2) - 1;
   d.g_mask = (1ull << global_log2) - 1;

@@ -56,13 +56,18 @@ struct KuCountsDev {
 // sends every unambiguous canonical k-mer -- with the size-independent half of its bucket hash -- to the rank that owns its
 // minimizer bin; the owner probes, accounts (HLL, n_kmers) and sends the slot back.  ku_lookup_kernel<3,...> is the scan:
 // a counting pass (fill = 0: k-mers per owner) and a filling pass (fill = 1: the owners' queues, in slice order per block).
+#define KU_ROUTE_CHUNK 512u          // entries of a queue a block claims at a time
+#define KU_ROUTE_CURSOR_STRIDE 16u   // the queues' cursors lie 128 bytes apart
+#define KU_ROUTE_NONE (~0ull)
+#define KU_ROUTE_NULL 0xFFFFFFFFu    // both k-mer words of a null entry (a k-mer has at most 62 bits), and its position
 struct KuRouteDev {
   const uint64_t *own_lo, *own_hi;  // [world] the ranks' minimizer ranges
-  unsigned long long *cursor;       // [world] entries claimed in each owner's queue (ends as the owner's total, also beyond cap)
+  unsigned long long *cursor;       // [world * KU_ROUTE_CURSOR_STRIDE] entries claimed in each owner's queue, whole chunks (ends as
+                                    // the owner's total incl. null entries, also beyond cap)
   const uint64_t *q_off;            // [world] first entry of each owner's queue
   uint32_t *q_ent;                  // 3 dwords per entry: k-mer low, k-mer high, bucket prehash
   uint32_t *q_pos;                  // the entry's position in the slice's per-k-mer array (where its slot goes)
-  uint64_t cap;                     // room per queue (0: the queues are exactly sized)
+  uint64_t cap;                     // room per queue in entries (0: the queues are exactly sized)
   uint32_t world;
 };
 // HyperLogLog++ sparse-mode emulation (ku_sparse.hip): tables of one context

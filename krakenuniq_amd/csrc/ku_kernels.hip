@@ -21,6 +21,7 @@
 // coalesced, and puts neighbouring lanes on neighbouring k-mers -- which share
 // their minimizer bin ~(k-nt+1)/2 times in a row, so the idx and pair gathers
 // of a wave collapse onto a handful of cache lines.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ku_device.h"
@@ -73,9 +74,21 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   // that a doubling step reads one and writes the other (one barrier per step)
   constexpr bool PK = LAYOUT == 1 && MODE != 2;
   constexpr bool ROUTE = MODE == 3;
-  __shared__ uint32_t s_rcnt[ROUTE ? 64 : 1];   // ROUTE: k-mers of the tile per owner
-  __shared__ unsigned long long s_rbase[ROUTE ? 64 : 1];
-  if (ROUTE) { if (threadIdx.x < 64) s_rcnt[threadIdx.x] = 0; }
+  // ROUTE, per owner: k-mers of the tile; where they go (up to the split index: the rest of the block's current chunk of
+  // the owner's queue, beyond it: the chunk claimed for this tile); the current chunk and how much of it is used; the
+  // owners' minimizer ranges
+  __shared__ uint32_t s_rcnt[ROUTE ? 64 : 1], s_rsplit[ROUTE ? 64 : 1], s_cused[ROUTE ? 64 : 1];
+  __shared__ unsigned long long s_rbase[ROUTE ? 64 : 1], s_rbase1[ROUTE ? 64 : 1], s_cbase[ROUTE ? 64 : 1];
+  __shared__ unsigned long long s_olo[ROUTE ? 64 : 1], s_ohi[ROUTE ? 64 : 1];
+  if (ROUTE) {
+    if (threadIdx.x < 64) {
+      s_rcnt[threadIdx.x] = 0;
+      s_cused[threadIdx.x] = KU_ROUTE_CHUNK;  // no chunk yet: the first tile claims one
+      s_cbase[threadIdx.x] = KU_ROUTE_NONE;
+      s_olo[threadIdx.x] = threadIdx.x < rt.world ? rt.own_lo[threadIdx.x] : 0ull;
+      s_ohi[threadIdx.x] = threadIdx.x < rt.world ? rt.own_hi[threadIdx.x] : 0ull;
+    }
+  }
   __shared__ uint32_t s_pa[PK ? KU_TILE + 64 : 1];
   __shared__ uint32_t s_pb[PK ? KU_TILE + 64 : 1];
   __shared__ uint32_t s_tie;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
           if (ROUTE) {
             n_b[j] = 0xFFu;  // the owner: the rank whose minimizer range holds the bin (none: the k-mer is nobody's, a miss)
             for (uint32_t q = 0; q < rt.world; ++q)
-              if (bin >= rt.own_lo[q] && bin < rt.own_hi[q]) n_b[j] = q;
+              if (bin >= s_olo[q] && bin < s_ohi[q]) n_b[j] = q;
           } else
           if (!SHARDED || (bin >= db.bin_lo && bin < db.bin_hi)) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
             if (LAYOUT == 0 || MODE == 2) {
@@ -276,10 +289,13 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     if (ROUTE) {
       // (n_b[j] = owner, 0xFF none.)  The tile's entries get consecutive places in their owners' queues: the lanes of a
       // wave that share an owner take their local index with ONE LDS add (neighbouring k-mers share a minimizer, so a wave
-      // sees one to three owners), the block claims its room once per owner and tile from the queue's global cursor --
-      // the k-mers of a read stay together and in read order, which keeps the owner's bucket probes on few lines per
-      // wave.  A queue has room for rt.cap entries (0: exactly sized); claims beyond it are counted, not written, so
-      // the cursors always end as the true per-owner totals and the host can size an exact second pass.
+      // sees one to three owners); the BLOCK owns a chunk of KU_ROUTE_CHUNK entries in every queue and claims the next one
+      // from the queue's global cursor only when a tile does not fit the rest of it (device-scope adds on a handful of
+      // addresses from every block and tile were the whole cost of this kernel: one per ~25 entries -> one per 512).
+      // The k-mers of a read stay together and in read order, which keeps the owner's bucket probes on few lines per
+      // wave.  What a block leaves unused of its last chunks is filled with null entries (KU_ROUTE_NULL: not a k-mer;
+      // the owner skips them).  A queue has room for rt.cap entries (0: exactly sized); chunks beyond it are counted, not
+      // written, so the cursors always end as the true per-owner totals and the host can size an exact second pass.
       uint32_t idx[KU_ITEMS];
       const uint32_t lane = tid & 63u;
       const unsigned long long below = (1ull << lane) - 1ull;
@@ -303,14 +319,31 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         if (pos < n_bytes) taxa[pos] = ok[j] ? 0u : KU_AMBIG;
       }
       __syncthreads();
-      if (tid < rt.world) s_rbase[tid] = s_rcnt[tid] ? atomicAdd(&rt.cursor[tid], (unsigned long long)s_rcnt[tid]) : 0ull;
+      if (tid < rt.world) {
+        const uint32_t n = s_rcnt[tid], used = s_cused[tid];
+        const unsigned long long base = s_cbase[tid];
+        s_rbase[tid] = base == KU_ROUTE_NONE ? KU_ROUTE_NONE : base + used;
+        if (used + n <= KU_ROUTE_CHUNK) {
+          s_rsplit[tid] = n;
+          s_cused[tid] = used + n;
+        } else {
+          // the chunk's rest is used up by the first entries of the tile, the others open the next chunk
+          unsigned long long nb = atomicAdd(&rt.cursor[tid * KU_ROUTE_CURSOR_STRIDE], (unsigned long long)KU_ROUTE_CHUNK);
+          if (rt.cap != 0 && nb + KU_ROUTE_CHUNK > rt.cap) nb = KU_ROUTE_NONE;
+          s_rsplit[tid] = KU_ROUTE_CHUNK - used;
+          s_rbase1[tid] = nb;
+          s_cbase[tid] = nb;
+          s_cused[tid] = n - (KU_ROUTE_CHUNK - used);
+        }
+      }
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < KU_ITEMS; ++j) {
         if (ok[j] && n_b[j] != 0xFFu) {
-          const unsigned long long loc = s_rbase[n_b[j]] + idx[j];
-          if (rt.cap == 0 || loc < rt.cap) {
-            const unsigned long long e = rt.q_off[n_b[j]] + loc;
+          const uint32_t o = n_b[j], split = s_rsplit[o];
+          const unsigned long long at = idx[j] < split ? s_rbase[o] : s_rbase1[o];
+          if (at != KU_ROUTE_NONE) {
+            const unsigned long long e = rt.q_off[o] + at + (idx[j] < split ? idx[j] : idx[j] - split);
             rt.q_ent[3 * e] = (uint32_t)canon[j];
             rt.q_ent[3 * e + 1] = (uint32_t)(canon[j] >> 32);
             rt.q_ent[3 * e + 2] = ku_locus_prehash(locus[j]);
@@ -488,6 +521,20 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     __syncthreads();
     ku_ct_flush(s_ctk, s_ctc, cnt.n_kmers);
   }
+  if (ROUTE) {  // the unused rest of the block's chunks: null entries
+    __syncthreads();
+    for (uint32_t o = 0; o < rt.world; ++o) {
+      const unsigned long long base = s_cbase[o];
+      if (base == KU_ROUTE_NONE) continue;
+      for (uint32_t i = s_cused[o] + tid; i < KU_ROUTE_CHUNK; i += KU_THREADS) {
+        const unsigned long long e = rt.q_off[o] + base + i;
+        rt.q_ent[3 * e] = KU_ROUTE_NULL;
+        rt.q_ent[3 * e + 1] = KU_ROUTE_NULL;
+        rt.q_ent[3 * e + 2] = 0u;
+        rt.q_pos[e] = KU_ROUTE_NULL;
+      }
+    }
+  }
   if (MODE == 2) {
     unsigned long long v[4] = {st_q, st_lg, st_ne, st_nb};
 #pragma unroll
@@ -541,7 +588,10 @@ int ku_launch_route_scan(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_by
                          hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
   if (!db.table || rt.world == 0 || rt.world > 64) return KU_EINVAL;
-  hipLaunchKernelGGL((ku_lookup_kernel<3, 1, true, false>), dim3(ku_lookup_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream, db,
+  // (a block pads its last chunk of every queue: at least 16 tiles per block keep that a small share of what it queues)
+  const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ku_lookup_grid(n_bytes, n_cu), (n_tiles + 15) / 16));
+  hipLaunchKernelGGL((ku_lookup_kernel<3, 1, true, false>), dim3(grid), dim3(KU_THREADS), 0, stream, db,
                      KuCountsDev{}, d_seqs, n_bytes, d_taxa, (unsigned long long *)nullptr, 0u, rt);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

@@ -807,15 +807,16 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
   // ---- device-side tables of this step: ranges, cursors, queue offsets
   uint64_t *d_lo = nullptr, *d_hi = nullptr, *d_qoff = nullptr;
   unsigned long long *d_cursor = nullptr;
-  if (st == KU_OK) st = r.rt_dev.reserve(4ull * W * 8);
+  if (st == KU_OK) st = r.rt_dev.reserve((3ull + KU_ROUTE_CURSOR_STRIDE) * W * 8);
   // One scanning pass: every owner's queue gets room for twice its fair share of the slice's k-mers (the shard bounds are
   // quantiles of the database, reads follow the database) and the cursors come back as the true totals; a queue that
   // did not hold its total (a batch from one corner of the minimizer space) sends the scan through a second, exactly
   // sized pass -- the results do not depend on which it was (KU_ROUTE_CAP: entries per queue, for the tests)
-  uint64_t cap = std::max<uint64_t>(2 * (nb / W) + 65536, 1);
+  // (a queue is claimed in chunks of KU_ROUTE_CHUNK entries by the scanning blocks, each of which pads its last one)
+  uint64_t cap = 2 * (nb / W) + 8192ull * KU_ROUTE_CHUNK;
   if (const char *e = std::getenv("KU_ROUTE_CAP")) cap = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
-  cap = std::min<uint64_t>(cap, std::max<uint64_t>(nb, 1));
   std::vector<uint64_t> cnt(W, 0), send_at(W, 0), all;
+  std::vector<unsigned long long> cur((size_t)W * KU_ROUTE_CURSOR_STRIDE, 0);
   for (uint32_t q = 0; q < W; ++q) send_at[q] = q * cap;
   KuRouteDev rt{};
   auto scan = [&](uint64_t room, uint64_t total) -> int {
@@ -824,20 +825,22 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
       return mfail(KU_ENOMEM, "device memory for the routing queues");
     d_lo = (uint64_t *)r.rt_dev.p;
     d_hi = d_lo + W;
-    d_cursor = (unsigned long long *)(d_hi + W);
-    d_qoff = (uint64_t *)(d_cursor + W);
+    d_qoff = d_hi + W;
+    d_cursor = (unsigned long long *)(d_qoff + W);
     if (hipMemcpyAsync(d_lo, m->own_lo.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(d_hi, m->own_hi.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(d_qoff, send_at.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemsetAsync(d_cursor, 0, 8ull * W, s) != hipSuccess)
+        hipMemsetAsync(d_cursor, 0, 8ull * W * KU_ROUTE_CURSOR_STRIDE, s) != hipSuccess)
       return mfail(KU_EHIP, "routing tables upload failed");
     rt.own_lo = d_lo; rt.own_hi = d_hi; rt.cursor = d_cursor; rt.q_off = d_qoff;
     rt.q_ent = (uint32_t *)r.q_ent.p;
     rt.q_pos = (uint32_t *)r.q_pos.p;
     rt.world = W; rt.cap = room;
     if (nb) M_TRY(ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s));
-    if (hipMemcpyAsync(cnt.data(), d_cursor, 8ull * W, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    if (hipMemcpyAsync(cur.data(), d_cursor, 8ull * W * KU_ROUTE_CURSOR_STRIDE, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
       return mfail(KU_EHIP, "routing counts copy failed");
+    for (uint32_t q = 0; q < W; ++q) cnt[q] = cur[(size_t)q * KU_ROUTE_CURSOR_STRIDE];
     return KU_OK;
   };
   if (st == KU_OK) st = scan(cap, cap * W);

@@ -23,11 +23,18 @@ __global__ __launch_bounds__(256) void ku_route_probe_kernel(KuDbDev db, KuCount
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < n; base += stride) {  // block-uniform trip count
     const uint64_t i = base + threadIdx.x;
-    const bool ok = i < n;
+    bool ok = i < n;
     uint32_t slot = 0;
     uint64_t canon = 0, hh = 0;
+    uint32_t lo = 0, hi = 0, g = 0;
     if (ok) {
-      const uint32_t lo = ent[3 * i], hi = ent[3 * i + 1], g = ent[3 * i + 2];
+      lo = ent[3 * i]; hi = ent[3 * i + 1]; g = ent[3 * i + 2];
+      if (lo == KU_ROUTE_NULL && hi == KU_ROUTE_NULL) {  // padding of a sender's chunk: nothing to look up or to book
+        slots[i] = 0;
+        ok = false;
+      }
+    }
+    if (ok) {
       canon = ((uint64_t)hi << 32) | lo;
       hh = ku_fmix64(canon);
       const uint32_t tag = ku_table_tag(hh);
@@ -72,7 +79,10 @@ __global__ __launch_bounds__(256) void ku_route_probe_kernel(KuDbDev db, KuCount
 
 // the slots the owners sent back, into the per-k-mer array at the positions the scan recorded
 __global__ void ku_route_scatter_kernel(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ slots, uint64_t n, uint32_t *taxa) {
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) taxa[pos[i]] = slots[i];
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t p = pos[i];
+    if (p != KU_ROUTE_NULL) taxa[p] = slots[i];
+  }
 }
 
 int ku_launch_route_probe(const KuDbDev &db, const KuCountsDev &cnt, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts,

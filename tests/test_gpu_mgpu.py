@@ -282,7 +282,7 @@ def test_device_step_matches_single_context(exchange, monkeypatch):
     scattered (owner routing) or broadcast (position-wise exchange) from rank 0, slices resolved per rank == one context
     holding the whole database"""
     if exchange == "route_tight":
-        monkeypatch.setenv("KU_ROUTE_CAP", "5000000")  # (a third of the slice's k-mers fit some queues, not others)
+        monkeypatch.setenv("KU_ROUTE_CAP", "3000000")  # (less than a queue gets: the exactly sized second pass)
         exchange = "route"
     if exchange == "slots":
         monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
