@@ -256,7 +256,6 @@ int main(int argc, char **argv) {
   // distinct k-mers exactly instead of estimating them
   const char *base = strrchr(argv[0], '/');
   const bool exact = strcmp(base ? base + 1 : argv[0], "classifyExact") == 0 || getenv("KU_EXACT") != nullptr;
-  if (exact && quick) die(EX_SOFTWARE, "exact counting with quick mode is not built into the MI355X classifyExact");
   const bool map_uids = !uid_map_file.empty();
   if (map_uids && dbs.size() > 1) { fprintf(stderr, "Cannot use more than one database with UID mapping!\n"); return 1; }  // src/classify.cpp:158-160
   if (map_uids && quick) { fprintf(stderr, "Quick mode not available when mapping UIDs\n"); return 1; }                  // :954-956
@@ -309,6 +308,7 @@ int main(int argc, char **argv) {
       fprintf(stderr, "classify: several databases on several GPUs: every GPU holds all of them (replicas), the reads are split\n");
       mflags = KU_MGPU_REPLICAS;
     }
+    if (exact && quick) die(EX_SOFTWARE, "exact counting in quick mode runs on one GPU (the shards' foreign-mark pass needs whole reads)");
     if (exact && mflags) die(EX_SOFTWARE, "exact counting on several GPUs needs the database sharded by minimizer range (not KU_MGPU_MODE=replicas / several databases)");
     KU_CHECK(ku_mgpu_create(devices.data(), (uint32_t)devices.size(), 0, (uint32_t)devices.size(), nullptr, mflags, &mg));
     fprintf(stderr, "Running on %zu GPU ranks (%s, %s exchange)\n", devices.size(), mflags ? "replicas" : "database sharded by minimizer range",
@@ -349,7 +349,6 @@ int main(int argc, char **argv) {
   }
   const bool chunked = !chunk_bounds.empty();
   if (map_uids && (mg || chunked)) die(EX_SOFTWARE, "UID mapping (-I) runs on one GPU with the database resident (no KU_DEVICES, no -x chunks)");
-  if (chunked && exact) die(EX_SOFTWARE, "exact counting with -x chunks is not built into the MI355X classifyExact");
   // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
   auto counts_file_good = [](const std::string &name, bool say) {
     bool good = false;
@@ -855,6 +854,10 @@ int main(int argc, char **argv) {
     if (tn == 0) fprintf(stderr, "total number of reads is zero - not creating a report!\n");
     Sink rs;
     if (!rs.open(report_out, /*append=*/true)) die(EX_OSERR, "can't open %s", report_out.c_str());
+    if (sparse_gave_up && tn) {  // the file says so too (a comment line, where the wrapper's "# CL:" header lines are)
+      static const char note[] = "# NOTE: kmers / dup / cov are dense HyperLogLog estimates (the sparse-sketch emulation ran out of device memory)\n";
+      rs.write(note, sizeof note - 1);
+    }
     rs.write(text, tn);
     rs.close();
     ku_free(text);

@@ -1404,8 +1404,8 @@ static int classify_device_impl(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
   // short reads against the resident probe table: one fused kernel, a wave per read (ku_short.hip)
   const bool exact = ctx->d_exact_set != nullptr;
   if (exact && !store_whole(ctx->m)) return fail(KU_EUNSUP, "exact counting on a shard runs through the multi-GPU driver (ku_mgpu_enable_exact)");
-  if (exact && (flags & (KU_F_QUICK | KU_F_KEEP_SLOTS | KU_F_NO_COUNTS)))
-    return fail(KU_EUNSUP, "exact counting goes with the plain classification only (no quick mode / slot output / count-less runs)");
+  if (exact && (flags & (KU_F_KEEP_SLOTS | KU_F_NO_COUNTS)))
+    return fail(KU_EUNSUP, "exact counting goes with a whole classification (no slot output / count-less runs)");
   const bool sparse = ctx->sp.on && !(flags & KU_F_NO_COUNTS);
   if (sparse && !h_len) return fail(KU_EUNSUP, "the sparse-mode emulation runs through the host-buffer entry points (it needs the read lengths on the host)");
   if (sparse && (flags & KU_F_KEEP_SLOTS)) return fail(KU_EUNSUP, "the sparse-mode emulation does not combine with slot output");
@@ -1456,7 +1456,8 @@ static int classify_device_impl(ku_ctx *ctx, const void *d_seqs, uint64_t n_byte
     if (n_reads && (!d_seqs || !d_seq_off || !d_seq_len || !d_taxa)) return fail(KU_EINVAL, "ku_classify_batch_device: null buffer");
     int st = ku_launch_exact(ctx->m.db.k, (const uint8_t *)d_seqs, d_seq_off, d_seq_len, n_reads, d_taxa, ctx->d_exact_set,
                              ctx->exact_mask, ctx->d_exact_unique, ctx->d_scalar + 6, ctx->n_cu,
-                             stream ? (hipStream_t)stream : ctx->stream);
+                             stream ? (hipStream_t)stream : ctx->stream,
+                             (flags & KU_F_QUICK) ? std::max(1u, opts ? opts->min_hits : 1u) : 0u);
     if (st != KU_OK) return fail(st, "exact counting kernel launch failed");
   }
   return ku_resolve_device(ctx, d_seqs, d_seq_off, d_seq_len, n_reads, opts, d_calls, d_taxa, d_hits, stream);
@@ -1982,7 +1983,6 @@ extern "C" int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts) {
   KU_TRY(check_ready(ctx));
   if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_lookup: batch of another context");
   if (b->finished) return fail(KU_ESTATE, "ku_batch_lookup: the batch was already finished");
-  if (ctx->d_exact_set) return fail(KU_EUNSUP, "exact counting is not available for resident batches");
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   // quick mode does not shorten a chunk pass: the reference's chunked run books every k-mer of every read and only
   // derives the call differently at the end (classify.cpp:686-737)
@@ -2017,6 +2017,13 @@ extern "C" int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, ui
       ctx_free_sparse(ctx);
       ctx->sp.gave_up = true;
     } else if (sst != KU_OK) return sst;
+  }
+  if (ctx->d_exact_set && !(o.flags & KU_F_NO_COUNTS)) {
+    // exact counting of a chunked run: the merged slots of all chunks are in place, and a chunked run books every k-mer of
+    // every read whatever the mode (classify.cpp:686-737)
+    int st = ku_launch_exact(ctx->m.db.k, (const uint8_t *)b->d_seqs, b->d_off, b->d_len, n_reads, b->d_taxa, ctx->d_exact_set, ctx->exact_mask,
+                             ctx->d_exact_unique, ctx->d_scalar + 6, ctx->n_cu, s);
+    if (st != KU_OK) return fail(st, "exact counting kernel launch failed");
   }
   if (o.flags & KU_F_QUICK) {  // the chunked run's quick mode: hits up to min_hits, call = the last k-mer's taxon
     int st = ku_launch_quick_chunked(ctx->tax, ctx->cnt, ctx->m.db.k, b->d_off, b->d_len, n_reads, o.flags, o.min_hits,

@@ -208,7 +208,7 @@ uint64_t ku_short_grid_waves(uint64_t n_reads, uint32_t max_kmers, int n_cu);
 uint64_t ku_resolve_workspace_bytes(uint32_t max_read_len, uint32_t k, int n_cu);
 int ku_launch_exact(uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                     const uint32_t *d_taxa, unsigned long long *d_set, uint64_t mask, unsigned long long *d_unique,
-                    uint32_t *d_overflow, int n_cu, hipStream_t stream);
+                    uint32_t *d_overflow, int n_cu, hipStream_t stream, uint32_t quick_min_hits = 0);
 int ku_launch_rle(const uint32_t *d_taxa, uint32_t k, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
                   uint64_t n_reads, uint64_t n_bytes, void *d_runs, uint64_t runs_cap, unsigned long long *d_counter,
                   uint64_t *d_run_off, uint32_t *d_run_cnt, int n_cu, hipStream_t stream);

@@ -979,13 +979,32 @@ __global__ __launch_bounds__(64) void ku_exact_kernel(uint32_t k, const uint8_t 
                                                       const uint64_t *__restrict__ seq_off,
                                                       const uint32_t *__restrict__ seq_len, uint64_t n_reads,
                                                       const uint32_t *__restrict__ taxa, unsigned long long *set,
-                                                      uint64_t mask, unsigned long long *unique, uint32_t *overflow) {
+                                                      uint64_t mask, unsigned long long *unique, uint32_t *overflow,
+                                                      uint32_t quick_min_hits) {
   const uint32_t tid = threadIdx.x;
   for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
     const uint32_t len = seq_len[r];
     const uint32_t n = len >= k ? len - k + 1 : 0;
     const uint64_t off = seq_off[r];
-    for (uint32_t i = tid; i < n; i += 64) {
+    uint32_t stop = n;
+    if (quick_min_hits) {  // quick mode counts the k-mers scanned up to and including the min_hits-th hit (ku_quick_kernel)
+      uint32_t total = 0;
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + tid;
+        const uint32_t s = i < n ? taxa[off + i] : 0;
+        const bool hit = s != 0 && s != KU_AMBIG;
+        const unsigned long long hm = __ballot(hit);
+        const uint32_t c = (uint32_t)__popcll(hm);
+        if (total + c >= quick_min_hits) {
+          const uint32_t need = quick_min_hits - total;
+          const bool is_stop = hit && (uint32_t)__popcll(hm & ((1ull << tid) - 1ull)) + 1 == need;
+          stop = base + (uint32_t)__ffsll((long long)__ballot(is_stop));
+          break;
+        }
+        total += c;
+      }
+    }
+    for (uint32_t i = tid; i < stop; i += 64) {
       const uint32_t s = taxa[off + i];
       if (s == KU_AMBIG || s == KU_FOREIGN_MARK) continue;  // (several GPUs: a k-mer another rank owns is that rank's to count)
       const uint64_t canon = ku_canon_from_ascii(seqs + off + i, k);
@@ -1007,11 +1026,11 @@ __global__ __launch_bounds__(64) void ku_exact_kernel(uint32_t k, const uint8_t 
 }
 int ku_launch_exact(uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len, uint64_t n_reads,
                     const uint32_t *d_taxa, unsigned long long *d_set, uint64_t mask, unsigned long long *d_unique,
-                    uint32_t *d_overflow, int n_cu, hipStream_t stream) {
+                    uint32_t *d_overflow, int n_cu, hipStream_t stream, uint32_t quick_min_hits) {
   if (n_reads == 0) return KU_OK;
   const uint64_t cap = (uint64_t)n_cu * 32;
   hipLaunchKernelGGL(ku_exact_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, k, d_seqs,
-                     d_seq_off, d_seq_len, n_reads, d_taxa, d_set, mask, d_unique, d_overflow);
+                     d_seq_off, d_seq_len, n_reads, d_taxa, d_set, mask, d_unique, d_overflow, quick_min_hits);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

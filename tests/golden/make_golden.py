@@ -60,6 +60,19 @@ def classify(db, args, reads, binary="classify"):
     return run(cmd)
 
 
+def make_f1_exact_variants(d=None):
+    """classifyExact with the other run modes (it is the same program with every flag, classify.cpp:46-53): quick mode
+    (only the scanned prefix of a read is counted) and a chunked run; `make_golden.py f1x` adds them to an existing f1"""
+    d = d or os.path.join(HERE, "f1")
+    rd = [f"{d}/reads.fq"]
+    tmp = f"{d}/_x.tsv"
+    classify(d, ["-q", "-m", "2", "-o", tmp, "-r", f"{d}/report_exact_quick.tsv"], rd, "classifyExact")
+    assert open(tmp, "rb").read() == open(f"{d}/out_quick.tsv", "rb").read()
+    classify(d, ["-x", "70K", "-t", "2", "-o", tmp, "-r", f"{d}/report_exact_chunk.tsv"], rd, "classifyExact")
+    assert open(tmp, "rb").read() == open(f"{d}/out_chunk.tsv", "rb").read()
+    os.remove(tmp)
+
+
 def make_f1():
     d = os.path.join(HERE, "f1")
     shutil.rmtree(d, ignore_errors=True)
@@ -101,6 +114,7 @@ def make_f1():
     rd = [f"{d}/reads.fq"]
     classify(d, ["-o", f"{d}/out.tsv", "-r", f"{d}/report.tsv"], rd)          # writes .counts too
     classify(d, ["-o", f"{d}/out_exact.tsv", "-r", f"{d}/report_exact.tsv"], rd, "classifyExact")
+    make_f1_exact_variants(d)
     classify(d, ["-u", "1000", "-o", f"{d}/out_u1000.tsv", "-r", f"{d}/report_u1000.tsv"], rd)
     classify(d, ["-x", "70K", "-t", "2", "-o", f"{d}/out_chunk.tsv", "-r", f"{d}/report_chunk.tsv"], rd)
     classify(d, ["-q", "-m", "2", "-o", f"{d}/out_quick.tsv"], rd)
@@ -543,6 +557,9 @@ def main():
         return
     if sys.argv[1:] == ["f10"]:
         make_f10(os.path.join(HERE, "f1"))
+        return
+    if sys.argv[1:] == ["f1x"]:
+        make_f1_exact_variants()
         return
     if sys.argv[1:] == ["f8"]:  # add the multi-database fixture without regenerating the others
         g4 = synth.procedural_genome(7, 4, 3000)

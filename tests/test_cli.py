@@ -226,8 +226,32 @@ def test_classify_exact_binary(tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
     assert rows(rep.read_text()) == rows(open(f"{F1}/report_exact.tsv").read())
-    assert subprocess.run([exact, "-q", "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB",
-                           f"{F1}/reads.fq"], stderr=subprocess.PIPE).returncode == 70
+    # classifyExact is the reference's classify with every flag (classify.cpp:46-53): quick mode counts the scanned prefix
+    # of each read, a chunked run every k-mer (golden: oracle/_ref/classifyExact -q -m 2 / -x 70K -t 2)
+    for extra, want_out, want_rep in ((["-q", "-m", "2"], "out_quick.tsv", "report_exact_quick.tsv"),
+                                      (["-x", "70K", "-t", "2"], "out_chunk.tsv", "report_exact_chunk.tsv")):
+        r = subprocess.run([exact, "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB", "-o", str(out),
+                            "-r", str(rep), *extra, f"{F1}/reads.fq"], stderr=subprocess.PIPE, env=dict(os.environ, KU_EXACT_LOG2="18"))
+        assert r.returncode == 0, r.stderr.decode()
+        assert out.read_bytes() == open(f"{F1}/{want_out}", "rb").read(), extra
+        assert rows(rep.read_text()) == rows(open(f"{F1}/{want_rep}").read()), extra
+
+
+@pytest.mark.gpu
+def test_report_says_when_the_sparse_emulation_gave_up(tmp_path):
+    """no device memory for the run-wide (slot, encoding) set (test hook: a ceiling of 2^11 cells): the run goes on, the
+    Kraken file is the reference's, stderr AND the report file say that kmers / dup / cov are dense estimates"""
+    out, rep = tmp_path / "out.tsv", tmp_path / "rep.tsv"
+    r = subprocess.run([BIN] + DB + ["-u", "1000", "-o", str(out), "-r", str(rep), f"{F1}/reads.fq"], stderr=subprocess.PIPE,
+                       env=dict(os.environ, KU_SPARSE_MAX_LOG2="11", KU_SPARSE_LOG2="10"))
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"dense-register estimates" in r.stderr
+    assert out.read_bytes() == open(f"{F1}/out_u1000.tsv", "rb").read()
+    text = rep.read_text()
+    assert text.startswith("# NOTE: kmers / dup / cov are dense HyperLogLog estimates")
+    body = [l for l in text.split("\n") if l and not l.startswith("#")]
+    want = [l for l in open(f"{F1}/report_u1000.tsv").read().split("\n") if l and not l.startswith("#")]
+    assert len(body) == len(want) and [l.split("\t")[1:3] for l in body] == [l.split("\t")[1:3] for l in want]  # reads / taxReads
 
 
 @pytest.mark.gpu
