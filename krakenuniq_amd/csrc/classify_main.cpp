@@ -396,8 +396,28 @@ int main(int argc, char **argv) {
   bool sparse = want_report && !exact && !getenv("KU_NO_SPARSE");
   if (sparse) {
     const char *e = getenv("KU_SPARSE_LOG2");
-    int st = mg ? ku_mgpu_enable_sparse(mg, work_unit_nt, e ? (uint32_t)atoi(e) : 0u)
-                : ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, e ? (uint32_t)atoi(e) : 0u);
+    uint32_t g_log2 = e ? (uint32_t)atoi(e) : 0u;
+    if (!e && !mg && !chunked) {
+      // The run-wide (slot, encoding) set holds at most one entry per k-mer of the input and is kept at most half full:
+      // start it at the size the input files suggest instead of growing it by rehashing in the middle of the run (a
+      // 10 M-read FASTQ grew it four times) -- within an eighth of the free device memory; pipes and small inputs: the
+      // default of 2^26 cells, which grows on demand as before
+      uint64_t est_nt = 0;
+      for (int fi = optind; fi < argc; ++fi) {
+        struct stat sb;
+        if (::stat(argv[fi], &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
+        const size_t ln = strlen(argv[fi]);
+        const bool gz = ln > 3 && strcmp(argv[fi] + ln - 3, ".gz") == 0;
+        est_nt += (uint64_t)sb.st_size * (gz ? 3 : 1) * 6 / 10;  // FASTQ: half the bytes are bases, FASTA: nearly all
+      }
+      uint64_t free_b = 0, total_b = 0;
+      if (est_nt > (1ull << 26) && ku_ctx_mem_info(ctx, &free_b, &total_b) == KU_OK) {
+        g_log2 = 26;
+        while (g_log2 < 34 && (1ull << g_log2) < est_nt && (16ull << g_log2) <= free_b / 8) ++g_log2;
+      }
+    }
+    int st = mg ? ku_mgpu_enable_sparse(mg, work_unit_nt, g_log2)
+                : ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, g_log2);
     if (st == KU_EUNSUP) { fprintf(stderr, "classify: %s -- the report will carry dense estimates\n", ku_last_error()); sparse = false; }
     else KU_CHECK(st);
   }

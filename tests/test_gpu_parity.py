@@ -436,10 +436,16 @@ def test_exact_counting_reproduces_classify_exact(golden, f1):
     got = capi.report_exact(f1["ctax"], counts, uniq, [f"{d}/database.kdb.counts"])
     assert rows(got) == rows(open(f"{d}/report_exact.tsv").read())
     assert (uniq <= counts["n_kmers"]).all() and uniq.sum() > 50000
-    with pytest.raises(capi.KuError):  # plain mode only
-        ctx.classify_batch(*ko.pack_reads(seqs[:10]), flags=capi.KU_F_QUICK)
+    with pytest.raises(capi.KuError):  # a whole classification only
+        ctx.classify_batch(*ko.pack_reads(seqs[:10]), flags=capi.KU_F_NO_COUNTS)
     ctx.reset_counts()
     assert not ctx.exact_counts().any()
+    # quick mode (-q -m 2): only the scanned prefix of a read is counted -> the reference's classifyExact -q report
+    for a, b in ((0, half), (half, 1000)):
+        gpu = ctx.classify_batch(*ko.pack_reads(seqs[a:b]), flags=capi.KU_F_QUICK, min_hits=2)
+    got = capi.report_exact(f1["ctax"], ctx.counts(), ctx.exact_counts(), [f"{d}/database.kdb.counts"])
+    assert rows(got) == rows(open(f"{d}/report_exact_quick.tsv").read())
+    ctx.reset_counts()
     # a set that is too small is reported, not silently wrong
     ctx.enable_exact(10)
     ctx.classify_batch(*ko.pack_reads(seqs))
