@@ -305,6 +305,23 @@ int ku_classify_batch_device(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, 
                              const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts,
                              uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits, void *stream);
 
+/* Device-resident batch in, the per-k-mer codes out as the Kraken line prints them (hitlist_string, classify.cpp:980-1010:
+ * runs of equal codes): d_runs[runs_cap] {code, first k-mer}, per read d_run_off / d_run_cnt (as ku_classify_batch_rle
+ * hands them to the host), *d_n_runs = the extent of d_runs in use.  The fused kernel writes the runs itself -- no
+ * per-k-mer array exists at any time (6 GB per 10 M x 150 bp reads that ku_classify_batch_device writes).  max_read_len
+ * in `opts` is REQUIRED here (the longest read of the batch; no host round trip to find it).  Asynchronous on `stream`.
+ * ku_device_rle_runs_cap() is the capacity that holds any batch whose reads change taxon at most every sixth base; when
+ * *d_n_runs comes back larger than runs_cap the run array was too small: calls and the per-taxon state are complete and
+ * correct, the runs are not (redo the batch with KU_F_NO_COUNTS and a larger array, or through
+ * ku_classify_batch_device).  KU_EUNSUP where the fused kernel does not apply (sorted layout, several databases, quick
+ * mode, exact counting, the sparse-sketch emulation -- which needs the read lengths on the host --, reads beyond 65535
+ * k-mers): use ku_classify_batch_device there. */
+int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
+                                 const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls,
+                                 ku_run *d_runs, uint64_t runs_cap, uint64_t *d_run_off, uint32_t *d_run_cnt,
+                                 uint64_t *d_n_runs, void *stream);
+uint64_t ku_device_rle_runs_cap(const ku_ctx *ctx, uint64_t n_bytes, uint64_t n_reads, uint32_t max_read_len);
+
 /* The two stages separately (sharded multi-GPU run: lookup on every rank, RCCL
  * max-reduce of d_taxa, resolve on the reads each rank owns):
  *  stage 1 = KmerScanner + canonical_representation + bin_key + kmer_query for

@@ -117,6 +117,10 @@ SIGNATURES = {
     "ku_fetch_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "ku_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ku_classify_batch_device_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                               C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]),
+    "ku_device_rle_runs_cap": (C.c_uint64, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]),
     "ku_lookup_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Opts), C.c_void_p, C.c_void_p]),
     "ku_resolve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Opts),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -509,6 +513,16 @@ class Ctx:
         o = Opts(flags, min_hits, max_read_len, 0)
         _chk(lib().ku_classify_batch_device(self.h, d_seqs, n_bytes, d_off, d_len, n_reads, C.byref(o), d_calls,
                                             d_taxa, d_hits, stream), "ku_classify_batch_device")
+
+    def classify_batch_device_rle(self, d_seqs, n_bytes, d_off, d_len, n_reads, d_calls, d_runs, runs_cap, d_run_off, d_run_cnt,
+                                  d_n_runs, max_read_len, flags=0, stream=None):
+        """device buffers in, run-length encoded per-k-mer codes out (the fused kernel's own runs; no per-k-mer array)"""
+        o = Opts(flags, 1, max_read_len, 0)
+        _chk(lib().ku_classify_batch_device_rle(self.h, d_seqs, n_bytes, d_off, d_len, n_reads, C.byref(o), d_calls, d_runs,
+                                                runs_cap, d_run_off, d_run_cnt, d_n_runs, stream), "ku_classify_batch_device_rle")
+
+    def device_rle_runs_cap(self, n_bytes, n_reads, max_read_len):
+        return int(lib().ku_device_rle_runs_cap(self.h, n_bytes, n_reads, max_read_len))
 
     def lookup_stats_device(self, d_seqs, n_bytes, stream=None):
         out = np.zeros(4, dtype=np.uint64)

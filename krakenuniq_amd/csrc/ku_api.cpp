@@ -1608,6 +1608,56 @@ static bool rle_fused_eligible(ku_ctx *ctx, uint32_t flags, uint32_t max_n, uint
   return true;
 }
 
+// chunk of the run array a wave claims at a time: large enough for few claims, small enough that the unused tails of the
+// last chunks do not dominate a small batch
+static uint32_t rle_chunk(uint64_t n_reads, uint64_t total_waves) {
+  const uint64_t reads_per_wave = n_reads / std::max<uint64_t>(total_waves, 1);
+  return reads_per_wave >= 64 ? 256u : (reads_per_wave >= 16 ? 64u : 16u);
+}
+
+extern "C" uint64_t ku_device_rle_runs_cap(const ku_ctx *ctx, uint64_t n_bytes, uint64_t n_reads, uint32_t max_read_len) {
+  if (!ctx || !ctx->tax_set) return 0;
+  const uint32_t max_n = max_read_len >= ctx->m.db.k ? max_read_len - ctx->m.db.k + 1 : 0;
+  const uint64_t waves = ku_short_grid_waves(n_reads, max_n, ctx->n_cu);
+  return n_bytes / 6 + 4 * n_reads + waves * rle_chunk(n_reads, waves) + 4096;
+}
+
+extern "C" int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, const uint64_t *d_seq_off,
+                                            const uint32_t *d_seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls,
+                                            ku_run *d_runs, uint64_t runs_cap, uint64_t *d_run_off, uint32_t *d_run_cnt,
+                                            uint64_t *d_n_runs, void *stream) {
+  KU_TRY(check_ready(ctx));
+  if (!d_n_runs || (n_reads && (!d_seqs || !d_seq_off || !d_seq_len || !d_calls || !d_runs || !d_run_off || !d_run_cnt)))
+    return fail(KU_EINVAL, "ku_classify_batch_device_rle: null buffer");
+  const ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  HIP_TRY(hipMemsetAsync(d_n_runs, 0, 8, s));
+  if (n_reads == 0) return KU_OK;
+  if (o.max_read_len == 0) return fail(KU_EINVAL, "ku_classify_batch_device_rle: opts->max_read_len (the longest read of the batch) is required");
+  const uint32_t max_n = o.max_read_len >= ctx->m.db.k ? o.max_read_len - ctx->m.db.k + 1 : 0;
+  if (ctx->sp.on && !(o.flags & KU_F_NO_COUNTS))
+    return fail(KU_EUNSUP, "the sparse-mode emulation runs through the host-buffer entry points (it needs the read lengths on the host)");
+  if (!store_whole(ctx->m) || !rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, true))
+    return fail(KU_EUNSUP, "ku_classify_batch_device_rle: the fused kernel does not apply to this context / these options (ku_classify_batch_device does)");
+  uint64_t ws = 0;
+  if (max_n > ku_short_max_kmers(ctx->m.db)) {  // windowed instance: its spill workspace
+    ws = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, n_reads, ctx->n_cu);
+    if (ws > ctx->b_ws.cap) HIP_TRY(hipStreamSynchronize(s));
+    if (ctx->b_ws.reserve(ws)) return fail(KU_ENOMEM, "device memory for the windowed kernel's workspace");
+  }
+  const uint64_t waves = ku_short_grid_waves(n_reads, max_n, ctx->n_cu);
+  KuRunsOut ro{};
+  ro.runs = (uint2 *)d_runs;
+  ro.counter = (unsigned long long *)d_n_runs;
+  ro.cap = runs_cap;
+  ro.chunk = rle_chunk(n_reads, waves);
+  ro.run_off = d_run_off;
+  ro.run_cnt = d_run_cnt;
+  int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len, n_reads, max_n, o.flags,
+                                    d_calls, nullptr, nullptr, ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s, &ro, nullptr);
+  return st == KU_OK ? KU_OK : fail(st, "fused kernel launch failed");
+}
+
 static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads,
                          uint64_t runs_cap, bool quick, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
                          uint32_t *run_cnt, uint64_t *n_runs);
@@ -1637,8 +1687,7 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
   }
   // a wave claims `chunk` run entries at a time: large enough for few claims, small enough that the unused tails of the
   // last chunks do not dominate a small batch
-  const uint64_t reads_per_wave = n_reads / std::max<uint64_t>(total_waves, 1);
-  const uint32_t chunk = reads_per_wave >= 64 ? 256u : (reads_per_wave >= 16 ? 64u : 16u);
+  const uint32_t chunk = rle_chunk(n_reads, total_waves);
   // room for ~ one run per 6 bases + the chunk tails; a batch that needs more (many taxa per read) is redone through
   // the per-k-mer array (below), whose run-length encoder cannot overflow
   uint64_t runs_cap = n_bytes / 6 + 4 * n_reads + total_waves * chunk + 4096;

@@ -85,6 +85,25 @@ def quantile_bin_bounds(sample_bins: torch.Tensor, n_bins: int, world_size: int)
     return b
 
 
+def expand_runs(runs: torch.Tensor, run_off: torch.Tensor, run_cnt: torch.Tensor, n_kmers: torch.Tensor) -> torch.Tensor:
+    """run-length encoded per-k-mer codes (ku_classify_batch_device_rle: runs int32 [cap, 2] = {code, first k-mer}, per read
+    run_off int64 / run_cnt int32) -> the codes of all k-mers, read after read (n_kmers int64 per read), as one int32
+    tensor.  A checker for tests and bench.py: plain tensor arithmetic, no library code."""
+    rc = run_cnt.to(torch.int64)
+    total = int(rc.sum().item())
+    first = torch.cumsum(rc, 0) - rc                      # index of each read's first run in read order
+    read_of = torch.repeat_interleave(torch.arange(len(rc), device=rc.device), rc)
+    idx = run_off.to(torch.int64)[read_of] + (torch.arange(total, device=rc.device) - first[read_of])
+    code, start = runs[idx, 0], runs[idx, 1].to(torch.int64)
+    end = torch.empty_like(start)
+    end[:-1] = start[1:]
+    last = first + rc - 1                                  # the last run of a read ends with the read's k-mers
+    has = rc > 0
+    end[last[has]] = n_kmers.to(torch.int64)[has]
+    assert bool((end > start).all()), "runs of a read must start at increasing k-mers"
+    return torch.repeat_interleave(code, end - start)
+
+
 class BenchDb:
     """Synthetic taxonomy + genomes + (optionally sharded) database resident in HBM."""
 

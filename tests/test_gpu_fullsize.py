@@ -160,6 +160,45 @@ def test_configs1_full_batch_fused_equals_staged(world, monkeypatch):
     w["calls"], w["taxa"], w["counts"] = calls_f, taxa_f, counts_f
 
 
+def test_configs1_full_batch_runs_from_the_kernel_equal_the_per_kmer_array(world):
+    """ku_classify_batch_device_rle (what bench.py times): device buffers in, the fused kernel's own run-length encoded
+    codes out -- expanded again they are the per-k-mer array of ku_classify_batch_device for all 10 M reads; calls and the
+    per-taxon state are the same; a run array that is too small is reported through the run total, calls stay right"""
+    torch, ctx, dev = world["torch"], world["ctx"], world["dev"]
+    seqs, off, lens = world["seqs"], world["off"], world["lens"]
+    stride, nk = L + 1, L - K + 1
+    ctx.reset_counts()
+    calls, taxa = gpu_classify(world, ctx, seqs, off, lens, N, L)
+    want_counts = ctx.counts()
+    cap = ctx.device_rle_runs_cap(seqs.numel(), N, L)
+    runs = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+    roff = torch.zeros(N, dtype=torch.int64, device=dev)
+    rcnt = torch.zeros(N, dtype=torch.int32, device=dev)
+    nruns = torch.zeros(1, dtype=torch.int64, device=dev)
+    calls2 = torch.zeros(N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.reset_counts()
+    ctx.classify_batch_device_rle(seqs.data_ptr(), seqs.numel(), off.data_ptr(), lens.data_ptr(), N, calls2.data_ptr(), runs.data_ptr(), cap,
+                                  roff.data_ptr(), rcnt.data_ptr(), nruns.data_ptr(), max_read_len=L)
+    ctx.synchronize()
+    assert 0 < int(nruns.item()) <= cap
+    assert torch.equal(calls2, calls)
+    flat = synth_torch.expand_runs(runs, roff, rcnt, torch.full((N,), nk, dtype=torch.int64, device=dev))
+    assert torch.equal(flat.view(N, nk), taxa.view(N, stride)[:, :nk])
+    assert int(rcnt.sum().item()) < 4 * N  # (a few runs per read: 224 MB instead of 6 GB)
+    assert same_counts(ctx.counts(), want_counts)
+    del flat, taxa
+    small = 50_000  # far too small for 10 M reads
+    ctx.classify_batch_device_rle(seqs.data_ptr(), seqs.numel(), off.data_ptr(), lens.data_ptr(), N, calls2.data_ptr(), runs.data_ptr(), small,
+                                  roff.data_ptr(), rcnt.data_ptr(), nruns.data_ptr(), max_read_len=L, flags=capi.KU_F_NO_COUNTS)
+    ctx.synchronize()
+    assert int(nruns.item()) > small and torch.equal(calls2, calls)
+    with pytest.raises(capi.KuError):  # the longest read must be named
+        ctx.classify_batch_device_rle(seqs.data_ptr(), seqs.numel(), off.data_ptr(), lens.data_ptr(), N, calls2.data_ptr(), runs.data_ptr(), cap,
+                                      roff.data_ptr(), rcnt.data_ptr(), nruns.data_ptr(), max_read_len=0)
+    ctx.reset_counts()
+
+
 def test_configs1_full_batch_batches_accumulate(world):
     w = world
     ctx = w["ctx"]

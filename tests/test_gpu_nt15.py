@@ -84,6 +84,23 @@ def run_both(w, seqs, off, lens, n, L, monkeypatch=None):
     counts = ctx.counts()
     assert_counts_equal_oracle(counts, run)
     assert int((calls != 0).sum()) > n // 3
+    # the same reads with the kernel's own run-length encoded output (ku_classify_batch_device_rle): expanded == taxa[]
+    cap = ctx.device_rle_runs_cap(seqs.numel(), n, L)
+    runs = torch.zeros((cap, 2), dtype=torch.int32, device=w["dev"])
+    roff = torch.zeros(n, dtype=torch.int64, device=w["dev"])
+    rcnt = torch.zeros(n, dtype=torch.int32, device=w["dev"])
+    nruns = torch.zeros(1, dtype=torch.int64, device=w["dev"])
+    c3 = torch.zeros_like(calls)
+    torch.cuda.synchronize()
+    ctx.reset_counts()
+    ctx.classify_batch_device_rle(seqs.data_ptr(), seqs.numel(), off.data_ptr(), lens.data_ptr(), n, c3.data_ptr(), runs.data_ptr(), cap,
+                                  roff.data_ptr(), rcnt.data_ptr(), nruns.data_ptr(), max_read_len=L)
+    ctx.synchronize()
+    assert int(nruns.item()) <= cap and torch.equal(c3, calls)
+    flat = synth_torch.expand_runs(runs, roff, rcnt, torch.full((n,), nk, dtype=torch.int64, device=w["dev"]))
+    assert torch.equal(flat.view(n, nk), taxa.view(n, stride)[:, :nk])
+    c = ctx.counts()
+    assert all(np.array_equal(c[key], counts[key]) for key in ("n_kmers", "registers", "n_reads"))
     if monkeypatch is not None:
         monkeypatch.setenv("KU_NO_FUSED", "1")
         t2 = torch.zeros_like(taxa)
