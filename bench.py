@@ -9,10 +9,10 @@
 Workload at N = 1 (BASELINE.json configs[1]): ~8 GB MiniKraken-style database (k = 31, minimizer nt = 13, ~0.61 G
 pairs, 2000 species) built directly in HBM by krakenuniq_amd/synth_torch.py; FOUR distinct batches of 10 M synthetic
 150 bp reads resident in HBM.  One "step" = one pass of the whole hot path over one 10 M-read batch
-(ku_classify_batch_device_rle): the fused wave-per-read kernel (scan, canonical k-mer, anchor / minimizer, bucket probe,
-HLL + n_kmers, hit counts, resolve_tree / LCA, n_reads, and the per-k-mer taxids as the Kraken line prints them: runs of
-equal codes -- `--output taxa` writes one code per base position instead, ku_classify_batch_device; the line reports that
-form's time too and checks the expanded runs against it) -- in one pass for reads of up to 222 bp, in
+(ku_classify_batch_device): the fused wave-per-read kernel (scan, canonical k-mer, anchor / minimizer, bucket probe,
+HLL + n_kmers, hit counts, resolve_tree / LCA, n_reads, per-k-mer taxids -- `--output runs`: as the Kraken line prints
+them, runs of equal codes written by the kernel itself, ku_classify_batch_device_rle; the line times both forms and checks
+the expanded runs against the per-position array) -- in one pass for reads of up to 222 bp, in
 windows of 128 k-mers for longer ones (--paired, --read-len 10000); with KU_NO_FUSED=1 / KU_NO_WINDOWED=1 or reads beyond
 65535 k-mers the two stages ku_lookup_device + ku_resolve_device.  The steps rotate through the batches and the
 per-taxon state is zeroed at the start of every rotation (inside the timed region), so each rotation is a fresh 40 M-read
@@ -87,10 +87,11 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the device-pipeline / end-to-end / sharded legs")
-    ap.add_argument("--output", choices=["runs", "taxa"], default="runs",
-                    help="per-k-mer codes of a step: run-length encoded by the fused kernel itself, as the Kraken line prints them and as "
-                         "the classify executable takes them (ku_classify_batch_device_rle; default) | one 32-bit code per base "
-                         "position (ku_classify_batch_device)")
+    ap.add_argument("--output", choices=["runs", "taxa"], default="taxa",
+                    help="per-k-mer codes of a step: one 32-bit code per base position (ku_classify_batch_device; default) | run-length "
+                         "encoded by the fused kernel itself, as the Kraken line prints them and as the classify executable takes them "
+                         "(ku_classify_batch_device_rle: 0.2 GB instead of 6 GB of output per 10 M reads; the kernel is bound by "
+                         "instruction issue, so the shorter output does not make it faster)")
     ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[i]; 2-4 = the 300 GB standard-geometry database in 8 shards, sharded mode")
     ap.add_argument("--db-shards", type=int, default=0,
@@ -537,7 +538,7 @@ def main():
     fused0 = (os.environ.get("KU_NO_FUSED") is None and os.environ.get("KU_NO_FUSED_RLE") is None and ctx.db_layout()["hash"]
               and (n_k0 <= int(os.environ.get('KU_SHORT_ONE_PASS_MAX', 192)) or (n_k0 <= 65535 and os.environ.get("KU_NO_WINDOWED") is None)))
     runs_out = a.output == "runs" and fused0
-    if runs_out:  # the step's output: calls + {code, first k-mer} runs per read, written by the kernel that classifies
+    if fused0:  # calls + {code, first k-mer} runs per read, written by the kernel that classifies (the step's output with --output runs)
         runs_cap = ctx.device_rle_runs_cap(n_bytes, a.reads, read_len)
         d_runs = torch.zeros((runs_cap, 2), dtype=torch.int32, device=dev)
         d_roff = torch.zeros(a.reads, dtype=torch.int64, device=dev)
@@ -604,19 +605,27 @@ def main():
 
     total_reads = a.reads * a.steps * ws
     value = total_reads / elapsed / 1e6
-    out_info = {"form": "one 32-bit code per base position (ku_classify_batch_device)"}
+    out_info = {"form": "calls + one 32-bit code per base position (ku_classify_batch_device)"}
     if runs_out:
-        # outside the timed region: the runs of one batch, expanded again, against the per-k-mer array of the same batch
-        # through ku_classify_batch_device (no accounting: the state of the timed run stays as it is), and that call's time
+        out_info = {"form": "calls + run-length encoded per-k-mer codes ({code, first k-mer} per run: the hit list of the Kraken line, "
+                            "classify.cpp:980-1010), written by the fused kernel itself (ku_classify_batch_device_rle; what the classify "
+                            "executable takes); no per-k-mer array exists"}
+    if fused0:
+        # outside the timed region, both output forms of one batch without accounting (the state of the timed run stays as it
+        # is): their times, and the runs expanded again against the per-k-mer array
         b = batches[0]
-        ctx.classify_batch_device_rle(b[0].data_ptr(), n_bytes, b[1].data_ptr(), b[2].data_ptr(), a.reads, d_calls.data_ptr(),
-                                      d_runs.data_ptr(), runs_cap, d_roff.data_ptr(), d_rcnt.data_ptr(), d_nruns.data_ptr(),
-                                      max_read_len=read_len, flags=capi.KU_F_NO_COUNTS, stream=stream)
-        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms_taxa, ms_runs = [], []
+        for rep in range(3):
+            e0.record()
+            ctx.classify_batch_device_rle(b[0].data_ptr(), n_bytes, b[1].data_ptr(), b[2].data_ptr(), a.reads, d_calls.data_ptr(),
+                                          d_runs.data_ptr(), runs_cap, d_roff.data_ptr(), d_rcnt.data_ptr(), d_nruns.data_ptr(),
+                                          max_read_len=read_len, flags=capi.KU_F_NO_COUNTS, stream=stream)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_runs.append(e0.elapsed_time(e1))
         extent, n_runs = int(d_nruns.item()), int(d_rcnt.sum().item())
         calls_runs = d_calls.clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ms_taxa = []
         for rep in range(3):
             e0.record()
             ctx.classify_batch_device(b[0].data_ptr(), n_bytes, b[1].data_ptr(), b[2].data_ptr(), a.reads, d_calls.data_ptr(),
@@ -631,12 +640,9 @@ def main():
             stride = read_len + 1
             same = bool(torch.equal(flat.view(a.reads, n_k0), d_taxa[:a.reads * stride].view(a.reads, stride)[:, :n_k0]))
             del flat
-        out_info = {"form": "calls + run-length encoded per-k-mer codes ({code, first k-mer} per run: the hit list of the Kraken line, "
-                            "classify.cpp:980-1010), written by the fused kernel itself (ku_classify_batch_device_rle; what the classify "
-                            "executable takes); no per-k-mer array exists",
-                    "runs_per_read": round(n_runs / a.reads, 2), "run_bytes_per_step": n_runs * 8, "run_array_extent_used": extent,
-                    "expanded_runs_equal_the_per_kmer_array": same,
-                    "per_kmer_array_form_ms_no_accounting": round(min(ms_taxa), 3)}
+        out_info.update({"runs_per_read": round(n_runs / a.reads, 2), "run_bytes_per_step": n_runs * 8, "run_array_extent_used": extent,
+                         "expanded_runs_equal_the_per_kmer_array": same,
+                         "ms_without_accounting": {"per_position_codes": round(min(ms_taxa), 3), "runs_from_the_kernel": round(min(ms_runs), 3)}})
     # roofline of the dominant kernel: algorithmic bytes per launch (mean over the batches) / HIP-event time
     stats = [ctx.lookup_stats_device(b[0].data_ptr(), n_bytes) for b in batches]
     lookups = float(np.mean([s["lookups"] for s in stats]))

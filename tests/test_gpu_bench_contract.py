@@ -30,7 +30,7 @@ def test_default_shape_line():
         assert isinstance(d[key], typ), key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
-    out = d["config"]["output"]  # the step writes the kernel's own runs; expanded again they are the per-k-mer array
+    out = d["config"]["output"]  # the kernel's own runs of one batch, expanded again, are the per-k-mer array
     assert out["expanded_runs_equal_the_per_kmer_array"] is True and out["run_array_extent_used"] > 0 and out["runs_per_read"] >= 1
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
@@ -43,9 +43,8 @@ def test_default_shape_line():
     assert d["e2e"]["calls_match_device_run"] is True and d["e2e"]["value"] > 0
 
 
-@pytest.mark.parametrize("shape", [("--paired",), ("--read-len", "3000", "--reads", "20000"), ("--nt", "15"), ("--output", "taxa")])
+@pytest.mark.parametrize("shape", [("--paired",), ("--read-len", "3000", "--reads", "20000"), ("--nt", "15"), ("--output", "runs")])
 def test_other_shapes_run(shape):
     d = run_bench("--cpu-sample", "0", "--no-extras", *shape)
     assert d["value"] > 0 and d["roofline"]["kernel"].startswith("ku_classify_short_kernel")
-    if "taxa" not in shape:
-        assert d["config"]["output"]["expanded_runs_equal_the_per_kmer_array"] is True
+    assert d["config"]["output"]["expanded_runs_equal_the_per_kmer_array"] is True
