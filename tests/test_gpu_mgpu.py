@@ -340,3 +340,68 @@ def test_device_step_matches_single_context(exchange, monkeypatch):
     mg.reduce_state()
     assert same_counts(mg.ctx(1).counts(), want)
     mg.close()
+
+
+def test_routed_step_of_eight_ranks_on_the_bench_database_matches_one_context():
+    """owner routing at size: the 8 GB bench database in eight minimizer-range shards, eight ranks on
+    the one device, 2 M reads per step -- calls, per-k-mer codes and the reduced per-taxon state equal one context that
+    holds the whole database; two steps, so the queues, their chunk cursors and the owners' counters are reused"""
+    import torch
+    dev = torch.device("cuda:0")
+    NT, L, N, W = 13, 150, 2_000_000, 8
+    geo = dict(n_species=2000, genome_len=310_000, k=K, nt=NT, seed=7)
+    db = synth_torch.BenchDb(dev, **geo)
+    ids, par = db.tax.arrays()
+    ctax = capi.Tax(ids=ids, parents=par)
+    bins = synth_torch.bin_key(db.kmers[torch.randperm(db.n_pairs, device=dev)[:1_000_000]], K, NT)
+    bounds = [int(x) for x in synth_torch.quantile_bin_bounds(bins, 4 ** NT, W)]
+    db.kmers = db.vals = None
+    batches = [db.sample_reads(N, L, seed=11 + i) for i in range(2)]
+    ctx = capi.Ctx(0)
+    ctx.adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), K, NT, 2, keep=db)
+    ctx.set_taxonomy(ctax)
+    stride = L + 1
+    nb = N * stride
+    want = []
+    for seqs, off, lens, _ in batches:
+        taxa1 = torch.zeros(nb, dtype=torch.int32, device=dev)
+        calls1 = torch.zeros(N, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.classify_batch_device(seqs.data_ptr(), nb, off.data_ptr(), lens.data_ptr(), N, calls1.data_ptr(), taxa1.data_ptr(), max_read_len=L)
+        ctx.synchronize()
+        want.append((calls1, taxa1))
+    want_counts = ctx.counts()
+    ctx.close()
+    db.pairs = None
+    torch.cuda.empty_cache()
+    mg = capi.Mgpu([0] * W)
+    shards = []
+    for r in range(W):
+        sh = synth_torch.BenchDb(dev, bin_lo=bounds[r], bin_hi=bounds[r + 1], **geo)
+        sh.kmers = sh.vals = None
+        mg.ctx(r).adopt_db(sh.pairs.data_ptr(), sh.n_pairs, sh.offsets.data_ptr(), K, NT, 2, bounds[r], bounds[r + 1])
+        shards.append(sh)
+    mg.set_taxonomy(ctax)
+    assert mg.uses_routing()
+    rb = [N * r // W for r in range(W + 1)]
+    pb = [x * stride for x in rb]
+    nk = L - K + 1
+    bufs = [{"seqs": torch.zeros(nb + 16, dtype=torch.uint8, device=dev), "off": torch.zeros(N, dtype=torch.int64, device=dev),
+             "len": torch.zeros(N, dtype=torch.int32, device=dev), "calls": torch.zeros(N, dtype=torch.int32, device=dev),
+             "taxa": torch.zeros(nb + 16, dtype=torch.int32, device=dev)} for r in range(W)]
+    for (seqs, off, lens, _), (calls1, taxa1) in zip(batches, want):
+        bufs[0]["seqs"][:nb] = seqs.reshape(-1)
+        bufs[0]["off"][:] = off
+        bufs[0]["len"][:] = lens
+        torch.cuda.synchronize()
+        mg.step_device([{"d_seqs": b["seqs"].data_ptr(), "d_seq_off": b["off"].data_ptr(), "d_seq_len": b["len"].data_ptr(),
+                         "d_calls": b["calls"].data_ptr(), "d_taxa": b["taxa"].data_ptr()} for b in bufs], nb, N, rb, pb, max_read_len=L)
+        for r in range(W):
+            mg.ctx(r).synchronize()
+        for r in range(W):
+            lo, hi = rb[r], rb[r + 1]
+            assert torch.equal(bufs[r]["calls"][lo:hi], calls1[lo:hi]), r
+            assert torch.equal(bufs[r]["taxa"][:nb].view(N, stride)[lo:hi, :nk], taxa1.view(N, stride)[lo:hi, :nk]), r
+    mg.reduce_state()
+    assert same_counts(mg.ctx(3).counts(), want_counts)
+    mg.close()
