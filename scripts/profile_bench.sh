@@ -26,5 +26,6 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
     echo "pmc group $i ($grp): rc=$?"
   done
 fi
+find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*agent_info.csv' -delete   # (gpurun returns at most 64 MiB)
 find $OUT -name '*.csv' -size +8M -delete
 find $OUT -name '*counter_collection.csv' | head
