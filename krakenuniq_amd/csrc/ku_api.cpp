@@ -2268,12 +2268,68 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       // own set, distinct already: histogram only): room for what its members offer -- at most every encoding there is
       // (2^25 indices; the 2^12 of them whose low 13 bits are zero come with up to 40 ranks) -- at a load of 2/3
       const uint64_t enc_space = (1ull << 25) + (1ull << 12) * 40;
+      const uint64_t flag_space = (1ull << 12) * 40;  // encodings that carry the rank flag
+      // BIG clades keep a bitmap over the 2^25 indices instead (4 MiB each; ku_report.hip): every clade that may receive
+      // at least KU_ROLLUP_BITMAP_MIN entries (default 2^17; a test hook), most entries first and, among equals, nearest
+      // the root first -- a clade's parent is offered at least as much as the clade, so whatever prefix of that order fits
+      // the memory budget (a quarter of the free device memory) is closed upwards: above a bitmap there are only bitmaps
+      std::vector<uint32_t> depth(n_clades, 0);
+      for (uint32_t c = 0; c < n_clades; ++c) {
+        int64_t q = tax->parent_row(clade_row[c]);
+        for (uint32_t guard = 0; q >= 0 && guard < 4096; ++guard, q = tax->parent_row((size_t)q)) ++depth[c];
+      }
+      uint64_t bm_min = 1ull << 17;
+      if (const char *e = getenv("KU_ROLLUP_BITMAP_MIN")) bm_min = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+      std::vector<uint32_t> cand;
+      for (uint32_t c = 0; c < n_clades; ++c)
+        if (m_off[c + 1] - m_off[c] > 1 && clade_pairs[c] >= bm_min && !clade_dense[c]) cand.push_back(c);
+      std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
+        return clade_pairs[a] != clade_pairs[b] ? clade_pairs[a] > clade_pairs[b] : (depth[a] != depth[b] ? depth[a] < depth[b] : a < b);
+      });
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const size_t bm_budget = free_b / 4 / ((size_t)KU_BM_WORDS * 4);
+      if (cand.size() > bm_budget) cand.resize(bm_budget);
+      std::vector<uint32_t> bm_of(n_clades, KU_BM_NONE), bm_clade(cand);
+      for (uint32_t b = 0; b < cand.size(); ++b) bm_of[cand[b]] = b;
+      const uint32_t n_bm = (uint32_t)cand.size();
+      // parents among the bitmap clades (the next clade up a slot's chain), children lists, parents by level
+      std::vector<uint32_t> bm_parent(n_bm, KU_BM_NONE);
+      for (size_t s = 0; s < ns; ++s)
+        for (uint32_t j = s_off[s]; j + 1 < s_off[s + 1]; ++j)
+          if (bm_of[s_clade[j]] != KU_BM_NONE) bm_parent[bm_of[s_clade[j]]] = bm_of[s_clade[j + 1]];
+      std::vector<uint32_t> ch_off(n_bm + 1, 0), ch;
+      for (uint32_t b = 0; b < n_bm; ++b)
+        if (bm_parent[b] != KU_BM_NONE) ++ch_off[bm_parent[b] + 1];
+      for (uint32_t b = 0; b < n_bm; ++b) ch_off[b + 1] += ch_off[b];
+      ch.resize(ch_off[n_bm]);
+      {
+        std::vector<uint32_t> at(ch_off.begin(), ch_off.end() - 1);
+        for (uint32_t b = 0; b < n_bm; ++b)
+          if (bm_parent[b] != KU_BM_NONE) ch[at[bm_parent[b]]++] = b;
+      }
+      std::vector<uint32_t> bm_parents_by_level;  // parents with children, deepest level first
+      std::vector<std::pair<uint32_t, uint32_t>> level_ranges;
+      {
+        std::vector<uint32_t> ps;
+        for (uint32_t b = 0; b < n_bm; ++b)
+          if (ch_off[b + 1] > ch_off[b]) ps.push_back(b);
+        std::sort(ps.begin(), ps.end(), [&](uint32_t a, uint32_t b) { return depth[bm_clade[a]] != depth[bm_clade[b]] ? depth[bm_clade[a]] > depth[bm_clade[b]] : a < b; });
+        for (size_t i = 0; i < ps.size();) {
+          size_t j = i;
+          while (j < ps.size() && depth[bm_clade[ps[j]]] == depth[bm_clade[ps[i]]]) ++j;
+          level_ranges.emplace_back((uint32_t)i, (uint32_t)j);
+          i = j;
+        }
+        bm_parents_by_level = ps;
+      }
       std::vector<unsigned long long> set_off(n_clades, 0);
       std::vector<uint32_t> set_cells(n_clades, 0);
       uint64_t cells = 0;
       for (uint32_t c = 0; c < n_clades; ++c) {
         if (m_off[c + 1] - m_off[c] <= 1 || !clade_pairs[c]) continue;
-        const uint64_t bound = std::min(clade_pairs[c], enc_space);
+        // a bitmap clade's table only takes the entries with the rank flag (1 in 8192 of what hashes offer)
+        const uint64_t bound = bm_of[c] != KU_BM_NONE ? std::min(clade_pairs[c] / 512 + 4096, flag_space) : std::min(clade_pairs[c], enc_space);
         set_off[c] = cells;
         set_cells[c] = (uint32_t)(bound + bound / 2 + 16);
         cells += set_cells[c];
@@ -2296,12 +2352,22 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       if (st == KU_OK) st = tmp.put(&d_hotc, hot_clades);
       if (st == KU_OK) st = tmp.put(&d_setoff, set_off);
       if (st == KU_OK) st = tmp.put(&d_setcells, set_cells);
+      uint32_t *d_bmof = nullptr, *d_bm = nullptr, *d_bmclade = nullptr, *d_choff = nullptr, *d_ch = nullptr, *d_bmpar = nullptr;
+      if (st == KU_OK) st = tmp.put(&d_bmof, bm_of);
+      if (st == KU_OK) st = tmp.put(&d_bmclade, bm_clade);
+      if (st == KU_OK) st = tmp.put(&d_choff, ch_off);
+      if (st == KU_OK) st = tmp.put(&d_ch, ch);
+      if (st == KU_OK) st = tmp.put(&d_bmpar, bm_parents_by_level);
       lap("union plan (host)");
       if (st == KU_OK) st = tmp.zeros(&d_set, cells);
+      if (st == KU_OK) st = tmp.zeros(&d_bm, (size_t)std::max<uint32_t>(n_bm, 1) * (n_bm ? KU_BM_WORDS : 1));
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
       lap("union set allocated + cleared");
       KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_setoff, d_setcells, d_chot, d_hotc, n_hot, d_set,
-                                     d_hist, d_err, ctx->n_cu, ctx->stream));
+                                     d_hist, d_err, d_bmof, d_bm, ctx->n_cu, ctx->stream));
+      for (const auto &lv : level_ranges)  // children into parents, deepest parents first
+        KU_TRY(ku_launch_bitmap_or_children(d_bm, d_bmpar + lv.first, lv.second - lv.first, d_choff, d_ch, ctx->stream));
+      KU_TRY(ku_launch_bitmap_hist(d_bm, d_bmclade, n_bm, d_hist, ctx->stream));
       uint32_t err = 0;
       HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -113,7 +113,13 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
                             const uint32_t *d_slot_clade, const unsigned long long *d_set_off, const uint32_t *d_set_cells,
                             const uint16_t *d_clade_hot, const uint32_t *d_hot_clades, uint32_t n_hot, uint32_t *d_set, uint32_t *d_hist,
-                            uint32_t *d_err, int n_cu, hipStream_t stream);
+                            uint32_t *d_err, const uint32_t *d_bm_of, uint32_t *d_bm, int n_cu, hipStream_t stream);
+// union bitmaps of the big all-sparse clades (ku_report.hip): one bit per 25-bit index, KU_BM_WORDS words per clade
+#define KU_BM_WORDS (1u << 20)
+#define KU_BM_NONE 0xFFFFFFFFu
+int ku_launch_bitmap_or_children(uint32_t *d_bm, const uint32_t *d_parents, uint32_t n_parents, const uint32_t *d_child_off,
+                                 const uint32_t *d_child, hipStream_t stream);
+int ku_launch_bitmap_hist(const uint32_t *d_bm, const uint32_t *d_bm_clade, uint32_t n_bm, uint32_t *d_hist, hipStream_t stream);
 int ku_launch_replace_calls(const uint32_t *d_old, const uint32_t *d_new, uint64_t n, const uint32_t *d_node_taxid, uint32_t n_nodes,
                             unsigned long long *d_n_reads, unsigned long long *d_dropped, hipStream_t stream);
 int ku_launch_count_g_slots(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, unsigned long long *d_per_slot,

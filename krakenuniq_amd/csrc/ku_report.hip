@@ -75,6 +75,14 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
 // The union sets are one open-addressing table PER CLADE of 4-byte cells holding the encoding alone (0 never is one: index
 // 0 carries the rank flag), laid out back to back: set_off[c] / set_cells[c]; half the memory of (clade, encoding) keys --
 // and the time goes into getting that memory (tens of GB for a run of many sparse taxa), not into the kernel.
+//
+// BIG clades (bm_of[c] != KU_BM_NONE) keep a BITMAP over the 2^25 indices instead: an encoding without the rank flag is its
+// index alone (encodeHashIn32Bit, hyperloglogplus.cpp:120-150), so the union of such entries is a bitwise OR.  An entry sets
+// its bit in the LOWEST big clade of its chain and stops there: the clades above take it with their children's whole
+// bitmaps (ku_bitmap_or_children, level by level, no atomics), and the rank histogram is read off the finished bitmap
+// (ku_bitmap_hist) -- one atomic per entry instead of one table insert per entry and level (3 G inserts for 0.6 G entries
+// under a five-level taxonomy were 237 of the report's 290 ms of kernels).  The few entries that carry the flag (index
+// bits p..p' all zero: 1 in 8192) walk on through small per-clade tables as before.
 __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells,
                                                                 const uint32_t *__restrict__ dense,
                                                                 const uint32_t *__restrict__ slot_off,
@@ -83,7 +91,8 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
                                                                 const uint32_t *__restrict__ set_cells,
                                                                 const uint16_t *__restrict__ clade_hot,
                                                                 const uint32_t *__restrict__ hot_clades, uint32_t n_hot,
-                                                                uint32_t *set, uint32_t *hist, uint32_t *err) {
+                                                                uint32_t *set, uint32_t *hist, uint32_t *err,
+                                                                const uint32_t *__restrict__ bm_of, uint32_t *bm) {
   __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
   for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
   __syncthreads();
@@ -100,6 +109,11 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
     g ^= g >> 13;
     for (uint32_t j = slot_off[slot]; j < slot_off[slot + 1]; ++j) {
       const uint32_t c = slot_clade[j];
+      const uint32_t b = bm_of[c];
+      if (b != KU_BM_NONE && !(enc & 1u)) {  // index = enc >> 7: word enc >> 12, bit (enc >> 7) & 31
+        atomicOr(&bm[(size_t)b * KU_BM_WORDS + (enc >> 12)], 1u << ((enc >> 7) & 31u));
+        break;
+      }
       bool fresh = true;
       const uint32_t cells = set_cells[c];  // 0: a clade with a single member (that member's own, distinct entries)
       if (cells) {
@@ -123,6 +137,60 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < n_hot * KU_ROLLUP_BINS; i += blockDim.x)
     if (hot[i]) atomicAdd(&hist[(size_t)hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
+}
+
+// bitmap of a parent clade |= the bitmaps of its children (all finished: the launches go level by level, deepest parents
+// first).  blockIdx.y = position in the list of this level's parents.
+__global__ __launch_bounds__(256) void ku_bitmap_or_children_kernel(uint32_t *bm, const uint32_t *__restrict__ parents,
+                                                                     const uint32_t *__restrict__ child_off,
+                                                                     const uint32_t *__restrict__ child) {
+  const uint32_t p = parents[blockIdx.y];
+  uint4 *dst = reinterpret_cast<uint4 *>(bm + (size_t)p * KU_BM_WORDS);
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < KU_BM_WORDS / 4; w += gridDim.x * blockDim.x) {
+    uint4 acc = dst[w];
+    for (uint32_t j = child_off[p]; j < child_off[p + 1]; ++j) {
+      const uint4 v = reinterpret_cast<const uint4 *>(bm + (size_t)child[j] * KU_BM_WORDS)[w];
+      acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+    }
+    dst[w] = acc;
+  }
+}
+
+// rank histogram of a finished bitmap, added to the clade's row of hist.  The rank of an index is clz of its low 13 bits + 1
+// (encoded_rank without the flag): word w holds the indices 32 w .. 32 w + 31, so unless the word's low byte is zero all
+// of its bits share one rank; else the rank comes from the bit position (bit 0 there is never set: that index carries the
+// flag and is not in the bitmap).
+__global__ __launch_bounds__(256) void ku_bitmap_hist_kernel(const uint32_t *__restrict__ bm, const uint32_t *__restrict__ bm_clade,
+                                                              uint32_t *hist) {
+  __shared__ uint32_t bins[16];
+  if (threadIdx.x < 16) bins[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t *src = bm + (size_t)blockIdx.y * KU_BM_WORDS;
+  uint32_t cnt[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) cnt[i] = 0;
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < KU_BM_WORDS; w += gridDim.x * blockDim.x) {
+    const uint32_t v = src[w];
+    if (!v) continue;
+    const uint32_t lo = w & 0xFFu;
+    if (lo) {
+      const uint32_t r = (uint32_t)__clz(lo) - 24u + 1u;  // 1 .. 8
+#pragma unroll
+      for (int i = 1; i <= 8; ++i) cnt[i] += r == (uint32_t)i ? (uint32_t)__popc(v) : 0u;
+    } else {
+      cnt[9] += (uint32_t)__popc(v & 0xFFFF0000u);
+      cnt[10] += (uint32_t)__popc(v & 0x0000FF00u);
+      cnt[11] += (uint32_t)__popc(v & 0x000000F0u);
+      cnt[12] += (uint32_t)__popc(v & 0x0000000Cu);
+      cnt[13] += (uint32_t)__popc(v & 0x00000002u);
+    }
+  }
+#pragma unroll
+  for (int i = 1; i < 14; ++i)
+    if (cnt[i]) atomicAdd(&bins[i], cnt[i]);
+  __syncthreads();
+  if (threadIdx.x >= 1 && threadIdx.x < 14 && bins[threadIdx.x])
+    atomicAdd(&hist[(size_t)bm_clade[blockIdx.y] * KU_ROLLUP_BINS + threadIdx.x], bins[threadIdx.x]);
 }
 
 // entries of G per slot (slots that stayed sparse only): sizes the union set.  Counted in a per-block LDS table keyed by
@@ -217,12 +285,25 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
                             const uint32_t *d_slot_clade, const unsigned long long *d_set_off, const uint32_t *d_set_cells,
                             const uint16_t *d_clade_hot, const uint32_t *d_hot_clades, uint32_t n_hot, uint32_t *d_set, uint32_t *d_hist,
-                            uint32_t *d_err, int n_cu, hipStream_t stream) {
+                            uint32_t *d_err, const uint32_t *d_bm_of, uint32_t *d_bm, int n_cu, hipStream_t stream) {
   if (!g_cells) return KU_OK;
   const uint64_t want = (g_cells + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
   ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_slot_off, d_slot_clade, d_set_off, d_set_cells, d_clade_hot,
-                                                       d_hot_clades, n_hot, d_set, d_hist, d_err);
+                                                       d_hot_clades, n_hot, d_set, d_hist, d_err, d_bm_of, d_bm);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+int ku_launch_bitmap_or_children(uint32_t *d_bm, const uint32_t *d_parents, uint32_t n_parents, const uint32_t *d_child_off,
+                                 const uint32_t *d_child, hipStream_t stream) {
+  if (!n_parents) return KU_OK;
+  ku_bitmap_or_children_kernel<<<dim3(64, n_parents), 256, 0, stream>>>(d_bm, d_parents, d_child_off, d_child);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+int ku_launch_bitmap_hist(const uint32_t *d_bm, const uint32_t *d_bm_clade, uint32_t n_bm, uint32_t *d_hist, hipStream_t stream) {
+  if (!n_bm) return KU_OK;
+  ku_bitmap_hist_kernel<<<dim3(64, n_bm), 256, 0, stream>>>(d_bm, d_bm_clade, d_hist);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 

@@ -12,6 +12,15 @@ from oracle import ku_oracle as ko
 import gpu_common as gc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["tables", "bitmaps"], autouse=True)
+def union_form(request, monkeypatch):
+    """clade unions of the sparse sketches in ku_ctx_report: per-clade hash tables, or (test hook: for every clade with
+    several members, not only the big ones) bitmaps over the 2^25 indices merged level by level"""
+    if request.param == "bitmaps":
+        monkeypatch.setenv("KU_ROLLUP_BITMAP_MIN", "1")
+    return request.param
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
 F1 = os.path.join(G, "f1")
