@@ -1052,13 +1052,7 @@ static int sparse_pass_tables(ku_ctx *ctx, uint64_t n_entries, KuSparseDev *view
   *view = d;
   view->l_mask = l_cells - 1;
   view->u_mask = u_cells - 1;
-  HIP_TRY(hipMemsetAsync(d.l_key, 0, l_cells * 8, s));
-  HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, l_cells * 4, s));
-  HIP_TRY(hipMemsetAsync(d.u_key, 0, u_cells * 8, s));
-  HIP_TRY(hipMemsetAsync(d.u_distinct, 0, u_cells * 4, s));
-  HIP_TRY(hipMemsetAsync(d.u_last, 0, u_cells * 4, s));
-  HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, u_cells * 4, s));
-  return KU_OK;
+  return ku_launch_sparse_clear(*view, s);
 }
 
 // the reads [r0, r1) of a batch whose taxa[] holds slot ids: one pass of the emulation (at most KU_SPARSE_MAX_UNITS
@@ -1088,12 +1082,7 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
     const bool open_after = acc > 0 || (sp.unit_nt == 0 && (sp.open || r1 > r0));
     const uint32_t n_closed = cur;  // units 0 .. cur-1 are complete; unit `cur` (if any read fell into it) stays open
     KU_TRY(sparse_reserve_global(ctx, bases + sp.n_carry_l, s));
-    HIP_TRY(hipMemsetAsync(d.l_key, 0, (d.l_mask + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(d.l_first, 0xFF, (d.l_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_key, 0, (d.u_mask + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(d.u_distinct, 0, (d.u_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_last, 0, (d.u_mask + 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(d.u_maxfirst, 0, (d.u_mask + 1) * 4, s));
+    KU_TRY(ku_launch_sparse_clear(d, s));
     if (sp.open) KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p,
                                                    sp.n_carry_u, s));
     HIP_TRY(hipMemcpyAsync((uint32_t *)sp.unit.p + r0, unit.data() + r0, (r1 - r0) * 4, hipMemcpyHostToDevice, s));

@@ -228,48 +228,59 @@ __global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed) {
 }
 
 // the open unit (index `unit`) moves on to the next batch: its encodings and its (unit, slot) statistics.  Places in
-// the carry arrays are claimed once per BLOCK and round: the entries of a block are counted through LDS (wave ballots,
-// then the four waves' totals), one thread adds to the global counter.  (One add per entry -- and still one per wave --
-// queued the grid on a single address: 0.5 ms per batch for a few hundred thousand entries.)
-__device__ __forceinline__ unsigned long long ks_block_claim(unsigned long long *counter, bool want, uint32_t *s_wave /* [5] */) {
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const unsigned long long bal = __ballot(want);
-  if (lane == 0) s_wave[wv] = (uint32_t)__popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t w = 0; w < blockDim.x / 64; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = run; run += c; }
-    const unsigned long long base = run ? atomicAdd(counter, (unsigned long long)run) : 0ull;
-    s_wave[4] = (uint32_t)base;
-    s_wave[5] = (uint32_t)(base >> 32);
-  }
-  __syncthreads();
-  const unsigned long long base = ((unsigned long long)s_wave[5] << 32) | s_wave[4];
-  const unsigned long long mine = base + s_wave[wv] + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
-  __syncthreads();  // s_wave is reused by the next claim
-  return mine;
-}
+// the carry arrays are claimed ONCE PER BLOCK: a block owns a contiguous stretch of the tables, counts what it will take
+// from it, adds that to the global counters (two adds per block), and goes over its stretch a second time to write --
+// the entries of a thread in the order of the first pass, the threads' shares laid out by a scan through LDS.  (One add
+// per entry, per wave, and even per block and 256 cells queued the grid on the two counters: 0.5 / 0.17 ms per batch.)
 __global__ __launch_bounds__(256) void ku_sparse_carry_out_kernel(KuSparseDev s, uint32_t unit, unsigned long long *carry_l, uint32_t *carry_u,
                                                                   unsigned long long *counters, uint64_t cap_l, uint64_t cap_u) {
-  __shared__ uint32_t s_wave[6];
-  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;  // a power of two >= 4096: whole blocks, same trip count
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long lk = i <= s.l_mask ? s.l_key[i] : 0ull;
-    const bool take_l = lk && (uint32_t)(lk >> 50) - 1 == unit && !s.dense[(uint32_t)(lk >> 32) & 0x3FFFFu];
-    const unsigned long long el = ks_block_claim(&counters[0], take_l, s_wave);
-    if (take_l) {
-      if (el < cap_l) carry_l[el] = lk & 0x3FFFFFFFFFFFFull;  // slot << 32 | encoding
-      else atomicOr(s.err, 1u);
+  __shared__ uint32_t s_l[256], s_u[256];
+  __shared__ unsigned long long s_base[2];
+  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;
+  const uint64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+  auto take_l = [&](uint64_t i, unsigned long long &lk) {
+    lk = i <= s.l_mask ? s.l_key[i] : 0ull;
+    return lk && (uint32_t)(lk >> 50) - 1 == unit && !s.dense[(uint32_t)(lk >> 32) & 0x3FFFFu];
+  };
+  auto take_u = [&](uint64_t i, unsigned long long &uk) {
+    uk = i <= s.u_mask ? s.u_key[i] : 0ull;
+    return uk && (uint32_t)(uk >> 32) - 1 == unit && !s.dense[(uint32_t)uk];
+  };
+  uint32_t nl = 0, nu = 0;
+  unsigned long long key;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    nl += take_l(i, key) ? 1u : 0u;
+    nu += take_u(i, key) ? 1u : 0u;
+  }
+  s_l[threadIdx.x] = nl;
+  s_u[threadIdx.x] = nu;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive scan over the threads' counts, then the block's two claims
+    uint32_t rl = 0, ru = 0;
+    for (uint32_t t = 0; t < blockDim.x; ++t) {
+      const uint32_t a = s_l[t], b = s_u[t];
+      s_l[t] = rl; s_u[t] = ru;
+      rl += a; ru += b;
     }
-    const unsigned long long uk = i <= s.u_mask ? s.u_key[i] : 0ull;
-    const bool take_u = uk && (uint32_t)(uk >> 32) - 1 == unit && !s.dense[(uint32_t)uk];
-    const unsigned long long eu = ks_block_claim(&counters[1], take_u, s_wave);
-    if (take_u) {
+    s_base[0] = rl ? atomicAdd(&counters[0], (unsigned long long)rl) : 0ull;
+    s_base[1] = ru ? atomicAdd(&counters[1], (unsigned long long)ru) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long el = s_base[0] + s_l[threadIdx.x], eu = s_base[1] + s_u[threadIdx.x];
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    if (take_l(i, key)) {
+      if (el < cap_l) carry_l[el] = key & 0x3FFFFFFFFFFFFull;  // slot << 32 | encoding
+      else atomicOr(s.err, 1u);
+      ++el;
+    }
+    if (take_u(i, key)) {
       if (eu < cap_u) {
-        carry_u[3 * eu] = (uint32_t)uk;
+        carry_u[3 * eu] = (uint32_t)key;
         carry_u[3 * eu + 1] = s.u_distinct[i];
         carry_u[3 * eu + 2] = s.u_last[i] > s.u_maxfirst[i] ? 1u : 0u;  // all that later inserts need of the order
       } else atomicOr(s.err, 2u);
+      ++eu;
     }
   }
 }
@@ -348,6 +359,16 @@ __global__ void ku_sparse_export_kernel(KuSparseDev s, unsigned long long *out, 
   }
 }
 
+// the per-pass tables start empty: one launch instead of six fills (a pass of the fast path is a few hundred microseconds
+// of kernels; six fill launches were a tenth of a `classify -r` run's emulation time)
+__global__ void ku_sparse_clear_kernel(KuSparseDev s) {
+  const uint64_t nl = s.l_mask + 1, nu = s.u_mask + 1, n = nl > nu ? nl : nu;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i < nl) { s.l_key[i] = 0ull; s.l_first[i] = 0xFFFFFFFFu; }
+    if (i < nu) { s.u_key[i] = 0ull; s.u_distinct[i] = 0u; s.u_last[i] = 0u; s.u_maxfirst[i] = 0u; }
+  }
+}
+
 // ---------------------------------------------------------------------------- launch wrappers
 static unsigned ks_grid(uint64_t n) {
   const uint64_t nb = (n + 255) / 256;
@@ -360,6 +381,11 @@ int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_s
   const uint64_t cap = (uint64_t)n_cu * 32;
   hipLaunchKernelGGL(ku_sparse_insert_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, s, k, d_seqs,
                      d_seq_off, d_seq_len, d_unit, n_reads, d_taxa, quick_min_hits);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream) {
+  const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;
+  hipLaunchKernelGGL(ku_sparse_clear_kernel, dim3(ks_grid((n + 3) / 4)), dim3(256), 0, stream, s);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream) {
@@ -375,8 +401,9 @@ int ku_launch_sparse_rehash(const KuSparseDev &s, const unsigned long long *d_ol
 int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,
                                unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream) {
   const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;
-  hipLaunchKernelGGL(ku_sparse_carry_out_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, s, unit, d_carry_l, d_carry_u, d_counters,
-                     cap_l, cap_u);
+  const uint64_t nb = (n + 4095) / 4096;  // at least 16 cells per thread: few blocks, two claims each
+  hipLaunchKernelGGL(ku_sparse_carry_out_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, stream, s, unit, d_carry_l, d_carry_u,
+                     d_counters, cap_l, cap_u);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_carry_l, uint64_t n_l, const uint32_t *d_carry_u,
