@@ -1717,13 +1717,11 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
     n_units = cur + (unit_first_read.back() < n_reads ? 1u : 0u);
     if (unit_first_read.back() < n_reads) unit_first_read.push_back(n_reads);
     const uint64_t cells = (uint64_t)n_units * ctx->tax.n_slots;
-    if (sp.unit.reserve(n_reads * 4) || sp.u_cnt.reserve(std::max<uint64_t>(cells, 1) * 4) || sp.u_flag.reserve(std::max<uint32_t>(n_units, 1)))
+    if (sp.unit.reserve(n_reads * 4) || sp.u_cnt.reserve(std::max<uint64_t>(cells, 1) * 4) || sp.u_flag.reserve(((uint64_t)std::max<uint32_t>(n_units, 1) + 3) & ~3ull))
       return fail(KU_ENOMEM, "device memory for the work-unit counters");
     uint64_t kmers = 0;  // upper bound of what the fused kernel may add to the run-wide set
     for (uint64_t r = 0; r < n_reads; ++r) kmers += seq_len[r] >= ctx->m.db.k ? seq_len[r] - ctx->m.db.k + 1 : 0;
     KU_TRY(sparse_reserve_global(ctx, kmers + sp.n_carry_l, s));
-    HIP_TRY(hipMemsetAsync(sp.u_cnt.p, 0, std::max<uint64_t>(cells, 1) * 4, s));
-    HIP_TRY(hipMemsetAsync(sp.u_flag.p, 0, std::max<uint32_t>(n_units, 1), s));
     sf.g_key = sp.dev.g_key;
     sf.g_mask = sp.dev.g_mask;
     sf.g_count = sp.dev.g_count;
@@ -1734,7 +1732,14 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
     sf.unit_base = 0;
   }
   unsigned long long *d_counter = (unsigned long long *)(ctx->d_scalar + 2);
-  HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
+  // the run counter and (emulation) the per-(unit, slot) insert counts and the unit flags start at zero: one launch
+  if (sparse) {
+    if (ku_launch_zero3(d_counter, 2, sp.u_cnt.p, std::max<uint64_t>((uint64_t)n_units * ctx->tax.n_slots, 1), sp.u_flag.p,
+                        ((uint64_t)std::max<uint32_t>(n_units, 1) + 3) / 4, s) != KU_OK)
+      return fail(KU_EHIP, "clearing the batch counters failed");
+  } else {
+    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
+  }
   HIP_TRY(hipEventRecord(ctx->seg_events[0], s));  // the copy stream starts behind whatever used the buffers before
   HIP_TRY(hipStreamWaitEvent(ctx->h2d_stream, ctx->seg_events[0], 0));
   KuRunsOut ro{};

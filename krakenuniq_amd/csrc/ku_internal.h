@@ -90,6 +90,7 @@ int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_s
                             const uint32_t *d_seq_len, const uint32_t *d_unit, uint64_t n_reads, const uint32_t *d_taxa,
                             uint32_t quick_min_hits, int n_cu, hipStream_t stream);
 int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream);
+int ku_launch_zero3(void *a, uint64_t a_dwords, void *b, uint64_t b_dwords, void *c, uint64_t c_dwords, hipStream_t stream);
 int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream);
 int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,
                                unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream);

@@ -369,6 +369,16 @@ __global__ void ku_sparse_clear_kernel(KuSparseDev s) {
   }
 }
 
+// up to three dword ranges zeroed by one launch (the small per-batch counters of the fast path)
+__global__ void ku_zero3_kernel(uint32_t *a, uint64_t na, uint32_t *b, uint64_t nb, uint32_t *c, uint64_t nc) {
+  const uint64_t n = na + nb + nc;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i < na) a[i] = 0u;
+    else if (i < na + nb) b[i - na] = 0u;
+    else c[i - na - nb] = 0u;
+  }
+}
+
 // ---------------------------------------------------------------------------- launch wrappers
 static unsigned ks_grid(uint64_t n) {
   const uint64_t nb = (n + 255) / 256;
@@ -381,6 +391,12 @@ int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_s
   const uint64_t cap = (uint64_t)n_cu * 32;
   hipLaunchKernelGGL(ku_sparse_insert_kernel, dim3((unsigned)(n_reads < cap ? n_reads : cap)), dim3(64), 0, stream, s, k, d_seqs,
                      d_seq_off, d_seq_len, d_unit, n_reads, d_taxa, quick_min_hits);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+int ku_launch_zero3(void *a, uint64_t a_dwords, void *b, uint64_t b_dwords, void *c, uint64_t c_dwords, hipStream_t stream) {
+  const uint64_t n = a_dwords + b_dwords + c_dwords;
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_zero3_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, (uint32_t *)a, a_dwords, (uint32_t *)b, b_dwords, (uint32_t *)c, c_dwords);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream) {
