@@ -49,6 +49,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -323,7 +324,7 @@ int main(int argc, char **argv) {
   // regions while this thread loads the database; it is joined before the first read is looked at.
   const int team_cap = getenv("KU_PARSE_TEAM") ? std::max(1, atoi(getenv("KU_PARSE_TEAM"))) : 8;
   const int parse_team = paired ? 1 : (fmt_threads < team_cap ? fmt_threads : team_cap);
-  const int n_batches = 3 + (parse_team > 1 ? parse_team : 0);
+  const int n_batches = 4 + (parse_team > 1 ? parse_team : 0);  // one per team member + device, formatter, writer and one queued
   ku_seqio::PinSwitch::enabled = !chunk_bytes;  // per-read arrays of the batches page-locked too (before any batch exists)
   std::vector<Batch> pool(n_batches);
   std::thread pool_setup([&] {
@@ -468,7 +469,7 @@ int main(int argc, char **argv) {
     { std::lock_guard<std::mutex> l(inflight_mu); inflight_nt -= nt; }
     inflight_cv.notify_all();
   };
-  double busy_reader = 0, busy_gpu = 0, busy_writer = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
+  double busy_reader = 0, busy_gpu = 0, busy_writer = 0, busy_format = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
 
   // Plain (uncompressed) regular files: the file is mapped, cut into record-aligned regions of about one work unit
   // and parsed by `parse_team` threads, each into its own batch; the batches go on in file order.  A member takes a
@@ -624,40 +625,77 @@ int main(int argc, char **argv) {
     parsed_q.push(nullptr);
   });
 
-  std::thread writer([&] {
-    std::vector<char *> parts(fmt_threads, nullptr);  // formatted Kraken lines of the helpers' read ranges
-    std::vector<size_t> part_len(fmt_threads, 0);
+  // Output stage in two steps that overlap: the formatter formats the Kraken lines of batch b + 1 (a standing team of
+  // `fmt_threads` helpers, disjoint read ranges) while the writer writes those of batch b, in input order.  (One thread
+  // doing both, with a team spawned per batch, was the slowest stage of the pipeline: 16 thread starts and a serial
+  // 12 MB write per batch.)
+  struct Formatted { Batch *bt; std::vector<char *> parts; std::vector<size_t> len; };
+  struct FQueue {
+    std::mutex m; std::condition_variable cv; std::deque<Formatted *> q;
+    void push(Formatted *f) { { std::lock_guard<std::mutex> l(m); q.push_back(f); } cv.notify_one(); }
+    Formatted *pop() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty(); }); Formatted *f = q.front(); q.pop_front(); return f; }
+  } write_q;
+  struct FmtTeam {  // the helpers: run(job) calls job(t) on every member and returns when all are done
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0; int pending = 0; bool quit = false; std::function<void(int)> job;
+    void start(int n) {
+      for (int t = 0; t < n; ++t) th.emplace_back([this, t] {
+        uint64_t seen = 0;
+        for (;;) {
+          std::function<void(int)> j;
+          { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; j = job; }
+          j(t);
+          { std::lock_guard<std::mutex> l(m); if (--pending == 0) cv_done.notify_one(); }
+        }
+      });
+    }
+    void run(const std::function<void(int)> &j) {
+      std::unique_lock<std::mutex> l(m);
+      job = j; pending = (int)th.size(); ++gen;
+      cv_go.notify_all();
+      cv_done.wait(l, [&] { return pending == 0; });
+    }
+    void stop() { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &x : th) x.join(); th.clear(); }
+  } fmt_team;
+  if (print_kraken) fmt_team.start(fmt_threads);
+  std::thread formatter([&] {
     for (;;) {
       Batch *bt = done_q.pop();
       if (!bt) break;
       const uint64_t n = bt->off.size();
-      const double t_write = now_s();
+      const double t_fmt = now_s();
+      Formatted *f = new Formatted{bt, std::vector<char *>(fmt_threads, nullptr), std::vector<size_t>(fmt_threads, 0)};
       if (print_kraken) {
-        // format disjoint read ranges in parallel, write them in order
-        std::vector<std::thread> helpers;
         std::vector<int> status(fmt_threads, KU_OK);
-        for (int t = 0; t < fmt_threads; ++t) {
-          helpers.emplace_back([&, t] {
-            const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
-            parts[t] = nullptr;
-            part_len[t] = 0;
-            if (hi <= lo) return;
-            status[t] = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
-                                             bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
-                                             bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
-                                             pflags, &parts[t], &part_len[t]);
-          });
-        }
-        for (auto &h : helpers) h.join();
-        for (int t = 0; t < fmt_threads; ++t) {
+        fmt_team.run([&](int t) {
+          const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
+          if (hi <= lo) return;
+          status[t] = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
+                                           bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
+                                           bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
+                                           pflags, &f->parts[t], &f->len[t]);
+        });
+        for (int t = 0; t < fmt_threads; ++t)
           if (status[t] != KU_OK) die(exit_code_of(status[t]), "%s", ku_strerror(status[t]));
-          if (parts[t]) {
-            s_kraken.write(parts[t], part_len[t]);
-            ku_free(parts[t]);
-            parts[t] = nullptr;
-          }
-        }
       }
+      busy_format += now_s() - t_fmt;
+      write_q.push(f);
+    }
+    write_q.push(nullptr);
+  });
+  std::thread writer([&] {
+    for (;;) {
+      Formatted *f = write_q.pop();
+      if (!f) break;
+      Batch *bt = f->bt;
+      const uint64_t n = bt->off.size();
+      const double t_write = now_s();
+      for (int t = 0; t < fmt_threads; ++t)
+        if (f->parts[t]) {
+          s_kraken.write(f->parts[t], f->len[t]);
+          ku_free(f->parts[t]);
+        }
+      delete f;
       if (keep_records) {  // print_sequence (src/classify.cpp:794-805)
         std::string rec;
         for (uint64_t i = 0; i < n; ++i) {
@@ -813,7 +851,9 @@ int main(int argc, char **argv) {
   }
   done_q.push(nullptr);
   reader.join();
+  formatter.join();
   writer.join();
+  fmt_team.stop();
   for (auto &bt : pool) bt.release();
   gettimeofday(&tv2, nullptr);
   {  // report_stats (src/classify.cpp:361-375)
@@ -827,7 +867,8 @@ int main(int argc, char **argv) {
   }
   s_kraken.close(); s_cls.close(); s_ucls.close();
   if (getenv("KU_CLI_TIMES"))
-    fprintf(stderr, "stage busy seconds: reader %.3f, device %.3f, writer %.3f\n", busy_reader, busy_gpu, busy_writer);
+    fprintf(stderr, "stage busy seconds: reader %.3f, device %.3f, writer %.3f (formatting %.3f + writing %.3f)\n", busy_reader, busy_gpu,
+            busy_format + busy_writer, busy_format, busy_writer);
 
   if (!report_out.empty() && report_out != "off") {
     gettimeofday(&tv1, nullptr);

@@ -21,22 +21,28 @@ del db, s
 torch.cuda.empty_cache()
 env = dict(os.environ)
 extra = []
+threads = "16"
 for kv in sys.argv[3:]:
     k, v = kv.split("=", 1)
     if k.startswith("SWEEP_"):
         continue
     if k == "REPORT":
         extra = ["-r", f"{tmp}/report.tsv"]
+    elif k == "THREADS":
+        threads = v
     else:
         env[k] = v
 cmd = [f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB",
-       "-t", "16", "-o", f"{tmp}/out.tsv"] + extra + [f"{tmp}/reads.fq"]
+       "-t", threads, "-o", f"{tmp}/out.tsv"] + extra + [f"{tmp}/reads.fq"]
 sweep = [kv for kv in sys.argv[3:] if kv.startswith("SWEEP_")]
 if sweep:
     k, vals = sweep[0][6:].split("=", 1)
     for v in vals.split(","):
         e2 = dict(env); e2[k] = v; e2["KU_CLI_TIMES"] = "1"
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e2)
+        c2 = list(cmd)
+        if k == "THREADS":  # SWEEP_THREADS=6,8,12: the -t value
+            c2[c2.index("-t") + 1] = v
+        r = subprocess.run(c2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e2)
         err = r.stderr.decode(errors="replace").replace("\r", "\n").split("\n")
         print(k, v, "rc", r.returncode, " | ".join(l.strip() for l in err if "processed in" in l or "stage busy" in l))
     shutil.rmtree(tmp, ignore_errors=True)
