@@ -274,21 +274,26 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
             thr = str(min(cores, 16))
             cmd = [cli_bin, "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB", "-t", thr,
                    "-o", f"{tmp}/e2e.tsv", f"{tmp}/reads.fq"]
-            t0 = time.time()
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_CLI_TIMES="1"))
-            wall = time.time() - t0
-            err = r.stderr.decode(errors="replace")
-            m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
-            if r.returncode != 0 or not m:
-                raise RuntimeError("classify failed: " + err[-300:])
-            secs = float(m.group(3))
+            runs_s = []
+            for rep in range(2):  # the executable twice: the host side (16 cores under a cgroup quota) varies by +-20 % from run to run
+                t0 = time.time()
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_CLI_TIMES="1"))
+                wall = time.time() - t0
+                err_i = r.stderr.decode(errors="replace")
+                m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err_i)
+                if r.returncode != 0 or not m:
+                    raise RuntimeError("classify failed: " + err_i[-300:])
+                runs_s.append(float(m.group(3)))
+                if runs_s[-1] == min(runs_s):
+                    err = err_i
+            secs = min(runs_s)
             mb = re.search(r"stage busy seconds: reader ([\d.]+), device ([\d.]+), writer ([\d.]+)", err)
             busy_plain = float(mb.group(2)) if mb else None
             import pandas as pd
             got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
             out["e2e"] = {"value": round(n_e / secs / 1e6, 2), "unit": "Mreads/s", "reads": n_e, "threads": int(thr),
                           "window": "the executable's report_stats window (classify.cpp:248-258): FASTQ parse -> GPU -> Kraken file",
-                          "seconds": secs, "wall_incl_db_load_s": round(wall, 1),
+                          "seconds": secs, "seconds_of_both_runs": runs_s, "wall_incl_db_load_s": round(wall, 1),
                           "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
             # the same run as scripts/krakenuniq starts it: with a report (-r), i.e. with the HyperLogLog++ sparse-sketch
             # emulation inside the timing window and the clade roll-up behind it
@@ -296,20 +301,28 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
                 os.remove(f"{tmp}/e2e.tsv")
                 env = dict(os.environ, KU_CLI_TIMES="1", KU_REPORT_TIMES="1")
                 cmd_r = cmd[:-1] + ["-r", f"{tmp}/report.tsv", cmd[-1]]
-                t0 = time.time()
-                r = subprocess.run(cmd_r, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-                wall = time.time() - t0
-                err = r.stderr.decode(errors="replace")
-                m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err)
+                runs_r = []
+                for rep in range(2):
+                    for fn in ("e2e.tsv", "report.tsv"):
+                        if os.path.exists(f"{tmp}/{fn}"):
+                            os.remove(f"{tmp}/{fn}")
+                    t0 = time.time()
+                    r = subprocess.run(cmd_r, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+                    wall = time.time() - t0
+                    err_i = r.stderr.decode(errors="replace")
+                    m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err_i)
+                    if r.returncode != 0 or not m or not re.search(r"Report finished in ([\d.]+) seconds", err_i):
+                        raise RuntimeError("classify -r failed: " + err_i[-300:])
+                    runs_r.append(float(m.group(3)))
+                    if runs_r[-1] == min(runs_r):
+                        err = err_i
                 m2 = re.search(r"Report finished in ([\d.]+) seconds", err)
                 m3 = re.search(r"stage busy seconds: reader ([\d.]+), device ([\d.]+), writer ([\d.]+)", err)
-                if r.returncode != 0 or not m or not m2:
-                    raise RuntimeError("classify -r failed: " + err[-300:])
-                secs_r = float(m.group(3))
+                secs_r = min(runs_r)
                 got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
                 n_rows = sum(1 for _ in open(f"{tmp}/report.tsv"))
                 out["e2e"]["with_report"] = {
-                    "value": round(n_e / secs_r / 1e6, 2), "unit": "Mreads/s", "seconds": secs_r,
+                    "value": round(n_e / secs_r / 1e6, 2), "unit": "Mreads/s", "seconds": secs_r, "seconds_of_both_runs": runs_r,
                     "report_seconds": float(m2.group(1)), "report_rows": n_rows,
                     "report_stages_ms": {mm.group(1).strip(): float(mm.group(2)) for mm in re.finditer(r"ku_ctx_report: (.+?) +([\d.]+) ms", err)},
                     "device_stage_busy_s": float(m3.group(2)) if m3 else None,
