@@ -210,7 +210,27 @@ extern "C" int ku_resolve_uids(const ku_tax *tax, const ku_uid_map *map, const k
 }
 
 // ---------------------------------------------------------------------------- Kraken lines
+// decimal digits, two at a time from a table; the values of a Kraken line (taxids, lengths, run lengths) are 32-bit and
+// mostly short: 32-bit arithmetic, digit count from comparisons, written front to back
+static const char ku_digit_pairs[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263"
+    "646566676869707172737475767778798081828384858687888990919293949596979899";
+static inline char *put_u32(char *p, uint32_t v) {
+  const int n = v < 10 ? 1 : v < 100 ? 2 : v < 1000 ? 3 : v < 10000 ? 4 : v < 100000 ? 5 : v < 1000000 ? 6 : v < 10000000 ? 7 : v < 100000000 ? 8
+                : v < 1000000000 ? 9 : 10;
+  char *e = p + n;
+  while (v >= 100) {
+    const uint32_t q = v / 100, r = v - q * 100;
+    e -= 2;
+    memcpy(e, ku_digit_pairs + 2 * r, 2);
+    v = q;
+  }
+  if (v >= 10) memcpy(e - 2, ku_digit_pairs + 2 * v, 2);
+  else e[-1] = (char)('0' + v);
+  return p + n;
+}
 static inline char *put_u64(char *p, uint64_t v) {
+  if (v <= 0xFFFFFFFFull) return put_u32(p, (uint32_t)v);
   char tmp[24];
   int n = 0;
   do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
@@ -287,7 +307,8 @@ extern "C" int ku_format_kraken_rle(const char *seqs, const uint64_t *seq_off, c
   if (!out || !out_len || (n_reads && (!seq_off || !seq_len || !ids || !calls))) { ku_set_error("ku_format_kraken_rle: null argument"); return KU_EINVAL; }
   const bool quick = flags & KU_P_QUICK, only_c = flags & KU_P_ONLY_CLASSIFIED, pseq = flags & KU_P_SEQUENCE;
   if ((!quick && n_reads && (!run_off || !run_cnt)) || (quick && !hits) || (pseq && !seqs)) { ku_set_error("ku_format_kraken_rle: missing array for the requested columns"); return KU_EINVAL; }
-  size_t cap = 1 << 16, len = 0;
+  // one allocation for the usual case (about 100 bytes per line; grows if the ids or hit lists are longer)
+  size_t cap = std::max<size_t>(1 << 16, (size_t)n_reads * 128), len = 0;
   char *buf = (char *)malloc(cap);
   if (!buf) return KU_ENOMEM;
   const char *id = ids;
