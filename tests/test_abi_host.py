@@ -245,6 +245,23 @@ def test_format_kraken_rle_reproduces_reference_output(golden, f1, fixture, read
         assert capi.format_kraken_rle(buf, off, lens, ids, 31, q, flags=capi.KU_P_QUICK) == open(f"{d}/out_quick.tsv").read()
 
 
+def test_integers_of_every_width_in_the_hit_list():
+    """taxids and run lengths are written two digits at a time: every digit count up to 2^32 - 2 (2^32 - 1 is KU_AMBIG, 'A')"""
+    vals = [0, 1, 9, 10, 11, 99, 100, 101, 999, 1000, 9999, 10000, 65535, 99999, 100000, 999999, 1000000, 9999999, 10000000,
+            99999999, 100000000, 999999999, 1000000000, 2147483647, 2147483648, 4294967294]
+    rng = np.random.default_rng(3)
+    vals += [int(x) for x in rng.integers(0, 2 ** 32 - 1, 200)]
+    taxa, want = [], []
+    for i, v in enumerate(vals):
+        run = 1 + (i * 7) % 23
+        taxa += [v] * run
+        if want and want[-1][0] == v:
+            want[-1][1] += run
+        else:
+            want.append([v, run])
+    assert capi.hitlist_string(np.array(taxa, dtype=np.uint32)) == " ".join(f"{v}:{c}" for v, c in want)
+
+
 def test_format_kraken_rle_equals_raw_on_random_codes():
     """randomised: any code sequence (taxids incl. > 2^31, 0, KU_AMBIG, runs crossing word sizes) formats the same from
     raw codes and from runs; -c / -s / quick flags included; both agree with the oracle's hitlist_string"""
