@@ -470,6 +470,7 @@ int main(int argc, char **argv) {
     inflight_cv.notify_all();
   };
   double busy_reader = 0, busy_gpu = 0, busy_writer = 0, busy_format = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
+  double busy_gpu_classify = 0, busy_gpu_fetch = 0;                       // ... of the device stage: the batch call, the runs' copy back
 
   // Plain (uncompressed) regular files: the file is mapped, cut into record-aligned regions of about one work unit
   // and parsed by `parse_team` threads, each into its own batch; the batches go on in file order.  A member takes a
@@ -839,11 +840,14 @@ int main(int argc, char **argv) {
     else
       KU_CHECK(ku_classify_batch_rle(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts,
                                      bt->calls.data(), bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), &n_runs));
+    const double t_fetch = now_s();
+    busy_gpu_classify += t_fetch - t_gpu;
     if ((print_kraken && !quick) || map_uids) {  // the runs feed the Kraken lines -- and the UID resolution
       bt->reserve_runs(n_runs);
       if (mg) KU_CHECK(ku_mgpu_fetch_runs(mg, bt->runs, n_runs));
       else KU_CHECK(ku_fetch_runs(ctx, bt->runs, n_runs));
     }
+    busy_gpu_fetch += now_s() - t_fetch;
     if (map_uids) {  // the calls of resolve_tree give way to resolve_uids3's; the read counts on the device follow
       KU_CHECK(ku_resolve_uids(tax, uid_map, bt->runs, bt->run_off.data(), bt->run_cnt.data(), bt->len.data(), n, info.k,
                                (uint32_t)fmt_threads, bt->calls.data()));
@@ -875,8 +879,8 @@ int main(int argc, char **argv) {
   }
   s_kraken.close(); s_cls.close(); s_ucls.close();
   if (getenv("KU_CLI_TIMES"))
-    fprintf(stderr, "stage busy seconds: reader %.3f, device %.3f, writer %.3f (formatting %.3f + writing %.3f)\n", busy_reader, busy_gpu,
-            busy_format + busy_writer, busy_format, busy_writer);
+    fprintf(stderr, "stage busy seconds: reader %.3f, device %.3f, writer %.3f (formatting %.3f + writing %.3f; device: batch call %.3f + runs back %.3f)\n",
+            busy_reader, busy_gpu, busy_format + busy_writer, busy_format, busy_writer, busy_gpu_classify, busy_gpu_fetch);
 
   if (!report_out.empty() && report_out != "off") {
     gettimeofday(&tv1, nullptr);

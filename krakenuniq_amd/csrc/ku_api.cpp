@@ -535,8 +535,10 @@ static void ctx_free_tax(ku_ctx *ctx) {
   ctx->tax_set = false;
 }
 
+static void rle_times_print();
 extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   if (!ctx) return;
+  rle_times_print();
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx_free_db(ctx);
@@ -1651,10 +1653,21 @@ static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_
                          uint64_t runs_cap, bool quick, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
                          uint32_t *run_cnt, uint64_t *n_runs);
 
+// KU_RLE_TIMES=1: where ku_classify_batch_rle spends its time on the host, summed over the run, printed when the context goes
+static double g_rle_t[9];  // checks, plan + enqueue, wait for the device, after the wait, calls; of the enqueue: H2D calls, launches, D2H calls
+static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
+static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static void rle_times_print() {
+  if (g_rle_times && g_rle_t[4] > 0)
+    fprintf(stderr, "ku_classify_batch_rle over %.0f calls: checks %.3f s, plan + enqueue %.3f s (H2D calls %.3f, launches %.3f, D2H calls %.3f), waiting for the device %.3f s, behind the wait %.3f s\n",
+            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[2], g_rle_t[3]);
+}
+
 static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
                            uint64_t n_reads, const ku_opts &o, uint32_t max_n, bool monotonic, uint32_t *calls, uint32_t *hits,
                            uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs, bool *classified) {
   hipStream_t s = ctx->stream;
+  const double t_in = g_rle_times ? rle_now() : 0.0;
   *classified = false;
   const bool counts = !(o.flags & KU_F_NO_COUNTS);
   const bool sparse = ctx->sp.on && counts;
@@ -1751,6 +1764,7 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
     const uint64_t a = seg[g], b = seg[g + 1];
     const uint64_t lo = g == 0 ? 0 : seq_off[a], hi = g + 1 == n_seg ? n_bytes : seq_off[b];
     hipStream_t cs = n_seg > 1 ? ctx->h2d_stream : s;
+    const double t_h0 = g_rle_times ? rle_now() : 0.0;
     if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)ctx->b_seqs.p + lo, seqs + lo, hi - lo, hipMemcpyHostToDevice, cs));
     if (b > a) {
       HIP_TRY(hipMemcpyAsync((uint64_t *)ctx->b_off.p + a, seq_off + a, (b - a) * 8, hipMemcpyHostToDevice, cs));
@@ -1761,17 +1775,22 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
       HIP_TRY(hipEventRecord(ctx->seg_events[g], cs));
       HIP_TRY(hipStreamWaitEvent(s, ctx->seg_events[g], 0));
     }
+    if (g_rle_times) g_rle_t[5] += rle_now() - t_h0;
     if (b == a) continue;
     ro.run_off = (uint64_t *)ctx->b_roff.p + a;
     ro.run_cnt = (uint32_t *)ctx->b_rcnt.p + a;
     sf.unit_of = sparse ? (const uint32_t *)sp.unit.p + a : nullptr;
+    const double t_l0 = g_rle_times ? rle_now() : 0.0;
     int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p + a,
                                       (const uint32_t *)ctx->b_len.p + a, b - a, max_n, o.flags, (uint32_t *)ctx->b_calls.p + a, nullptr, nullptr,
                                       ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
+    if (g_rle_times) g_rle_t[6] += rle_now() - t_l0;
     if (st != KU_OK) { (void)hipStreamSynchronize(ctx->h2d_stream); (void)hipStreamSynchronize(s); return fail(st, "fused kernel launch failed"); }
+    const double t_d0 = g_rle_times ? rle_now() : 0.0;
     HIP_TRY(hipMemcpyAsync(calls + a, (uint32_t *)ctx->b_calls.p + a, (b - a) * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(run_off + a, (uint64_t *)ctx->b_roff.p + a, (b - a) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(run_cnt + a, (uint32_t *)ctx->b_rcnt.p + a, (b - a) * 4, hipMemcpyDeviceToHost, s));
+    if (g_rle_times) g_rle_t[7] += rle_now() - t_d0;
   }
   unsigned long long total = 0;
   HIP_TRY(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
@@ -1786,7 +1805,10 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
     HIP_TRY(hipMemcpyAsync(&g_now, sp.dev.g_count, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&sp_err, sp.dev.err, 4, hipMemcpyDeviceToHost, s));
   }
+  const double t_enq = g_rle_times ? rle_now() : 0.0;
   HIP_TRY(hipStreamSynchronize(s));
+  const double t_sync = g_rle_times ? rle_now() : 0.0;
+  struct Lap { double a, b, c; ~Lap() { if (g_rle_times) { g_rle_t[1] += b - a; g_rle_t[2] += c - b; g_rle_t[3] += rle_now() - c; g_rle_t[4] += 1; } } } lap_{t_in, t_enq, t_sync};
   if (hits) memset(hits, 0, n_reads * 4);  // "Q:n" is quick mode only
   if (total > runs_cap) {
     // the run array was too small for this batch (reads that change taxon every few k-mers): the per-k-mer codes once more
@@ -1837,12 +1859,14 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
   if (n_reads == 0) return KU_OK;
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   o.flags &= ~KU_F_KEEP_SLOTS;
+  const double t_chk = g_rle_times ? rle_now() : 0.0;
   if (o.max_read_len == 0) for (uint64_t i = 0; i < n_reads; ++i) o.max_read_len = std::max(o.max_read_len, seq_len[i]);
   bool monotonic = true;
   for (uint64_t i = 0; i < n_reads; ++i) {
     if (seq_off[i] + seq_len[i] > n_bytes) return fail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
     if (i && seq_off[i] < seq_off[i - 1] + seq_len[i - 1]) monotonic = false;
   }
+  if (g_rle_times) g_rle_t[0] += rle_now() - t_chk;
   {
     const uint32_t max_n = o.max_read_len >= ctx->m.db.k ? o.max_read_len - ctx->m.db.k + 1 : 0;
     if (rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic)) {

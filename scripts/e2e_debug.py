@@ -40,11 +40,13 @@ if sweep:
     for v in vals.split(","):
         e2 = dict(env); e2[k] = v; e2["KU_CLI_TIMES"] = "1"
         c2 = list(cmd)
+        if k == "CPULIST" and v != "all":  # SWEEP_CPULIST=all,0-63: taskset
+            c2 = ["taskset", "-c", v.replace("+", ",")] + c2
         if k == "THREADS":  # SWEEP_THREADS=6,8,12: the -t value
             c2[c2.index("-t") + 1] = v
         r = subprocess.run(c2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e2)
         err = r.stderr.decode(errors="replace").replace("\r", "\n").split("\n")
-        print(k, v, "rc", r.returncode, " | ".join(l.strip() for l in err if "processed in" in l or "stage busy" in l))
+        print(k, v, "rc", r.returncode, " | ".join(l.strip() for l in err if "processed in" in l or "stage busy" in l or "ku_classify_batch_rle over" in l))
     shutil.rmtree(tmp, ignore_errors=True)
     sys.exit(0)
 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
