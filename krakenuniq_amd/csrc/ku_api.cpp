@@ -1323,10 +1323,38 @@ int ku_ctx_route_scan(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint32_
   int st = ku_launch_route_scan(ctx->m.db, (const uint8_t *)d_seqs, n_bytes, d_taxa, rt, ctx->n_cu, s);
   return st == KU_OK ? KU_OK : fail(st, "route scan kernel launch failed");
 }
-int ku_ctx_route_probe(ku_ctx *ctx, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts, hipStream_t s) {
+// whether the resolve stage of a routed step can run as the fused kernel's ROUTE instance (KU_EUNSUP: no -- quick mode, reads
+// beyond 65535 k-mers, unknown read length); reserves the windowed instance's spill workspace for any number of reads, so
+// that the per-round calls below never reallocate it under a kernel of the other stream
+int ku_ctx_route_resolve_prepare(ku_ctx *ctx, const ku_opts *opts, hipStream_t s) {
   KU_TRY(check_ready(ctx));
-  int st = ku_launch_route_probe(ctx->m.db, ctx->cnt, d_ent, n, d_slots, do_counts, ctx->n_cu, s);
-  return st == KU_OK ? KU_OK : fail(st, "route probe kernel launch failed");
+  const uint32_t flags = opts ? opts->flags : 0;
+  const uint32_t max_len = opts ? opts->max_read_len : 0;
+  if (max_len == 0 || (flags & (KU_F_QUICK | KU_F_KEEP_SLOTS)) || getenv("KU_NO_FUSED")) return KU_EUNSUP;  // (no message: the caller has another path)
+  const uint32_t max_n = max_len >= ctx->m.db.k ? max_len - ctx->m.db.k + 1 : 0;
+  if (max_n > ku_route_resolve_max_kmers()) return KU_EUNSUP;
+  if (max_n > 128) {
+    const uint64_t ws = ku_short_workspace_bytes(std::max(max_n, 193u), ctx->tax.n_slots, ~0ull >> 8, ctx->n_cu);
+    if (ws > ctx->b_ws.cap) {
+      HIP_TRY(hipStreamSynchronize(s));
+      if (ctx->b_ws.reserve(ws) != KU_OK) { (void)hipGetLastError(); return KU_EUNSUP; }
+    }
+  }
+  return KU_OK;
+}
+int ku_ctx_route_resolve(ku_ctx *ctx, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls,
+                         uint32_t *d_taxa, uint32_t *d_hits, const uint32_t *d_kb, const uint32_t *d_ret, hipStream_t s) {
+  const uint32_t flags = opts ? opts->flags : 0;
+  const uint32_t max_len = opts ? opts->max_read_len : 0;
+  const uint32_t max_n = max_len >= ctx->m.db.k ? max_len - ctx->m.db.k + 1 : 0;
+  int st = ku_launch_route_resolve(ctx->m.db, ctx->tax, ctx->cnt, d_off, d_len, n_reads, max_n, flags, d_calls, d_taxa, d_hits, d_kb, d_ret,
+                                   ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s);
+  return st == KU_OK ? KU_OK : fail(st, "routed resolve kernel launch failed");
+}
+int ku_ctx_route_owner(ku_ctx *ctx, const void *d_rec, uint64_t n_rec, const uint32_t *d_kb, uint32_t *d_slots, bool do_counts, hipStream_t s) {
+  KU_TRY(check_ready(ctx));
+  int st = ku_launch_route_owner(ctx->m.db, ctx->cnt, d_rec, n_rec, d_kb, d_slots, do_counts, ctx->n_cu, s);
+  return st == KU_OK ? KU_OK : fail(st, "route owner kernel launch failed");
 }
 
 int ku_exact_owned_step(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads, uint64_t n_bytes,

@@ -52,23 +52,38 @@ struct KuCountsDev {
   unsigned long long *n_reads;        // n_nodes
 };
 
-// Owner routing of the sharded multi-GPU path (ku_mgpu.cpp, ku_route.hip): a rank scans only its own slice of the reads and
-// sends every unambiguous canonical k-mer -- with the size-independent half of its bucket hash -- to the rank that owns its
-// minimizer bin; the owner probes, accounts (HLL, n_kmers) and sends the slot back.  ku_lookup_kernel<3,...> is the scan:
-// a counting pass (fill = 0: k-mers per owner) and a filling pass (fill = 1: the owners' queues, in slice order per block).
-#define KU_ROUTE_CHUNK 512u          // entries of a queue a block claims at a time
+// Owner routing of the sharded multi-GPU path (ku_mgpu.cpp, ku_route.hip).  A rank scans only its own slice of
+// the reads (ku_lookup_kernel<3,...>) and sends every maximal run of consecutive unambiguous k-mers that share their
+// ANCHOR occurrence (= minimizer occurrence, ku_device.h) to the rank that owns the run's minimizer bin -- as ONE 16-byte
+// record ("super-k-mer": the run's k + n - 1 bases, 2 bits each, + n + the anchor's offset): ~2 B per k-mer on the wire where
+// round 3 sent 12 B {k-mer, bucket prehash} + kept 4 B of position per k-mer.  The owner expands the records, probes its
+// table, books the k-mers (HLL, n_kmers -- owner-computes) and returns one 4-byte slot per k-mer, in record order; the
+// sender finds a k-mer's slot through the TICKET the scan left at the k-mer's position of the per-k-mer array:
+//     record      d0..d2 = bases 0..47 (first base in bits 31..30 of d0), d3 = bases 48..55 << 16 | anchor offset << 8 | n
+//                 (n = 0: padding; n <= KU_ROUTE_MAXN(k) so that k + n - 1 <= 56 bases; anchor offset = base index of
+//                 the anchor m-mer within the record, read order)
+//     ticket      record index in the sender's queue buffer << 5 | index of the k-mer within the record;
+//                 KU_AMBIG: ambiguous k-mer; KU_ROUTE_MISS: nobody owns the k-mer's bin (slot 0, not booked)
+//     slot of a ticket = returned[kb[record] + index], kb = exclusive prefix sum of n over the queue buffer
+//                 (ku_launch_route_prefix: the owner numbers what it received the same way)
+#define KU_ROUTE_CHUNK 64u           // unit of a queue: a block claims KuRouteDev::chunk records at a time, a multiple of this (the owner works on groups of 64)
 #define KU_ROUTE_CURSOR_STRIDE 16u   // the queues' cursors lie 128 bytes apart
 #define KU_ROUTE_NONE (~0ull)
-#define KU_ROUTE_NULL 0xFFFFFFFFu    // both k-mer words of a null entry (a k-mer has at most 62 bits), and its position
+#define KU_ROUTE_MISS 0xFFFFFFFEu
+#define KU_ROUTE_MAX_RECORDS ((1u << 27) - 2u)  // per rank and step (27-bit record index in a ticket)
+__host__ __device__ static inline uint32_t ku_route_maxn(uint32_t k, uint32_t nt) {  // k-mers per record
+  const uint32_t w = k - nt + 1, room = 57u - k;
+  const uint32_t a = w < room ? w : room;
+  return a < 31u ? a : 31u;
+}
 struct KuRouteDev {
   const uint64_t *own_lo, *own_hi;  // [world] the ranks' minimizer ranges
-  unsigned long long *cursor;       // [world * KU_ROUTE_CURSOR_STRIDE] entries claimed in each owner's queue, whole chunks (ends as
-                                    // the owner's total incl. null entries, also beyond cap)
-  const uint64_t *q_off;            // [world] first entry of each owner's queue
-  uint32_t *q_ent;                  // 3 dwords per entry: k-mer low, k-mer high, bucket prehash
-  uint32_t *q_pos;                  // the entry's position in the slice's per-k-mer array (where its slot goes)
-  uint64_t cap;                     // room per queue in entries (0: the queues are exactly sized)
+  unsigned long long *cursor;       // [world * KU_ROUTE_CURSOR_STRIDE] records claimed in each owner's queue, whole chunks (ends as
+                                    // the owner's total incl. padding, also beyond cap)
+  uint4 *q_rec;                     // the queues: owner o's records at [o * cap, o * cap + cursor[o])
+  uint64_t cap;                     // room per queue in records (a multiple of chunk)
   uint32_t world;
+  uint32_t chunk;                   // records a block claims at a time (few owners: larger claims, fewer adds on the same cursor)
 };
 // HyperLogLog++ sparse-mode emulation (ku_sparse.hip): tables of one context
 struct KuSparseDev {
@@ -146,7 +161,12 @@ int ku_launch_sparse_absorb(const KuSparseDev &s, const unsigned long long *d_ke
 
 int ku_ctx_route_info(const ku_ctx *ctx, uint64_t *bin_lo, uint64_t *bin_hi, int *is_hash, int *single_db);
 int ku_ctx_route_scan(ku_ctx *ctx, const void *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, hipStream_t s);
-int ku_ctx_route_probe(ku_ctx *ctx, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts, hipStream_t s);
+// gather + resolve in one kernel (reads of up to 65535 k-mers, no quick mode); prepare: KU_EUNSUP = take
+// ku_launch_route_gather + ku_resolve_device
+int ku_ctx_route_resolve_prepare(ku_ctx *ctx, const ku_opts *opts, hipStream_t s);
+int ku_ctx_route_resolve(ku_ctx *ctx, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads, const ku_opts *opts, uint32_t *d_calls,
+                         uint32_t *d_taxa, uint32_t *d_hits, const uint32_t *d_kb, const uint32_t *d_ret, hipStream_t s);
+int ku_ctx_route_owner(ku_ctx *ctx, const void *d_rec, uint64_t n_rec, const uint32_t *d_kb, uint32_t *d_slots, bool do_counts, hipStream_t s);
 // context internals the multi-GPU driver (ku_mgpu.cpp) needs
 struct ku_ctx;
 hipStream_t ku_ctx_stream_of(ku_ctx *ctx);
@@ -162,9 +182,19 @@ int ku_launch_lookup(const KuDbDev &db, const KuCountsDev &cnt, const uint8_t *d
 // owner routing (ku_route.hip; the scan is ku_lookup_kernel<3, 1, true, false> in ku_kernels.hip)
 int ku_launch_route_scan(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, int n_cu,
                          hipStream_t stream);
-int ku_launch_route_probe(const KuDbDev &db, const KuCountsDev &cnt, const uint32_t *d_ent, uint64_t n, uint32_t *d_slots, bool do_counts,
-                          int n_cu, hipStream_t stream);
-int ku_launch_route_scatter(const uint32_t *d_pos, const uint32_t *d_slots, uint64_t n, uint32_t *d_taxa, hipStream_t stream);
+unsigned ku_route_scan_grid(uint64_t n_bytes, int n_cu);  // blocks of that launch (each may leave one padded chunk per queue)
+// kb[i] = sum of n over the records before i, kb[n_rec] = the total.  cap != 0: the buffer is `n_rec / cap` queues of `cap`
+// records of which only the first min(cursor[q * KU_ROUTE_CURSOR_STRIDE], cap) count (the sender's side); cap == 0: every
+// record counts (what an owner received).  d_tot (optional, cap != 0): per queue {records = cursor, k-mers}, then cap.
+// d_work: ku_route_prefix_work_bytes(n_rec) bytes of scratch.
+uint64_t ku_route_prefix_work_bytes(uint64_t n_rec);
+int ku_launch_route_prefix(const void *d_rec, uint64_t n_rec, uint64_t cap, const unsigned long long *d_cursor, uint32_t *d_kb,
+                           unsigned long long *d_tot, void *d_work, hipStream_t stream);
+// the owner's side: n_rec (a multiple of 64) received records -> d_slots[kb[i] + j] = slot of k-mer j of record i (+ HLL, n_kmers)
+int ku_launch_route_owner(const KuDbDev &db, const KuCountsDev &cnt, const void *d_rec, uint64_t n_rec, const uint32_t *d_kb,
+                          uint32_t *d_slots, bool do_counts, int n_cu, hipStream_t stream);
+// the sender's side: tickets in d_taxa[0 .. n) become slots (KU_AMBIG stays)
+int ku_launch_route_gather(uint32_t *d_taxa, uint64_t n, const uint32_t *d_kb, const uint32_t *d_ret, hipStream_t stream);
 int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, unsigned long long *d_stats,
                            int n_cu, hipStream_t stream);
 int ku_launch_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint8_t *d_seqs,
@@ -200,6 +230,11 @@ struct KuSparseFast {
   uint32_t n_slots;
   uint32_t unit_base;
 };
+// owner-routed path: where the fused kernel's ROUTE instances find the slot of a ticket (ku_route.hip)
+struct KuRouteIn {
+  const uint32_t *kb;   // k-mers before each record of this rank's queue buffer
+  const uint32_t *ret;  // the slots the owners returned, in that numbering
+};
 #define KU_SPARSE_SWITCH_INSERTS 1025u  // fewest inserts with which a sparse sketch can turn dense (hyperloglogplus.cpp:496-498)
 // fused wave-per-read path for short reads (ku_short.hip)
 uint32_t ku_short_max_kmers(const KuDbDev &db);           // reads taken in one pass
@@ -210,6 +245,12 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
                              uint32_t max_kmers, uint32_t flags, uint32_t *d_calls, uint32_t *d_taxa, uint32_t *d_hits,
                              void *d_workspace, uint64_t workspace_bytes, int n_cu, hipStream_t stream,
                              const KuRunsOut *runs_out = nullptr, const KuSparseFast *sparse = nullptr);
+// resolve stage of the owner-routed path fused with the gather of the returned slots (ku_short.hip, ROUTE instances)
+uint32_t ku_route_resolve_max_kmers();
+int ku_launch_route_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint64_t *d_seq_off,
+                            const uint32_t *d_seq_len, uint64_t n_reads, uint32_t max_kmers, uint32_t flags, uint32_t *d_calls,
+                            uint32_t *d_taxa, uint32_t *d_hits, const uint32_t *d_kb, const uint32_t *d_ret, void *d_workspace,
+                            uint64_t workspace_bytes, int n_cu, hipStream_t stream, const KuRunsOut *runs_out = nullptr);
 // waves of the fused kernel's persistent grid for a batch of n_reads (sizing of the run array: every wave may leave one
 // partly used chunk behind)
 uint64_t ku_short_grid_waves(uint64_t n_reads, uint32_t max_kmers, int n_cu);

@@ -45,15 +45,19 @@
 // only -- no search, accumulates {queries, sum ceil(log2(n_b+1)), queries into
 // non-empty bins, sum n_b} into stats[4] (the algorithmic-bytes model of
 // SURVEY.md 8(d), DESIGN.md "Roofline").  MODE 3: the scan of the owner-routed multi-GPU path (KuRouteDev): stages 1-3
-// only, every unambiguous k-mer goes -- canonical form + bucket prehash -- into the queue of the rank that owns its
-// minimizer bin; taxa[] gets KU_AMBIG / 0 placeholders.
+// only; every maximal run of consecutive unambiguous k-mers that share their anchor occurrence goes as one 16-byte record
+// (its bases + length + anchor offset, ku_internal.h) into the queue of the rank that owns the run's minimizer bin;
+// taxa[] gets the k-mers' tickets (record index, index within the record), KU_AMBIG or KU_ROUTE_MISS.
 // LAYOUT 0: sorted bins + binary search (the on-disk order); LAYOUT 1: hash table.
 // SHARDED: the context owns a strict sub-range of the minimizer bins, so the minimizer of
 // every k-mer is needed for the ownership test (always needed by LAYOUT 0 and MODE 2).
 // PRIOR: a later database of a hierarchical run (classify.cpp:928-936): taxa[] holds the slots found in the earlier
 // databases; positions that already have one are not searched again, and the accounting (MODE 1, last database
 // only) books the k-mer under whichever slot it ends up with.
-template <int MODE, int LAYOUT, bool SHARDED, bool PRIOR>
+// ITEMS: k-mer positions per lane and block iteration (ITEMS = 1 for the probing instances, see above; the scan of the
+// owner-routed path has no probes in flight and amortises its barriers and LDS traffic over two: 42.9 -> 40.6 ms per 10 M reads
+// over eight ranks)
+template <int MODE, int LAYOUT, bool SHARDED, bool PRIOR, int ITEMS = KU_ITEMS>
 __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuDbDev db, KuCountsDev cnt,
                                                                const uint8_t *__restrict__ seqs,
                                                                uint64_t n_bytes, uint32_t *__restrict__ taxa,
@@ -62,14 +66,16 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   // another chunk keep what that chunk's pass wrote ("non-zero wins" merge, classify.cpp:445-452).  The other
   // bits are a measurement knob (env KU_ABLATE, scripts/ablate_lookup.py): bit0 skip the table/bin probe,
   // bit1 skip the HLL update, bit2 skip the n_kmers counter, bit3 skip the taxa store.  0 in production.
+  constexpr int TILE = KU_THREADS * ITEMS;        // k-mer start positions per block iteration
+  constexpr int PACKW = (TILE + 64) / 16;         // 16-base words staged per tile (covers TILE + 63 bases)
   constexpr bool DO_COUNTS = MODE == 1;
   constexpr bool NEED_MIN = true;  // every variant uses the LDS sliding-window minimizer (bin, and for LAYOUT 1 its position)
   unsigned long long st_q = 0, st_lg = 0, st_ne = 0, st_nb = 0;
   // 16 bases per word, MSB first (base 16w in bits 31..30): a k-mer is a
   // funnel shift over three consecutive words.
-  __shared__ uint32_t s_codes[KU_PACKW + 4];
-  __shared__ uint32_t s_amb[(KU_PACKW + 4) / 2 + 2];       // 32 bases per word, MSB first
-  __shared__ uint32_t s_mm[NEED_MIN ? KU_TILE + 64 : 1];   // scrambled canonical m-mer per start position (raw value)
+  __shared__ uint32_t s_codes[PACKW + 4];
+  __shared__ uint32_t s_amb[(PACKW + 4) / 2 + 2];       // 32 bases per word, MSB first
+  __shared__ uint32_t s_mm[NEED_MIN ? TILE + 64 : 1];   // scrambled canonical m-mer per start position (raw value)
   // hash layout: packed window elements (key, offset, strand bit; ku_device.h) of the anchor search, two buffers so
   // that a doubling step reads one and writes the other (one barrier per step)
   constexpr bool PK = LAYOUT == 1 && MODE != 2;
@@ -83,14 +89,14 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   if (ROUTE) {
     if (threadIdx.x < 64) {
       s_rcnt[threadIdx.x] = 0;
-      s_cused[threadIdx.x] = KU_ROUTE_CHUNK;  // no chunk yet: the first tile claims one
+      s_cused[threadIdx.x] = rt.chunk;  // no chunk yet: the first tile claims one
       s_cbase[threadIdx.x] = KU_ROUTE_NONE;
       s_olo[threadIdx.x] = threadIdx.x < rt.world ? rt.own_lo[threadIdx.x] : 0ull;
       s_ohi[threadIdx.x] = threadIdx.x < rt.world ? rt.own_hi[threadIdx.x] : 0ull;
     }
   }
-  __shared__ uint32_t s_pa[PK ? KU_TILE + 64 : 1];
-  __shared__ uint32_t s_pb[PK ? KU_TILE + 64 : 1];
+  __shared__ uint32_t s_pa[PK ? TILE + 64 : 1];
+  __shared__ uint32_t s_pb[PK ? TILE + 64 : 1];
   __shared__ uint32_t s_tie;
   __shared__ uint32_t s_ctk[KU_CT_CAP];
   __shared__ uint32_t s_ctc[KU_CT_CAP];
@@ -99,9 +105,9 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   const uint32_t tid = threadIdx.x;
   const uint32_t k = db.k, m = db.nt;
   const uint32_t w = k - m + 1;  // m-mers per k-mer (krakendb.cpp:208)
-  const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
+  const uint64_t n_tiles = (n_bytes + TILE - 1) / TILE;
   const uint32_t key_shift = ku_key_shift(m);
-  const uint32_t n_pos = KU_TILE + w - 1;  // m-mer positions a tile needs
+  const uint32_t n_pos = TILE + w - 1;  // m-mer positions a tile needs
   uint16_t *s_amb16 = reinterpret_cast<uint16_t *>(s_amb);
 
   if (PK) {  // unique sentinels behind the last position: the widest doubling step reads 16 elements ahead
@@ -111,17 +117,17 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
   if (DO_COUNTS) ku_ct_clear(s_ctk, s_ctc, &s_ctu);
 
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t tile0 = tile * KU_TILE;
+    const uint64_t tile0 = tile * TILE;
     __syncthreads();  // previous iteration's LDS readers are done
     if (DO_COUNTS) ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, cnt.n_kmers);
     // ---- stage 1: ASCII -> packed 2-bit codes + ambiguity bits: four bases per thread (one dword, SWAR), the four
     // lanes of a quad OR their bytes into one 16-base word
-    static_assert(4 * (KU_PACKW + 4) <= KU_THREADS, "one packing pass");
-    if (tid < 4 * (KU_PACKW + 4)) {
+    static_assert(4 * (PACKW + 4) <= KU_THREADS, "one packing pass");
+    if (tid < 4 * (PACKW + 4)) {
       const uint32_t wi = tid >> 2, q4 = tid & 3u;
       const uint64_t b0 = tile0 + 4ull * tid;
       uint32_t c8 = 0, a4 = 0xFu;
-      if (wi < KU_PACKW && b0 < n_bytes) {
+      if (wi < PACKW && b0 < n_bytes) {
         const uint8_t *src = seqs + b0;
         const uintptr_t mis = (uintptr_t)src & 3u;
         uint32_t d;
@@ -147,17 +153,18 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     __syncthreads();
 
     // ---- stage 2: forward k-mer, ambiguity, canonical form (+ m-mer value) per position
-    uint64_t canon[KU_ITEMS];
-    bool is_fwd[KU_ITEMS];   // the read-strand k-mer is the canonical one
-    bool ok[KU_ITEMS];       // k-mer is unambiguous, inside the buffer and (after stage 3) owned by this shard
-    bool foreign[KU_ITEMS];  // unambiguous but its bin belongs to another shard
-    uint32_t pk[KU_ITEMS + 1];  // packed window element of the position, then of growing blocks starting there
+    uint64_t canon[ITEMS];
+    uint64_t kfwd[ROUTE ? ITEMS : 1];  // ROUTE: the read-strand k-mer
+    bool is_fwd[ITEMS];   // the read-strand k-mer is the canonical one
+    bool ok[ITEMS];       // k-mer is unambiguous, inside the buffer and (after stage 3) owned by this shard
+    bool foreign[ITEMS];  // unambiguous but its bin belongs to another shard
+    uint32_t pk[ITEMS + 1];  // packed window element of the position, then of growing blocks starting there
     bool tie = false;
 #pragma unroll
-    for (int j = 0; j <= KU_ITEMS; ++j) {
+    for (int j = 0; j <= ITEMS; ++j) {
       uint32_t p = j * KU_THREADS + tid;
       pk[j] = 0;
-      if (j == KU_ITEMS && (!NEED_MIN || p >= n_pos)) break;
+      if (j == ITEMS && (!NEED_MIN || p >= n_pos)) break;
       uint32_t wi = p >> 4, sh = (p & 15u) * 2;
       const uint32_t c0 = s_codes[wi], c1 = s_codes[wi + 1], c2 = s_codes[wi + 2];
       // 32 bases from p: two 64-bit shifts, no special case for sh = 0
@@ -173,11 +180,17 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
           if ((m & 1u) == 0) tie |= mm == mrc;  // palindromic m-mer: its strand bit is not enough
         }
       }
-      if (j < KU_ITEMS) {
+      if (j < ITEMS) {
         uint64_t fwd = x >> (64 - 2 * k);
-        uint64_t rc = ku_revcomp64(fwd, k);
-        canon[j] = fwd <= rc ? fwd : rc;
-        is_fwd[j] = fwd <= rc;
+        if (ROUTE) {  // the k-mer itself is the owner's business; its strand is needed where ties are resolved only
+          kfwd[j] = fwd;
+          canon[j] = 0;
+          is_fwd[j] = true;
+        } else {
+          uint64_t rc = ku_revcomp64(fwd, k);
+          canon[j] = fwd <= rc ? fwd : rc;
+          is_fwd[j] = fwd <= rc;
+        }
         uint32_t ai = p >> 5, as = p & 31u;
         uint64_t a = (((uint64_t)s_amb[ai] << 32) | s_amb[ai + 1]) << as;
         ok[j] = (a >> (64 - k)) == 0 && (tile0 + p + k <= n_bytes);
@@ -185,18 +198,21 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       }
     }
 
-    uint32_t prior[KU_ITEMS];  // PRIOR: slot from an earlier database (0 = not found yet)
+    uint32_t prior[ITEMS];  // PRIOR: slot from an earlier database (0 = not found yet)
 #pragma unroll
-    for (int j = 0; j < KU_ITEMS; ++j) prior[j] = (PRIOR && ok[j]) ? taxa[tile0 + (uint64_t)j * KU_THREADS + tid] : 0u;
+    for (int j = 0; j < ITEMS; ++j) prior[j] = (PRIOR && ok[j]) ? taxa[tile0 + (uint64_t)j * KU_THREADS + tid] : 0u;
 
     // ---- stage 3: minimizer = sliding-window minimum of the m-mer values; ownership; idx fetch
-    uint32_t n_b[KU_ITEMS];          // bin size (LAYOUT 0 / MODE 2)
-    const uint32_t *bp[KU_ITEMS];    // first pair of the bin (LAYOUT 0)
-    uint64_t locus[KU_ITEMS];        // locus key (LAYOUT 1), see ku_locus_key()
+    uint32_t n_b[ITEMS];          // bin size (LAYOUT 0 / MODE 2); ROUTE: the owner
+    uint32_t tro[ITEMS];          // ROUTE: offset of the anchor occurrence from the k-mer's first base, read order
+    const uint32_t *bp[ITEMS];    // first pair of the bin (LAYOUT 0)
+    uint64_t locus[ITEMS];        // locus key (LAYOUT 1), see ku_locus_key()
     if (NEED_MIN) {
       __syncthreads();
-      uint32_t key[KU_ITEMS], aoff[KU_ITEMS], bin_v[KU_ITEMS];
-      bool plus[KU_ITEMS];
+      uint32_t key[ITEMS], aoff[ITEMS], bin_v[ITEMS];
+      bool plus[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) tro[j] = 0;
       if (PK) {
         // anchor search (ku_device.h): block minima of 2, 4, 8, 16 positions by doubling, then one overlapping step
         // for the window length -- five packed dword minima per position for any minimizer length
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         uint32_t blk = 1;
         for (uint32_t st = 1; 2 * st <= w; st <<= 1) {
 #pragma unroll
-          for (int j = 0; j <= KU_ITEMS; ++j) {
+          for (int j = 0; j <= ITEMS; ++j) {
             const uint32_t p = j * KU_THREADS + tid;
             if (p < n_pos) {
               pk[j] = ku_pk_combine(pk[j], src[p + st], st, tie);
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         }
         if (w > blk) {
 #pragma unroll
-          for (int j = 0; j < KU_ITEMS; ++j) {
+          for (int j = 0; j < ITEMS; ++j) {
             const uint32_t p = j * KU_THREADS + tid;
             pk[j] = ku_pk_combine_overlap(pk[j], src[p + (w - blk)], w - blk, tie);
           }
@@ -226,19 +242,22 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         __syncthreads();
         const bool exact = s_tie != 0;  // block-uniform
 #pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
           const uint32_t p = j * KU_THREADS + tid;
           if (!exact) {
             const uint32_t t = (pk[j] >> 1) & 31u;  // read-order offset of the first minimal key
             key[j] = pk[j] >> KU_PK_KEYSHIFT;
             aoff[j] = is_fwd[j] ? t : w - 1 - t;
             plus[j] = ((pk[j] & 1u) != 0) == is_fwd[j];
+            tro[j] = t;
             // a unique minimal key is the minimizer occurrence: its raw value is the bin
             bin_v[j] = (SHARDED && key_shift) ? s_mm[p + t] : key[j];
           } else if (ok[j]) {
             // rare (low-complexity sequence): scan the raw values in the canonical k-mer's frame
+            if (ROUTE) is_fwd[j] = kfwd[j] <= ku_revcomp64(kfwd[j], k);
             key[j] = ku_anchor_exact(s_mm + p, w, key_shift, is_fwd[j], aoff[j], bin_v[j]);
-            const uint32_t q = p + (is_fwd[j] ? aoff[j] : w - 1 - aoff[j]);
+            tro[j] = is_fwd[j] ? aoff[j] : w - 1 - aoff[j];
+            const uint32_t q = p + tro[j];
             const uint32_t wi = q >> 4, sh = (q & 15u) * 2;
             const uint64_t two = ((uint64_t)s_codes[wi] << 32) | s_codes[wi + 1];
             const uint32_t mmf = (uint32_t)((two << sh) >> (64 - 2 * m));
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         }
       }
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
+      for (int j = 0; j < ITEMS; ++j) {
         uint32_t p = j * KU_THREADS + tid;
         n_b[j] = 0;
         if (ok[j]) {
@@ -267,9 +286,15 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
           }
           uint64_t bin = mn;
           if (ROUTE) {
-            n_b[j] = 0xFFu;  // the owner: the rank whose minimizer range holds the bin (none: the k-mer is nobody's, a miss)
-            for (uint32_t q = 0; q < rt.world; ++q)
-              if (bin >= s_olo[q] && bin < s_ohi[q]) n_b[j] = q;
+            // the owner: the rank whose minimizer range holds the bin (none: the k-mer is nobody's, a miss).  The ranges
+            // ascend with the rank (ku_mgpu checks): the last one that starts at or below the bin, if it reaches beyond it
+            uint32_t q = 0;
+            for (uint32_t nq = rt.world; nq > 1;) {  // uniform trip count
+              const uint32_t half = nq >> 1;
+              if (s_olo[q + half] <= bin) q += half;
+              nq -= half;
+            }
+            n_b[j] = (bin >= s_olo[q] && bin < s_ohi[q]) ? q : 0xFFu;
           } else
           if (!SHARDED || (bin >= db.bin_lo && bin < db.bin_hi)) {  // is_minimizer_in_chunk (krakendb.cpp:524-526)
             if (LAYOUT == 0 || MODE == 2) {
@@ -287,69 +312,88 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     }
 
     if (ROUTE) {
-      // (n_b[j] = owner, 0xFF none.)  The tile's entries get consecutive places in their owners' queues: the lanes of a
-      // wave that share an owner take their local index with ONE LDS add (neighbouring k-mers share a minimizer, so a wave
-      // sees one to three owners); the BLOCK owns a chunk of KU_ROUTE_CHUNK entries in every queue and claims the next one
-      // from the queue's global cursor only when a tile does not fit the rest of it (device-scope adds on a handful of
-      // addresses from every block and tile were the whole cost of this kernel: one per ~25 entries -> one per 512).
-      // The k-mers of a read stay together and in read order, which keeps the owner's bucket probes on few lines per
-      // wave.  What a block leaves unused of its last chunks is filled with null entries (KU_ROUTE_NULL: not a k-mer;
-      // the owner skips them).  A queue has room for rt.cap entries (0: exactly sized); chunks beyond it are counted, not
-      // written, so the cursors always end as the true per-owner totals and the host can size an exact second pass.
-      uint32_t idx[KU_ITEMS];
+      // (n_b[j] = owner, 0xFF none.)  Runs: a k-mer continues the run of the lane below when both are unambiguous and
+      // share the anchor POSITION (then they share bin and owner); a wave's lane 0 always starts one, and a run is cut at
+      // KU_ROUTE_MAXN k-mers (the record holds 56 bases).  The run's first lane writes the record.  The tile's records get
+      // consecutive places in their owners' queues (a local index per start lane from an LDS counter); the BLOCK owns a chunk of rt.chunk records in every queue and claims the next one(s) from
+      // the queue's global cursor only when a tile does not fit the rest of it (device-scope adds on a handful of
+      // addresses from every block and tile were the whole cost of this kernel once).  The records of a read stay
+      // together and in read order, which keeps the owner's bucket probes on few lines per wave.  What a block leaves
+      // unused of its last chunks is filled with null records (n = 0).  A queue has room for rt.cap records; chunks
+      // beyond it are counted, not written, so the cursors always end as the true per-owner totals and the host can size a
+      // second pass.
+      uint32_t idx[ITEMS], rs[ITEMS], rn[ITEMS];
+      bool st[ITEMS];
       const uint32_t lane = tid & 63u;
-      const unsigned long long below = (1ull << lane) - 1ull;
+      const unsigned long long below = (1ull << lane) - 1ull, incl = below | (1ull << lane);
+      const uint32_t nmax = ku_route_maxn(k, m);
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
+      for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t p = j * KU_THREADS + tid;
         const bool go = ok[j] && n_b[j] != 0xFFu;
-        idx[j] = 0;
-        unsigned long long todo = __ballot(go);
-        while (todo) {  // wave-uniform
-          const uint32_t lead = (uint32_t)__ffsll((long long)todo) - 1u;
-          const uint32_t o = ku_wave_bcast(n_b[j], lead);
-          const bool mine = go && n_b[j] == o;
-          const unsigned long long same = __ballot(mine);
-          uint32_t base = 0;
-          if (lane == lead) base = atomicAdd(&s_rcnt[o], (uint32_t)__popcll(same));
-          base = ku_wave_bcast(base, lead);
-          if (mine) idx[j] = base + (uint32_t)__popcll(same & below);
-          todo &= ~same;
-        }
-        const uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
-        if (pos < n_bytes) taxa[pos] = ok[j] ? 0u : KU_AMBIG;
+        const uint32_t qa = p + tro[j];
+        const uint32_t up_q = ku_wave_up1(qa), up_go = ku_wave_up1((uint32_t)go);
+        bool start = go && (lane == 0 || up_go == 0 || up_q != qa);
+        unsigned long long sm = __ballot(start);
+        uint32_t r0 = (sm & incl) ? 63u - (uint32_t)__builtin_clzll(sm & incl) : lane;
+        start = start || (go && lane - r0 == nmax);  // (a run has at most w <= 31 < 2 * nmax k-mers: one cut is enough)
+        sm = __ballot(start);
+        r0 = (sm & incl) ? 63u - (uint32_t)__builtin_clzll(sm & incl) : lane;
+        rs[j] = r0;
+        const unsigned long long bound = sm | ~__ballot(go);   // where a run ends: the next start, or a lane that queues nothing
+        const unsigned long long rest = lane == 63u ? 0ull : (bound >> (lane + 1u));
+        rn[j] = rest ? (uint32_t)__builtin_ctzll(rest) + 1u : 64u - lane;
+        st[j] = start;
+        // the record's place among the tile's records of its owner: one LDS add per start lane (a handful per wave; a
+        // wave-level loop over the distinct owners cost ten times the instructions).  The order within (tile, owner) is
+        // whatever the adds make it: a ticket names its record, nothing depends on the order.
+        idx[j] = start ? atomicAdd(&s_rcnt[n_b[j]], 1u) : 0u;
       }
       __syncthreads();
       if (tid < rt.world) {
         const uint32_t n = s_rcnt[tid], used = s_cused[tid];
         const unsigned long long base = s_cbase[tid];
         s_rbase[tid] = base == KU_ROUTE_NONE ? KU_ROUTE_NONE : base + used;
-        if (used + n <= KU_ROUTE_CHUNK) {
+        if (used + n <= rt.chunk) {
           s_rsplit[tid] = n;
           s_cused[tid] = used + n;
         } else {
-          // the chunk's rest is used up by the first entries of the tile, the others open the next chunk
-          unsigned long long nb = atomicAdd(&rt.cursor[tid * KU_ROUTE_CURSOR_STRIDE], (unsigned long long)KU_ROUTE_CHUNK);
-          if (rt.cap != 0 && nb + KU_ROUTE_CHUNK > rt.cap) nb = KU_ROUTE_NONE;
-          s_rsplit[tid] = KU_ROUTE_CHUNK - used;
+          // the chunk's rest is used up by the first records of the tile, the others open the next chunk(s)
+          const uint32_t need = n - (rt.chunk - used), nch = (need + rt.chunk - 1u) / rt.chunk;
+          unsigned long long nb = atomicAdd(&rt.cursor[tid * KU_ROUTE_CURSOR_STRIDE], (unsigned long long)nch * rt.chunk);
+          if (nb + (unsigned long long)nch * rt.chunk > rt.cap) nb = KU_ROUTE_NONE;
+          s_rsplit[tid] = rt.chunk - used;
           s_rbase1[tid] = nb;
-          s_cbase[tid] = nb;
-          s_cused[tid] = n - (KU_ROUTE_CHUNK - used);
+          s_cbase[tid] = nb == KU_ROUTE_NONE ? KU_ROUTE_NONE : nb + (unsigned long long)(nch - 1u) * rt.chunk;
+          s_cused[tid] = need - (nch - 1u) * rt.chunk;
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
-        if (ok[j] && n_b[j] != 0xFFu) {
+      for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t p = j * KU_THREADS + tid;
+        uint32_t e32 = 0xFFFFFFFFu;  // the record's index in the queue buffer (none: the queue was full, the pass is redone)
+        if (st[j]) {
           const uint32_t o = n_b[j], split = s_rsplit[o];
           const unsigned long long at = idx[j] < split ? s_rbase[o] : s_rbase1[o];
           if (at != KU_ROUTE_NONE) {
-            const unsigned long long e = rt.q_off[o] + at + (idx[j] < split ? idx[j] : idx[j] - split);
-            rt.q_ent[3 * e] = (uint32_t)canon[j];
-            rt.q_ent[3 * e + 1] = (uint32_t)(canon[j] >> 32);
-            rt.q_ent[3 * e + 2] = ku_locus_prehash(locus[j]);
-            rt.q_pos[e] = (uint32_t)(tile0 + (uint64_t)j * KU_THREADS + tid);
+            const unsigned long long e = (unsigned long long)o * rt.cap + at + (idx[j] < split ? idx[j] : idx[j] - split);
+            // 56 bases from position p: four funnel shifts over five code words
+            const uint32_t wi = p >> 4, sh = (p & 15u) * 2;
+            const uint32_t c0 = s_codes[wi], c1 = s_codes[wi + 1], c2 = s_codes[wi + 2], c3 = s_codes[wi + 3], c4 = s_codes[wi + 4];
+            uint4 rec;
+            rec.x = (uint32_t)(((((uint64_t)c0 << 32) | c1) << sh) >> 32);
+            rec.y = (uint32_t)(((((uint64_t)c1 << 32) | c2) << sh) >> 32);
+            rec.z = (uint32_t)(((((uint64_t)c2 << 32) | c3) << sh) >> 32);
+            rec.w = ((uint32_t)(((((uint64_t)c3 << 32) | c4) << sh) >> 32) & 0xFFFF0000u) | (tro[j] << 8) | rn[j];
+            rt.q_rec[e] = rec;
+            e32 = (uint32_t)e;
           }
         }
+        const uint32_t eb = (uint32_t)__shfl((int)e32, (int)rs[j]);  // the record of the run this k-mer belongs to
+        const uint64_t pos = tile0 + p;
+        if (pos < n_bytes)
+          taxa[pos] = !ok[j] ? KU_AMBIG : ((n_b[j] == 0xFFu || eb == 0xFFFFFFFFu) ? KU_ROUTE_MISS : ((eb << 5) | (lane - rs[j])));
       }
       __syncthreads();
       if (tid < 64) s_rcnt[tid] = 0;
@@ -357,7 +401,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     }
     if (MODE == 2) {
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j)
+      for (int j = 0; j < ITEMS; ++j)
         if (ok[j]) {
           st_q += 1;
           st_lg += n_b[j] ? 32 - __builtin_clz(n_b[j]) : 0;
@@ -367,17 +411,17 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       continue;
     }
 
-    // ---- stage 4: the lookup proper, KU_ITEMS independent probes in flight per lane
-    uint32_t slot[KU_ITEMS];
-    uint64_t hh[KU_ITEMS];  // fmix64(kmer + 1): table position and HLL index/rank
+    // ---- stage 4: the lookup proper, ITEMS independent probes in flight per lane
+    uint32_t slot[ITEMS];
+    uint64_t hh[ITEMS];  // fmix64(kmer + 1): table position and HLL index/rank
     if (LAYOUT == 1) {
-      const uint32_t *lp[KU_ITEMS];  // the bucket (line) being examined
-      uint32_t tag[KU_ITEMS], cand[KU_ITEMS];
-      bool act[KU_ITEMS], ovf[KU_ITEMS];
-      uint4 h4[KU_ITEMS];
+      const uint32_t *lp[ITEMS];  // the bucket (line) being examined
+      uint32_t tag[ITEMS], cand[ITEMS];
+      bool act[ITEMS], ovf[ITEMS];
+      uint4 h4[ITEMS];
       const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
+      for (int j = 0; j < ITEMS; ++j) {
         hh[j] = ku_fmix64(canon[j]);
         lp[j] = tab + (ok[j] ? ku_locus_line(locus[j], db.n_lines) : 0) * KU_LINE_DWORDS;
         tag[j] = ku_table_tag(hh[j]);
@@ -386,10 +430,10 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       }
       // round trip 1: the 16-byte bucket headers of all items
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j)
+      for (int j = 0; j < ITEMS; ++j)
         if (act[j]) h4[j] = *reinterpret_cast<const uint4 *>(lp[j]);
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
+      for (int j = 0; j < ITEMS; ++j) {
         cand[j] = 0;
         ovf[j] = false;
         if (act[j]) {
@@ -399,12 +443,12 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         }
       }
       // round trip 2 (same line: L1/L2 hit): the first candidate entry of every item
-      KuPair pr[KU_ITEMS];
+      KuPair pr[ITEMS];
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j)
+      for (int j = 0; j < ITEMS; ++j)
         if (cand[j]) pr[j] = *reinterpret_cast<const KuPair *>(lp[j] + KU_LINE_ENTRY0 + 3 * (__builtin_ctz(cand[j])));
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j)
+      for (int j = 0; j < ITEMS; ++j)
         if (cand[j]) {
           if ((((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo) == canon[j]) {
             slot[j] = pr[j].slot;
@@ -418,13 +462,13 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       // lane advance in lockstep so their round trips overlap
       bool any = false;
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) any |= act[j];
+      for (int j = 0; j < ITEMS; ++j) any |= act[j];
       while (any) {
         any = false;
-        KuPair e[KU_ITEMS];
-        uint4 a4[KU_ITEMS];
+        KuPair e[ITEMS];
+        uint4 a4[ITEMS];
 #pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
           if (act[j]) {
             if (cand[j]) {
               e[j] = *reinterpret_cast<const KuPair *>(lp[j] + KU_LINE_ENTRY0 + 3 * (__builtin_ctz(cand[j])));
@@ -436,7 +480,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
           }
         }
 #pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
           if (act[j]) {
             if (cand[j]) {
               cand[j] &= cand[j] - 1;
@@ -454,9 +498,9 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
         }
       }
     } else {
-      uint32_t lo[KU_ITEMS], hi[KU_ITEMS];
+      uint32_t lo[ITEMS], hi[ITEMS];
 #pragma unroll
-      for (int j = 0; j < KU_ITEMS; ++j) {
+      for (int j = 0; j < ITEMS; ++j) {
         lo[j] = 0;
         hi[j] = ((ablate & 1u) || (PRIOR && prior[j])) ? 0 : n_b[j];
         slot[j] = 0;
@@ -465,15 +509,15 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
       bool any = true;
       while (any) {
         any = false;
-        KuPair pr[KU_ITEMS];
-        uint32_t mid[KU_ITEMS];
+        KuPair pr[ITEMS];
+        uint32_t mid[ITEMS];
 #pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
           mid[j] = (lo[j] + hi[j]) >> 1;
           if (lo[j] < hi[j]) pr[j] = reinterpret_cast<const KuPair *>(bp[j])[mid[j]];  // one 12-byte load: key + value
         }
 #pragma unroll
-        for (int j = 0; j < KU_ITEMS; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
           if (lo[j] < hi[j]) {
             uint64_t key = ((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo;
             if (key == canon[j]) {
@@ -492,7 +536,7 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
 
     // ---- stage 5: per-taxon accounting (classify.cpp:939) + coalesced store
 #pragma unroll
-    for (int j = 0; j < KU_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
       uint64_t pos = tile0 + (uint64_t)j * KU_THREADS + tid;
       if (PRIOR && prior[j]) slot[j] = prior[j];
       if (DO_COUNTS) {
@@ -521,18 +565,13 @@ __global__ __launch_bounds__(KU_THREADS, KU_MIN_WAVES) void ku_lookup_kernel(KuD
     __syncthreads();
     ku_ct_flush(s_ctk, s_ctc, cnt.n_kmers);
   }
-  if (ROUTE) {  // the unused rest of the block's chunks: null entries
+  if (ROUTE) {  // the unused rest of the block's chunks: null records
     __syncthreads();
     for (uint32_t o = 0; o < rt.world; ++o) {
       const unsigned long long base = s_cbase[o];
       if (base == KU_ROUTE_NONE) continue;
-      for (uint32_t i = s_cused[o] + tid; i < KU_ROUTE_CHUNK; i += KU_THREADS) {
-        const unsigned long long e = rt.q_off[o] + base + i;
-        rt.q_ent[3 * e] = KU_ROUTE_NULL;
-        rt.q_ent[3 * e + 1] = KU_ROUTE_NULL;
-        rt.q_ent[3 * e + 2] = 0u;
-        rt.q_pos[e] = KU_ROUTE_NULL;
-      }
+      for (uint32_t i = s_cused[o] + tid; i < rt.chunk; i += KU_THREADS)
+        rt.q_rec[(unsigned long long)o * rt.cap + base + i] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
   if (MODE == 2) {
@@ -584,14 +623,21 @@ int ku_launch_lookup_stats(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_
 }
 
 // the scan of the owner-routed path over one rank's slice of the reads
+#ifndef KU_ROUTE_ITEMS
+#define KU_ROUTE_ITEMS 2
+#endif
+unsigned ku_route_scan_grid(uint64_t n_bytes, int n_cu) {
+  // (a block pads its last chunk of every queue: at least 8 tiles per block keep that a small share of what it queues)
+  const uint64_t tile = (uint64_t)KU_THREADS * KU_ROUTE_ITEMS, n_tiles = (n_bytes + tile - 1) / tile;
+  const uint64_t max_blocks = (uint64_t)n_cu * 2 * KU_MIN_WAVES;  // two rounds of the blocks a CU holds at once
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(n_tiles, max_blocks), (n_tiles + 7) / 8));
+}
 int ku_launch_route_scan(const KuDbDev &db, const uint8_t *d_seqs, uint64_t n_bytes, uint32_t *d_taxa, const KuRouteDev &rt, int n_cu,
                          hipStream_t stream) {
   if (n_bytes == 0) return KU_OK;
-  if (!db.table || rt.world == 0 || rt.world > 64) return KU_EINVAL;
-  // (a block pads its last chunk of every queue: at least 16 tiles per block keep that a small share of what it queues)
-  const uint64_t n_tiles = (n_bytes + KU_TILE - 1) / KU_TILE;
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ku_lookup_grid(n_bytes, n_cu), (n_tiles + 15) / 16));
-  hipLaunchKernelGGL((ku_lookup_kernel<3, 1, true, false>), dim3(grid), dim3(KU_THREADS), 0, stream, db,
+  if (!db.table || rt.world == 0 || rt.world > 64 || rt.cap == 0 || rt.chunk == 0 || rt.chunk % KU_ROUTE_CHUNK || rt.cap % rt.chunk) return KU_EINVAL;
+  if ((uint64_t)rt.world * rt.cap > KU_ROUTE_MAX_RECORDS) return KU_EUNSUP;
+  hipLaunchKernelGGL((ku_lookup_kernel<3, 1, true, false, KU_ROUTE_ITEMS>), dim3(ku_route_scan_grid(n_bytes, n_cu)), dim3(KU_THREADS), 0, stream, db,
                      KuCountsDev{}, d_seqs, n_bytes, d_taxa, (unsigned long long *)nullptr, 0u, rt);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

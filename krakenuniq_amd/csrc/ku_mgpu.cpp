@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -147,7 +148,14 @@ struct ku_mgpu {
     ku_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     DBuf seqs, off, len, taxa, calls, hits, runs, roff, rcnt, scratch, small;
-    DBuf q_ent, q_pos, r_ent, r_slots, ret_slots, rt_dev;  // owner routing: send queues, what this rank received, what came back
+    // owner routing, two sets (the rounds of a step alternate between them, each set on a stream of its own): the send
+    // queues (records) + their k-mer numbering, what this rank received + its numbering, the slots it found, the slots that
+    // came back, scratch of the prefix sums, the small device tables of a round
+    struct RouteSet {
+      DBuf q_rec, q_kb, r_rec, r_kb, r_slots, ret_slots, pfx_work, rt_dev;
+    } rs[2];
+    hipStream_t aux = nullptr;            // the second set's stream
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_r = nullptr;
     uint64_t n_runs = 0;   // runs of the last host batch still in `runs`
     uint64_t run_base = 0; // where they start in the caller's array
   };
@@ -482,6 +490,32 @@ int comm_allgather_u64(ku_mgpu *m, ku_mgpu::Rank &r, int st, const uint64_t *min
   return gate_out(m, st);
 }
 
+// the same for numbers that lie in DEVICE memory (written by work queued on s): ONE host round trip -- over RCCL the
+// all-gather runs on the device and one copy brings everything back
+int comm_allgather_u64_dev(ku_mgpu *m, ku_mgpu::Rank &r, int st, const unsigned long long *d_mine, uint32_t n, std::vector<uint64_t> &all,
+                           hipStream_t s) {
+  all.assign((size_t)m->world * n, 0);
+  if (m->use_rccl && !comm_noop(m)) {
+    st = rccl_gate(m, st);
+    if (st != KU_OK) return st;
+    M_TRY(r.small.reserve(8ull * n * m->world + 64));
+    M_NCCL(g_rccl.AllGather(d_mine, r.small.p, n, ncclUint64, r.comm, s));
+    M_HIP(hipMemcpyAsync(all.data(), r.small.p, 8ull * n * m->world, hipMemcpyDeviceToHost, s));
+    M_HIP(hipStreamSynchronize(s));
+    return KU_OK;
+  }
+  std::vector<uint64_t> mine(n, 0);
+  if (st == KU_OK && (hipMemcpyAsync(mine.data(), d_mine, 8ull * n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+    st = mfail(KU_EHIP, "routing counts copy failed");
+  if (comm_noop(m)) { std::copy(mine.begin(), mine.end(), all.begin()); return st; }
+  m->sh.u64s[r.local] = mine;
+  gate_in(m, st);
+  barrier(m);
+  for (uint32_t q = 0; q < m->n_local; ++q) std::copy(m->sh.u64s[q].begin(), m->sh.u64s[q].end(), all.begin() + (size_t)q * n);
+  barrier(m);
+  return gate_out(m, st);
+}
+
 // all-to-all of variable-size segments: rank r sends send[send_off[q] .. send_off[q + 1]) (elements of `elem` bytes) to rank
 // q and receives rank p's segment for it at recv[recv_off[p] ..).  Over xGMI every pair of GPUs has its own link: the
 // world - 1 transfers of a rank run side by side (grouped ncclSend / ncclRecv).
@@ -580,9 +614,13 @@ extern "C" void ku_mgpu_destroy(ku_mgpu *m) {
     (void)hipSetDevice(r.device);
     if (r.ctx) (void)ku_ctx_synchronize(r.ctx);
     if (r.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r.comm);
-    for (DBuf *b : {&r.seqs, &r.off, &r.len, &r.taxa, &r.calls, &r.hits, &r.runs, &r.roff, &r.rcnt, &r.scratch, &r.small, &r.q_ent, &r.q_pos,
-                    &r.r_ent, &r.r_slots, &r.ret_slots, &r.rt_dev})
+    for (DBuf *b : {&r.seqs, &r.off, &r.len, &r.taxa, &r.calls, &r.hits, &r.runs, &r.roff, &r.rcnt, &r.scratch, &r.small})
       b->release();
+    for (auto &t : r.rs)
+      for (DBuf *b : {&t.q_rec, &t.q_kb, &t.r_rec, &t.r_kb, &t.r_slots, &t.ret_slots, &t.pfx_work, &t.rt_dev}) b->release();
+    if (r.aux) (void)hipStreamDestroy(r.aux);
+    for (hipEvent_t e : {r.ev_a, r.ev_b, r.ev_r})
+      if (e) (void)hipEventDestroy(e);
     if (r.ctx) ku_ctx_destroy(r.ctx);
   }
   if (m->sh.bar_init) pthread_barrier_destroy(&m->sh.bar);
@@ -674,8 +712,12 @@ extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
       m->own_hi.assign(m->world, 0);
       bool ok = true;
       for (uint32_t q = 0; q < m->world; ++q) { m->own_lo[q] = allinfo[4 * q]; m->own_hi[q] = allinfo[4 * q + 1]; ok = ok && allinfo[4 * q + 2]; }
+      // the scan finds a bin's owner by bisection: the ranges must ascend with the rank (a shard plan's do) and not overlap
+      for (uint32_t q = 0; q + 1 < m->world; ++q) ok = ok && m->own_lo[q] <= m->own_hi[q] && m->own_hi[q] <= m->own_lo[q + 1];
       const char *ex = getenv("KU_MGPU_EXCHANGE");
-      m->route = ok && m->world > 1 && m->world <= 64 && !(m->flags & KU_MGPU_REPLICAS) && !(ex && (!strcmp(ex, "slots") || !strcmp(ex, "reduce")));
+      // (KU_MGPU_FORCE_ROUTE=1: also a world of one rank takes the routed path -- scan, records, owner kernel, gather on one
+      // stream, nothing on the wire: the device work of a routed step in one clean kernel trace)
+      m->route = ok && (m->world > 1 || std::getenv("KU_MGPU_FORCE_ROUTE")) && m->world <= 64 && !(m->flags & KU_MGPU_REPLICAS) && !(ex && (!strcmp(ex, "slots") || !strcmp(ex, "reduce")));
     }
     return st;
   }));
@@ -789,10 +831,33 @@ int rank_step_sharded(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64
   return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
 }
 
-// The owner-routed sharded batch on one rank: the rank scans only ITS slice of the reads, every
-// unambiguous k-mer travels to the rank that owns its minimizer bin, the slot comes back.
+// The owner-routed sharded batch on one rank: the rank scans only ITS slice of the reads, every run of
+// k-mers that share a minimizer occurrence travels as one 16-byte record to the rank that owns the bin, one slot per k-mer
+// comes back.  The slice is taken in ROUNDS of whole reads (about KU_ROUTE_ROUND positions each; every rank runs the same
+// number of rounds: it owns bins in all of them), and a round is four stages:
+//   S  scan -> records in W queues, tickets in the per-k-mer array; prefix sum of the records' k-mer counts, per-queue totals
+//   G  all-gather of {records, k-mers} per queue: the ONE host round trip of a round (a queue that overflowed: rescan)
+//   X  all-to-all of the records (16 B each); prefix sum over what arrived; owner kernel: probe + HLL + n_kmers
+//   Y  all-to-all of the slots (4 B per k-mer); tickets -> slots fused with the resolve stage of the round's reads
+// The scan and the resolve stage are bound by instruction issue and latency, the owner kernel by the random line rate of the
+// memory system.  Consecutive rounds alternate between two buffer sets on two streams, issued
+// S(0) G(0) { X(r)  S(r+1)  G(r+1)  Y(r) }: the owner kernel of round r runs beside the scan of round r + 1 and the resolve
+// of round r - 1, and the copies of one round's exchange under the kernels of the other.  Measured (one rank forced
+// through this path, 10 M reads): two streams 41.2 ms against 43.0 on one -- whole kernels side by side hide each other far
+// less than the stages inside the fused single-GPU kernel do -- and every round costs ~0.5-1 ms (padding of the queues,
+// launches, the host round trip), so rounds are LARGE (256 M positions: a 10 M-read step over eight ranks is one round);
+// what the rounds are for is bounded buffers, and a record index that fits a ticket, whatever the size of a slice.
 //   have_slice: the rank's slice of seqs / off / len is in place already (host batches: every rank uploads its own part);
 //   else rank 0 holds the whole batch and the slices are scattered first (device batches).
+struct RouteRound {
+  uint64_t a = 0, sb = 0;    // first position (relative to the slice) and bytes to scan
+  uint64_t ra = 0, rn = 0;   // the round's reads (relative to the slice's first read)
+  uint64_t cap = 0;
+  uint32_t chunk = 0;
+  std::vector<uint64_t> all, send_at, send_n, ret_at, ret_n, recv_at, recv_n, rk_at, rk_n;
+  uint64_t n_recv = 0, k_recv = 0, k_send = 0;
+};
+
 int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_t *d_off, uint32_t *d_len, uint32_t *d_calls,
                      uint32_t *d_taxa, uint32_t *d_hits, uint64_t n_bytes, uint64_t n_reads, const uint64_t *rb, const uint64_t *pos,
                      const ku_opts &opts, hipStream_t s, const uint64_t *h_off, const uint32_t *h_len, bool have_slice) {
@@ -804,77 +869,216 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
     st = comm_scatter_slices(m, r, st, d_off, rb, 8, s);
     st = comm_scatter_slices(m, r, st, d_len, rb, 4, s);
   }
-  // ---- device-side tables of this step: ranges, cursors, queue offsets
-  uint64_t *d_lo = nullptr, *d_hi = nullptr, *d_qoff = nullptr;
-  unsigned long long *d_cursor = nullptr;
-  if (st == KU_OK) st = r.rt_dev.reserve((3ull + KU_ROUTE_CURSOR_STRIDE) * W * 8);
-  // One scanning pass: every owner's queue gets room for twice its fair share of the slice's k-mers (the shard bounds are
-  // quantiles of the database, reads follow the database) and the cursors come back as the true totals; a queue that
-  // did not hold its total (a batch from one corner of the minimizer space) sends the scan through a second, exactly
-  // sized pass -- the results do not depend on which it was (KU_ROUTE_CAP: entries per queue, for the tests)
-  // (a queue is claimed in chunks of KU_ROUTE_CHUNK entries by the scanning blocks, each of which pads its last one)
-  uint64_t cap = 2 * (nb / W) + 8192ull * KU_ROUTE_CHUNK;
-  if (const char *e = std::getenv("KU_ROUTE_CAP")) cap = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
-  std::vector<uint64_t> cnt(W, 0), send_at(W, 0), all;
-  std::vector<unsigned long long> cur((size_t)W * KU_ROUTE_CURSOR_STRIDE, 0);
-  for (uint32_t q = 0; q < W; ++q) send_at[q] = q * cap;
-  KuRouteDev rt{};
-  auto scan = [&](uint64_t room, uint64_t total) -> int {
-    if (r.q_ent.reserve(std::max<uint64_t>(total, 1) * 12) || r.q_pos.reserve(std::max<uint64_t>(total, 1) * 4) ||
-        r.ret_slots.reserve(std::max<uint64_t>(total, 1) * 4))
-      return mfail(KU_ENOMEM, "device memory for the routing queues");
-    d_lo = (uint64_t *)r.rt_dev.p;
-    d_hi = d_lo + W;
-    d_qoff = d_hi + W;
-    d_cursor = (unsigned long long *)(d_qoff + W);
-    if (hipMemcpyAsync(d_lo, m->own_lo.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(d_hi, m->own_hi.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(d_qoff, send_at.data(), 8ull * W, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemsetAsync(d_cursor, 0, 8ull * W * KU_ROUTE_CURSOR_STRIDE, s) != hipSuccess)
-      return mfail(KU_EHIP, "routing tables upload failed");
-    rt.own_lo = d_lo; rt.own_hi = d_hi; rt.cursor = d_cursor; rt.q_off = d_qoff;
-    rt.q_ent = (uint32_t *)r.q_ent.p;
-    rt.q_pos = (uint32_t *)r.q_pos.p;
-    rt.world = W; rt.cap = room;
-    if (nb) M_TRY(ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0, nb, d_taxa + p0, rt, s));
-    if (hipMemcpyAsync(cur.data(), d_cursor, 8ull * W * KU_ROUTE_CURSOR_STRIDE, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-      return mfail(KU_EHIP, "routing counts copy failed");
-    for (uint32_t q = 0; q < W; ++q) cnt[q] = cur[(size_t)q * KU_ROUTE_CURSOR_STRIDE];
-    return KU_OK;
-  };
-  if (st == KU_OK) st = scan(cap, cap * W);
-  if (st == KU_OK && *std::max_element(cnt.begin(), cnt.end()) > cap) {
-    uint64_t total = 0;
-    for (uint32_t q = 0; q < W; ++q) { send_at[q] = total; total += cnt[q]; }
-    st = scan(0, total);
-  }
-  // ---- every rank learns how much it gets from whom
-  st = comm_allgather_u64(m, r, st, cnt.data(), W, all, s);
-  if (st != KU_OK) return st;
-  std::vector<uint64_t> recv_at(W, 0), recv_n(W, 0);
-  uint64_t n_recv = 0, n_send = 0;
-  for (uint32_t q = 0; q < W; ++q) {
-    recv_at[q] = n_recv;
-    recv_n[q] = all[(size_t)q * W + r.rank];
-    n_recv += recv_n[q];
-    n_send += cnt[q];
-  }
-  if (n_send >= (1ull << 32) || n_recv >= (1ull << 32) || nb >= (1ull << 32)) st = mfail(KU_EUNSUP, "owner routing: more than 2^32 k-mers per rank and batch");
-  if (st == KU_OK && (r.r_ent.reserve(std::max<uint64_t>(n_recv, 1) * 12) || r.r_slots.reserve(std::max<uint64_t>(n_recv, 1) * 4)))
-    st = mfail(KU_ENOMEM, "device memory for the routing queues");
-  // ---- k-mers to their owners (12 B each), probe + accounting there, slots back (4 B each), into place
-  st = comm_alltoallv(m, r, st, r.q_ent.p, send_at.data(), cnt.data(), r.r_ent.p, recv_at.data(), recv_n.data(), 12, s);
+  // ---- rounds: every rank takes part in every round, so their number follows from the largest slice
+  uint64_t round_pos = 256ull << 20;
+  if (const char *e = std::getenv("KU_ROUTE_ROUND")) round_pos = std::max<uint64_t>(256, std::strtoull(e, nullptr, 10));
+  uint64_t nb_max = 0;
+  for (uint32_t q = 0; q < W; ++q) nb_max = std::max(nb_max, pos[q + 1] - pos[q]);
+  const uint32_t R = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(1, (nb_max + round_pos - 1) / round_pos));
   const bool counts = !(opts.flags & (KU_F_NO_COUNTS | KU_F_QUICK));  // quick mode books the scanned prefix in the resolve stage
-  if (st == KU_OK) st = ku_ctx_route_probe(r.ctx, (const uint32_t *)r.r_ent.p, n_recv, (uint32_t *)r.r_slots.p, counts, s);
-  st = comm_alltoallv(m, r, st, r.r_slots.p, recv_at.data(), recv_n.data(), r.ret_slots.p, send_at.data(), cnt.data(), 4, s);
-  for (uint32_t q = 0; q < W && st == KU_OK; ++q)
-    st = ku_launch_route_scatter((const uint32_t *)r.q_pos.p + send_at[q], (const uint32_t *)r.ret_slots.p + send_at[q], cnt[q], d_taxa + p0, s);
-  if (st != KU_OK) return st;
-  if (nr == 0) return KU_OK;
+  const bool emulate = m->sparse && h_len && !(opts.flags & KU_F_NO_COUNTS);
   ku_opts ro = opts;
   ro.flags &= ~(KU_F_KEEP_SLOTS | KU_F_MERGE_CHUNK);
-  if (m->sparse && h_len && !(opts.flags & KU_F_NO_COUNTS))
+  // the resolve stage inside the rounds (the fused kernel's ROUTE instance: slot through the ticket, hit counts,
+  // resolve_tree, call, taxids in place); quick mode, reads beyond 65535 k-mers and the sparse-sketch emulation (it wants the
+  // slots in the array) turn the tickets into slots per round and resolve the slice behind the last one
+  bool fused = !emulate && st == KU_OK && ku_ctx_route_resolve_prepare(r.ctx, &ro, s) == KU_OK;
+  // a round ends on a read boundary: the first position of every round's first read
+  std::vector<RouteRound> rd(R);
+  {
+    std::vector<uint64_t> cut(R + 1, nb);
+    cut[0] = 0;
+    std::vector<uint64_t> rc(R + 1);
+    for (uint32_t i = 0; i <= R; ++i) rc[i] = nr * i / R;
+    if (R > 1 && nr) {
+      if (h_off) {
+        for (uint32_t i = 1; i < R; ++i) cut[i] = rc[i] < nr ? h_off[r0 + rc[i]] - p0 : nb;
+      } else {
+        std::vector<uint64_t> tmp(R, 0);
+        for (uint32_t i = 1; i < R && st == KU_OK; ++i)
+          if (rc[i] < nr && hipMemcpyAsync(&tmp[i], d_off + r0 + rc[i], 8, hipMemcpyDeviceToHost, s) != hipSuccess) st = mfail(KU_EHIP, "read offsets copy failed");
+        if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "read offsets copy failed");
+        for (uint32_t i = 1; i < R; ++i) cut[i] = rc[i] < nr ? tmp[i] - p0 : nb;
+      }
+      for (uint32_t i = 1; i < R; ++i)
+        if (st == KU_OK && (cut[i] < cut[i - 1] || cut[i] > nb)) st = mfail(KU_EINVAL, "owner routing: the reads of a slice must be in buffer order");
+    }
+    for (uint32_t i = 0; i < R; ++i) {
+      rd[i].a = cut[i];
+      rd[i].sb = st == KU_OK ? cut[i + 1] - cut[i] : 0;
+      rd[i].ra = rc[i];
+      rd[i].rn = rc[i + 1] - rc[i];
+    }
+  }
+  // ---- the second set's stream follows the caller's up to here
+  hipStream_t str[2] = {s, s};
+  if (R > 1 && !std::getenv("KU_ROUTE_ONE_STREAM")) {
+    if (!r.aux && hipStreamCreateWithFlags(&r.aux, hipStreamNonBlocking) != hipSuccess) { r.aux = nullptr; st = st == KU_OK ? mfail(KU_EHIP, "stream creation failed") : st; }
+    for (hipEvent_t *e : {&r.ev_a, &r.ev_b, &r.ev_r})
+      if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; st = st == KU_OK ? mfail(KU_EHIP, "event creation failed") : st; }
+    if (st == KU_OK) {
+      if (hipEventRecord(r.ev_a, s) != hipSuccess || hipStreamWaitEvent(r.aux, r.ev_a, 0) != hipSuccess) st = mfail(KU_EHIP, "stream fork failed");
+      str[1] = r.aux;
+    }
+  }
+  const uint32_t n_info = 2 * W + 1;
+  struct Tables { uint64_t *lo, *hi; unsigned long long *cursor, *info; } tb[2] = {};
+  for (int i = 0; i < 2; ++i) {
+    auto &t = r.rs[i];
+    if (st == KU_OK) st = t.rt_dev.reserve((2ull * W + (uint64_t)W * KU_ROUTE_CURSOR_STRIDE + n_info + 8) * 8);
+    if (st != KU_OK) break;
+    tb[i].lo = (uint64_t *)t.rt_dev.p;
+    tb[i].hi = tb[i].lo + W;
+    tb[i].cursor = (unsigned long long *)(tb[i].hi + W);
+    tb[i].info = tb[i].cursor + (size_t)W * KU_ROUTE_CURSOR_STRIDE;
+    if (hipMemcpyAsync(tb[i].lo, m->own_lo.data(), 8ull * W, hipMemcpyHostToDevice, str[i]) != hipSuccess ||
+        hipMemcpyAsync(tb[i].hi, m->own_hi.data(), 8ull * W, hipMemcpyHostToDevice, str[i]) != hipSuccess)
+      st = mfail(KU_EHIP, "routing tables upload failed");
+  }
+  bool resolved_before = false;  // a resolve kernel was queued: the next one (other stream) waits for it (they share the context's spill workspace)
+
+  // S: scan + prefix of round i on its set's stream (first attempt: the default room per queue)
+  auto scan_round = [&](uint32_t i) {
+    RouteRound &x = rd[i];
+    auto &t = r.rs[i & 1];
+    hipStream_t q = str[i & 1];
+    const uint64_t n_q = (uint64_t)W * x.cap;
+    if (st == KU_OK && n_q > KU_ROUTE_MAX_RECORDS) st = mfail(KU_EUNSUP, "owner routing: more records per rank and round than a ticket can number");
+    if (st == KU_OK && (t.q_rec.reserve(n_q * 16) || t.q_kb.reserve((n_q + 1) * 4) || t.pfx_work.reserve(ku_route_prefix_work_bytes(n_q))))
+      st = mfail(KU_ENOMEM, "device memory for the routing queues");
+    if (st == KU_OK && hipMemsetAsync(tb[i & 1].cursor, 0, 8ull * W * KU_ROUTE_CURSOR_STRIDE, q) != hipSuccess) st = mfail(KU_EHIP, "routing cursors reset failed");
+    if (st != KU_OK) return;
+    KuRouteDev rt{};
+    rt.own_lo = tb[i & 1].lo; rt.own_hi = tb[i & 1].hi; rt.cursor = tb[i & 1].cursor;
+    rt.q_rec = (uint4 *)t.q_rec.p;
+    rt.cap = x.cap; rt.world = W; rt.chunk = x.chunk;
+    if (x.sb) st = ku_ctx_route_scan(r.ctx, (const char *)d_seqs + p0 + x.a, x.sb, d_taxa + p0 + x.a, rt, q);
+    if (st == KU_OK) {
+      st = ku_launch_route_prefix(t.q_rec.p, n_q, x.cap, tb[i & 1].cursor, (uint32_t *)t.q_kb.p, tb[i & 1].info, t.pfx_work.p, q);
+      if (st != KU_OK) st = mfail(st, "routing prefix kernels failed");
+    }
+  };
+  auto stage_S = [&](uint32_t i) {
+    RouteRound &x = rd[i];
+    // One scanning pass: every owner's queue gets room for about 2.5 times its fair share of the records a slice of random
+    // sequence makes (a record per ~10 positions; the shard bounds are quantiles of the database's k-mers, reads follow
+    // the database -- but the owners of the high bins get up to twice the records per k-mer: a large minimizer does not
+    // stay one for long), plus the chunk every block of the scan may leave partly used; the cursors come back as the
+    // true totals.  A queue that did not hold its total (low-complexity reads, a batch from one corner of the minimizer
+    // space) sends the rank through a second pass with queues of the size the first one counted -- the results do not
+    // depend on which it was (KU_ROUTE_CAP: records per queue, for the tests).
+    const unsigned grid = x.sb ? ku_route_scan_grid(x.sb, ku_ctx_cus_of(r.ctx)) : 1u;
+    // (a block claims `chunk` records of a queue at a time: with few owners larger claims keep the adds on one cursor apart)
+    x.chunk = KU_ROUTE_CHUNK * std::max(1u, 8u / W);
+    x.cap = x.sb / (4ull * W) + ((uint64_t)grid + 1) * x.chunk;
+    if (const char *e = std::getenv("KU_ROUTE_CAP")) x.cap = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    x.cap = (x.cap + x.chunk - 1) / x.chunk * x.chunk;
+    scan_round(i);
+  };
+  // G: every rank learns how much it gets from whom (records and k-mers), and whether anybody's queues overflowed (then
+  // the ranks concerned scan again and everybody gathers again: all see the same numbers, so all agree)
+  auto stage_G = [&](uint32_t i) -> int {
+    RouteRound &x = rd[i];
+    auto &t = r.rs[i & 1];
+    hipStream_t q = str[i & 1];
+    for (int attempt = 0;; ++attempt) {
+      st = comm_allgather_u64_dev(m, r, st, tb[i & 1].info, n_info, x.all, q);
+      if (st != KU_OK) return st;
+      if (std::getenv("KU_ROUTE_DEBUG") && r.rank == 0) {
+        fprintf(stderr, "[ku_route] round %u/%u attempt %d: sb %llu reads %llu", i, R, attempt, (unsigned long long)x.sb, (unsigned long long)x.rn);
+        for (uint32_t qq = 0; qq < W; ++qq) {
+          fprintf(stderr, " | rank %u cap %llu:", qq, (unsigned long long)x.all[(size_t)qq * n_info + 2 * W]);
+          for (uint32_t o = 0; o < W; ++o)
+            fprintf(stderr, " %llu/%llu", (unsigned long long)x.all[(size_t)qq * n_info + 2 * o], (unsigned long long)x.all[(size_t)qq * n_info + 2 * o + 1]);
+        }
+        fprintf(stderr, "\n");
+      }
+      bool over_any = false, over_mine = false;
+      uint64_t mine_max = 0;
+      for (uint32_t qq = 0; qq < W; ++qq)
+        for (uint32_t o = 0; o < W; ++o) {
+          const bool ov = x.all[(size_t)qq * n_info + 2 * o] > x.all[(size_t)qq * n_info + 2 * W];
+          over_any |= ov;
+          if (qq == r.rank) { over_mine |= ov; mine_max = std::max(mine_max, x.all[(size_t)qq * n_info + 2 * o]); }
+        }
+      if (!over_any) break;
+      if (attempt >= 1) return mfail(KU_ESTATE, "owner routing: a queue overflowed twice");
+      if (over_mine) {
+        x.cap = (mine_max + x.chunk - 1) / x.chunk * x.chunk;
+        scan_round(i);
+      }
+    }
+    // segment tables: what goes where (records / k-mers), what comes from whom
+    const uint64_t *mine = x.all.data() + (size_t)r.rank * n_info;
+    for (auto *v : {&x.send_at, &x.send_n, &x.ret_at, &x.ret_n, &x.recv_at, &x.recv_n, &x.rk_at, &x.rk_n}) v->assign(W, 0);
+    x.n_recv = x.k_recv = x.k_send = 0;
+    for (uint32_t qq = 0; qq < W; ++qq) {
+      x.send_at[qq] = (uint64_t)qq * x.cap;
+      x.send_n[qq] = mine[2 * qq];
+      x.ret_at[qq] = x.k_send;
+      x.ret_n[qq] = mine[2 * qq + 1];
+      x.k_send += x.ret_n[qq];
+      x.recv_at[qq] = x.n_recv;
+      x.recv_n[qq] = x.all[(size_t)qq * n_info + 2 * r.rank];
+      x.n_recv += x.recv_n[qq];
+      x.rk_at[qq] = x.k_recv;
+      x.rk_n[qq] = x.all[(size_t)qq * n_info + 2 * r.rank + 1];
+      x.k_recv += x.rk_n[qq];
+    }
+    if (x.n_recv >= (1ull << 32) || x.k_recv >= (1ull << 32) || x.k_send >= (1ull << 32)) st = mfail(KU_EUNSUP, "owner routing: more than 2^32 k-mers per rank and round");
+    if (st == KU_OK && (t.r_rec.reserve(std::max<uint64_t>(x.n_recv, 1) * 16) || t.r_kb.reserve((x.n_recv + 1) * 4) ||
+                        t.pfx_work.reserve(ku_route_prefix_work_bytes(std::max(x.n_recv, (uint64_t)W * x.cap))) ||
+                        t.r_slots.reserve(std::max<uint64_t>(x.k_recv, 1) * 4) || t.ret_slots.reserve(std::max<uint64_t>(x.k_send, 1) * 4)))
+      st = mfail(KU_ENOMEM, "device memory for the routing queues");
+    return st;
+  };
+  // X: records to their owners (16 B per run of k-mers), probe + accounting there
+  auto stage_X = [&](uint32_t i) {
+    RouteRound &x = rd[i];
+    auto &t = r.rs[i & 1];
+    hipStream_t q = str[i & 1];
+    st = comm_alltoallv(m, r, st, t.q_rec.p, x.send_at.data(), x.send_n.data(), t.r_rec.p, x.recv_at.data(), x.recv_n.data(), 16, q);
+    if (st == KU_OK) {
+      st = ku_launch_route_prefix(t.r_rec.p, x.n_recv, 0, nullptr, (uint32_t *)t.r_kb.p, nullptr, t.pfx_work.p, q);
+      if (st != KU_OK) st = mfail(st, "routing prefix kernels failed");
+    }
+    if (st == KU_OK) st = ku_ctx_route_owner(r.ctx, t.r_rec.p, x.n_recv, (const uint32_t *)t.r_kb.p, (uint32_t *)t.r_slots.p, counts, q);
+  };
+  // Y: slots back (4 B per k-mer), into place: resolve stage of the round's reads, or tickets -> slots
+  auto stage_Y = [&](uint32_t i) {
+    RouteRound &x = rd[i];
+    auto &t = r.rs[i & 1];
+    hipStream_t q = str[i & 1];
+    st = comm_alltoallv(m, r, st, t.r_slots.p, x.rk_at.data(), x.rk_n.data(), t.ret_slots.p, x.ret_at.data(), x.ret_n.data(), 4, q);
+    if (st != KU_OK) return;
+    if (fused && x.rn) {
+      if (resolved_before && str[0] != str[1] && hipStreamWaitEvent(q, r.ev_r, 0) != hipSuccess) { st = mfail(KU_EHIP, "stream wait failed"); return; }
+      const uint64_t f = r0 + x.ra;
+      st = ku_ctx_route_resolve(r.ctx, d_off + f, d_len + f, x.rn, &ro, d_calls + f, d_taxa, d_hits ? d_hits + f : nullptr,
+                                (const uint32_t *)t.q_kb.p, (const uint32_t *)t.ret_slots.p, q);
+      if (st == KU_OK && str[0] != str[1] && hipEventRecord(r.ev_r, q) != hipSuccess) st = mfail(KU_EHIP, "event record failed");
+      resolved_before = true;
+    } else if (!fused && x.sb) {
+      st = ku_launch_route_gather(d_taxa + p0 + x.a, x.sb, (const uint32_t *)t.q_kb.p, (const uint32_t *)t.ret_slots.p, q);
+      if (st != KU_OK) st = mfail(st, "routing gather kernel failed");
+    }
+  };
+
+  stage_S(0);
+  M_TRY(stage_G(0));
+  for (uint32_t i = 0; i < R; ++i) {
+    stage_X(i);                            // ... ends with the owner kernel queued on this round's stream
+    if (i + 1 < R) stage_S(i + 1);         // the next round's scan beside it, on the other stream
+    if (i + 1 < R) M_TRY(stage_G(i + 1));  // (host: waits for that scan)
+    stage_Y(i);                            // (host: waits for the owner kernel) slots back, resolve stage queued
+  }
+  // the caller's stream takes over again
+  if (str[1] != s && r.ev_b) {
+    if (hipEventRecord(r.ev_b, str[1]) != hipSuccess || hipStreamWaitEvent(s, r.ev_b, 0) != hipSuccess) st = st == KU_OK ? mfail(KU_EHIP, "stream join failed") : st;
+  }
+  if (st != KU_OK) return st;
+  if (nr == 0 || fused) return KU_OK;
+  if (emulate)
     M_TRY(ku_ctx_sparse_pass_slots(r.ctx, d_seqs, d_off + r0, d_len + r0, h_off + r0, h_len + r0, nr, n_bytes, d_taxa,
                                    (opts.flags & KU_F_QUICK) ? std::max(1u, opts.min_hits) : 0u, s));
   return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);

@@ -316,12 +316,17 @@ __device__ __forceinline__ uint32_t ks_g_insert_items(unsigned long long *g_key,
 // {code, start} pairs, each read's runs contiguous in a run array the waves claim in chunks (KuRunsOut; everything
 // hitlist_string prints, classify.cpp:826-861, at ~20 B instead of 604 B per 150 bp read -- and no second kernel reads
 // the codes back); 2: as 1, plus the sparse-mode emulation's fast path (KuSparseFast).
-template <int ITEMS, bool DO_COUNTS, int KK, int MM, bool WIN, int OUT>
+// ROUTE: the resolve stage of the owner-routed multi-GPU path (ku_route.hip, ku_mgpu.cpp): stages 1-4 and the k-mer
+// accounting ran elsewhere (the scan on this rank, probe + HLL + n_kmers on the owners); taxa[] holds the TICKET of every
+// k-mer position, the slot is returned[kb[ticket >> 5] + (ticket & 31)] (KuRouteIn).  Everything behind the probe -- hit
+// counts, resolve_tree, call, n_reads (DO_COUNTS), the per-k-mer taxids in place of the tickets or as runs -- is the
+// code below, unchanged: the gather of the slots and the resolve are one pass over the per-k-mer array.
+template <int ITEMS, bool DO_COUNTS, int KK, int MM, bool WIN, int OUT, bool ROUTE = false>
 __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_short_kernel(
     KuDbDev db, KuTaxDev tax, KuCountsDev cnt, const uint8_t *__restrict__ seqs, uint64_t n_bytes,
     const uint64_t *__restrict__ seq_off, const uint32_t *__restrict__ seq_len, uint64_t n_reads,
     uint32_t *__restrict__ calls, uint32_t *__restrict__ taxa, uint32_t ablate, uint32_t *__restrict__ spill,
-    uint32_t spill_cap, KuRunsOut ro, KuSparseFast sf) {
+    uint32_t spill_cap, KuRunsOut ro, KuSparseFast sf, KuRouteIn rin) {
   // KS_ABL(bit): measurement knob, compiled in only with -DKU_ABLATION (then env KU_ABLATE selects the bits; the
   // production build has no trace of it -- the flag checks cost scalar registers and branches in the read loop):
   // 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
@@ -352,7 +357,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   const uint32_t *tab = reinterpret_cast<const uint32_t *>(db.table);
 
   for (uint32_t i = lane; i < TCAP; i += 64) { t_key[i] = 0; t_cnt[i] = 0; }
-  for (uint32_t i = lane; i < (1u << G::KCT_LOG2); i += 64) { s_kk[wv][i] = 0; s_kc[wv][i] = 0; }
+  if (!ROUTE)  // (ROUTE: the k-mers are booked by their owners)
+    for (uint32_t i = lane; i < (1u << G::KCT_LOG2); i += 64) { s_kk[wv][i] = 0; s_kc[wv][i] = 0; }
   for (uint32_t i = lane; i < (1u << G::RCT_LOG2); i += 64) { s_rk[wv][i] = 0; s_rc[wv][i] = 0; }
   if (lane < 4) misc[lane] = 0;
   ks_wave_sync();
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     const uint64_t off = roff + win0;
     const uint32_t n = len >= k ? len - k + 1 : 0;
     if (DO_COUNTS) {
-      if (misc[0] > (1u << G::KCT_LOG2) / 2) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
+      if (!ROUTE && misc[0] > (1u << G::KCT_LOG2) / 2) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
       if (!WIN || win0 == 0)
         if (misc[1] > (1u << G::RCT_LOG2) / 2) ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
     }
@@ -464,7 +470,23 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) { v[j] = 0; amb_k[j] = false; hh[j] = 0; }
 
-    if (n > 0) {
+    if (ROUTE) {
+      // the slots of this window's k-mers through their tickets: ticket (coalesced), record base, slot -- the loads of all
+      // items go out together at every level
+      uint32_t tk[ITEMS], kbv[ITEMS];
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t p = j * 64 + lane;
+        tk[j] = p < n ? taxa[off + p] : KU_ROUTE_MISS;
+      }
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        amb_k[j] = tk[j] == KU_AMBIG;
+        kbv[j] = tk[j] < KU_ROUTE_MISS ? rin.kb[tk[j] >> 5] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) v[j] = tk[j] < KU_ROUTE_MISS ? rin.ret[(uint64_t)kbv[j] + (tk[j] & 31u)] : 0u;
+    } else if (n > 0) {
       // ---- stage 1: ASCII -> 2-bit codes + ambiguity bits in wave-private LDS: four bases per lane (one dword,
       // SWAR), the four lanes of a quad OR their bytes into one 16-base word
 #pragma unroll
@@ -771,7 +793,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     // ---- ReadCounts::add_kmer for every unambiguous k-mer, misses included (classify.cpp:939): HLL register per
     // k-mer; n_kmers per read when the read met one taxon at most (two counter updates instead of one per lane)
     uint32_t n_hit = 0, n_miss = 0;
-    if (DO_COUNTS && n > 0) {
+    if (DO_COUNTS && !ROUTE && n > 0) {
       uint8_t *reg[ITEMS];
       uint32_t rank[ITEMS], seen[ITEMS];
 #pragma unroll
@@ -891,7 +913,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     // next window: behind this one, and behind every k-mer that holds the last ambiguous base seen so far (those
     // k-mers are ambiguous whatever follows: they get their code here and no lane of a window)
     uint32_t nxt = win0 + (uint32_t)G::MAXN;
-    if (nxt < n_all) {
+    if (!ROUTE && nxt < n_all) {  // (ROUTE: the ambiguity words of stage 1 do not exist; every position has its ticket)
       uint32_t last1 = 0;  // 1 + window index of the last ambiguous base among the window's `len` bases
       if (lane < (uint32_t)G::NAMB) {
         const uint32_t lo = 32u * lane;
@@ -939,7 +961,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     }
   }
   if (DO_COUNTS) {
-    ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
+    if (!ROUTE) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
     ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
   }
   if (OUT == 2 && lane == 0 && sp_fresh) atomicAdd(sf.g_count, (unsigned long long)sp_fresh);
@@ -1007,7 +1029,7 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
   const int out = sparse ? 2 : (runs_out ? 1 : 0);
 #define KS_LAUNCH(I, C, K, M, W, O)                                                                                          \
   hipLaunchKernelGGL((ku_classify_short_kernel<I, C, K, M, W, O>), grid, block, 0, stream, db, tax, cnt, d_seqs, n_bytes,    \
-                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate, (uint32_t *)d_workspace, spill_cap, ro, sf)
+                     d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, ablate, (uint32_t *)d_workspace, spill_cap, ro, sf, KuRouteIn{})
   // specialised geometries (accounting runs only): k = 31 with nt = 13 (MiniKraken-size databases) or 15 (standard)
   const int geo = !counts || db.k != 31 ? 0 : (db.nt == 13 ? 13 : (db.nt == 15 ? 15 : 0));
 #define KS_GEO(I, W, O)                                      \
@@ -1029,5 +1051,42 @@ int ku_launch_classify_short(const KuDbDev &db, const KuTaxDev &tax, const KuCou
 #undef KS_OUT
 #undef KS_GEO
 #undef KS_LAUNCH
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+// The resolve stage of the owner-routed path, fused with the gather of the returned slots (ROUTE instances): d_taxa holds
+// tickets on entry, taxids (or nothing: runs_out) afterwards.  Reads of up to 128 k-mers in one pass, up to 65535 in windows
+// (workspace as for the windowed fused kernel); longer ones: ku_launch_route_gather + the resolve kernel.
+uint32_t ku_route_resolve_max_kmers() { return 65535u; }
+int ku_launch_route_resolve(const KuDbDev &db, const KuTaxDev &tax, const KuCountsDev &cnt, const uint64_t *d_seq_off,
+                            const uint32_t *d_seq_len, uint64_t n_reads, uint32_t max_kmers, uint32_t flags, uint32_t *d_calls,
+                            uint32_t *d_taxa, uint32_t *d_hits, const uint32_t *d_kb, const uint32_t *d_ret, void *d_workspace,
+                            uint64_t workspace_bytes, int n_cu, hipStream_t stream, const KuRunsOut *runs_out) {
+  if (n_reads == 0) return KU_OK;
+  if (!d_taxa || !d_kb || !d_seq_off || !d_seq_len || !d_calls || max_kmers > 65535u) return KU_EINVAL;
+  if (flags & (KU_F_KEEP_SLOTS | KU_F_QUICK)) return KU_EINVAL;
+  if (d_hits && hipMemsetAsync(d_hits, 0, n_reads * 4, stream) != hipSuccess) return KU_EHIP;  // "Q:n" is quick mode only
+  const bool counts = !(flags & KU_F_NO_COUNTS), windowed = max_kmers > 128;
+  const dim3 grid(ks_grid(n_reads, 2, n_cu)), block(64 * KS_WAVES);
+  uint32_t spill_cap = 0;
+  if (windowed) {
+    spill_cap = ks_spill_cap(max_kmers, tax.n_slots);
+    if (!d_workspace || workspace_bytes < (uint64_t)grid.x * KS_WAVES * 2ull * spill_cap * 4ull) return KU_EINVAL;
+  }
+  const KuRunsOut ro = runs_out ? *runs_out : KuRunsOut{};
+  const KuRouteIn rin{d_kb, d_ret};
+#define KS_RLAUNCH(C, W, O)                                                                                                     \
+  hipLaunchKernelGGL((ku_classify_short_kernel<2, C, 0, 0, W, O, true>), grid, block, 0, stream, db, tax, cnt, (const uint8_t *)nullptr, \
+                     (uint64_t)0, d_seq_off, d_seq_len, n_reads, d_calls, d_taxa, 0u, (uint32_t *)d_workspace, spill_cap, ro,    \
+                     KuSparseFast{}, rin)
+#define KS_RSEL(W, O)                  \
+  do {                                 \
+    if (counts) KS_RLAUNCH(true, W, O); \
+    else KS_RLAUNCH(false, W, O);      \
+  } while (0)
+  if (windowed) { if (runs_out) KS_RSEL(true, 1); else KS_RSEL(true, 0); }
+  else { if (runs_out) KS_RSEL(false, 1); else KS_RSEL(false, 0); }
+#undef KS_RSEL
+#undef KS_RLAUNCH
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

@@ -48,8 +48,8 @@ def same_counts(a, b):
 @pytest.mark.parametrize("devices", device_lists())
 @pytest.mark.parametrize("flags,exchange", [(0, "route"), (0, "route_tight"), (0, "slots"), (capi.KU_MGPU_REPLICAS, None)])
 def test_group_reproduces_reference_output_and_state(f1, devices, flags, exchange, monkeypatch):
-    if exchange == "route_tight":  # queues far too small for their totals: the exactly sized second scanning pass
-        monkeypatch.setenv("KU_ROUTE_CAP", "700")
+    if exchange == "route_tight":  # queues far too small for their totals: the second scanning pass, sized by the first
+        monkeypatch.setenv("KU_ROUTE_CAP", "128")
         exchange = "route"
     if exchange == "slots":
         monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
@@ -276,13 +276,16 @@ def test_cli_with_several_ranks(tmp_path):
     assert rows(rep.read_text()) == rows(open(f"{F1}/report_exact.tsv").read())
 
 
-@pytest.mark.parametrize("exchange", ["route", "route_tight", "slots"])
+@pytest.mark.parametrize("exchange", ["route", "route_tight", "route_rounds", "slots"])
 def test_device_step_matches_single_context(exchange, monkeypatch):
     """ku_mgpu_step_device (the bench path) with three ranks on one device: shards adopted from device memory, batch
     scattered (owner routing) or broadcast (position-wise exchange) from rank 0, slices resolved per rank == one context
     holding the whole database"""
     if exchange == "route_tight":
-        monkeypatch.setenv("KU_ROUTE_CAP", "3000000")  # (less than a queue gets: the exactly sized second pass)
+        monkeypatch.setenv("KU_ROUTE_CAP", "100000")  # (records; less than a queue gets: the second pass, sized by the first)
+        exchange = "route"
+    if exchange == "route_rounds":
+        monkeypatch.setenv("KU_ROUTE_ROUND", "3000017")  # a slice of 15.1 M positions in six rounds, cut inside reads
         exchange = "route"
     if exchange == "slots":
         monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
