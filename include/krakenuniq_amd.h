@@ -427,6 +427,14 @@ int ku_mgpu_uses_rccl(const ku_mgpu *m);
  * rank scanning every read and exchanging 4 B per base position.  The default for sharded groups whose ranks all hold a
  * probe table of one database; KU_MGPU_EXCHANGE=slots keeps the position-wise exchange. */
 int ku_mgpu_uses_routing(const ku_mgpu *m);
+/* Measurement aid (bench.py): with timing on, every owner-routed step brackets its stages with HIP events on the streams
+ * they run on; ku_mgpu_step_times waits for the last step of local rank `local_index` and returns, in milliseconds,
+ * out[0] the scan (+ the numbering of its records), out[1] the owner side (numbering + probe / accounting kernel),
+ * out[2] the resolve stage (tickets -> slots -> calls), out[3] the number of rounds, out[4] records received, out[5]
+ * k-mers received (both summed over the rounds).  The exchanges themselves are not in these figures; a timed step runs its
+ * rounds on one stream (no overlap between the owner kernel of one round and the scan of the next), so the figures add up. */
+int ku_mgpu_set_timing(ku_mgpu *m, int on);
+int ku_mgpu_step_times(ku_mgpu *m, uint32_t local_index, double *out /* [6] */);
 /* shard plan (ku_db_shard_plan over the world) + upload of every local rank's range + taxonomy with the slot table of
  * the whole database (the ranks' distinct values are all-gathered); KU_MGPU_REPLICAS: the whole database everywhere */
 int ku_mgpu_load(ku_mgpu *m, const ku_db *db, const ku_tax *tax);

@@ -149,6 +149,8 @@ SIGNATURES = {
     "ku_mgpu_ctx": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "ku_mgpu_uses_rccl": (C.c_int, [C.c_void_p]),
     "ku_mgpu_uses_routing": (C.c_int, [C.c_void_p]),
+    "ku_mgpu_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ku_mgpu_step_times": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]),
     "ku_mgpu_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ku_mgpu_load_dbs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p]),
     "ku_mgpu_enable_sparse": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
@@ -593,6 +595,17 @@ class Mgpu:
 
     def uses_routing(self):
         return bool(lib().ku_mgpu_uses_routing(self.h))
+
+    def set_timing(self, on=True):
+        _chk(lib().ku_mgpu_set_timing(self.h, 1 if on else 0), "ku_mgpu_set_timing")
+
+    def step_times(self, local=0):
+        """stages of the last owner-routed step of one local rank (HIP events): ms of scan / owner / resolve, rounds,
+        records and k-mers received"""
+        out = (C.c_double * 6)()
+        _chk(lib().ku_mgpu_step_times(self.h, local, out), "ku_mgpu_step_times")
+        return {"scan_ms": out[0], "owner_ms": out[1], "resolve_ms": out[2], "rounds": int(out[3]), "records_received": int(out[4]),
+                "kmers_received": int(out[5])}
 
     def load(self, db: Db, tax: Tax):
         self._keep += [db, tax]

@@ -154,6 +154,11 @@ struct ku_mgpu {
     struct RouteSet {
       DBuf q_rec, q_kb, r_rec, r_kb, r_slots, ret_slots, pfx_work, rt_dev;
     } rs[2];
+    // ku_mgpu_set_timing: event pairs of the last routed step, [stage 0 scan, 1 owner, 2 resolve], and what it received
+    std::vector<hipEvent_t> tev_pool;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> tev;
+    size_t tev_used = 0;
+    double t_rounds = 0, t_rec = 0, t_kmers = 0;
     hipStream_t aux = nullptr;            // the second set's stream
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_r = nullptr;
     uint64_t n_runs = 0;   // runs of the last host batch still in `runs`
@@ -171,6 +176,7 @@ struct ku_mgpu {
   // owner routing of the sharded path (set up with the taxonomy): every rank's minimizer range
   bool route = false;
   std::vector<uint64_t> own_lo, own_hi;
+  bool timing = false;
 };
 
 namespace {
@@ -619,6 +625,7 @@ extern "C" void ku_mgpu_destroy(ku_mgpu *m) {
     for (auto &t : r.rs)
       for (DBuf *b : {&t.q_rec, &t.q_kb, &t.r_rec, &t.r_kb, &t.r_slots, &t.ret_slots, &t.pfx_work, &t.rt_dev}) b->release();
     if (r.aux) (void)hipStreamDestroy(r.aux);
+    for (hipEvent_t e : r.tev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : {r.ev_a, r.ev_b, r.ev_r})
       if (e) (void)hipEventDestroy(e);
     if (r.ctx) ku_ctx_destroy(r.ctx);
@@ -689,6 +696,28 @@ extern "C" ku_ctx *ku_mgpu_ctx(ku_mgpu *m, uint32_t local_index) {
 }
 extern "C" int ku_mgpu_uses_rccl(const ku_mgpu *m) { return m && m->use_rccl ? 1 : 0; }
 extern "C" int ku_mgpu_uses_routing(const ku_mgpu *m) { return m && m->route && !m->exact ? 1 : 0; }
+
+extern "C" int ku_mgpu_set_timing(ku_mgpu *m, int on) {
+  if (!m) return mfail(KU_EINVAL, "ku_mgpu_set_timing: null argument");
+  m->timing = on != 0;
+  return KU_OK;
+}
+extern "C" int ku_mgpu_step_times(ku_mgpu *m, uint32_t local_index, double *out) {
+  if (!m || !out || local_index >= m->n_local) return mfail(KU_EINVAL, "ku_mgpu_step_times: bad argument");
+  ku_mgpu::Rank &r = m->ranks[local_index];
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
+  for (auto &t : r.tev) {
+    float ms = 0;
+    if (hipEventSynchronize(t.second.second) != hipSuccess || hipEventElapsedTime(&ms, t.second.first, t.second.second) != hipSuccess)
+      return mfail(KU_EHIP, "ku_mgpu_step_times: an event of the last step is not complete");
+    if (t.first >= 0 && t.first < 3) out[t.first] += ms;
+  }
+  out[3] = r.t_rounds;
+  out[4] = r.t_rec;
+  out[5] = r.t_kmers;
+  return KU_OK;
+}
 
 extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
   if (!m || !tax) return mfail(KU_EINVAL, "ku_mgpu_set_taxonomy: null argument");
@@ -912,7 +941,8 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
   }
   // ---- the second set's stream follows the caller's up to here
   hipStream_t str[2] = {s, s};
-  if (R > 1 && !std::getenv("KU_ROUTE_ONE_STREAM")) {
+  // (with the stage timing on, everything stays on one stream: kernels side by side would stretch each other's event pairs)
+  if (R > 1 && !std::getenv("KU_ROUTE_ONE_STREAM") && !m->timing) {
     if (!r.aux && hipStreamCreateWithFlags(&r.aux, hipStreamNonBlocking) != hipSuccess) { r.aux = nullptr; st = st == KU_OK ? mfail(KU_EHIP, "stream creation failed") : st; }
     for (hipEvent_t *e : {&r.ev_a, &r.ev_b, &r.ev_r})
       if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; st = st == KU_OK ? mfail(KU_EHIP, "event creation failed") : st; }
@@ -935,6 +965,24 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
         hipMemcpyAsync(tb[i].hi, m->own_hi.data(), 8ull * W, hipMemcpyHostToDevice, str[i]) != hipSuccess)
       st = mfail(KU_EHIP, "routing tables upload failed");
   }
+  // ku_mgpu_set_timing: stage `tag` between two events on stream q
+  if (m->timing) { r.tev.clear(); r.tev_used = 0; r.t_rounds = R; r.t_rec = r.t_kmers = 0; }
+  auto t_begin = [&](int tag, hipStream_t q) {
+    if (!m->timing || st != KU_OK) return;
+    while (r.tev_pool.size() < r.tev_used + 2) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      r.tev_pool.push_back(e);
+    }
+    hipEvent_t e0 = r.tev_pool[r.tev_used], e1 = r.tev_pool[r.tev_used + 1];
+    r.tev_used += 2;
+    (void)hipEventRecord(e0, q);
+    r.tev.push_back({tag, {e0, e1}});
+  };
+  auto t_end = [&](hipStream_t q) {
+    if (!m->timing || r.tev.empty()) return;
+    (void)hipEventRecord(r.tev.back().second.second, q);
+  };
   bool resolved_before = false;  // a resolve kernel was queued: the next one (other stream) waits for it (they share the context's spill workspace)
 
   // S: scan + prefix of round i on its set's stream (first attempt: the default room per queue)
@@ -948,6 +996,7 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
       st = mfail(KU_ENOMEM, "device memory for the routing queues");
     if (st == KU_OK && hipMemsetAsync(tb[i & 1].cursor, 0, 8ull * W * KU_ROUTE_CURSOR_STRIDE, q) != hipSuccess) st = mfail(KU_EHIP, "routing cursors reset failed");
     if (st != KU_OK) return;
+    t_begin(0, q);
     KuRouteDev rt{};
     rt.own_lo = tb[i & 1].lo; rt.own_hi = tb[i & 1].hi; rt.cursor = tb[i & 1].cursor;
     rt.q_rec = (uint4 *)t.q_rec.p;
@@ -957,6 +1006,7 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
       st = ku_launch_route_prefix(t.q_rec.p, n_q, x.cap, tb[i & 1].cursor, (uint32_t *)t.q_kb.p, tb[i & 1].info, t.pfx_work.p, q);
       if (st != KU_OK) st = mfail(st, "routing prefix kernels failed");
     }
+    t_end(q);
   };
   auto stage_S = [&](uint32_t i) {
     RouteRound &x = rd[i];
@@ -1038,11 +1088,14 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
     auto &t = r.rs[i & 1];
     hipStream_t q = str[i & 1];
     st = comm_alltoallv(m, r, st, t.q_rec.p, x.send_at.data(), x.send_n.data(), t.r_rec.p, x.recv_at.data(), x.recv_n.data(), 16, q);
+    t_begin(1, q);
+    if (m->timing) { r.t_rec += (double)x.n_recv; r.t_kmers += (double)x.k_recv; }
     if (st == KU_OK) {
       st = ku_launch_route_prefix(t.r_rec.p, x.n_recv, 0, nullptr, (uint32_t *)t.r_kb.p, nullptr, t.pfx_work.p, q);
       if (st != KU_OK) st = mfail(st, "routing prefix kernels failed");
     }
     if (st == KU_OK) st = ku_ctx_route_owner(r.ctx, t.r_rec.p, x.n_recv, (const uint32_t *)t.r_kb.p, (uint32_t *)t.r_slots.p, counts, q);
+    t_end(q);
   };
   // Y: slots back (4 B per k-mer), into place: resolve stage of the round's reads, or tickets -> slots
   auto stage_Y = [&](uint32_t i) {
@@ -1051,6 +1104,7 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
     hipStream_t q = str[i & 1];
     st = comm_alltoallv(m, r, st, t.r_slots.p, x.rk_at.data(), x.rk_n.data(), t.ret_slots.p, x.ret_at.data(), x.ret_n.data(), 4, q);
     if (st != KU_OK) return;
+    t_begin(2, q);
     if (fused && x.rn) {
       if (resolved_before && str[0] != str[1] && hipStreamWaitEvent(q, r.ev_r, 0) != hipSuccess) { st = mfail(KU_EHIP, "stream wait failed"); return; }
       const uint64_t f = r0 + x.ra;
@@ -1062,6 +1116,7 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
       st = ku_launch_route_gather(d_taxa + p0 + x.a, x.sb, (const uint32_t *)t.q_kb.p, (const uint32_t *)t.ret_slots.p, q);
       if (st != KU_OK) st = mfail(st, "routing gather kernel failed");
     }
+    t_end(q);
   };
 
   stage_S(0);
@@ -1081,7 +1136,10 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
   if (emulate)
     M_TRY(ku_ctx_sparse_pass_slots(r.ctx, d_seqs, d_off + r0, d_len + r0, h_off + r0, h_len + r0, nr, n_bytes, d_taxa,
                                    (opts.flags & KU_F_QUICK) ? std::max(1u, opts.min_hits) : 0u, s));
-  return ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
+  t_begin(2, s);
+  st = ku_resolve_device(r.ctx, d_seqs, d_off + r0, d_len + r0, nr, &ro, d_calls + r0, d_taxa, d_hits ? d_hits + r0 : nullptr, s);
+  t_end(s);
+  return st;
 }
 }  // namespace
 
