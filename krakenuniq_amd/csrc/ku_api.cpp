@@ -1841,6 +1841,7 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
   if (total > runs_cap) {
     // the run array was too small for this batch (reads that change taxon every few k-mers): the per-k-mer codes once more
     // without any accounting, through the array parallel to the reads and its own run-length encoder
+    HIP_TRY(hipStreamSynchronize(s));  // (the buffers below may be reallocated)
     if (ctx->b_taxa.reserve((n_bytes + 16) * 4) || ctx->b_runs.reserve((n_bytes + 1) * 8)) return fail(KU_ENOMEM, "device batch buffers");
     uint64_t ws2 = ws;
     if (max_n > ku_short_max_kmers(ctx->m.db)) ws2 = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, n_reads, ctx->n_cu);

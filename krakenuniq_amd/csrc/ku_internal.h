@@ -96,7 +96,7 @@ struct KuSparseDev {
   unsigned long long *g_key;  // (slot + 1) << 32 | encoding; 0 = empty
   uint64_t g_mask;
   uint32_t *dense;            // per slot
-  uint32_t *err;              // bit 0: L full, bit 1: U full, bit 2: G full
+  uint32_t *err;              // bit 0: L full, bit 1: U full, bit 2: G full, bit 3: a run code that is no slot's taxid
   unsigned long long *g_count;
 };
 #define KU_SPARSE_MAX_UNITS 16000u  // per batch (14-bit unit field)

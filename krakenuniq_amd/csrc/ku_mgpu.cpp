@@ -66,9 +66,18 @@ pthread_once_t g_rccl_once = PTHREAD_ONCE_INIT;
 std::string g_rccl_err;
 
 void rccl_load() {
+  // KU_RCCL_LIB=<path>: bind that library instead (tests/rccl_shim: the peer paths between processes on a 1-GPU box;
+  // RTLD_LOCAL + the handle-first lookup of dlsym keep it apart from an RCCL the process already holds)
+  if (const char *over = getenv("KU_RCCL_LIB")) {
+    g_rccl.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    if (!g_rccl.h) {
+      g_rccl_err = std::string("cannot load KU_RCCL_LIB=") + over + ": " + dlerror();
+      return;
+    }
+  }
   for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-    g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.h) break;
+    g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!g_rccl.h) {
     g_rccl_err = std::string("cannot load librccl: ") + dlerror();
@@ -1188,6 +1197,19 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
   // emulation on whole units; the unit that is still open when the batch ends continues on rank 0 with the next batch
   const uint32_t W = m->world;
   std::vector<uint64_t> rb(W + 1), pos(W + 1);
+  if (m->sparse && ku_mgpu_sparse_state(m) == 2) {
+    // a rank ran out of memory for the emulation's tables in an earlier batch and switched it off there: no rank's sets
+    // are the run's any more.  The whole group goes on with the dense registers (no unit bookkeeping, no open unit to move
+    // -- ku_ctx_sparse_move_open_unit would refuse a context without tables and take the run down); ku_mgpu_sparse_state
+    // keeps saying 2, the report carries its estimates and says so.
+    for (auto &r : m->ranks) {
+      if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
+      if (ku_ctx_sparse_on(r.ctx)) M_TRY(ku_ctx_disable_sparse(r.ctx));
+    }
+    m->sparse = false;
+    m->open_rank = -1;
+    m->acc_nt = 0;
+  }
   const bool sparse = m->sparse && !(o.flags & KU_F_NO_COUNTS);
   rb[0] = 0;
   if (sparse) {

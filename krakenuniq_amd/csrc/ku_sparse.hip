@@ -154,7 +154,11 @@ __global__ __launch_bounds__(64) void ku_sparse_insert_runs_kernel(KuSparseDev s
         if (slot_taxid[mid] < run.x) lo = mid + 1; else hi = mid;
       }
       const uint32_t slot = lo;
-      if (slot >= n_slots || s.dense[slot]) continue;
+      if (slot >= n_slots || slot_taxid[slot] != run.x) {  // a code that is no slot's taxid: never book it under a neighbour
+        if (lane == 0) atomicOr(s.err, 8u);
+        continue;
+      }
+      if (s.dense[slot]) continue;
       if (!all && urow[slot] < KU_SPARSE_SWITCH_INSERTS) continue;
       const uint32_t end = j + 1 < nr ? runs[ro + j + 1].y : n;
       for (uint32_t i = run.y + lane; i < end; i += 64) {

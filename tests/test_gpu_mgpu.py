@@ -152,6 +152,36 @@ def test_group_report_equals_the_reference(f1, devices, flags, exchange, unit, r
     mg.close()
 
 
+@pytest.mark.parametrize("flags,exchange", [(0, "route"), (0, "slots"), (capi.KU_MGPU_REPLICAS, None)])
+def test_group_goes_on_when_a_rank_runs_out_of_memory_for_the_emulation(f1, flags, exchange, monkeypatch):
+    """a ceiling of 2^11 cells for the run-wide set (test hook) makes ranks give the emulation up in mid-run -- also the rank
+    that holds the open work unit: the later batches must not stumble over a context without tables (the open unit used to be
+    moved into / out of it: KU_ESTATE took the run down).  Classification is untouched, the state says 2, the report is the
+    dense-register one"""
+    if exchange == "slots":
+        monkeypatch.setenv("KU_MGPU_EXCHANGE", "slots")
+    monkeypatch.setenv("KU_SPARSE_MAX_LOG2", "11")
+    mg = capi.Mgpu([0, 0, 0], flags=flags)
+    mg.load(f1["cdb"], f1["ctax"])
+    mg.enable_sparse(1000, 10)
+    n = len(f1["lens"])
+    cuts = [0, n // 7, n // 3, n // 3 + 5, n // 2, n]
+    text = ""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo = int(f1["off"][a])
+        hi = int(f1["off"][b]) if b < n else len(f1["buf"])
+        r = mg.classify_batch_rle(f1["buf"][lo:hi], f1["off"][a:b] - lo, f1["lens"][a:b])
+        text += capi.format_kraken_rle(f1["buf"][lo:hi], f1["off"][a:b] - lo, f1["lens"][a:b], f1["ids"][a:b], K, r)
+    assert text == f1["text"]
+    assert mg.sparse_state() == 2
+    mg.reduce_state()
+    assert mg.sparse_state() == 2
+    assert same_counts(mg.ctx(0).counts(), f1["counts"])
+    paths = [f"{F1}/database.kdb.counts"]
+    assert mg.ctx(0).report(f1["ctax"], paths) == capi.report(f1["ctax"], mg.ctx(0).counts(), paths)
+    mg.close()
+
+
 def test_group_sparse_state_equals_the_oracle_on_a_random_database():
     """taxa of very different abundance over three ranks, sharded and replicas: which sketches switch to dense and the exact
     sets of the ones that do not (as tests/test_gpu_sparse.py checks for one GPU)"""
