@@ -370,7 +370,9 @@ def shard_bounds(synth_torch, dev, a, k, n_shards):
     """every rank derives the same shard plan from the same deterministic sample of the DB's bin keys"""
     probe = synth_torch.BenchDb(dev, n_species=min(a.species, 32), genome_len=min(a.genome_len, 50_000), k=k,
                                 nt=a.nt, seed=7)
-    bins = synth_torch.bin_key(probe.kmers[torch.randperm(probe.n_pairs, device=dev)[:1_000_000]], k, a.nt)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260927)  # the SAME sample in every process (an unseeded one gave every rank bounds of its own: gaps between the shards)
+    bins = synth_torch.bin_key(probe.kmers[torch.randperm(probe.n_pairs, device=dev, generator=g)[:1_000_000]], k, a.nt)
     return synth_torch.quantile_bin_bounds(bins, 4 ** a.nt, n_shards)
 
 
@@ -440,7 +442,7 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if ws > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # every read was resolved exactly once over the whole world
@@ -448,6 +450,8 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
     ctx = mg.ctx(0)
     b = batches[0]
     nk = L - k + 1.0
+    if os.environ.get("KU_ROUTE_DEBUG"):
+        sys.stderr.write(f"[bench] rank {rank}: uses_routing {mg.uses_routing()} uses_rccl {mg.uses_rccl()}\n")
     if mg.uses_routing():
         # ---- the stages of this rank's routed step (HIP events on the streams the kernels run on), mean of three more steps
         mg.set_timing(True)
@@ -557,11 +561,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from krakenuniq_amd import capi, synth_torch
+    # KU_BENCH_ONE_DEVICE=1 (every rank on cuda:0; the C++ driver then needs KU_RCCL_LIB=tests/rccl_shim/libku_rccl_shim.so, RCCL
+    # itself refuses two ranks on a device): the few torch.distributed calls of this script go through gloo on host tensors
+    one_dev = os.environ.get("KU_BENCH_ONE_DEVICE") == "1"
+    cdev = torch.device("cpu") if one_dev else dev
+
     def fresh_uid():
         """id of one RCCL communicator of the C++ driver: rank 0 makes it, everybody gets it (an id serves one init)"""
         if ws <= 1:
             return None
-        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        t = torch.zeros(128, dtype=torch.uint8, device=cdev)
         if rank == 0:
             t.copy_(torch.from_numpy(capi.mgpu_unique_id()))
         dist.broadcast(t, 0)
@@ -569,7 +578,10 @@ def main():
 
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     uid = fresh_uid()
 
     k = 31
@@ -696,7 +708,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if ws > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev])) if a.steps else 0.0

@@ -752,6 +752,11 @@ extern "C" int ku_mgpu_set_taxonomy(ku_mgpu *m, const ku_tax *tax) {
       for (uint32_t q = 0; q < m->world; ++q) { m->own_lo[q] = allinfo[4 * q]; m->own_hi[q] = allinfo[4 * q + 1]; ok = ok && allinfo[4 * q + 2]; }
       // the scan finds a bin's owner by bisection: the ranges must ascend with the rank (a shard plan's do) and not overlap
       for (uint32_t q = 0; q + 1 < m->world; ++q) ok = ok && m->own_lo[q] <= m->own_hi[q] && m->own_hi[q] <= m->own_lo[q + 1];
+      if (std::getenv("KU_ROUTE_DEBUG")) {
+        fprintf(stderr, "[ku_route] rank %u: hash+single everywhere / ascending ranges: %d;", r.rank, (int)ok);
+        for (uint32_t q = 0; q < m->world; ++q) fprintf(stderr, " [%llu, %llu) flag %llu", (unsigned long long)m->own_lo[q], (unsigned long long)m->own_hi[q], (unsigned long long)allinfo[4 * q + 2]);
+        fprintf(stderr, "\n");
+      }
       const char *ex = getenv("KU_MGPU_EXCHANGE");
       // (KU_MGPU_FORCE_ROUTE=1: also a world of one rank takes the routed path -- scan, records, owner kernel, gather on one
       // stream, nothing on the wire: the device work of a routed step in one clean kernel trace)

@@ -48,3 +48,35 @@ def test_other_shapes_run(shape):
     d = run_bench("--cpu-sample", "0", "--no-extras", *shape)
     assert d["value"] > 0 and d["roofline"]["kernel"].startswith("ku_classify_short_kernel")
     assert d["config"]["output"]["expanded_runs_equal_the_per_kmer_array"] is True
+
+
+def run_bench_world(n, *extra):
+    """`bench.py --gpus n` on a box with ONE GPU: every rank on cuda:0 (KU_BENCH_ONE_DEVICE), the C++ driver bound to the test
+    stand-in for RCCL (tests/rccl_shim), which moves the ranks' messages between the processes"""
+    shim = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
+    assert os.path.exists(shim)
+    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_SHIM_TIMEOUT="120")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--reads", "120000",
+                        "--species", "60", "--genome-len", "60000", "--cpu-sample", "0", *extra], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_two_ranks_sharded_line_with_real_peers():
+    """the N > 1 sharded line (owner routing over the send / receive pairs of two processes): every read resolved once, the
+    rank's own stage roofline and the wire figures present"""
+    d = run_bench_world(2, "--mode", "sharded", "--nt", "11", "--no-extras")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["every_read_resolved_once"] is True and d["config"]["exchange"] == "RCCL"
+    rf = d["roofline"]
+    assert rf["stage_ms_measured"]["owner_ms"] > 0 and rf["kmers_received"] > 0 and 0 < rf["frac"] < 1
+    assert d["wire"]["exchange"].startswith("owner routing") and d["wire"]["records_in_bytes_per_read"] > 0
+
+
+def test_two_ranks_replicas_line_with_real_peers():
+    d = run_bench_world(2, "--mode", "replicas", "--no-extras")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["merged_read_count_ok"] is True
