@@ -769,12 +769,16 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            same_wl = (tj.get("reads") == a.reads and tj.get("nt") == a.nt and tj.get("species") == a.species
-                       and tj.get("read_len", 150) == read_len
-                       and tj.get("kernel", "").startswith("ku_classify_short" if fused else "ku_lookup"))
+            # the default workload at the top level, the other read shapes (--paired, --read-len ..., --nt 15) under "shapes"
+            skey = f"reads{a.reads}_nt{a.nt}_species{a.species}_len{read_len}" + ("_paired" if a.paired else "")
+            ent = tj.get("shapes", {}).get(skey)
+            if ent is None and tj.get("reads") == a.reads and tj.get("nt") == a.nt and tj.get("species") == a.species and \
+                    tj.get("read_len", 150) == read_len and not a.paired:
+                ent = tj
+            same_wl = ent is not None and ent.get("kernel", "").startswith("ku_classify_short" if fused else "ku_lookup")
             if same_wl and tj.get("kernel_rev") == rev:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_note = tj.get("source", "profiles/lookup_traffic.json")
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_note = ent.get("source", "profiles/lookup_traffic.json")
             elif same_wl:
                 traffic_note = f"profiles/lookup_traffic.json is of kernel source {tj.get('kernel_rev')}, this is {rev}: refused"
         except Exception:

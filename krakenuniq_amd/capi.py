@@ -205,7 +205,7 @@ def kernel_rev():
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for fn in ("ku_device.h", "ku_short.hip", "ku_kernels.hip"):  # device code of the classify kernels (not the host-side declarations)
+    for fn in ("ku_device.h", "ku_short.hip", "ku_kernels.hip", "ku_route.hip"):  # device code of the classify kernels (not the host-side declarations)
         h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:12]
 

@@ -179,6 +179,7 @@ struct ku_mgpu {
   bool reduced = false;  // ku_mgpu_reduce_state ran and no batch was classified since: a second call would add the sums again
   // HyperLogLog++ sparse-mode emulation over the group (ku_mgpu_enable_sparse): every rank runs it on whole work units
   bool sparse = false;
+  bool sparse_gave_up = false;       // the emulation was given up for the whole group (a rank ran out of memory)
   uint64_t unit_nt = 0, acc_nt = 0;  // -u, and the nt of the unit that is still open (classify.cpp:510-521)
   int open_rank = -1;                // the rank whose context holds that unit's state
   bool exact = false;                // classifyExact on the sharded group (ku_mgpu_enable_exact)
@@ -827,7 +828,7 @@ extern "C" int ku_mgpu_sparse_close_unit(ku_mgpu *m) {
 }
 extern "C" int ku_mgpu_sparse_state(const ku_mgpu *m) {
   if (!m) return 0;
-  int worst = m->sparse ? 1 : 0;
+  int worst = m->sparse_gave_up ? 2 : (m->sparse ? 1 : 0);
   for (const auto &r : m->ranks) {
     const int s = ku_ctx_sparse_state(r.ctx);
     if (s == 2) worst = 2;
@@ -1212,6 +1213,7 @@ extern "C" int ku_mgpu_classify_batch_rle(ku_mgpu *m, const char *seqs, uint64_t
       if (ku_ctx_sparse_on(r.ctx)) M_TRY(ku_ctx_disable_sparse(r.ctx));
     }
     m->sparse = false;
+    m->sparse_gave_up = true;
     m->open_rank = -1;
     m->acc_nt = 0;
   }
@@ -1361,31 +1363,39 @@ extern "C" int ku_mgpu_reduce_state(ku_mgpu *m, void *const *streams) {
     if (st == KU_OK && m->exact) st = comm_allreduce_exact(m, r, s);
     return st;
   }));
-  if (m->sparse && ku_mgpu_sparse_state(m) == 1) {
+  bool degraded = m->sparse && ku_mgpu_sparse_state(m) != 1;
+  if (m->sparse && !degraded) {
     // the emulation's state of the whole run ends up in rank 0's context: the last unit closes where it is, a taxon is
     // dense if any rank found it dense, the sparse taxa's sets are the union of the ranks' sets (hyperloglogplus.cpp:586-665)
     const size_t ns = [&] { ku_counts_dims d{}; (void)ku_counts_dims_get(m->ranks[0].ctx, &d); return (size_t)d.n_slots; }();
     std::vector<uint32_t> dense(ns, 0), one(ns);
+    int fs = KU_OK;
     for (auto &r : m->ranks) {
       if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
-      M_TRY(ku_ctx_sparse_finish(r.ctx, one.data()));
+      fs = ku_ctx_sparse_finish(r.ctx, one.data());  // (the keys of the fast path's log join the rank's set here)
+      if (fs != KU_OK) break;
       for (size_t i = 0; i < ns; ++i) dense[i] |= one[i];
     }
     for (auto &r : m->ranks) {
+      if (fs != KU_OK) break;
       if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
-      M_TRY(ku_ctx_sparse_set_dense(r.ctx, dense.data()));
+      fs = ku_ctx_sparse_set_dense(r.ctx, dense.data());
     }
-    for (uint32_t q = 1; q < m->n_local; ++q) M_TRY(ku_ctx_sparse_absorb(m->ranks[0].ctx, m->ranks[q].ctx));
+    for (uint32_t q = 1; q < m->n_local && fs == KU_OK; ++q) fs = ku_ctx_sparse_absorb(m->ranks[0].ctx, m->ranks[q].ctx);
+    if (fs == KU_ENOMEM) degraded = true;  // no room for a rank's set (or the union): dense estimates, as below
+    else if (fs != KU_OK) return fs;
     m->acc_nt = 0;
     m->open_rank = -1;
-  } else if (m->sparse) {
-    // a rank ran out of memory for its tables during the run: no rank's sets are the run's any more -- the report falls
-    // back to the dense registers everywhere (ku_mgpu_sparse_state said 2 before this call)
+  }
+  if (m->sparse && degraded) {
+    // a rank ran out of memory for its tables: no rank's sets are the run's any more -- the report falls back to the
+    // dense registers everywhere (ku_mgpu_sparse_state says 2)
     for (auto &r : m->ranks) {
       if (hipSetDevice(r.device) != hipSuccess) return mfail(KU_EHIP, "hipSetDevice failed");
       M_TRY(ku_ctx_disable_sparse(r.ctx));
     }
     m->sparse = false;
+    m->sparse_gave_up = true;
   }
   m->reduced = true;
   return KU_OK;

@@ -840,7 +840,17 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
           const bool okc = j * 64 + lane < n && !amb_k[j];
-          if (okc) atomicAdd(&urow[v[j]], 1u);
+          // inserts per (unit, slot): one add per DISTINCT slot among the item's k-mers.  A read of two or three taxa had every
+          // lane add 1 on its own -- 64 lanes queueing on two or three words -- which was a third of this instance's time
+          // (98.5 -> 69.3 ms per 10 M reads of `classify -r`, profiles/r04_cli_report_kernel_stats.csv)
+          unsigned long long todo = __ballot(okc);
+          while (todo) {  // wave-uniform
+            const uint32_t lead = (uint32_t)__ffsll((long long)todo) - 1u;
+            const uint32_t s0 = ku_wave_bcast(v[j], lead);
+            const unsigned long long same = __ballot(okc && v[j] == s0);
+            if (lane == lead) atomicAdd(&urow[s0], (uint32_t)__popcll(same));
+            todo &= ~same;
+          }
           want[j] = okc && !sf.dense[v[j]];
         }
         sp_fresh += ks_g_insert_items<ITEMS>(sf.g_key, sf.g_mask, v, hh, want, sf.err);

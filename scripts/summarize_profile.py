@@ -59,6 +59,28 @@ j = {"reads": 10000000, "nt": 13, "species": 2000, "read_len": 150, "kernel": kn
      "correction": "gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM; scripts/calib_gather.hip: a random "
                    "16-B gather moves one 128-B line): read bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 as is (uncalibrated)",
      "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024)}
+# the other read shapes: FETCH_SIZE / WRITE_SIZE passes of scripts/profile_shapes.sh (gpurun_out/<tag>_<shape>_{FETCH,WRITE}_SIZE)
+shapes = {}
+for name, key in (("paired", "reads5000000_nt13_species2000_len301_paired"), ("long", "reads100000_nt13_species2000_len10000"),
+                  ("nt15", "reads10000000_nt15_species2000_len150")):
+    tot, kn, launches = {}, None, 0
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        fs = newest(f'gpurun_out/{tag}_{name}_{c}/runc/*counter_collection.csv')
+        if not fs:
+            break
+        v = [(r['Kernel_Name'], float(r['Counter_Value'])) for r in csv.DictReader(open(fs[0]))
+             if r['Counter_Name'] == c and 'ku_classify_short_kernel' in r['Kernel_Name']]
+        if not v:
+            break
+        kn = v[0][0].split('(')[0].replace('void ', '')
+        vv = [x for _, x in v][1:] if len(v) > 1 else [x for _, x in v]  # first dispatch = untimed warm-up step
+        tot[c], launches = sum(vv) / len(vv), len(vv)
+    if len(tot) == 2:
+        shapes[key] = {"kernel": kn, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"], "launches": launches,
+                       "hbm_bytes_per_launch": int(tot["FETCH_SIZE"] * 2048 + tot["WRITE_SIZE"] * 1024),
+                       "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py ({tag}_{name}), same correction"}
+        print(key, 'traffic GB', shapes[key]["hbm_bytes_per_launch"] / 1e9)
+j["shapes"] = shapes
 json.dump(j, open('profiles/lookup_traffic.json', 'w'), indent=1)
 print({k: '%.4g' % v['per_launch_mean'] for k, v in lk.items()})
 print('traffic GB', j['hbm_bytes_per_launch'] / 1e9)
