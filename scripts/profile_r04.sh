@@ -16,6 +16,7 @@ if [[ $WHAT == *shapes* ]]; then
     name=${sh%%:*}; args=${sh#*:}
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${name}_stats -- python $REPO/bench.py $A $args > $OUT/${TAG}_${name}.log 2>&1
     for grp in FETCH_SIZE WRITE_SIZE; do
+      [ $name = nt15 ] && continue   # (kernel stats only for the nt = 15 shape)
       timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "$REGEX" --output-format csv -d $OUT/${TAG}_${name}_$grp -- python $REPO/bench.py $A $args > $OUT/${TAG}_${name}_$grp.log 2>&1
     done
     echo "shape $name done"; tail -1 $OUT/${TAG}_${name}.log | cut -c1-300

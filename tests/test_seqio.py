@@ -113,3 +113,38 @@ def test_pipes_are_read_through_one_handle(tmp_path):
         recs = [ln.split(b"\t") for ln in r.stdout.split(b"\n")[:-1]]
         i4, s4 = synth.read_seqfile(f"{G}/f4/merged.fa")
         assert [a.decode() for a, _ in recs] == ids + i4 and [b for _, b in recs] == seqs + s4
+
+
+def bgzf(data, block=65280, level=6):
+    """BGZF: every block a gzip member with its size in a "BC" extra field (SAM specification 4.1), an empty block at the end"""
+    import struct
+    import zlib
+
+    def one(b):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(b) + c.flush()
+        hdr = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, ord("B"), ord("C"), 2, 18 + len(comp) + 8 - 1)
+        return hdr + comp + struct.pack("<II", zlib.crc32(b) & 0xffffffff, len(b))
+    return b"".join(one(data[i:i + block]) for i in range(0, len(data), block)) + one(b"")
+
+
+def test_bgzf_input_is_inflated_by_a_team_and_parses_like_the_text(tmp_path):
+    """blocked gzip: the blocks are independent deflate streams (a team of threads inflates them, -T: as the executable reads);
+    same records as the plain text, in file order, whatever the block size (records straddle blocks and tasks); a file
+    that only starts like BGZF goes through zlib's reader"""
+    rng = np.random.default_rng(3)
+    n = 30000
+    text = b"".join(b"@r%d x\n" % i + bytes(rng.choice(list(b"ACGTN"), size=int(rng.integers(30, 260))).astype(np.uint8)) + b"\n+\n" +
+                    b"I" * 5 + b"\n" for i in range(n))
+    # (quality lines shorter than the sequence: the parser does not care, the reference's does not either)
+    plain = tmp_path / "r.fq"
+    plain.write_bytes(text)
+    want = dump([str(plain)])[:2]
+    for block in (65280, 4093, 700):
+        z = tmp_path / f"r{block}.fq.gz"
+        z.write_bytes(bgzf(text, block))
+        assert dump(["-T", str(z)])[:2] == want, block
+        assert dump([str(z)])[:2] == want, block  # without the producer side: zlib reads the members one after the other
+    mixed = tmp_path / "mixed.fq.gz"
+    mixed.write_bytes(bgzf(text[:len(text) // 2])[:-28] + gzip.compress(text[len(text) // 2:]))
+    assert dump(["-T", str(mixed)])[:2] == want
