@@ -6,7 +6,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 TAG=${1:-r04}
-STATS=${2:-"2 3 4"}
+STATS=${2-2 3 4}
 PMC=${3-2}
 mkdir -p $OUT
 B="--gpus 1 --steps 4 --warmup 1 --no-extras --cpu-sample 0"
