@@ -201,10 +201,17 @@ int ku_sparse_export(ku_ctx *ctx, uint8_t *slot_is_sparse, uint64_t *pairs, uint
  * first such sequence in call order wins, values that already are one of the two stay). */
 #define KU_SL_RESET 0x1u
 #define KU_SL_FORCE_CONTAMINANT 0x2u
+/* -I, UID databases (src/set_lcas.cpp:451-455, src/uid_mapping.cpp:32-91): the value of a k-mer becomes the id of the SET
+ * of taxids whose sequences hold it; a set gets the next UID when it first comes up, so the numbering follows the order of
+ * the calls and of the k-mers within a sequence (the reference on one thread).  The GPU finds each k-mer's pair, the host
+ * walks them in order.  ku_setlcas_finish then returns UIDs; ku_setlcas_uid_map the map file's content: per UID, in
+ * creation order, {taxid added, UID of the set it was added to (0: none)} -- what classify -I reads (ku_uid_map_open). */
+#define KU_SL_UIDS 0x4u
 typedef struct ku_setlcas ku_setlcas;
 int ku_setlcas_open(int device, const ku_db *db, const ku_tax *tax, uint32_t flags, ku_setlcas **out);
 int ku_setlcas_add(ku_setlcas *s, const char *seq, uint64_t len, uint32_t taxid);
 int ku_setlcas_finish(ku_setlcas *s, uint32_t *values_out, uint64_t *n_missing);
+int ku_setlcas_uid_map(const ku_setlcas *s, const uint32_t **blocks /* 2 * n_uids words, owned by s */, uint64_t *n_uids);
 void ku_setlcas_close(ku_setlcas *s);
 
 /* ------------------------------------------------------------------ classification */

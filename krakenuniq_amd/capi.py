@@ -69,6 +69,7 @@ SIGNATURES = {
     "ku_setlcas_open": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "ku_setlcas_add": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32]),
     "ku_setlcas_finish": (C.c_int, [C.c_void_p, u32p, u64p]),
+    "ku_setlcas_uid_map": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint64)]),
     "ku_setlcas_close": (None, [C.c_void_p]),
     "ku_db_sort_files": (C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
     "ku_ctx_swap_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),

@@ -7,6 +7,7 @@
 // with compare-and-swap give the sequential result.  Offline tool, not on the classify hot path.
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -34,9 +35,13 @@ struct SlDev {
   uint32_t k, nt, xor_mask;
 };
 
-// mode 0: val = lca(node, val); mode 1: reset to 0 (-R); mode 2: contaminant sequence under -T (record the first one)
+// mode 0: val = lca(node, val); mode 1: reset to 0 (-R); mode 2: contaminant sequence under -T (record the first one);
+// mode 3 (-I, UID databases): nothing is folded here -- where[p] = index of the pair that holds the k-mer at position p
+// (KU_SL_NOWHERE: ambiguous or not in the database); the host applies uid_mapping in position order (its numbering of the
+// taxid sets depends on that order, src/uid_mapping.cpp:32-91)
+#define KU_SL_NOWHERE (~0ull)
 __global__ void setlcas_kernel(SlDev d, const uint8_t *__restrict__ seq, uint64_t len, uint32_t node, uint32_t mode,
-                               uint32_t contam_code, unsigned long long *n_missing) {
+                               uint32_t contam_code, unsigned long long *n_missing, unsigned long long *where) {
   const uint32_t k = d.k, m = d.nt, w = k - m + 1;
   const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
   const uint64_t n = len >= k ? len - k + 1 : 0;
@@ -48,7 +53,7 @@ __global__ void setlcas_kernel(SlDev d, const uint8_t *__restrict__ seq, uint64_
       amb |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
       fwd = (fwd << 2) | (((c >> 1) ^ (c >> 2)) & 3u);
     }
-    if (amb) continue;
+    if (amb) { if (mode == 3) where[p] = KU_SL_NOWHERE; continue; }
     const uint64_t rc = ku_revcomp64(fwd, k);
     const uint64_t canon = fwd < rc ? fwd : rc;
     uint32_t bin = 0xFFFFFFFFu;
@@ -68,8 +73,10 @@ __global__ void setlcas_kernel(SlDev d, const uint8_t *__restrict__ seq, uint64_
     }
     if (!found) {  // "kmer found in sequence that is not in database" (src/set_lcas.cpp:441-448)
       atomicAdd(n_missing, 1ull);
+      if (mode == 3) where[p] = KU_SL_NOWHERE;
       continue;
     }
+    if (mode == 3) { where[p] = lo; continue; }
     if (mode == 1) { d.nodes[lo] = 0; continue; }
     if (mode == 2) { atomicMin(&d.contam[lo], contam_code); continue; }
     uint32_t old = __hip_atomic_load(&d.nodes[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -136,6 +143,14 @@ struct ku_setlcas {
   uint8_t *d_seq = nullptr;
   uint64_t seq_cap = 0;
   SlDev dev{};
+  // -I (KU_SL_UIDS): the values are UIDs, kept on the host; uid_mapping's containers (src/uid_mapping.cpp:32-91)
+  unsigned long long *d_where = nullptr;
+  uint64_t where_cap = 0;
+  std::vector<unsigned long long> h_where;
+  std::vector<uint32_t> h_uids;                                  // per pair
+  std::map<std::vector<uint32_t>, uint32_t> taxids_to_uid;       // taxid set (ascending) -> UID
+  std::vector<const std::vector<uint32_t> *> uid_to_taxids;      // UID - 1 -> its set
+  std::vector<uint32_t> uid_blocks;                              // {taxid, parent UID} per UID, in creation order: the map file
 };
 
 #define SL_HIP(expr)                                                                                     \
@@ -150,7 +165,7 @@ extern "C" void ku_setlcas_close(ku_setlcas *s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (void *p : {(void *)s->d_kmers, (void *)s->d_offsets, (void *)s->d_nodes, (void *)s->d_contam, (void *)s->d_parent,
-                  (void *)s->d_node_taxid, (void *)s->d_missing, (void *)s->d_seq})
+                  (void *)s->d_node_taxid, (void *)s->d_missing, (void *)s->d_seq, (void *)s->d_where})
     if (p) (void)hipFree(p);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -215,6 +230,10 @@ static int setlcas_open_impl(ku_setlcas *s, const ku_db *db, const ku_tax *tax) 
   const uint64_t INDEX2_XOR_MASK = 0xe37e28c4271b5a2dULL;  // krakendb.cpp:45
   s->dev = SlDev{s->d_kmers, s->d_nodes, s->d_contam, s->d_offsets, s->d_parent, info.k, info.nt,
                  info.idx_type == 1 ? 0u : (uint32_t)(INDEX2_XOR_MASK & (n_bins - 1))};
+  if (s->flags & KU_SL_UIDS) {  // the values as they are in the file (UIDs of an earlier run would need that run's map: uid_mapping exits on them)
+    s->h_uids.resize(n);
+    for (uint64_t i = 0; i < n; ++i) memcpy(&s->h_uids[i], pairs + i * ps + info.key_len, 4);
+  }
   return KU_OK;
 }
 
@@ -254,6 +273,63 @@ extern "C" int ku_setlcas_add(ku_setlcas *s, const char *seq, uint64_t len, uint
   // the previous sequence's kernel reads d_seq: the copy is ordered behind it on the same stream
   SL_HIP(hipMemcpyAsync(s->d_seq, seq, len, hipMemcpyHostToDevice, s->stream));
   uint32_t mode = 0, code = 0;
+  if (s->flags & KU_SL_UIDS) {
+    // -I (src/set_lcas.cpp:451-455): value = uid_mapping(value, taxid) for every k-mer of the sequence IN ORDER -- a new set
+    // of taxids gets the next UID when it first comes up, so the numbering is the order of the k-mers.  The GPU finds the
+    // pairs (canonical k-mer, bin, search: the expensive part), the host walks them.
+    const uint64_t n = len - s->dev.k + 1;
+    if (n > s->where_cap) {
+      if (s->d_where) (void)hipFree(s->d_where);
+      s->d_where = nullptr;
+      s->where_cap = 0;
+      SL_HIP(hipMalloc((void **)&s->d_where, (n + n / 4 + 1024) * 8));
+      s->where_cap = n + n / 4 + 1024;
+    }
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(setlcas_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, s->d_seq, len, node, 3u, 0u, s->d_missing, s->d_where);
+    SL_HIP(hipGetLastError());
+    s->h_where.resize(n);
+    SL_HIP(hipMemcpyAsync(s->h_where.data(), s->d_where, n * 8, hipMemcpyDeviceToHost, s->stream));
+    SL_HIP(hipStreamSynchronize(s->stream));
+    // within a sequence the taxid is fixed: uid_mapping(old, taxid) is a function of the old UID alone
+    std::map<uint32_t, uint32_t> memo;
+    for (uint64_t p = 0; p < n; ++p) {
+      const unsigned long long at = s->h_where[p];
+      if (at == KU_SL_NOWHERE) continue;
+      const uint32_t old = s->h_uids[at];
+      auto hit = memo.find(old);
+      if (hit != memo.end()) { s->h_uids[at] = hit->second; continue; }
+      uint32_t nw;
+      std::vector<uint32_t> set;
+      bool have = false;
+      if (old == 0) set.push_back(taxid);
+      else {
+        if (old > s->uid_to_taxids.size())
+          return fail(KU_EINVAL, "set_lcas -I: kmer_uid (" + std::to_string(old) + ") greater than UID vector size (" +
+                                     std::to_string(s->uid_to_taxids.size()) + "): the database holds values of an earlier run");
+        set = *s->uid_to_taxids[old - 1];
+        auto it = std::lower_bound(set.begin(), set.end(), taxid);
+        if (it == set.end() || *it != taxid) set.insert(it, taxid);
+        else have = true;  // the taxid is part of the k-mer's set already
+      }
+      if (have) nw = old;
+      else {
+        const uint32_t next = (uint32_t)s->uid_to_taxids.size() + 1;
+        auto ins = s->taxids_to_uid.insert({std::move(set), next});
+        if (!ins.second) nw = ins.first->second;  // the set has a UID
+        else {
+          if (next == 0xFFFFFFFFu) return fail(KU_EUNSUP, "set_lcas -I: maxxed out on UIDs");
+          s->uid_to_taxids.push_back(&ins.first->first);
+          s->uid_blocks.push_back(taxid);
+          s->uid_blocks.push_back(old);
+          nw = next;
+        }
+      }
+      memo[old] = nw;
+      s->h_uids[at] = nw;
+    }
+    return KU_OK;
+  }
   if (s->flags & KU_SL_RESET) mode = 1;  // -R wins (src/set_lcas.cpp:458-459)
   else if ((s->flags & KU_SL_FORCE_CONTAMINANT) && (taxid == TID_CONTAMINANT1 || taxid == TID_CONTAMINANT2)) {
     mode = 2;
@@ -262,9 +338,17 @@ extern "C" int ku_setlcas_add(ku_setlcas *s, const char *seq, uint64_t len, uint
   const uint64_t n = len - s->dev.k + 1;
   const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16);
   hipLaunchKernelGGL(setlcas_kernel, dim3(grid), dim3(256), 0, s->stream, s->dev, s->d_seq, len, node, mode, code,
-                     s->d_missing);
+                     s->d_missing, (unsigned long long *)nullptr);
   SL_HIP(hipGetLastError());
   SL_HIP(hipStreamSynchronize(s->stream));  // `seq` may be reused by the caller; offline tool, no pipelining needed
+  return KU_OK;
+}
+
+extern "C" int ku_setlcas_uid_map(const ku_setlcas *s, const uint32_t **blocks, uint64_t *n_uids) {
+  if (!s || !blocks || !n_uids) return fail(KU_EINVAL, "ku_setlcas_uid_map: null argument");
+  if (!(s->flags & KU_SL_UIDS)) return fail(KU_ESTATE, "ku_setlcas_uid_map: the fold was not opened with KU_SL_UIDS");
+  *blocks = s->uid_blocks.data();
+  *n_uids = s->uid_blocks.size() / 2;
   return KU_OK;
 }
 
@@ -272,6 +356,14 @@ extern "C" int ku_setlcas_finish(ku_setlcas *s, uint32_t *values_out, uint64_t *
   if (!s || (s->key_ct && !values_out)) return fail(KU_EINVAL, "ku_setlcas_finish: null argument");
   SL_HIP(hipSetDevice(s->device));
   const uint64_t n = s->key_ct;
+  if (s->flags & KU_SL_UIDS) {
+    unsigned long long miss = 0;
+    SL_HIP(hipMemcpyAsync(&miss, s->d_missing, 8, hipMemcpyDeviceToHost, s->stream));
+    SL_HIP(hipStreamSynchronize(s->stream));
+    if (n) memcpy(values_out, s->h_uids.data(), n * 4);
+    if (n_missing) *n_missing = miss;
+    return KU_OK;
+  }
   const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>((n + 255) / 256, 1), 1u << 16);
   hipLaunchKernelGGL(setlcas_to_taxids_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_nodes, n, s->d_node_taxid,
                      s->d_contam);

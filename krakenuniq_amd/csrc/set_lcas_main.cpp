@@ -1,6 +1,6 @@
 // Drop-in for the reference's `set_lcas` (src/set_lcas.cpp): same getopt string, same files; the per-k-mer LCA fold
-// runs on the GPU through ku_setlcas_*.  Built: -d -i -b -o -x -f / -F -m -c -T -R -E -p -v -a -A (-t and -M are accepted
-// and have nothing left to do).  Not built (EX_SOFTWARE): -I (UID databases).  Unlike the reference without -M, the
+// runs on the GPU through ku_setlcas_*.  Built: -d -i -b -o -x -f / -F -m -c -T -R -E -p -v -a -A -I (-t and -M are accepted
+// and have nothing left to do; -I: UID databases, the set numbering of the reference on one thread).  Unlike the reference without -M, the
 // input database file is never modified when -o names another file.
 #include <getopt.h>
 #include <sysexits.h>
@@ -156,7 +156,7 @@ struct TaxTable {
 static const uint32_t TID_HUMAN = 9606, TID_MOUSE = 10090;  // no sequence taxids for host genomes (src/set_lcas.cpp:83-85)
 
 int main(int argc, char **argv) {
-  std::string db_name, idx_name, out_name, taxdb_name, counts_name, file_map_name, id_map_name, fasta_name;
+  std::string db_name, idx_name, out_name, taxdb_name, counts_name, file_map_name, id_map_name, fasta_name, uid_map_name;
   bool force_contaminant = false, reset = false, allow_extra = false, verbose = false, pretend = false;
   bool add_for_sequences = false, add_for_assembly = false;  // -a, -A (src/set_lcas.cpp:528-533)
   uint32_t min_size = 0;
@@ -182,7 +182,7 @@ int main(int argc, char **argv) {
       case 'p': pretend = true; break;
       case 'a': add_for_sequences = true; break;
       case 'A': add_for_assembly = true; break;
-      case 'I': fatal(EX_SOFTWARE, "UID databases (-I) are not built into the MI355X set_lcas");
+      case 'I': uid_map_name = optarg; break;
       default: usage(EX_USAGE);
     }
   }
@@ -248,7 +248,7 @@ int main(int argc, char **argv) {
     for (const auto &kv : tt.entries) { ids.push_back(kv.first); parents.push_back(kv.second.file_parent); }
     CHECK(ku_tax_from_arrays(ids.data(), parents.data(), ids.size(), &tax));
     const char *dev_env = getenv("KU_DEVICE");
-    CHECK(ku_setlcas_open(dev_env ? atoi(dev_env) : 0, db, tax, (reset ? KU_SL_RESET : 0u) | (force_contaminant ? KU_SL_FORCE_CONTAMINANT : 0u), &sl));
+    CHECK(ku_setlcas_open(dev_env ? atoi(dev_env) : 0, db, tax, (reset ? KU_SL_RESET : 0u) | (force_contaminant ? KU_SL_FORCE_CONTAMINANT : 0u) | (uid_map_name.empty() ? 0u : KU_SL_UIDS), &sl));
   }
   // Parent_map membership (src/set_lcas.cpp:313-318,338): taxids with an entry in taxDB
   auto in_taxonomy = [&](uint32_t taxid) { return taxid != 0 && tt.has(taxid); };
@@ -340,6 +340,15 @@ int main(int argc, char **argv) {
   std::vector<uint32_t> values(info.key_ct + 1);
   uint64_t n_missing = 0;
   CHECK(ku_setlcas_finish(sl, values.data(), &n_missing));
+  if (!uid_map_name.empty()) {  // the UID-to-taxid map (src/uid_mapping.cpp:85-88: {taxid, parent UID} per UID, binary)
+    const uint32_t *blocks = nullptr;
+    uint64_t n_uids = 0;
+    CHECK(ku_setlcas_uid_map(sl, &blocks, &n_uids));
+    FILE *uf = fopen(uid_map_name.c_str(), "wb");
+    if (!uf) fatal(EX_OSERR, "Something went wrong while creating the file %s", uid_map_name.c_str());
+    if (n_uids && fwrite(blocks, 8, n_uids, uf) != n_uids) fatal(EX_OSERR, "can't write %s", uid_map_name.c_str());
+    fclose(uf);
+  }
   ku_setlcas_close(sl);
   if (n_missing && !allow_extra) fatal(EX_DATAERR, "kmer found in sequence that is not in database");
   if (n_missing && verbose) fprintf(stderr, "%llu kmers found in sequences that are not in database\n", (unsigned long long)n_missing);

@@ -20,7 +20,6 @@ def test_cli_usage_without_gpu():
     r = subprocess.run([BIN], stderr=subprocess.PIPE)
     assert r.returncode == 64 and b"Usage: set_lcas" in r.stderr
     assert subprocess.run([BIN, "-d", "a", "-i", "b", "-b", "c"], stderr=subprocess.PIPE).returncode == 64  # no -f / -F -m
-    assert subprocess.run([BIN, "-I", "uid.map", "-d", "a", "-i", "b", "-b", "c", "-F", "x", "-m", "y"], stderr=subprocess.PIPE).returncode == 70
     assert subprocess.run([BIN, "-h"], stderr=subprocess.PIPE).returncode == 0
 
 
@@ -148,3 +147,40 @@ def test_new_taxids_end_to_end(tmp_path, tag, flags):
     assert (tmp_path / "counts").read_text() == open(f"{G}/f9/counts_{tag}").read()
     assert r.stdout == open(f"{G}/f9/map_{tag}.out", "rb").read()
     assert (tmp_path / "taxDB").read_bytes() == open(f"{G}/f9/taxDB_{tag}", "rb").read()
+
+
+@pytest.mark.gpu
+def test_uid_database_equals_the_reference_build(tmp_path):
+    """set_lcas -I (src/set_lcas.cpp:451-455, src/uid_mapping.cpp:32-91): the value of a k-mer is the id of the SET of taxids
+    whose library sequences hold it, sets numbered in the order they first come up.  tests/golden/f11 holds what the
+    reference's set_lcas -I built from f1's k-mers (values zeroed) and a library of six sequences -- sets of one, two and
+    three taxids -- whose inputs tests/golden/make_golden.py:make_f11 derives from fixed seeds; rebuilt here the same way.
+    Database, UID map and counts byte for byte."""
+    _zeroed_db(tmp_path)
+    rng = np.random.default_rng(7)
+    g4 = synth.procedural_genome(7, 4, 3000)
+    g5 = synth.mutate(g4, 0.03, rng)
+    g6 = synth.procedural_genome(7, 6, 3000)
+    gp = np.concatenate([g6[2000:2300], synth.procedural_genome(7, 99, 300)])
+    a = synth.codes_to_ascii
+    g4, g5, g6, gp = a(g4), a(g5), a(g6), a(gp)
+    recs = [(b"seqA", g4), (b"seqB", g5), (b"seqC", g6), (b"seqP", gp), (b"seqD part of the first genome under another taxid", g4[500:1500]),
+            (b"seqE part of the second genome under the genus", g5[1200:2200])]
+    with open(tmp_path / "library.fa", "wb") as f:
+        for h, sq in recs:
+            f.write(b">" + h + b"\n")
+            for i in range(0, len(sq), 70):
+                f.write(sq[i:i + 70] + b"\n")
+    (tmp_path / "seqid2taxid.map").write_text("seqA\t4\nseqB\t5\nseqC\t6\nseqP\t1000000001\nseqD\t6\nseqE\t2\n")
+    r = subprocess.run([BIN, "-M", "-x", "-d", str(tmp_path / "database.kdb"), "-I", str(tmp_path / "uid.map"), "-o", str(tmp_path / "uid.kdb"),
+                        "-i", str(tmp_path / "database.idx"), "-b", f"{G}/f1/taxDB", "-m", str(tmp_path / "seqid2taxid.map"),
+                        "-F", str(tmp_path / "library.fa"), "-c", str(tmp_path / "uid.counts")], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert (tmp_path / "uid.map").read_bytes() == open(f"{G}/f11/uid_to_taxid.map", "rb").read()
+    assert (tmp_path / "uid.kdb").read_bytes() == open(f"{G}/f11/uid_database.kdb", "rb").read()
+    assert (tmp_path / "uid.counts").read_text() == open(f"{G}/f11/uid_database.kdb.counts").read()
+    # a second run over the result: its values are UIDs of a map this run does not have -- the reference exits there too
+    r2 = subprocess.run([BIN, "-x", "-d", str(tmp_path / "uid.kdb"), "-I", str(tmp_path / "uid2.map"), "-o", str(tmp_path / "uid2.kdb"),
+                         "-i", str(tmp_path / "database.idx"), "-b", f"{G}/f1/taxDB", "-m", str(tmp_path / "seqid2taxid.map"),
+                         "-F", str(tmp_path / "library.fa")], stderr=subprocess.PIPE)
+    assert r2.returncode != 0 and b"greater than UID vector size" in r2.stderr
