@@ -303,6 +303,14 @@ int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts);
 int ku_batch_finish(ku_ctx *ctx, ku_batch *b, const ku_opts *opts, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
                     uint32_t *run_cnt, uint64_t *n_runs);
 void ku_batch_destroy(ku_batch *b);
+/* Several GPUs on one out-of-core run (classify KU_DEVICES=0,1,... -x SIZE): every GPU keeps its own copy of the resident
+ * batches and streams ITS share of the chunks over them (ku_batch_lookup: a pass only writes the positions whose bin the
+ * resident chunk owns, so each position is written on exactly one GPU); ku_batch_absorb folds the slots another GPU's
+ * copy collected into `dst` ("non-zero wins", src/classify.cpp:445-452), after which ku_batch_finish on dst's context
+ * sees what a single GPU would have after all chunks.  ku_ctx_merge_state adds the per-taxon state the other GPU's passes
+ * booked (registers MAX, n_kmers SUM, n_reads SUM) to dst's -- once, at the end of the run. */
+int ku_batch_absorb(ku_ctx *ctx, ku_batch *dst, const ku_batch *src);
+int ku_ctx_merge_state(ku_ctx *dst, ku_ctx *src);
 
 /* Same on device-resident buffers, asynchronous on `stream` (a hipStream_t
  * passed as void*; NULL = the context's own, non-blocking stream).  The caller orders the work: whatever produced

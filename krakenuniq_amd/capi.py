@@ -79,6 +79,8 @@ SIGNATURES = {
     "ku_batch_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts)]),
     "ku_batch_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Opts), u32p, u32p, u64p, u32p, u64p]),
     "ku_batch_destroy": (None, [C.c_void_p]),
+    "ku_batch_absorb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ku_ctx_merge_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ku_tax_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ku_tax_from_arrays": (C.c_int, [u32p, u32p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "ku_tax_close": (None, [C.c_void_p]),

@@ -287,8 +287,23 @@ int main(int argc, char **argv) {
     fprintf(stderr, "Reading UID mapping file %s\n", uid_map_file.c_str());  // src/classify.cpp:163
     KU_CHECK(ku_uid_map_open(uid_map_file.c_str(), &uid_map));
   }
+  // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference; one chunk = everything resident as usual
+  std::vector<uint64_t> chunk_bounds;
+  if (chunk_bytes) {
+    chunk_bounds.resize(info.n_bins + 2 < (1u << 20) ? info.n_bins + 2 : (1u << 20));
+    uint32_t n_chunks = 0;
+    KU_CHECK(ku_db_chunk_plan(db, chunk_bytes, chunk_bounds.data(), (uint32_t)chunk_bounds.size() - 1, &n_chunks));
+    chunk_bounds.resize(n_chunks + 1);
+    chunk_bounds.back() = info.n_bins;  // the bins behind the last chunk hold no pairs
+    if (n_chunks <= 1) chunk_bounds.clear();
+  }
+  const bool chunked = !chunk_bounds.empty();
   ku_ctx *ctx = nullptr;
   ku_mgpu *mg = nullptr;  // KU_DEVICES=0,1,...: several GPUs through the multi-GPU driver
+  // KU_DEVICES with -x (more chunks than one): the first GPU runs the out-of-core pipeline, the others are HELPERS -- each
+  // streams its share of the chunks (chunk c on GPU c mod N) over its own copies of the resident batches; the slots they
+  // collect are folded into the first GPU's batches before the finish, their per-taxon state at the end of the run
+  std::vector<ku_ctx *> helpers;
   std::vector<int> devices;
   if (const char *dl = getenv("KU_DEVICES")) {
     for (const char *p = dl; *p;) {
@@ -300,8 +315,7 @@ int main(int argc, char **argv) {
       if (*end && *end != ',') die(EX_USAGE, "can't parse KU_DEVICES=%s", dl);
     }
   }
-  if (devices.size() > 1) {
-    if (chunk_bytes) die(EX_SOFTWARE, "KU_DEVICES with -x is not supported: the shards are resident on the GPUs");
+  if (devices.size() > 1 && !chunked) {
     const char *mode = getenv("KU_MGPU_MODE");
     uint32_t mflags = (mode && strcmp(mode, "replicas") == 0) ? KU_MGPU_REPLICAS : 0u;
     if (db_handles.size() > 1 && !mflags) {
@@ -317,7 +331,13 @@ int main(int argc, char **argv) {
     ctx = ku_mgpu_ctx(mg, 0);
   } else {
     const char *dev_env = getenv("KU_DEVICE");
-    KU_CHECK(ku_ctx_create(devices.size() == 1 ? devices[0] : (dev_env ? atoi(dev_env) : 0), &ctx));
+    KU_CHECK(ku_ctx_create(!devices.empty() ? devices[0] : (dev_env ? atoi(dev_env) : 0), &ctx));
+    for (size_t r = 1; r < devices.size(); ++r) {  // (only with -x chunks, see above)
+      ku_ctx *h = nullptr;
+      KU_CHECK(ku_ctx_create(devices[r], &h));
+      helpers.push_back(h);
+    }
+    if (!helpers.empty()) fprintf(stderr, "Running on %zu GPUs: the database chunks of the out-of-core run are dealt out among them\n", devices.size());
   }
   // The batch buffers of the host pipeline (below) are page-locked memory, which is slow to allocate (a few hundred MB
   // take longer than classifying the first millions of reads).  A helper sizes the pool's buffers for plain-text
@@ -338,17 +358,6 @@ int main(int argc, char **argv) {
       bt.run_off.reserve(reads); bt.run_cnt.reserve(reads);
     }
   });
-  // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference; one chunk = everything resident as usual
-  std::vector<uint64_t> chunk_bounds;
-  if (chunk_bytes) {
-    chunk_bounds.resize(info.n_bins + 2 < (1u << 20) ? info.n_bins + 2 : (1u << 20));
-    uint32_t n_chunks = 0;
-    KU_CHECK(ku_db_chunk_plan(db, chunk_bytes, chunk_bounds.data(), (uint32_t)chunk_bounds.size() - 1, &n_chunks));
-    chunk_bounds.resize(n_chunks + 1);
-    chunk_bounds.back() = info.n_bins;  // the bins behind the last chunk hold no pairs
-    if (n_chunks <= 1) chunk_bounds.clear();
-  }
-  const bool chunked = !chunk_bounds.empty();
   if (map_uids && (mg || chunked)) die(EX_SOFTWARE, "UID mapping (-I) runs on one GPU with the database resident (no KU_DEVICES, no -x chunks)");
   // database.kdb.counts of a chunked run is summed up chunk by chunk while each one is resident
   auto counts_file_good = [](const std::string &name, bool say) {
@@ -363,15 +372,22 @@ int main(int argc, char **argv) {
   const bool want_report = !report_out.empty() && report_out != "off";
   const bool sum_chunk_counts = chunked && want_report && !counts_file_good(dbs[0] + ".counts", false);
   std::map<uint32_t, uint64_t> chunk_counts;
-  auto add_chunk_counts = [&] {
+  std::mutex chunk_counts_mu;
+  auto add_chunk_counts = [&](ku_ctx *c) {  // the chunk that is resident on c
     if (!sum_chunk_counts) return;
     uint64_t nc = 0;
-    KU_CHECK(ku_ctx_count_taxons(ctx, nullptr, nullptr, &nc));
+    KU_CHECK(ku_ctx_count_taxons(c, nullptr, nullptr, &nc));
     std::vector<uint32_t> ct(nc + 1); std::vector<uint64_t> cc(nc + 1);
     uint64_t cap = nc;
-    KU_CHECK(ku_ctx_count_taxons(ctx, ct.data(), cc.data(), &cap));
+    KU_CHECK(ku_ctx_count_taxons(c, ct.data(), cc.data(), &cap));
+    std::lock_guard<std::mutex> l(chunk_counts_mu);
     for (uint64_t i = 0; i < cap; ++i) chunk_counts[ct[i]] += cc[i];
   };
+  // chunk c belongs to GPU c mod N (N = 1 + helpers): rank_chunks[r] in ascending order; rank 0 starts with chunk 0
+  const size_t n_ranks_x = 1 + helpers.size();
+  std::vector<std::vector<size_t>> rank_chunks(n_ranks_x);
+  if (chunked)
+    for (size_t c = 0; c + 1 < chunk_bounds.size(); ++c) rank_chunks[c % n_ranks_x].push_back(c);
   if (chunked) {
     if (db_handles.size() > 1) die(EX_SOFTWARE, "-x with several databases is not supported (the reference only searches the first one there)");
     fprintf(stderr, "Streaming the database through the GPU in %zu chunks of at most %" PRIu64 " bytes\n", chunk_bounds.size() - 1, chunk_bytes);
@@ -382,7 +398,14 @@ int main(int argc, char **argv) {
     KU_CHECK(ku_db_values(db, values.data(), &cap));
     KU_CHECK(ku_ctx_load_db(ctx, db, chunk_bounds[0], chunk_bounds[1]));
     KU_CHECK(ku_ctx_set_taxonomy(ctx, tax, values.data(), cap));
-    add_chunk_counts();
+    add_chunk_counts(ctx);
+    for (size_t r = 1; r < n_ranks_x; ++r) {  // the helpers: their first chunk, the slot table of the whole database as everywhere
+      if (rank_chunks[r].empty()) continue;
+      const size_t c0 = rank_chunks[r][0];
+      KU_CHECK(ku_ctx_load_db(helpers[r - 1], db, chunk_bounds[c0], chunk_bounds[c0 + 1]));
+      KU_CHECK(ku_ctx_set_taxonomy(helpers[r - 1], tax, values.data(), cap));
+      add_chunk_counts(helpers[r - 1]);
+    }
   } else if (mg) {
     KU_CHECK(ku_mgpu_load_dbs(mg, db_handles.data(), (uint32_t)db_handles.size(), tax));
   } else {
@@ -747,34 +770,65 @@ int main(int argc, char **argv) {
     inflight_cv.notify_all();
     const size_t n_chunks = chunk_bounds.size() - 1;
     ku_opts opts = base_opts;
-    std::thread prefetcher;
-    int prefetch_status = KU_OK;
-    std::string prefetch_error;
+    // One stream of chunks per GPU: its context, its share of the chunks, and the helper thread that uploads and lays out the
+    // NEXT chunk while the resident one is searched.
     // -x SIZE is the reference's bound on ONE resident chunk (src/krakendb.cpp:463-522).  Double buffering needs room for a
     // second one next to it: when the device has none (KU_ENOMEM from the helper) the run goes on with one chunk at a time --
     // ku_ctx_swap_shard then uploads synchronously, as before there was a prefetch
-    bool prefetch_off = getenv("KU_NO_PREFETCH") != nullptr;
-    auto start_prefetch = [&](size_t c) {
-      if (prefetch_off) return;
-      prefetcher = std::thread([&, c] {
-        prefetch_status = ku_ctx_prefetch_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]);
-        if (prefetch_status != KU_OK) prefetch_error = ku_last_error();
+    struct ChunkStream {
+      ku_ctx *c = nullptr;
+      const std::vector<size_t> *list = nullptr;
+      std::thread prefetcher;
+      int status = KU_OK;
+      std::string error;
+      bool off = false;
+    };
+    std::vector<ChunkStream> cs(n_ranks_x);
+    for (size_t r = 0; r < n_ranks_x; ++r) {
+      cs[r].c = r == 0 ? ctx : helpers[r - 1];
+      cs[r].list = &rank_chunks[r];
+      cs[r].off = getenv("KU_NO_PREFETCH") != nullptr;
+    }
+    auto start_prefetch = [&](ChunkStream &st, size_t c) {
+      if (st.off) return;
+      st.prefetcher = std::thread([&st, c, db, &chunk_bounds] {
+        st.status = ku_ctx_prefetch_shard(st.c, db, chunk_bounds[c], chunk_bounds[c + 1]);
+        if (st.status != KU_OK) st.error = ku_last_error();
       });
     };
-    auto join_prefetch = [&] {
-      if (prefetcher.joinable()) prefetcher.join();
-      if (prefetch_status == KU_ENOMEM) {
+    auto join_prefetch = [&](ChunkStream &st) {
+      if (st.prefetcher.joinable()) st.prefetcher.join();
+      if (st.status == KU_ENOMEM) {
         fprintf(stderr, "\rclassify: no device memory for a second database chunk next to the resident one: chunks are uploaded one at a time from here on\n");
-        prefetch_status = KU_OK;
-        prefetch_off = true;
+        st.status = KU_OK;
+        st.off = true;
       }
-      if (prefetch_status != KU_OK) die(exit_code_of(prefetch_status), "%s: %s", ku_strerror(prefetch_status), prefetch_error.c_str());
+      if (st.status != KU_OK) die(exit_code_of(st.status), "%s: %s", ku_strerror(st.status), st.error.c_str());
     };
     bool input_done = false, first_super = true;
     size_t n_super = 0;
+    // the further chunks of one GPU's list over its copies of the super-batch, then (input still coming) its first chunk back
+    auto further_passes = [&](ChunkStream &st, const std::vector<ku_batch *> &mine, bool more_input, bool say) {
+      const std::vector<size_t> &L = *st.list;
+      for (size_t i = 1; i < L.size(); ++i) {
+        if (say) fprintf(stderr, "\r Database chunk %zu of %zu", L[i] + 1, n_chunks);
+        join_prefetch(st);
+        KU_CHECK(ku_ctx_swap_shard(st.c, db, chunk_bounds[L[i]], chunk_bounds[L[i] + 1]));
+        if (first_super) add_chunk_counts(st.c);
+        // the chunk after this one -- or the list's first again for the next super-batch -- comes in underneath the passes
+        if (i + 1 < L.size()) start_prefetch(st, L[i + 1]);
+        else if (more_input) start_prefetch(st, L[0]);
+        for (ku_batch *b : mine) KU_CHECK(ku_batch_lookup(st.c, b, &opts));
+      }
+      if (more_input && L.size() > 1) {
+        join_prefetch(st);
+        KU_CHECK(ku_ctx_swap_shard(st.c, db, chunk_bounds[L[0]], chunk_bounds[L[0] + 1]));
+      }
+    };
     while (!input_done) {
-      // chunk 0 is resident here (loaded at start-up, or swapped back in at the end of the previous super-batch)
-      if (n_chunks > 1) start_prefetch(1);
+      // every GPU's first chunk is resident here (loaded at start-up, or swapped back in at the end of the previous super-batch)
+      for (auto &st : cs)
+        if (st.list->size() > 1) start_prefetch(st, (*st.list)[1]);
       std::vector<Batch *> all;
       uint64_t resident = 0;
       while (resident < budget) {
@@ -785,19 +839,35 @@ int main(int argc, char **argv) {
         resident += 5 * (uint64_t)bt->seqs_len + 12 * (uint64_t)bt->off.size();
         all.push_back(bt);
       }
-      if (all.empty()) { join_prefetch(); break; }
+      if (all.empty()) { for (auto &st : cs) join_prefetch(st); break; }
       ++n_super;
-      for (size_t c = 1; c < n_chunks; ++c) {
-        fprintf(stderr, "\r Database chunk %zu of %zu", c + 1, n_chunks);
-        join_prefetch();
-        KU_CHECK(ku_ctx_swap_shard(ctx, db, chunk_bounds[c], chunk_bounds[c + 1]));
-        if (first_super) add_chunk_counts();
-        // the chunk after this one -- or chunk 0 again for the next super-batch -- comes in underneath the passes
-        if (c + 1 < n_chunks) start_prefetch(c + 1);
-        else if (!input_done) start_prefetch(0);
-        for (Batch *bt : all) KU_CHECK(ku_batch_lookup(ctx, bt->dev, &opts));
+      // the helpers: their copies of the super-batch, every chunk of their lists over them
+      std::vector<std::vector<ku_batch *>> copies(n_ranks_x);
+      std::vector<std::thread> team;
+      for (size_t r = 1; r < n_ranks_x; ++r) {
+        if (cs[r].list->empty()) continue;
+        team.emplace_back([&, r] {
+          ChunkStream &st = cs[r];
+          for (Batch *bt : all) {
+            ku_batch *b = nullptr;
+            KU_CHECK(ku_batch_create(st.c, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), bt->off.size(), &b));
+            KU_CHECK(ku_batch_lookup(st.c, b, &opts));
+            copies[r].push_back(b);
+          }
+          further_passes(st, copies[r], !input_done, false);
+        });
       }
-      for (Batch *bt : all) {
+      std::vector<ku_batch *> mine;
+      for (Batch *bt : all) mine.push_back(bt->dev);
+      further_passes(cs[0], mine, !input_done, true);
+      for (auto &t : team) t.join();
+      for (size_t i = 0; i < all.size(); ++i) {
+        Batch *bt = all[i];
+        for (size_t r = 1; r < n_ranks_x; ++r)
+          if (i < copies[r].size()) {  // "non-zero wins" (src/classify.cpp:445-452): what the other GPUs' chunks found
+            KU_CHECK(ku_batch_absorb(ctx, bt->dev, copies[r][i]));
+            ku_batch_destroy(copies[r][i]);
+          }
         const uint64_t n = bt->off.size();
         bt->calls.assign(n, 0); bt->hits.assign(n, 0); bt->run_off.assign(n, 0); bt->run_cnt.assign(n, 0);
         uint64_t n_runs = 0;
@@ -811,12 +881,11 @@ int main(int argc, char **argv) {
         done_q.push(bt);
       }
       first_super = false;
-      if (!input_done && n_chunks > 1) {
-        join_prefetch();
-        KU_CHECK(ku_ctx_swap_shard(ctx, db, chunk_bounds[0], chunk_bounds[1]));
-      }
     }
-    join_prefetch();
+    for (auto &st : cs) join_prefetch(st);
+    // what the helpers' passes booked (HLL registers, k-mer counts) joins the first GPU's state: the report is written from there
+    for (size_t r = 1; r < n_ranks_x; ++r)
+      if (!rank_chunks[r].empty()) KU_CHECK(ku_ctx_merge_state(ctx, helpers[r - 1]));
     if (n_super > 1) fprintf(stderr, "\r %zu passes over the %zu database chunks (the input did not fit the device at once)\n", n_super, n_chunks);
   } else
   for (;;) {  // GPU stage
@@ -940,6 +1009,7 @@ int main(int argc, char **argv) {
   fprintf(stderr, "Finishing up ...\n");
   if (mg) ku_mgpu_destroy(mg);
   else ku_ctx_destroy(ctx);
+  for (ku_ctx *h : helpers) ku_ctx_destroy(h);
   ku_tax_close(tax);
   ku_uid_map_close(uid_map);
   for (ku_db *h : db_handles) ku_db_close(h);

@@ -2075,6 +2075,58 @@ extern "C" int ku_batch_create(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, 
   return KU_OK;
 }
 
+extern "C" int ku_batch_absorb(ku_ctx *ctx, ku_batch *dst, const ku_batch *src) {
+  KU_TRY(check_ready(ctx));
+  if (!dst || !src || dst->ctx != ctx || !src->ctx) return fail(KU_EINVAL, "ku_batch_absorb: null argument / batch of another context");
+  if (dst->n_bytes != src->n_bytes || dst->n_reads != src->n_reads) return fail(KU_EINVAL, "ku_batch_absorb: the batches hold different reads");
+  if (dst->finished || src->finished) return fail(KU_ESTATE, "ku_batch_absorb: a batch was already finished");
+  if (dst->n_bytes == 0 || dst == src) return KU_OK;
+  // the other copy's passes must be complete; then its slots come over (staged on this device when it lives on another)
+  if (hipSetDevice(src->ctx->device) != hipSuccess || hipStreamSynchronize(src->ctx->stream) != hipSuccess) return fail(KU_EHIP, "ku_batch_absorb: the source context's stream failed");
+  KU_TRY(ctx_activate(ctx));
+  hipStream_t s = ctx->stream;
+  const uint32_t *from = src->d_taxa;
+  if (src->ctx->device != ctx->device) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ctx->b_taxa.reserve(dst->n_bytes * 4) != KU_OK) return fail(KU_ENOMEM, "device memory for the slots of another GPU's batch");
+    HIP_TRY(hipMemcpyAsync(ctx->b_taxa.p, src->d_taxa, dst->n_bytes * 4, hipMemcpyDefault, s));
+    from = (const uint32_t *)ctx->b_taxa.p;
+  }
+  if (ku_launch_merge_max_u32(dst->d_taxa, from, dst->n_bytes, s) != KU_OK) return fail(KU_EHIP, "slot merge kernel launch failed");
+  HIP_TRY(hipStreamSynchronize(s));
+  return KU_OK;
+}
+
+extern "C" int ku_ctx_merge_state(ku_ctx *dst, ku_ctx *src) {
+  KU_TRY(check_ready(dst));
+  KU_TRY(check_ready(src));
+  if (dst == src) return KU_OK;
+  if (dst->tax.n_slots != src->tax.n_slots || dst->tax.n_nodes != src->tax.n_nodes) return fail(KU_EINVAL, "ku_ctx_merge_state: the contexts number their taxa differently");
+  if (hipSetDevice(src->device) != hipSuccess || hipStreamSynchronize(src->stream) != hipSuccess) return fail(KU_EHIP, "ku_ctx_merge_state: the source context's stream failed");
+  KU_TRY(ctx_activate(dst));
+  hipStream_t s = dst->stream;
+  const uint64_t n_regs = (uint64_t)dst->tax.n_slots * KU_HLL_M, n_slots = dst->tax.n_slots, n_nodes = dst->tax.n_nodes;
+  const uint8_t *regs = src->cnt.registers;
+  const unsigned long long *nk = src->cnt.n_kmers, *nr = src->cnt.n_reads;
+  DevBuf stage;
+  if (src->device != dst->device) {
+    if (stage.reserve(n_regs + (n_slots + n_nodes) * 8) != KU_OK) return fail(KU_ENOMEM, "device memory for another GPU's per-taxon state");
+    uint8_t *sp = (uint8_t *)stage.p;
+    HIP_TRY(hipMemcpyAsync(sp, regs, n_regs, hipMemcpyDefault, s));
+    HIP_TRY(hipMemcpyAsync(sp + n_regs, nk, n_slots * 8, hipMemcpyDefault, s));
+    HIP_TRY(hipMemcpyAsync(sp + n_regs + n_slots * 8, nr, n_nodes * 8, hipMemcpyDefault, s));
+    regs = sp;
+    nk = (const unsigned long long *)(sp + n_regs);
+    nr = (const unsigned long long *)(sp + n_regs + n_slots * 8);
+  }
+  if (ku_launch_merge_max_u8(dst->cnt.registers, regs, n_regs, s) != KU_OK || ku_launch_merge_add_u64(dst->cnt.n_kmers, nk, n_slots, s) != KU_OK ||
+      ku_launch_merge_add_u64(dst->cnt.n_reads, nr, n_nodes, s) != KU_OK)
+    return fail(KU_EHIP, "state merge kernel launch failed");
+  HIP_TRY(hipStreamSynchronize(s));
+  stage.release();
+  return KU_OK;
+}
+
 extern "C" int ku_batch_lookup(ku_ctx *ctx, ku_batch *b, const ku_opts *opts) {
   KU_TRY(check_ready(ctx));
   if (!b || b->ctx != ctx) return fail(KU_EINVAL, "ku_batch_lookup: batch of another context");

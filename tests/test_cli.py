@@ -196,6 +196,44 @@ def test_out_of_core_chunked_run(tmp_path, size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices,size", [("0,0", "30K"), ("0,0,0", "30K"), ("0,0,0,0,0,0,0", "70K")])
+def test_out_of_core_run_on_several_gpus(tmp_path, devices, size):
+    """KU_DEVICES with -x: the chunks are dealt out among the GPUs (chunk c on GPU c mod N; more GPUs than chunks: the rest
+    stay idle), every GPU streams its share over its own copies of the resident batches, the slots are folded into the
+    first GPU's batches before the finish, the per-taxon state at the end -- the reference's -x files, the counts file summed
+    over all GPUs' chunks, several super-batches, quick mode"""
+    d = tmp_path / "db"
+    d.mkdir()
+    for fn in ("database.kdb", "database.idx", "taxDB"):
+        (d / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
+    db = ["-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB"]
+    out, rep = tmp_path / "out.tsv", tmp_path / "rep.tsv"
+    env = {**os.environ, "KU_DEVICES": devices}
+    r = run(db + ["-x", size, "-t", "2", "-o", str(out), "-r", str(rep), f"{F1}/reads.fq"], env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"the database chunks of the out-of-core run are dealt out among them" in r.stderr
+    assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
+    assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
+    assert rows(rep.read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())
+    env2 = {**env, "KU_SUPERBATCH_BYTES": "100000", "KU_BATCH_NT": "65536"}
+    (d / "database.kdb.counts").unlink()
+    r2 = run(db + ["-x", size, "-t", "2", "-o", str(out), "-r", str(tmp_path / "rep2.tsv"), f"{F1}/reads.fq"], env=env2)
+    assert r2.returncode == 0, r2.stderr.decode()
+    assert b"passes over the" in r2.stderr
+    assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
+    assert rows((tmp_path / "rep2.tsv").read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())
+    assert (d / "database.kdb.counts").read_text() == open(f"{F1}/database.kdb.counts").read()
+    r3 = run(db + ["-x", size, "-t", "2", "-q", "-m", "2", "-o", str(out), "-r", str(tmp_path / "rep3.tsv"), f"{F1}/reads.fq"], env=env)
+    assert r3.returncode == 0, r3.stderr.decode()
+    assert out.read_bytes() == open(f"{F1}/out_chunk_quick.tsv", "rb").read()
+    assert rows((tmp_path / "rep3.tsv").read_text()) == rows(open(f"{F1}/report_chunk_quick.tsv").read())
+    # a preload size that takes the whole database: no chunks, the group runs sharded as without -x
+    r4 = run(db + ["-x", "10M", "-t", "2", "-o", str(out), f"{F1}/reads.fq"], env=env)
+    assert r4.returncode == 0 and b"database sharded by minimizer range" in r4.stderr
+    assert out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+
+
+@pytest.mark.gpu
 def test_mate_pairs_merged_on_the_fly(tmp_path):
     """-P r_1.fq r_2.fq == read_merger.pl | classify (scripts/krakenuniq:230-238): the reference's f4 outputs"""
     g = os.path.join(ROOT, "tests", "golden")
