@@ -407,9 +407,11 @@ int ku_counts_device_ptrs(ku_ctx *ctx, uint8_t **d_registers, uint64_t *n_regist
  * has this partitioning only in time (--preload-size chunk mode): ownership KrakenDB::prepare_chunking / upper_bound /
  * is_minimizer_in_chunk (krakendb.cpp:430-526), per-chunk lookup classify_sequence_with_db_chunk (classify.cpp:1014-1056),
  * "non-zero wins" merge (classify.cpp:445-452), final resolve pass (classify.cpp:676-785).  Here, per batch, either
- *   OWNER ROUTING (default): rank r takes slice r of the reads, scans it once (k-mers, minimizers), sends every
- *   unambiguous canonical k-mer to the rank that owns its bin (all-to-all), which probes its shard and accounts the k-mer
- *   -- HLL, n_kmers, misses under taxon 0: owner-computes, nothing is counted twice -- and sends the slot back; or
+ *   OWNER ROUTING (default): rank r takes slice r of the reads, scans it once (minimizers), sends every RUN of unambiguous
+ *   k-mers that share their minimizer occurrence -- one 16-byte record: the run's bases at 2 bits, its length, the offset
+ *   of the minimizer -- to the rank that owns the bin (all-to-all), which expands the records, probes its shard and
+ *   accounts the k-mers -- HLL, n_kmers, misses under taxon 0: owner-computes, nothing is counted twice -- and sends one
+ *   slot per k-mer back; or
  *   POSITION-WISE (KU_MGPU_EXCHANGE=slots; shards in the sorted layout, several passes): broadcast of the read batch from
  *   rank 0 -> ku_lookup_device(KU_F_KEEP_SLOTS) on every rank (each searches and accounts only the k-mers whose bin it
  *   owns) -> max-reduce of the per-k-mer slots, scattered over the read dimension;
@@ -438,8 +440,8 @@ ku_ctx *ku_mgpu_ctx(ku_mgpu *m, uint32_t local_index);
 /* 1 when the ranks exchange through RCCL, 0 for the same-process copy + merge exchange */
 int ku_mgpu_uses_rccl(const ku_mgpu *m);
 /* 1 when sharded batches are owner-routed (valid after the load / ku_mgpu_set_taxonomy): a rank scans only its own slice of
- * the reads and sends every k-mer to the rank that owns its minimizer bin (12 B out, a 4-B slot back) instead of every
- * rank scanning every read and exchanging 4 B per base position.  The default for sharded groups whose ranks all hold a
+ * the reads and sends every run of k-mers to the rank that owns its minimizer bin (~2 B per k-mer out, a 4-B slot back)
+ * instead of every rank scanning every read and exchanging 4 B per base position.  The default for sharded groups whose ranks all hold a
  * probe table of one database; KU_MGPU_EXCHANGE=slots keeps the position-wise exchange. */
 int ku_mgpu_uses_routing(const ku_mgpu *m);
 /* Measurement aid (bench.py): with timing on, every owner-routed step brackets its stages with HIP events on the streams

@@ -1,8 +1,10 @@
 // ku_mgpu.cpp -- the classify hot path over several GPUs: host C++ over the C ABI + RCCL (include/krakenuniq_amd.h,
 // "several GPUs").  One host thread per rank; the database is sharded by minimizer-bin range (the reference's
-// --preload-size partitioning, krakendb.cpp:430-526, laid out in space instead of in time), read batches are broadcast,
-// per-k-mer slots are max-reduced ("non-zero wins", classify.cpp:445-452) and scattered over the read dimension, every
-// rank resolves its slice (classify.cpp:676-785), the per-taxon state is reduced at the end of the run.
+// --preload-size partitioning, krakendb.cpp:430-526, laid out in space instead of in time).  Default exchange: OWNER
+// ROUTING (rank_step_routed) -- a rank scans its slice of the reads, runs of k-mers travel as 16-byte records to the rank
+// that owns their bin, one slot per k-mer comes back.  Kept beside it: the position-wise exchange -- read batches are
+// broadcast, per-k-mer slots are max-reduced ("non-zero wins", classify.cpp:445-452) and scattered over the read dimension.
+// Either way every rank resolves its slice (classify.cpp:676-785), the per-taxon state is reduced at the end of the run.
 //
 // Two exchange back ends behind one small interface (Comm):
 //   RCCL      ncclBroadcast / grouped ncclReduce (a reduce-scatter whose slices end on read boundaries) / ncclAllReduce /
