@@ -851,8 +851,11 @@ def main():
             if headline:
                 # configs[2] scaled to this world: the standard geometry, one ~37 GB minimizer-range shard (12 000 species) per GPU
                 # -- at N = 8 the ~300 GB database of BASELINE.json --, 10 M x 150 bp reads per step over all ranks
-                a2.nt, a2.species, a2.genome_len, a2.db_shards = 15, 12_000 * ws, 310_000, ws
-                a2.reads, a2.read_len, a2.paired, a2.batches = 10_000_000, 150, False, 2
+                # (KU_BENCH_SHARD_SPECIES / _GENOME_LEN / _READS / _NT: the same flow at a size a test box holds N times)
+                a2.nt, a2.db_shards = int(os.environ.get("KU_BENCH_SHARD_NT", "15")), ws
+                a2.species = int(os.environ.get("KU_BENCH_SHARD_SPECIES", "12000")) * ws
+                a2.genome_len = int(os.environ.get("KU_BENCH_SHARD_GENOME_LEN", "310000"))
+                a2.reads, a2.read_len, a2.paired, a2.batches = int(os.environ.get("KU_BENCH_SHARD_READS", "10000000")), 150, False, 2
             s_steps = a.steps if headline else max(2, min(a.steps, 4))
             s_warm = a.warmup if headline else 1
             sr = sharded_run(a2, capi, synth_torch, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, s_warm, stream)
@@ -875,7 +878,7 @@ def main():
         result = {"metric": "Mreads/s (150 bp)", "value": sh["value"], "unit": "Mreads/s", "n_gpus": ws, "steps": sh["steps"],
                   "warmup": sh["warmup"], "ms_per_step": sh["ms_per_step"], "higher_is_better": True, "scaling": "strong",
                   "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-                  "config": {"workload": f"configs[2] scaled to {ws} GPUs: standard-geometry DB (k=31, nt=15, {sh['taxa']} taxa, ~{37 * ws} GB of pairs) "
+                  "config": {"workload": f"configs[2] scaled to {ws} GPUs: standard-geometry DB (k=31, nt={sh['nt']}, {sh['taxa']} taxa, {sh['db_pairs_per_gpu'] * 12 / 1e9:.1f} GB of pairs per GPU) "
                                          f"sharded by minimizer bin, rank r holds shard r of {sh['db_shards']}; {sh['reads_per_step']} reads of 150 bp per step, "
                                          "scattered from rank 0, owner-routed over RCCL",
                              "db_pairs_per_gpu": sh["db_pairs_per_gpu"], "hbm_layout": sh["hbm_layout"], "k": k, "nt": sh["nt"], "taxa": sh["taxa"],

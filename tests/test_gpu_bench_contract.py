@@ -80,3 +80,23 @@ def test_two_ranks_replicas_line_with_real_peers():
     d = run_bench_world(2, "--mode", "replicas", "--no-extras")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["merged_read_count_ok"] is True
+
+
+def test_two_ranks_plain_line_has_the_sharded_layout_as_its_headline():
+    """`bench.py --gpus 2` without --mode / --config: both legs run, the line is the sharded layout's (configs[2] scaled to the
+    world -- here at a size two ranks on one GPU hold), the replicas are the second leg"""
+    shim = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
+    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_SHIM_TIMEOUT="120", KU_BENCH_SHARD_SPECIES="40",
+               KU_BENCH_SHARD_GENOME_LEN="50000", KU_BENCH_SHARD_READS="100000", KU_BENCH_SHARD_NT="11")  # (nt = 15: 8.6 GB of index per rank, minutes)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "100000",
+                        "--species", "60", "--genome-len", "60000", "--cpu-sample", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert d["config"]["parallelism"] == "sharded2" and d["config"]["nt"] == 11 and d["config"]["every_read_resolved_once"] is True
+    assert d["roofline"]["stage_ms_measured"]["owner_ms"] > 0 and d["wire"]["exchange"].startswith("owner routing")
+    rep = d["replicas"]
+    assert rep["scaling"] == "weak" and rep["value"] > 0 and rep["config"]["merged_read_count_ok"] is True
