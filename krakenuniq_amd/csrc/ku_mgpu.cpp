@@ -958,8 +958,10 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
   }
   // ---- the second set's stream follows the caller's up to here
   hipStream_t str[2] = {s, s};
-  // (with the stage timing on, everything stays on one stream: kernels side by side would stretch each other's event pairs)
-  if (R > 1 && !std::getenv("KU_ROUTE_ONE_STREAM") && !m->timing) {
+  // (with the stage timing on, everything stays on one stream: kernels side by side would stretch each other's event pairs.
+  // Over RCCL too, unless KU_ROUTE_TWO_STREAMS=1: collectives of one communicator issued from two streams are ordered by the
+  // library, but that path has never run on more than one physical GPU here, and what the second stream buys is ~4 %.)
+  if (R > 1 && !std::getenv("KU_ROUTE_ONE_STREAM") && !m->timing && (!m->use_rccl || std::getenv("KU_ROUTE_TWO_STREAMS"))) {
     if (!r.aux && hipStreamCreateWithFlags(&r.aux, hipStreamNonBlocking) != hipSuccess) { r.aux = nullptr; st = st == KU_OK ? mfail(KU_EHIP, "stream creation failed") : st; }
     for (hipEvent_t *e : {&r.ev_a, &r.ev_b, &r.ev_r})
       if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; st = st == KU_OK ? mfail(KU_EHIP, "event creation failed") : st; }

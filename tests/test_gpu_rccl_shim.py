@@ -50,4 +50,5 @@ def test_processes_with_real_peers_match_one_context(world, mode):
 
 def test_routed_rounds_on_two_streams_with_real_peers():
     """several rounds per step (two buffer sets, two streams) through the send / receive pairs"""
-    run_world(2, "route", {"KU_ROUTE_ROUND": "1500000"})
+    run_world(2, "route", {"KU_ROUTE_ROUND": "1500000", "KU_ROUTE_TWO_STREAMS": "1"})
+    run_world(2, "route", {"KU_ROUTE_ROUND": "1500000"})  # (the default over RCCL: the rounds on one stream)
