@@ -375,6 +375,71 @@ def test_device_step_matches_single_context(exchange, monkeypatch):
     mg.close()
 
 
+@pytest.mark.parametrize("shape", ["pairs", "long", "long_rounds"])
+def test_routed_step_with_windowed_reads_matches_single_context(shape, monkeypatch):
+    """reads beyond 128 k-mers through the routed step: the resolve stage is then the WINDOWED `ROUTE` instance of the fused
+    kernel (tickets -> slots window by window, hit counts across windows).  Mate pairs 2 x 150 + N and 3 kbp reads (with
+    ambiguous bases), three ranks on one device, against one context that holds the whole database (whose windowed
+    kernel the oracle tests pin); `long_rounds`: the same in several rounds cut at read boundaries"""
+    import torch
+    if shape == "long_rounds":
+        monkeypatch.setenv("KU_ROUTE_ROUND", "2000003")
+    dev = torch.device("cuda:0")
+    NT, W = 11, 3
+    db = synth_torch.BenchDb(dev, n_species=100, genome_len=60_000, k=K, nt=NT, seed=3)
+    ids, par = db.tax.arrays()
+    ctax = capi.Tax(ids=ids, parents=par)
+    if shape == "pairs":
+        N, L = 60_000, 301
+        seqs, off, lens = db.sample_pairs(N, 150, seed=9)
+    else:
+        N, L = 6_000, 3000
+        seqs, off, lens, _ = db.sample_reads(N, L, seed=9)
+    seqs = seqs.reshape(-1)
+    nb = seqs.numel()
+    stride = nb // N
+    ctx = capi.Ctx(0)
+    ctx.adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), K, NT, 2, keep=db)
+    ctx.set_taxonomy(ctax)
+    taxa1 = torch.zeros(nb, dtype=torch.int32, device=dev)
+    calls1 = torch.zeros(N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.classify_batch_device(seqs.data_ptr(), nb, off.data_ptr(), lens.data_ptr(), N, calls1.data_ptr(), taxa1.data_ptr(), max_read_len=L)
+    ctx.synchronize()
+    want = ctx.counts()
+    offs = db.offsets
+    bounds = [0] + [int(torch.searchsorted(offs, offs[-1] * q // W).item()) for q in range(1, W)] + [4 ** NT]
+    mg = capi.Mgpu([0] * W)
+    shards = []
+    for r in range(W):
+        sh = synth_torch.BenchDb(dev, n_species=100, genome_len=60_000, k=K, nt=NT, seed=3, bin_lo=bounds[r], bin_hi=bounds[r + 1])
+        mg.ctx(r).adopt_db(sh.pairs.data_ptr(), sh.n_pairs, sh.offsets.data_ptr(), K, NT, 2, bounds[r], bounds[r + 1])
+        shards.append(sh)
+    mg.set_taxonomy(ctax)
+    assert mg.uses_routing()
+    rb = [N * r // W for r in range(W + 1)]
+    pb = [x * stride for x in rb]
+    bufs = []
+    for r in range(W):
+        bufs.append({"seqs": seqs if r == 0 else torch.zeros(nb + 16, dtype=torch.uint8, device=dev),
+                     "off": off if r == 0 else torch.zeros(N, dtype=torch.int64, device=dev),
+                     "len": lens if r == 0 else torch.zeros(N, dtype=torch.int32, device=dev),
+                     "calls": torch.zeros(N, dtype=torch.int32, device=dev), "taxa": torch.zeros(nb + 16, dtype=torch.int32, device=dev)})
+    torch.cuda.synchronize()
+    mg.step_device([{"d_seqs": b["seqs"].data_ptr(), "d_seq_off": b["off"].data_ptr(), "d_seq_len": b["len"].data_ptr(),
+                     "d_calls": b["calls"].data_ptr(), "d_taxa": b["taxa"].data_ptr()} for b in bufs], nb, N, rb, pb, max_read_len=L)
+    for r in range(W):
+        mg.ctx(r).synchronize()
+    nk = L - K + 1
+    for r in range(W):
+        lo, hi = rb[r], rb[r + 1]
+        assert torch.equal(bufs[r]["calls"][lo:hi], calls1[lo:hi]), r
+        assert torch.equal(bufs[r]["taxa"][:nb].view(N, stride)[lo:hi, :nk], taxa1.view(N, stride)[lo:hi, :nk]), r
+    mg.reduce_state()
+    assert same_counts(mg.ctx(2).counts(), want)
+    mg.close()
+
+
 def test_routed_step_of_eight_ranks_on_the_bench_database_matches_one_context():
     """owner routing at size: the 8 GB bench database in eight minimizer-range shards, eight ranks on
     the one device, 2 M reads per step -- calls, per-k-mer codes and the reduced per-taxon state equal one context that
