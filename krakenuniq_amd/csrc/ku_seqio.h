@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/krakenuniq_amd.h"
+#include "ku_pgzip.h"
 
 namespace ku_seqio {
 
@@ -156,6 +157,19 @@ struct Reader {
   std::vector<BgzfSlot> bz_slots;
   std::vector<std::thread> bz_team;
 
+  // plain .gz input (ONE deflate stream): inflated by a team all the same, ku_pgzip.h -- spans of the compressed file are
+  // decoded side by side from block starts found by search, their unknown 32 KiB of history resolved afterwards.  A
+  // coordinator thread runs the rounds and hands their text on through two slots; zlib (gzread) remains for pipes,
+  // small files and KU_NO_PGZIP=1.
+  ku_pgzip::ParallelGunzip *pgz = nullptr;
+  struct PgzSlot { ku_pgzip::RawBuf<char> text; size_t n = 0; bool full = false; };
+  PgzSlot pgz_slot[2];
+  size_t pgz_put = 0, pgz_get = 0;
+  bool pgz_done = false;
+  std::thread pgz_thread;
+  const unsigned char *pgz_map = nullptr;
+  size_t pgz_len = 0;
+
   Reader() = default;
   Reader(const Reader &) = delete;
   Reader &operator=(const Reader &) = delete;
@@ -251,6 +265,49 @@ struct Reader {
     g = nullptr;
     return true;
   }
+  bool open_pgzip(const char *path, size_t n) {
+    if (n < ((size_t)64 << 10)) return false;
+    const int f = ::open(path, O_RDONLY);
+    if (f < 0) return false;
+    void *mp = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, f, 0);
+    ::close(f);
+    if (mp == MAP_FAILED) return false;
+    const unsigned char *p = (const unsigned char *)mp;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) { munmap(mp, n); return false; }
+    int team = (int)std::thread::hardware_concurrency();
+    team = std::max(1, std::min(team, 8));
+    if (const char *e = getenv("KU_PGZIP_TEAM")) team = std::max(1, std::min(atoi(e), 64));
+    pgz_map = p;
+    pgz_len = n;
+    pgz = new ku_pgzip::ParallelGunzip;
+    pgz->open(p, n, team);
+    pgz_put = pgz_get = 0;
+    pgz_done = false;
+    pgz_slot[0].full = pgz_slot[1].full = false;
+    pgz_thread = std::thread([this] {
+      for (;;) {
+        PgzSlot *sl;
+        {
+          std::unique_lock<std::mutex> l(mu);
+          cv.wait(l, [&] { return stop || !pgz_slot[pgz_put & 1].full; });
+          if (stop) return;
+          sl = &pgz_slot[pgz_put & 1];
+        }
+        size_t got = 0;
+        const bool more = pgz->round(sl->text, got);
+        {
+          std::lock_guard<std::mutex> l(mu);
+          if (!more) pgz_done = true;
+          else { sl->n = got; sl->full = true; ++pgz_put; }
+        }
+        cv.notify_all();
+        if (!more) return;
+      }
+    });
+    gzclose(g);
+    g = nullptr;
+    return true;
+  }
   void open(const char *path, bool prefetch = false) {
     g = gzopen(path, "rb");
     if (!g) fatal(66, "can't open %s", path);
@@ -267,6 +324,11 @@ struct Reader {
     valid = true; eof = false;
     produced_all = stop = false;
     if (prefetch && g && S_ISREG(st.st_mode) && !getenv("KU_NO_BGZF") && open_bgzf(path, (size_t)st.st_size)) {
+      more();
+      fastq = len > 0 && buf[0] == '@';
+      return;
+    }
+    if (prefetch && g && S_ISREG(st.st_mode) && !getenv("KU_NO_PGZIP") && open_pgzip(path, (size_t)st.st_size)) {
       more();
       fastq = len > 0 && buf[0] == '@';
       return;
@@ -311,6 +373,16 @@ struct Reader {
       for (auto &t : bz_team) t.join();
       bz_team.clear();
     }
+    if (pgz_thread.joinable()) {
+      { std::lock_guard<std::mutex> l(mu); stop = true; }
+      cv.notify_all();
+      pgz_thread.join();
+    }
+    delete pgz;
+    pgz = nullptr;
+    if (pgz_map) munmap((void *)pgz_map, pgz_len);
+    pgz_map = nullptr;
+    for (PgzSlot &sl : pgz_slot) { sl.full = false; sl.n = 0; }
     if (bz_map) munmap((void *)bz_map, bz_len);
     bz_map = nullptr;
     bz_tasks.clear(); bz_slots.clear();
@@ -331,6 +403,25 @@ struct Reader {
       if (len > pos) memmove(buf.data(), buf.data() + pos, len - pos);
       len -= pos;
       pos = 0;
+    }
+    if (pgz) {  // the next round's text
+      PgzSlot &sl = pgz_slot[pgz_get & 1];
+      {
+        std::unique_lock<std::mutex> l(mu);
+        cv.wait(l, [&] { return sl.full || pgz_done; });
+        if (!sl.full) {
+          if (!pgz->error.empty()) fatal(65, "%s", pgz->error.c_str());
+          eof = true;
+          return false;
+        }
+      }
+      if (len + sl.n > buf.size()) buf.resize(std::max(buf.size() * 2, len + sl.n));
+      memcpy(buf.data() + len, sl.text.d, sl.n);
+      len += sl.n;
+      const bool any = sl.n > 0;
+      { std::lock_guard<std::mutex> l(mu); sl.full = false; ++pgz_get; }
+      cv.notify_all();
+      return any || more();
     }
     if (bz_map) {  // the next task's text, in file order
       if (bz_next_out >= bz_tasks.size()) { eof = true; return false; }

@@ -1,6 +1,7 @@
 // Test / measurement aid for the classify executable's input stage (ku_seqio.h): parses FASTA/FASTQ(+gz) files
 // exactly as the reader thread does and prints "id<TAB>sequence" per read, or with -n only the parsing rate.
 // -j N parses N record-aligned regions of each (plain) file independently, as the executable's parser team does.
+// -z J inflates each file with the J-thread gzip team alone (ku_pgzip.h) and writes the bytes (with -n: the rate).
 // Host-only: does not link the GPU library (pinned allocation is replaced by malloc here), classifies nothing.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -14,6 +15,7 @@
 #include <cstdlib>
 
 #include "ku_seqio.h"
+#include "ku_pgzip.h"
 
 // the batches of this tool are plain host memory (Batch::pinned = false); these are never called
 extern "C" int ku_host_alloc(size_t, void **out) { *out = nullptr; return KU_ENOMEM; }
@@ -30,19 +32,46 @@ void ku_seqio::fatal(int code, const char *fmt, ...) {
 
 int main(int argc, char **argv) {
   bool paired = false, quiet = false, prefetch = false, warm = false;
-  int regions = 0;
+  int regions = 0, gunzip_team = 0;
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
     if (argv[a][1] == 'P') paired = true;
     else if (argv[a][1] == 'n') quiet = true;
     else if (argv[a][1] == 'T') prefetch = true;
     else if (argv[a][1] == 'w') warm = true;  // -j: parse every region twice into the same batch, time the second pass (buffers and pages warm)
+    else if (argv[a][1] == 'z' && a + 1 < argc) gunzip_team = atoi(argv[++a]);
     else if (argv[a][1] == 'j' && a + 1 < argc) regions = atoi(argv[++a]);  // producer thread per file, as the classify executable runs
   }
   timeval t0, t1;
   gettimeofday(&t0, nullptr);
   uint64_t n_reads = 0, n_bytes = 0;
   std::string header, header2;
+  for (; gunzip_team > 0 && a < argc; ++a) {
+    int fd = ::open(argv[a], O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) ku_seqio::fatal(66, "can't open %s", argv[a]);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *data = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)"";
+    ::close(fd);
+    ku_pgzip::ParallelGunzip pg;
+    pg.open(data, n, gunzip_team);
+    ku_pgzip::RawBuf<char> out;
+    size_t got = 0;
+    uint64_t total = 0;
+    while (pg.round(out, got)) {
+      total += got;
+      if (!quiet) fwrite(out.d, 1, got, stdout);
+    }
+    if (!pg.error.empty()) ku_seqio::fatal(65, "%s: %s", argv[a], pg.error.c_str());
+    gettimeofday(&t1, nullptr);
+    const double s = (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_usec - t0.tv_usec) / 1e6;
+    fprintf(stderr, "%llu bytes in %.3f s: %.1f MB/s; %llu rounds, %llu spans, %llu dropped\n", (unsigned long long)total, s, total / s / 1e6,
+            (unsigned long long)pg.n_rounds, (unsigned long long)pg.n_spans, (unsigned long long)pg.n_dropped);
+    fprintf(stderr, "  decode %.3f s (span 0 alone %.3f; block search %.3f summed over spans), windows %.3f, translate + crc %.3f\n", pg.t_decode, pg.t_first,
+            pg.search_us.load() / 1e6, pg.t_resolve, pg.t_translate);
+    if (n) munmap((void *)data, n);
+    if (a + 1 == argc) return 0;
+  }
   for (; regions > 0 && a < argc; ++a) {  // region-parallel parse of plain files
     int fd = ::open(argv[a], O_RDONLY);
     struct stat st;

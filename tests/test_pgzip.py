@@ -1,0 +1,175 @@
+"""One gzip stream inflated by a team of threads (krakenuniq_amd/csrc/ku_pgzip.h), the .gz side of the classify executable's
+input stage.  The reference reads .gz through zlib's gzread (src/seqreader.cpp:26-133 via kseq/gzFile); the bytes handed
+to the parser must be the bytes zlib would hand over, for every shape a deflate stream can take, and damaged files must be
+refused.  Checked through bin/seqio_dump -z J (the inflater alone, J threads) against Python's zlib."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "krakenuniq_amd", "bin", "seqio_dump")
+
+
+def fastq(n, seed=1):
+    r = np.random.default_rng(seed)
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, (n, 150))]
+    quals = (r.integers(0, 40, (n, 150)) // 8 * 8 + 33).astype(np.uint8)
+    return b"".join(b"@read%d some/description\n" % i + seqs[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n" for i in range(n))
+
+
+def fasta(n, seed=3):
+    r = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        L = int(r.integers(100, 5000))
+        s = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[r.integers(0, 9, L)].tobytes()
+        out.append(b">seq%d desc\n" % i + b"\n".join(s[j:j + 60] for j in range(0, L, 60)) + b"\n")
+    return b"".join(out)
+
+
+def deflate_raw(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, flush_every=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    if not flush_every:
+        return c.compress(data) + c.flush()
+    out = []
+    for i in range(0, len(data), flush_every):  # (what pigz and "gzip --rsyncable"-like writers leave: empty stored blocks)
+        out.append(c.compress(data[i:i + flush_every]))
+        out.append(c.flush(zlib.Z_SYNC_FLUSH if (i // flush_every) % 2 else zlib.Z_FULL_FLUSH))
+    out.append(c.flush())
+    return b"".join(out)
+
+
+def member(data, raw=None, flg=0, extra=b"", hcrc_xor=0):
+    raw = deflate_raw(data) if raw is None else raw
+    head = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\0\x03" + extra
+    if flg & 2:  # FHCRC
+        head += struct.pack("<H", (zlib.crc32(head) & 0xffff) ^ hcrc_xor)
+    return head + raw + struct.pack("<II", zlib.crc32(data), len(data) & 0xffffffff)
+
+
+def zlib_accepts(blob):
+    """every member decodes to its end with a matching trailer; bytes behind the last member that do not start with the gzip
+    magic are ignored (gzread's rule)"""
+    while blob[:2] == b"\x1f\x8b":
+        d = zlib.decompressobj(31)
+        try:
+            d.decompress(blob)
+        except zlib.error:
+            return False
+        if not d.eof:
+            return False
+        blob = d.unused_data
+    return True
+
+
+def inflate(path, team, span_kb=None):
+    env = dict(os.environ)
+    if span_kb:
+        env["KU_PGZIP_SPAN_KB"] = str(span_kb)
+    return subprocess.run([DUMP, "-z", str(team), str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+
+
+FQ = fastq(24000)
+FA = fasta(1500)
+RND = np.random.default_rng(5).integers(0, 256, 1_500_000, dtype=np.uint8).tobytes()
+BINC = (np.random.default_rng(6).integers(0, 4, 3_000_000, dtype=np.uint8) * 50).tobytes()
+STREAMS = {
+    "fastq_level1": lambda: (member(FQ, deflate_raw(FQ, 1)), FQ),
+    "fastq_level6": lambda: (member(FQ), FQ),
+    "fastq_level9": lambda: (member(FQ, deflate_raw(FQ, 9)), FQ),
+    "fasta": lambda: (member(FA), FA),
+    "two_members": lambda: (member(FQ[:3000000]) + member(FQ[3000000:]), FQ),
+    "many_members": lambda: (b"".join(member(FQ[i:i + 200000]) for i in range(0, len(FQ), 200000)), FQ),
+    "stored_blocks": lambda: (member(FQ, deflate_raw(FQ, 0)), FQ),
+    "fixed_huffman": lambda: (member(FQ, deflate_raw(FQ, 6, zlib.Z_FIXED)), FQ),
+    "huffman_only": lambda: (member(FQ, deflate_raw(FQ, 6, zlib.Z_HUFFMAN_ONLY)), FQ),
+    "rle": lambda: (member(FQ, deflate_raw(FQ, 6, zlib.Z_RLE)), FQ),
+    "flush_points": lambda: (member(FQ, deflate_raw(FQ, 6, flush_every=131072)), FQ),
+    "random_bytes": lambda: (member(RND), RND),                 # not text, incompressible: stored blocks, no span validates
+    "binary_compressible": lambda: (member(BINC), BINC),        # not text: the search never validates, one decoder
+    "empty": lambda: (member(b""), b""),
+    "tiny": lambda: (member(b"@a\nACGT\n+\nIIII\n"), b"@a\nACGT\n+\nIIII\n"),
+    "trailing_zeros": lambda: (member(FQ) + b"\0" * 1000, FQ),  # zlib's gzread ignores what does not start with the magic
+    "header_fields": lambda: (member(FQ, flg=4 | 8 | 16 | 2, extra=b"\x05\0hello" + b"name.fq\0" + b"a comment\0"), FQ),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(STREAMS))
+def test_team_inflate_equals_zlib(shape, tmp_path):
+    """every stream shape, with one, two, four and seven threads and with spans of 2 MiB (default), 64 KiB and 4 KiB of
+    compressed data (many rounds, spans smaller than a deflate block, spans that find no block start)"""
+    assert os.path.exists(DUMP), "build with make -C krakenuniq_amd/csrc"
+    blob, want = STREAMS[shape]()
+    assert zlib_accepts(blob)
+    p = tmp_path / "t.gz"
+    p.write_bytes(blob)
+    for span_kb in (None, 64, 4):
+        for team in (1, 2, 4, 7):
+            r = inflate(p, team, span_kb)
+            assert r.returncode == 0, (shape, team, span_kb, r.stderr.decode()[-300:])
+            assert r.stdout == want, (shape, team, span_kb, len(r.stdout), len(want))
+
+
+def test_spans_are_really_decoded_side_by_side(tmp_path):
+    """the block search finds the deflate blocks of FASTQ text and the chain of spans holds: with four threads about four
+    spans per round, none dropped"""
+    p = tmp_path / "t.gz"
+    p.write_bytes(member(FQ))
+    r = subprocess.run([DUMP, "-n", "-z", "4", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_PGZIP_SPAN_KB="256"))
+    assert r.returncode == 0
+    import re
+    m = re.search(r"(\d+) rounds, (\d+) spans, (\d+) dropped", r.stderr.decode())
+    rounds, spans, dropped = map(int, m.groups())
+    assert spans >= 3 * rounds and dropped == 0, r.stderr.decode()
+
+
+@pytest.mark.parametrize("damage", ["truncated", "no_trailer", "flipped_bit", "bad_crc", "bad_isize", "garbage_member", "header_crc"])
+def test_damaged_files_are_refused(damage, tmp_path):
+    """as gzread fails on them (Z_DATA_ERROR / Z_BUF_ERROR): nonzero exit, whatever the team"""
+    blob = member(FQ)
+    at = len(blob) // 2
+    bad = {"truncated": blob[:at], "no_trailer": blob[:-8], "flipped_bit": blob[:at] + bytes([blob[at] ^ 0x10]) + blob[at + 1:],
+           "bad_crc": blob[:-8] + b"\0\0\0\0" + blob[-4:], "bad_isize": blob[:-4] + b"\1\0\0\0",
+           "garbage_member": blob + b"\x1f\x8b\x08\0\0\0\0\0\0\x03" + b"\xff" * 64,
+           "header_crc": member(FQ, flg=2 | 8, extra=b"name\0", hcrc_xor=1)}[damage]
+    p = tmp_path / "t.gz"
+    p.write_bytes(bad)
+    assert not zlib_accepts(bad)
+    for team in (1, 4):
+        for span_kb in (None, 64):
+            r = inflate(p, team, span_kb)
+            assert r.returncode != 0, (damage, team, span_kb)
+
+
+def test_reader_takes_plain_gz_through_the_team(tmp_path):
+    """the executable's reader (-T: with its producer side) parses a plain .gz through the team: same records as the text and
+    as zlib's reader (KU_NO_PGZIP=1), single file and mate pairs"""
+    text = fastq(9000, seed=11)
+    plain = tmp_path / "r.fq"
+    plain.write_bytes(text)
+    z1 = tmp_path / "r1.fq.gz"
+    z1.write_bytes(member(text))
+    z2 = tmp_path / "r2.fq.gz"
+    z2.write_bytes(member(fastq(9000, seed=12), deflate_raw(fastq(9000, seed=12), 1)))
+
+    def run(args, **env):
+        r = subprocess.run([DUMP] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()
+        return r.stdout
+    want = run([str(plain)])
+    assert run(["-T", str(z1)]) == want
+    assert run(["-T", str(z1)], KU_PGZIP_SPAN_KB="64", KU_PGZIP_TEAM="3") == want
+    assert run(["-T", str(z1)], KU_NO_PGZIP="1") == want
+    pairs = run(["-P", "-T", str(z1), str(z2)], KU_NO_PGZIP="1")
+    assert run(["-P", "-T", str(z1), str(z2)]) == pairs
+    assert run(["-P", "-T", str(z1), str(z2)], KU_PGZIP_SPAN_KB="128") == pairs
+    # damage is an error of the run (gzread's -1 ended the input silently before)
+    bad = tmp_path / "bad.fq.gz"
+    blob = member(text)
+    bad.write_bytes(blob[:len(blob) // 2])
+    r = subprocess.run([DUMP, "-T", str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 65 and b"gzip" in r.stderr
