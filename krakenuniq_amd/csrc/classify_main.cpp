@@ -495,65 +495,83 @@ int main(int argc, char **argv) {
   double busy_reader = 0, busy_gpu = 0, busy_writer = 0, busy_format = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
   double busy_gpu_classify = 0, busy_gpu_fetch = 0;                       // ... of the device stage: the batch call, the runs' copy back
 
-  // Plain (uncompressed) regular files: the file is mapped, cut into record-aligned regions of about one work unit
-  // and parsed by `parse_team` threads, each into its own batch; the batches go on in file order.  A member takes a
-  // batch BEFORE it takes a region number, so the lowest outstanding region always owns one and the team cannot
-  // starve itself.  false: not a plain regular file -> the sequential reader below handles it.
-  auto parse_plain_file_in_regions = [&](const char *path) -> bool {
+  // Regular files, plain or .gz: the text is cut into record-aligned regions of about a quarter work unit and parsed by
+  // `parse_team` threads, each into its own batch; the batches go on in file order.  A plain file is mapped; a .gz file
+  // (BGZF or one gzip stream, ku_pgzip.h) is inflated by its own team into text that grows while it is parsed
+  // (ku_seqio::GrowingText) -- the single reader below managed 5 M reads/s of it, with zlib's one inflate 1.7.  A member
+  // takes a batch BEFORE it takes a region number, so the lowest outstanding region always owns one and the team cannot
+  // starve itself.  false: neither (a pipe, an empty file, no room) -> the sequential reader below handles it.
+  auto parse_file_in_regions = [&](const char *path) -> bool {
     struct stat st;
     if (::stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) return false;  // pipes: one sequential reader
+    bool direct;
     {
       gzFile g = gzopen(path, "rb");
       if (!g) die(EX_NOINPUT, "can't open %s", path);
-      const bool direct = gzdirect(g) != 0;
+      direct = gzdirect(g) != 0;
       gzclose(g);
-      if (!direct) return false;
     }
-    int fd = ::open(path, O_RDONLY);
-    if (fd < 0) return false;
+    ku_seqio::GrowingText gtext;
+    ku_seqio::GzTextStream gz;
+    ku_seqio::RegionCutter cut;
+    void *map = MAP_FAILED;
     const size_t n = (size_t)st.st_size;
-    void *map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (map == MAP_FAILED) return false;
-    const char *data = (const char *)map;
+    if (direct) {
+      int fd = ::open(path, O_RDONLY);
+      if (fd < 0) return false;
+      map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      ::close(fd);
+      if (map == MAP_FAILED) return false;
+      cut.data = (const char *)map;
+      cut.n = n;
+    } else {
+      if (getenv("KU_NO_GZ_REGIONS") || !gz.open(path, gtext)) return false;
+      bool complete;
+      if (gtext.wait_for(1, &complete) == 0) {  // no text at all
+        gz.close();
+        if (!gtext.error.empty()) die(EX_DATAERR, "%s: %s", path, gtext.error.c_str());
+        return true;
+      }
+      cut.data = gtext.base;
+      cut.gt = &gtext;
+    }
+    const char *data = cut.data;
     const bool fastq = data[0] == '@';  // determine_input_file_type (src/classify.cpp:377-388)
+    cut.fastq = fastq;
     const double t_parse = now_s();
     // a quarter of a work unit per region: the team's batches are pinned memory, smaller ones are quicker to set up
     // and keep the three stages busier.  FASTQ text is ~2.2 bytes per base (header, '+', qualities), FASTA ~1.05
-    const size_t region_bytes = std::max<size_t>((size_t)1 << 16, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
+    cut.region_bytes = std::max<size_t>((size_t)1 << 16, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
     std::mutex mu;
     std::condition_variable cv;
-    size_t next_cut = 0, next_region = 0, next_out = 0;
-    bool stop = false;  // the stream ended inside a region: nothing behind it counts
+    size_t next_out = 0;
     bool file_start_pending = false;  // the file's first region held no bases: the next batch that goes on opens the file
-    std::map<size_t, std::pair<Batch *, bool>> ready;
+    struct Parsed { Batch *bt; bool whole; size_t hi; };
+    std::map<size_t, Parsed> ready;
     auto member = [&] {
       for (;;) {
         Batch *bt = chunked ? new Batch() : free_q.pop();
         size_t lo, hi, idx;
-        {
-          std::lock_guard<std::mutex> l(mu);
-          if (stop || next_cut >= n) { if (chunked) { bt->release(); delete bt; } else free_q.push(bt); return; }
-          lo = next_cut;
-          hi = ku_seqio::find_record_start(data, n, lo + region_bytes, fastq);
-          next_cut = hi;
-          idx = next_region++;
+        if (!cut.claim(lo, hi, idx)) {
+          if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
+          { std::lock_guard<std::mutex> l(mu); }
+          cv.notify_all();
+          return;
         }
         bt->clear();
         bt->fastq = fastq;
         bt->first_of_file = lo == 0;
         bt->reserve_seq(fastq ? (hi - lo) / 2 + 4096 : hi - lo);  // one allocation: the sequences are at most that long
 #ifdef MADV_POPULATE_READ
-        {  // the region's pages into this process's page table with one call instead of one fault per 4 KiB (eight threads
-           // faulting in one address space queue on its locks: a third of the team's time); failure is harmless
+        if (direct) {  // the region's pages into this process's page table with one call instead of one fault per 4 KiB (eight
+                       // threads faulting in one address space queue on its locks: a third of the team's time); failure is harmless
           static const bool populate = !(getenv("KU_NO_POPULATE") && atoi(getenv("KU_NO_POPULATE")));
           const size_t pg = 4096, a0 = lo & ~(pg - 1);
           if (populate) (void)madvise((void *)(data + a0), hi - a0, MADV_POPULATE_READ);
         }
 #endif
         const bool whole = ku_seqio::parse_region(data + lo, hi - lo, fastq, *bt, keep_records);
-        std::lock_guard<std::mutex> l(mu);
-        ready[idx] = {bt, whole};
+        { std::lock_guard<std::mutex> l(mu); ready[idx] = Parsed{bt, whole, hi}; }
         cv.notify_all();
       }
     };
@@ -561,16 +579,19 @@ int main(int argc, char **argv) {
     for (int t = 0; t < parse_team; ++t) team.emplace_back(member);
     for (;;) {  // forward the batches in file order
       std::unique_lock<std::mutex> l(mu);
-      cv.wait(l, [&] { return ready.count(next_out) || (next_cut >= n && next_out == next_region) || (stop && next_out == next_region); });
+      size_t handed = 0;
+      cv.wait(l, [&] { return ready.count(next_out) || (cut.finished(&handed) && next_out == handed); });
       auto it = ready.find(next_out);
       if (it == ready.end()) break;  // every region handed out and forwarded
-      Batch *bt = it->second.first;
-      const bool whole = it->second.second;
+      Batch *bt = it->second.bt;
+      const bool whole = it->second.whole;
+      const size_t region_end = it->second.hi;
       ready.erase(it);
       ++next_out;
       const bool ends = !whole || bt->nt == 0;  // malformed record, or a unit without nucleotides (src/classify.cpp:522-523)
-      if (ends) stop = true;
       l.unlock();
+      if (ends) { cut.halt(); if (!direct) gtext.cancel(); }
+      else if (!direct) gtext.release_before(region_end);  // (its sequences are in the batch: the text's pages go back)
       if (bt->nt == 0) {
         file_start_pending |= bt->first_of_file;
         if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
@@ -585,9 +606,15 @@ int main(int argc, char **argv) {
     for (auto &t : team) t.join();
     {  // batches parsed behind the end of the stream are dropped
       std::lock_guard<std::mutex> l(mu);
-      for (auto &kv : ready) { Batch *bt = kv.second.first; if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
+      for (auto &kv : ready) { Batch *bt = kv.second.bt; if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
     }
-    munmap(map, n);
+    if (direct) munmap(map, n);
+    else {
+      size_t handed = 0;
+      const bool cut_short = cut.finished(&handed) && cut.stop;
+      gz.close();
+      if (!gtext.error.empty() && !cut_short) die(EX_DATAERR, "%s: %s", path, gtext.error.c_str());
+    }
     busy_reader += now_s() - t_parse;
     return true;
   };
@@ -598,7 +625,7 @@ int main(int argc, char **argv) {
       bt->add_meta(hdr, id_lo, id_hi, q, keep_records);
     };
     for (int fi = optind; fi < argc; fi += paired ? 2 : 1) {
-      if (parse_team > 1 && parse_plain_file_in_regions(argv[fi])) continue;  // plain text: the parser team took it
+      if (parse_team > 1 && parse_file_in_regions(argv[fi])) continue;  // a regular file, plain or .gz: the parser team took it
       Reader rd, rd2;
       rd.open(argv[fi], /*prefetch=*/true);
       if (paired) rd2.open(argv[fi + 1], /*prefetch=*/true);

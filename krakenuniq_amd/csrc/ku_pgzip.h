@@ -23,6 +23,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -565,6 +566,8 @@ struct ParallelGunzip {
   void open(const uint8_t *map, size_t len, int threads) {
     m = map; n = len;
     team = threads < 1 ? 1 : threads;
+    // smaller spans for smaller files: several rounds, so that decoding and emitting overlap and the last round is short
+    span = std::min((size_t)2 << 20, std::max((size_t)256 << 10, n / ((size_t)team * 6)));
     if (const char *e = getenv("KU_PGZIP_SPAN_KB")) span = (size_t)atol(e) << 10;
     if (span < 4096) span = 4096;
     if (search_max > span) search_max = span;
@@ -755,15 +758,16 @@ struct ParallelGunzip {
   }
 
   // emit side: every accepted span to bytes (and its CRCs) side by side into out[0, n_out); members checked
-  bool emit(Set &st, RawBuf<char> &out, size_t &n_out) {
+  bool emit(Set &st, const std::function<char *(size_t)> &place, size_t &n_out) {
     n_out = 0;
     const double tC = now();
     const size_t total = st.o_at.back();
-    if (!out.ensure(total + 8)) { error = "out of memory"; return false; }
+    char *const out_d = place(total);
+    if (!out_d) { error = "no room for the text"; return false; }
     struct Seg { uLong crc; size_t len; };
     std::vector<std::vector<Seg>> segs(st.acc.size());
     auto translate = [&](size_t a) {
-      char *dst = out.d + st.o_at[a];
+      char *dst = out_d + st.o_at[a];
       const size_t len = st.len_of(a);
       const std::vector<Event> *ev;
       if (st.acc[a] == 0) {
@@ -818,6 +822,10 @@ struct ParallelGunzip {
   // the next piece of text: out[0, n_out).  false: nothing more (end of the stream, or `error` says what broke).
   // The round behind it is decoded meanwhile.
   bool round(RawBuf<char> &out, size_t &n_out) {
+    return round_to([&](size_t total) { return out.ensure(total + 8) ? out.d : nullptr; }, n_out);
+  }
+  // ... to where `place(bytes)` says (nullptr: give up)
+  bool round_to(const std::function<char *(size_t)> &place, size_t &n_out) {
     n_out = 0;
     if (!error.empty()) return false;
     if (!primed) { decode(sets[0]); primed = true; cur = 0; }
@@ -829,7 +837,7 @@ struct ParallelGunzip {
     std::thread ahead;
     Set &nx = sets[1 - cur];
     ahead = std::thread([&] { decode(nx); });
-    const bool ok = emit(st, out, n_out);
+    const bool ok = emit(st, place, n_out);
     ahead.join();
     if (!ok) return false;
     cur = 1 - cur;

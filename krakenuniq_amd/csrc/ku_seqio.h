@@ -652,6 +652,289 @@ inline bool parse_region(const char *data, size_t n, bool fastq, Batch &bt, bool
   return rd.pos == rd.len;
 }
 
+// ---- compressed input parsed in regions: the text of a .gz file arrives in one contiguous (virtual) range, written front
+// to back by the inflating team while the parser team already cuts and parses record-aligned regions of it, exactly as it
+// does with a mapped plain file.  Pages behind the parsed regions go back to the system (MADV_DONTNEED), the producer
+// stays at most `max_ahead` bytes in front of them.
+struct GrowingText {
+  char *base = nullptr;
+  size_t reserved = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  size_t avail = 0, freed = 0, max_ahead = (size_t)1 << 30;
+  int starving = 0;  // consumers waiting for more text: the producer may then run further ahead than max_ahead
+  bool done = false, cancelled = false;
+  std::string error;
+  GrowingText() = default;
+  GrowingText(const GrowingText &) = delete;
+  GrowingText &operator=(const GrowingText &) = delete;
+  ~GrowingText() { if (base) munmap(base, reserved); }
+  bool reserve(size_t bytes) {
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) return false;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(p, bytes, MADV_HUGEPAGE);  // 2 MiB faults where the system allows them
+#endif
+    base = (char *)p;
+    reserved = bytes;
+    if (const char *e = getenv("KU_TEXT_AHEAD_MB")) max_ahead = (size_t)std::max(1L, atol(e)) << 20;
+    return true;
+  }
+  // producer: where the next n bytes go (nullptr: cancelled, or the reservation is used up)
+  char *place(size_t n) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return cancelled || starving > 0 || avail == freed || avail + n - freed <= max_ahead; });
+    if (cancelled || avail + n > reserved) return nullptr;
+    return base + avail;
+  }
+  void publish(size_t n) {
+    { std::lock_guard<std::mutex> l(m); avail += n; }
+    cv.notify_all();
+  }
+  void finish(const std::string &err = std::string()) {
+    { std::lock_guard<std::mutex> l(m); done = true; if (!err.empty()) error = err; }
+    cv.notify_all();
+  }
+  // consumers: wait until `need` bytes are there or the text is complete; the bytes there now
+  size_t wait_for(size_t need, bool *complete) {
+    std::unique_lock<std::mutex> l(m);
+    if (avail < need && !done && !cancelled) {
+      ++starving;
+      cv.notify_all();
+      cv.wait(l, [&] { return avail >= need || done || cancelled; });
+      --starving;
+    }
+    *complete = done || cancelled;
+    return avail;
+  }
+  void release_before(size_t pos) {
+    pos &= ~(size_t)((2u << 20) - 1);
+    std::unique_lock<std::mutex> l(m);
+    if (pos <= freed) return;
+    const size_t lo = freed;
+    freed = pos;
+    l.unlock();
+    (void)madvise(base + lo, pos - lo, MADV_DONTNEED);
+    cv.notify_all();
+  }
+  void cancel() {
+    { std::lock_guard<std::mutex> l(m); cancelled = true; }
+    cv.notify_all();
+  }
+};
+
+// the producer side: a regular .gz file (BGZF, or any gzip stream through ku_pgzip.h) inflated into a GrowingText
+struct GzTextStream {
+  GrowingText *gt = nullptr;
+  const unsigned char *map = nullptr;
+  size_t len = 0;
+  ku_pgzip::ParallelGunzip *pgz = nullptr;
+  std::thread coord;
+  struct Task { size_t in_lo, in_hi, out_off, out_len; };
+  std::vector<Task> tasks;
+  std::vector<char> task_done;
+  std::vector<std::thread> team;
+  std::mutex tm;
+  size_t next_claim = 0, next_pub = 0;
+  bool bad = false;
+  GzTextStream() = default;
+  GzTextStream(const GzTextStream &) = delete;
+  GzTextStream &operator=(const GzTextStream &) = delete;
+  ~GzTextStream() { close(); }
+
+  bool plan_bgzf() {
+    size_t at = 0, in_task = 0, out = 0;
+    Task cur{0, 0, 0, 0};
+    while (at < len) {
+      const size_t bs = Reader::bgzf_block_size(map + at, len - at);
+      if (bs < 26 || at + bs > len) return false;
+      const size_t isize = (size_t)map[at + bs - 4] | ((size_t)map[at + bs - 3] << 8) | ((size_t)map[at + bs - 2] << 16) | ((size_t)map[at + bs - 1] << 24);
+      if (isize > 65536) return false;
+      at += bs;
+      out += isize;
+      if (++in_task == Reader::BGZF_TASK || at == len) {
+        cur.in_hi = at;
+        cur.out_len = out - cur.out_off;
+        tasks.push_back(cur);
+        cur = Task{at, 0, out, 0};
+        in_task = 0;
+      }
+    }
+    return !tasks.empty();
+  }
+  bool inflate_task(const Task &t, char *dst) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) return false;
+    bool ok = true;
+    size_t o = 0;
+    for (size_t p = t.in_lo; p < t.in_hi && ok;) {
+      const size_t bs = Reader::bgzf_block_size(map + p, len - p);
+      const size_t xlen = map[p + 10] | ((size_t)map[p + 11] << 8);
+      const size_t isize = (size_t)map[p + bs - 4] | ((size_t)map[p + bs - 3] << 8) | ((size_t)map[p + bs - 2] << 16) | ((size_t)map[p + bs - 1] << 24);
+      const uint32_t crc = (uint32_t)map[p + bs - 8] | ((uint32_t)map[p + bs - 7] << 8) | ((uint32_t)map[p + bs - 6] << 16) | ((uint32_t)map[p + bs - 5] << 24);
+      if (bs < 12 + xlen + 8 || o + isize > t.out_len) { ok = false; break; }
+      z.next_in = const_cast<unsigned char *>(map + p + 12 + xlen);
+      z.avail_in = (unsigned)(bs - 12 - xlen - 8);
+      z.next_out = (unsigned char *)dst + o;
+      z.avail_out = (unsigned)isize;
+      const int rc = isize ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+      if (rc != Z_STREAM_END || z.avail_out != 0 || (uint32_t)ku_pgzip::crc_of((const uint8_t *)dst + o, isize) != crc) ok = false;
+      o += isize;
+      inflateReset(&z);
+      p += bs;
+    }
+    inflateEnd(&z);
+    return ok && o == t.out_len;
+  }
+
+  // false: not a regular gzip file (or no room to reserve): the sequential reader takes it
+  bool open(const char *path, GrowingText &text) {
+    struct stat st;
+    if (::stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 20) return false;
+    const int f = ::open(path, O_RDONLY);
+    if (f < 0) return false;
+    len = (size_t)st.st_size;
+    void *mp = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, f, 0);
+    ::close(f);
+    if (mp == MAP_FAILED) return false;
+    map = (const unsigned char *)mp;
+    if (map[0] != 0x1f || map[1] != 0x8b || map[2] != 8) { munmap(mp, len); map = nullptr; return false; }
+    // virtual room for the text: deflate expands at most 1032-fold; nothing of it is touched before it is written
+    const size_t room = std::min((size_t)8 << 40, std::max((size_t)1 << 30, len * 1100));
+    if (!text.reserve(room)) { munmap(mp, len); map = nullptr; return false; }
+    gt = &text;
+    int hw = (int)std::thread::hardware_concurrency();
+    if (!getenv("KU_NO_BGZF") && plan_bgzf()) {
+      int n = std::max(1, std::min(hw, 8));
+      if (const char *e = getenv("KU_BGZF_TEAM")) n = std::max(1, std::min(atoi(e), 64));
+      task_done.assign(tasks.size(), 0);
+      for (int t = 0; t < n; ++t)
+        team.emplace_back([this] {
+          for (;;) {
+            size_t ti;
+            {
+              std::lock_guard<std::mutex> l(tm);
+              if (bad || next_claim >= tasks.size()) return;
+              ti = next_claim++;
+            }
+            const Task &tk = tasks[ti];
+            // (tasks are claimed in order, so waiting for room here cannot block an earlier task)
+            bool room_ok;
+            {
+              std::unique_lock<std::mutex> l(gt->m);
+              gt->cv.wait(l, [&] { return gt->cancelled || gt->starving > 0 || tk.out_off == gt->freed || tk.out_off + tk.out_len - gt->freed <= gt->max_ahead; });
+              room_ok = !gt->cancelled && tk.out_off + tk.out_len <= gt->reserved;
+            }
+            const bool ok = room_ok && inflate_task(tk, gt->base + tk.out_off);
+            {  // published in task order, and "complete" only behind the last publication: both under the one lock
+              std::lock_guard<std::mutex> l(tm);
+              if (!ok) bad = true;
+              task_done[ti] = 1;
+              size_t add = 0;
+              while (!bad && next_pub < tasks.size() && task_done[next_pub]) add += tasks[next_pub++].out_len;
+              if (add) gt->publish(add);
+              if (bad || next_pub == tasks.size()) gt->finish(bad ? "corrupt BGZF block in the input (deflate stream, length or crc)" : "");
+              if (bad) return;
+            }
+          }
+        });
+      return true;
+    }
+    tasks.clear();
+    int n = std::max(1, std::min(hw, 8));
+    if (const char *e = getenv("KU_PGZIP_TEAM")) n = std::max(1, std::min(atoi(e), 64));
+    pgz = new ku_pgzip::ParallelGunzip;
+    pgz->open(map, len, n);
+    coord = std::thread([this] {
+      size_t got = 0;
+      while (pgz->round_to([this](size_t total) { return gt->place(total); }, got)) gt->publish(got);
+      gt->finish(pgz->error);
+    });
+    return true;
+  }
+  void close() {
+    if (gt) gt->cancel();
+    if (coord.joinable()) coord.join();
+    for (auto &t : team) t.join();
+    team.clear();
+    delete pgz;
+    pgz = nullptr;
+    if (map) munmap((void *)map, len);
+    map = nullptr;
+    gt = nullptr;
+  }
+};
+
+// Record-aligned regions of a text, handed out in order to the members of a parser team: a fixed text (mapped file) or
+// one that is still growing.  A region ends at the first record start at or behind its nominal end; with growing text
+// the decision is only taken on lines that are completely there.
+struct RegionCutter {
+  const char *data = nullptr;
+  size_t n = 0;            // fixed text: its size
+  GrowingText *gt = nullptr;
+  bool fastq = false;
+  size_t region_bytes = (size_t)1 << 20;
+  std::mutex mu;
+  size_t next_cut = 0, next_region = 0;
+  bool stop = false, exhausted = false;
+
+  void halt() { std::lock_guard<std::mutex> l(mu); stop = true; }
+  bool finished(size_t *handed_out) {
+    std::lock_guard<std::mutex> l(mu);
+    *handed_out = next_region;
+    if (!gt) exhausted |= next_cut >= n;
+    else {
+      std::lock_guard<std::mutex> g(gt->m);
+      exhausted |= (gt->done || gt->cancelled) && next_cut >= gt->avail;
+    }
+    return exhausted || stop;
+  }
+  // is `p` (a line start in [0, avail)) decided as a record start by lines that are completely visible?
+  bool decided(size_t p, size_t avail) const {
+    if (p >= avail) return false;
+    if (!fastq) return true;
+    const char *l1 = (const char *)memchr(data + p, '\n', avail - p);
+    const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', avail - (size_t)(l1 + 1 - data)) : nullptr;
+    return l2 && (size_t)(l2 + 1 - data) < avail;
+  }
+  bool claim(size_t &lo, size_t &hi, size_t &idx) {
+    for (;;) {
+      size_t cand;
+      {
+        std::lock_guard<std::mutex> l(mu);
+        if (stop || exhausted) return false;
+        cand = next_cut;
+      }
+      size_t avail = n, end;
+      bool complete = true;
+      if (gt) avail = gt->wait_for(cand + region_bytes + ((size_t)64 << 10), &complete);
+      if (complete && cand >= avail) {
+        std::lock_guard<std::mutex> l(mu);
+        if (next_cut == cand) exhausted = true;
+        continue;
+      }
+      if (complete && cand + region_bytes >= avail) end = avail;
+      else {
+        end = find_record_start(data, avail, cand + region_bytes, fastq);
+        if (!complete && !decided(end, avail)) {  // the boundary lies in lines that are not all there yet
+          bool c2;
+          gt->wait_for(avail + 1, &c2);
+          continue;
+        }
+      }
+      std::lock_guard<std::mutex> l(mu);
+      if (stop) return false;
+      if (next_cut != cand) continue;  // another member took it meanwhile
+      lo = cand;
+      hi = end;
+      next_cut = end;
+      idx = next_region++;
+      return true;
+    }
+  }
+};
+
 // read_merger.pl:182 "$id =~ s/[\/_.][12]$//"
 inline size_t strip_mate_suffix(const char *id, size_t n) {
   if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && (id[n - 2] == '/' || id[n - 2] == '_' || id[n - 2] == '.')) return n - 2;

@@ -9,6 +9,7 @@
 #include <sys/time.h>
 #include <unistd.h>
 
+#include <map>
 #include <thread>
 
 #include <cstdarg>
@@ -72,33 +73,63 @@ int main(int argc, char **argv) {
     if (n) munmap((void *)data, n);
     if (a + 1 == argc) return 0;
   }
-  for (; regions > 0 && a < argc; ++a) {  // region-parallel parse of plain files
-    int fd = ::open(argv[a], O_RDONLY);
-    struct stat st;
-    if (fd < 0 || fstat(fd, &st) != 0) ku_seqio::fatal(66, "can't open %s", argv[a]);
-    const size_t n = (size_t)st.st_size;
-    const char *data = n ? (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : "";
-    ::close(fd);
-    const bool fastq = n && data[0] == '@';
-    std::vector<size_t> cut{0};
-    for (int r = 1; r < regions; ++r) cut.push_back(ku_seqio::find_record_start(data, n, std::max(cut.back(), n * r / regions), fastq));
-    cut.push_back(n);
-    std::vector<ku_seqio::Batch> bts(regions);
-    for (auto &b : bts) b.pinned = false;
-    std::vector<char> ok(regions, 1);
-    std::vector<std::thread> team;
-    for (int r = 0; r < regions; ++r)
-      team.emplace_back([&, r] { ok[r] = ku_seqio::parse_region(data + cut[r], cut[r + 1] - cut[r], fastq, bts[r], false); });
-    for (auto &t : team) t.join();
-    if (warm) {
-      team.clear();
-      gettimeofday(&t0, nullptr);
-      for (int r = 0; r < regions; ++r)
-        team.emplace_back([&, r] { bts[r].clear(); ok[r] = ku_seqio::parse_region(data + cut[r], cut[r + 1] - cut[r], fastq, bts[r], false); });
-      for (auto &t : team) t.join();
+  for (; regions > 0 && a < argc; ++a) {  // region-parallel parse: plain files mapped, .gz files as text that grows while it is parsed
+    ku_seqio::GrowingText gt;
+    ku_seqio::GzTextStream gz;
+    const bool growing = gz.open(argv[a], gt);
+    const char *data = "";
+    size_t n = 0;
+    if (!growing) {
+      int fd = ::open(argv[a], O_RDONLY);
+      struct stat st;
+      if (fd < 0 || fstat(fd, &st) != 0) ku_seqio::fatal(66, "can't open %s", argv[a]);
+      n = (size_t)st.st_size;
+      if (n) data = (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      ::close(fd);
     }
-    for (int r = 0; r < regions; ++r) {
-      ku_seqio::Batch &bt = bts[r];
+    ku_seqio::RegionCutter cut;
+    bool complete = true;
+    if (growing) {
+      cut.gt = &gt;
+      cut.data = gt.base;
+      if (gt.wait_for(1, &complete) == 0) { gz.close(); if (!gt.error.empty()) ku_seqio::fatal(65, "%s", gt.error.c_str()); continue; }
+      cut.region_bytes = (size_t)(getenv("KU_REGION_KB") ? atol(getenv("KU_REGION_KB")) : 8192) << 10;
+    } else {
+      cut.data = data;
+      cut.n = n;
+      cut.region_bytes = std::max<size_t>(1, (n + (size_t)regions - 1) / (size_t)regions);
+    }
+    cut.fastq = growing ? gt.base[0] == '@' : (n && data[0] == '@');
+    std::mutex rm;
+    std::map<size_t, std::pair<ku_seqio::Batch *, size_t>> parsed;  // region -> (batch, end of the region)
+    size_t next_out = 0;
+    bool broken = false;
+    auto member = [&] {
+      size_t lo, hi, idx;
+      while (cut.claim(lo, hi, idx)) {
+        ku_seqio::Batch *bt = new ku_seqio::Batch;
+        bt->pinned = false;
+        const bool whole = ku_seqio::parse_region(cut.data + lo, hi - lo, cut.fastq, *bt, false);
+        if (warm && !growing) { bt->clear(); ku_seqio::parse_region(cut.data + lo, hi - lo, cut.fastq, *bt, false); }
+        std::lock_guard<std::mutex> l(rm);
+        parsed[idx] = {bt, hi};
+        if (!whole) { broken = true; cut.halt(); }
+        if (growing) {  // the text behind the regions parsed so far (in order) is not needed any more
+          size_t upto = 0;
+          for (size_t i = next_out; parsed.count(i); ++i) { upto = parsed[i].second; next_out = i + 1; }
+          if (upto) gt.release_before(upto);
+        }
+      }
+    };
+    std::vector<std::thread> team;
+    for (int r = 0; r < regions; ++r) team.emplace_back(member);
+    for (auto &t : team) t.join();
+    if (growing) {
+      gz.close();
+      if (!gt.error.empty() && !broken) ku_seqio::fatal(65, "%s", gt.error.c_str());
+    }
+    for (auto &kv : parsed) {  // (std::map: in region order)
+      ku_seqio::Batch &bt = *kv.second.first;
       for (size_t i = 0; i < bt.off.size(); ++i) {
         ++n_reads;
         n_bytes += bt.len[i];
@@ -110,9 +141,9 @@ int main(int argc, char **argv) {
         }
       }
       bt.release();
-      if (!ok[r]) break;  // the stream ended inside this region
+      delete kv.second.first;
     }
-    if (n) munmap((void *)data, n);
+    if (!growing && n) munmap((void *)data, n);
   }
   for (; a < argc; a += paired ? 2 : 1) {
     ku_seqio::Reader rd, rd2;

@@ -18,4 +18,18 @@ for out in ("/dev/shm/ku_out.tsv", "off"):
                         "-t", thr, "-o", out, path], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, env=dict(os.environ, KU_CLI_TIMES="1"))
     line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l or "stage busy" in l]
     print(f"-o {out}: wall {time.time() - t:.2f}s rc={r.returncode}", " | ".join(line) if line else r.stderr.decode()[-300:])
+# the same reads as one gzip stream: zlib's single inflate against the gzip team (ku_pgzip.h)
+subprocess.run(f"gzip -1 -c {path} > {path}.gz", shell=True, check=True)
+for label, env in (("zlib", {"KU_NO_PGZIP": "1"}), ("gzip team", {}), ("gzip team of 16", {"KU_PGZIP_TEAM": "16"})):
+    t = time.time()
+    r = subprocess.run([f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB",
+                        "-t", thr, "-o", "/dev/shm/ku_out_gz.tsv", path + ".gz"], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL,
+                       env=dict(os.environ, KU_CLI_TIMES="1", **env))
+    line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l or "stage busy" in l]
+    same = subprocess.run(["cmp", "-s", "/dev/shm/ku_out.tsv", "/dev/shm/ku_out_gz.tsv"]).returncode == 0
+    print(f".gz input, {label}: wall {time.time() - t:.2f}s rc={r.returncode} output identical to the plain run: {same}", " | ".join(line) if line else r.stderr.decode()[-300:])
 os.remove(path)
+os.remove(path + ".gz")
+for f in ("/dev/shm/ku_out.tsv", "/dev/shm/ku_out_gz.tsv"):
+    if os.path.exists(f):
+        os.remove(f)

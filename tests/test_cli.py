@@ -320,3 +320,43 @@ def test_uid_mapping_matches_reference(tmp_path, unit, rep):
     assert out.read_bytes() == open(f"{F11}/out_uid.tsv", "rb").read()
     assert rows(report.read_text()) == rows(open(f"{F11}/{rep}").read())
     assert b"Reading UID mapping file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gz_input_is_parsed_in_regions_like_the_plain_file(tmp_path):
+    """a regular .gz file (one gzip stream, or BGZF) is inflated by a team into text that the parser team cuts into regions
+    while it arrives (ku_seqio.h GrowingText / RegionCutter, ku_pgzip.h): Kraken output and report identical to the plain
+    file's and to the sequential reader's (KU_NO_GZ_REGIONS=1), with small batches / spans / look-ahead (many regions and
+    rounds), -C/-U records included; a truncated file is a data error of the run"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_seqio import bgzf
+    src = open(f"{F1}/reads.fq", "rb").read().split(b"\n")
+    recs = [src[i:i + 4] for i in range(0, len(src) - 1, 4)]
+    text = b"".join(b"@" + r[0][1:] + b"_%d extra words\n" % rep + r[1] + b"\n+\n" + r[3] + b"\n" for rep in range(30) for r in recs)
+    plain = tmp_path / "big.fq"
+    plain.write_bytes(text)
+    z = tmp_path / "big.fq.gz"
+    z.write_bytes(gzip.compress(text, 6))
+    b = tmp_path / "big.bgzf.fq.gz"
+    b.write_bytes(bgzf(text, 65280))
+
+    def go(path, tag, **env):
+        out, rep, c = tmp_path / f"{tag}.tsv", tmp_path / f"{tag}.rep", tmp_path / f"{tag}.c.fq"
+        r = run(DB + ["-t", "8", "-o", str(out), "-r", str(rep), "-C", str(c), str(path)], env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr.decode()
+        return out.read_bytes(), rows(rep.read_text()), c.read_bytes()
+    want = go(plain, "plain")
+    assert want[0].count(b"\n") == 30 * len(recs)
+    small = {"KU_BATCH_NT": "1000000", "KU_PGZIP_SPAN_KB": "64", "KU_TEXT_AHEAD_MB": "1"}
+    want_small = go(plain, "plain_small", **small)  # (the regions are cut by the text alone: the same ones, plain or .gz)
+    assert (want_small[0], want_small[2]) == (want[0], want[2])
+    for tag, path in (("gz", z), ("bgzf", b)):
+        assert go(path, tag) == want, tag
+        assert go(path, tag + "_seq", KU_NO_GZ_REGIONS="1") == want, tag
+        assert go(path, tag + "_small", **small) == want_small, tag
+    blob = z.read_bytes()
+    cut = tmp_path / "cut.fq.gz"
+    cut.write_bytes(blob[:len(blob) // 2])
+    r = run(DB + ["-t", "8", "-o", "off", str(cut)])
+    assert r.returncode == 65 and b"gzip" in r.stderr

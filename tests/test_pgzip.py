@@ -173,3 +173,40 @@ def test_reader_takes_plain_gz_through_the_team(tmp_path):
     bad.write_bytes(blob[:len(blob) // 2])
     r = subprocess.run([DUMP, "-T", str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 65 and b"gzip" in r.stderr
+
+
+def test_gz_text_is_parsed_in_regions_while_it_arrives(tmp_path):
+    """-j N on a .gz file: the team inflates into one growing text, the parser team cuts record-aligned regions off its front
+    as it arrives (decisions only on lines that are completely there) and releases the pages behind them; same records, in
+    order, as the sequential reader -- FASTQ and multi-line FASTA (records longer than a region), plain gzip and BGZF, tiny
+    regions / spans / look-ahead, a malformed record in the middle, a truncated file"""
+    from test_seqio import bgzf
+    text = fastq(20000, seed=21)
+    fa = fasta(400, seed=22)
+    bad_rec = text[:1500000] + b"@broken\nACGT\nIIII\n" + text[1500000:]  # ('+' line missing: the reference stops reading there)
+    cases = {"fq": text, "fa": fa, "broken": bad_rec[:bad_rec.index(b"\n", 1500000 - 400) + 1] + bad_rec[bad_rec.index(b"\n@", 1500000 - 400) + 1:]}
+
+    def run(args, ok=True, **env):
+        r = subprocess.run([DUMP] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert (r.returncode == 0) == ok, r.stderr.decode()[-300:]
+        return r.stdout
+    for name, t in cases.items():
+        plain = tmp_path / f"{name}.txt"
+        plain.write_bytes(t)
+        want = run([str(plain)])
+        assert want.count(b"\n") > 300
+        for kind, blob in (("gz", member(t)), ("gz1", member(t, deflate_raw(t, 1))), ("bgzf", bgzf(t, 65280)), ("bgzf_small", bgzf(t, 3001))):
+            z = tmp_path / f"{name}.{kind}.gz"
+            z.write_bytes(blob)
+            assert run(["-j", "4", str(z)]) == want, (name, kind)
+            assert run(["-j", "3", str(z)], KU_REGION_KB="64", KU_PGZIP_SPAN_KB="64", KU_TEXT_AHEAD_MB="1") == want, (name, kind)
+            assert run(["-j", "7", str(z)], KU_REGION_KB="16", KU_PGZIP_SPAN_KB="16", KU_PGZIP_TEAM="3", KU_BGZF_TEAM="3") == want, (name, kind)
+    blob = member(text)
+    cut = tmp_path / "cut.gz"
+    cut.write_bytes(blob[:len(blob) // 2])
+    r = subprocess.run([DUMP, "-j", "4", str(cut)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 65 and b"gzip" in r.stderr
+    bz = bgzf(text, 65280)
+    cut.write_bytes(bz[:len(bz) // 2 + 11] + bz[len(bz) // 2 + 12:])
+    r = subprocess.run([DUMP, "-j", "4", str(cut)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
