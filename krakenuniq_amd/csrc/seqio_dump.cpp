@@ -102,6 +102,7 @@ int main(int argc, char **argv) {
     cut.fastq = growing ? gt.base[0] == '@' : (n && data[0] == '@');
     std::mutex rm;
     std::map<size_t, std::pair<ku_seqio::Batch *, size_t>> parsed;  // region -> (batch, end of the region)
+    size_t first_broken = (size_t)-1;  // the stream ends inside this region: what was parsed behind it does not count
     size_t next_out = 0;
     bool broken = false;
     auto member = [&] {
@@ -113,7 +114,7 @@ int main(int argc, char **argv) {
         if (warm && !growing) { bt->clear(); ku_seqio::parse_region(cut.data + lo, hi - lo, cut.fastq, *bt, false); }
         std::lock_guard<std::mutex> l(rm);
         parsed[idx] = {bt, hi};
-        if (!whole) { broken = true; cut.halt(); }
+        if (!whole) { broken = true; first_broken = std::min(first_broken, idx); cut.halt(); }
         if (growing) {  // the text behind the regions parsed so far (in order) is not needed any more
           size_t upto = 0;
           for (size_t i = next_out; parsed.count(i); ++i) { upto = parsed[i].second; next_out = i + 1; }
@@ -130,7 +131,7 @@ int main(int argc, char **argv) {
     }
     for (auto &kv : parsed) {  // (std::map: in region order)
       ku_seqio::Batch &bt = *kv.second.first;
-      for (size_t i = 0; i < bt.off.size(); ++i) {
+      for (size_t i = 0; i < bt.off.size() && kv.first <= first_broken; ++i) {
         ++n_reads;
         n_bytes += bt.len[i];
         if (!quiet) {
