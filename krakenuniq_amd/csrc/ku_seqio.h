@@ -842,6 +842,12 @@ struct GzTextStream {
       return true;
     }
     tasks.clear();
+    if (getenv("KU_NO_PGZIP")) {  // zlib's one inflate is asked for: the sequential reader
+      gt = nullptr;
+      munmap(mp, len);
+      map = nullptr;
+      return false;
+    }
     int n = std::max(1, std::min(hw, 8));
     if (const char *e = getenv("KU_PGZIP_TEAM")) n = std::max(1, std::min(atoi(e), 64));
     pgz = new ku_pgzip::ParallelGunzip;

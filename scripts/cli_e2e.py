@@ -18,9 +18,43 @@ for out in ("/dev/shm/ku_out.tsv", "off"):
                         "-t", thr, "-o", out, path], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, env=dict(os.environ, KU_CLI_TIMES="1"))
     line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l or "stage busy" in l]
     print(f"-o {out}: wall {time.time() - t:.2f}s rc={r.returncode}", " | ".join(line) if line else r.stderr.decode()[-300:])
+for team in ("12", "16"):  # the parser team's size (default: 8)
+    t = time.time()
+    r = subprocess.run([f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB",
+                        "-t", thr, "-o", "/dev/shm/ku_out2.tsv", path], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL,
+                       env=dict(os.environ, KU_CLI_TIMES="1", KU_PARSE_TEAM=team))
+    line = [l for l in r.stderr.decode().replace("\r", "\n").split("\n") if "processed in" in l or "stage busy" in l]
+    print(f"KU_PARSE_TEAM={team}: wall {time.time() - t:.2f}s rc={r.returncode}", " | ".join(line) if line else r.stderr.decode()[-300:], flush=True)
 # the same reads as one gzip stream: zlib's single inflate against the gzip team (ku_pgzip.h)
-subprocess.run(f"gzip -1 -c {path} > {path}.gz", shell=True, check=True)
-for label, env in (("zlib", {"KU_NO_PGZIP": "1"}), ("gzip team", {}), ("gzip team of 16", {"KU_PGZIP_TEAM": "16"})):
+# (written the way pigz writes: chunks deflated side by side, each closed with a sync flush, concatenated into ONE deflate
+#  stream inside one gzip member -- no member boundaries, no index; `gzip -6` of 3 GB alone would take a minute)
+import multiprocessing, struct, zlib
+CH = 32 << 20
+def _deflate(args):
+    off, last = args
+    with open(path, "rb") as f:
+        f.seek(off)
+        d = f.read(CH)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    return c.compress(d) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
+size = os.path.getsize(path)
+offs = list(range(0, size, CH))
+t = time.time()
+with multiprocessing.Pool(min(32, os.cpu_count() or 1)) as pool, open(path + ".gz", "wb") as g:
+    g.write(b"\x1f\x8b\x08\0\0\0\0\0\0\x03")
+    for comp in pool.imap(_deflate, [(o, o == offs[-1]) for o in offs]):
+        g.write(comp)
+    crc = 0
+    with open(path, "rb") as f:
+        while True:
+            d = f.read(64 << 20)
+            if not d:
+                break
+            crc = zlib.crc32(d, crc)
+    g.write(struct.pack("<II", crc, size & 0xffffffff))
+print(f"{path}.gz: {os.path.getsize(path + '.gz')} bytes, one deflate stream (level 6), written in {time.time() - t:.1f}s", flush=True)
+for label, env in (("zlib (one inflate, one parser)", {"KU_NO_PGZIP": "1"}), ("gzip team, one parser", {"KU_NO_GZ_REGIONS": "1"}),
+                   ("gzip team + parser team", {}), ("gzip team of 16 + parser team", {"KU_PGZIP_TEAM": "16"})):
     t = time.time()
     r = subprocess.run([f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{db}/database.kdb", "-i", f"{db}/database.idx", "-a", f"{db}/taxDB",
                         "-t", thr, "-o", "/dev/shm/ku_out_gz.tsv", path + ".gz"], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL,
@@ -30,6 +64,6 @@ for label, env in (("zlib", {"KU_NO_PGZIP": "1"}), ("gzip team", {}), ("gzip tea
     print(f".gz input, {label}: wall {time.time() - t:.2f}s rc={r.returncode} output identical to the plain run: {same}", " | ".join(line) if line else r.stderr.decode()[-300:])
 os.remove(path)
 os.remove(path + ".gz")
-for f in ("/dev/shm/ku_out.tsv", "/dev/shm/ku_out_gz.tsv"):
+for f in ("/dev/shm/ku_out.tsv", "/dev/shm/ku_out2.tsv", "/dev/shm/ku_out_gz.tsv"):
     if os.path.exists(f):
         os.remove(f)
