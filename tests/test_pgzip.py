@@ -184,7 +184,16 @@ def test_gz_text_is_parsed_in_regions_while_it_arrives(tmp_path):
     text = fastq(20000, seed=21)
     fa = fasta(400, seed=22)
     bad_rec = text[:1500000] + b"@broken\nACGT\nIIII\n" + text[1500000:]  # ('+' line missing: the reference stops reading there)
-    cases = {"fq": text, "fa": fa, "broken": bad_rec[:bad_rec.index(b"\n", 1500000 - 400) + 1] + bad_rec[bad_rec.index(b"\n@", 1500000 - 400) + 1:]}
+    # long reads whose quality lines start with '@' or '+' (Q31, Q10): a record start is only decided by the lines behind it,
+    # and those may not have arrived yet (lines far longer than a region and than the look-ahead)
+    r = np.random.default_rng(23)
+    long_fq = b""
+    for i in range(24):
+        L = int(r.integers(60_000, 400_000))
+        q = (r.integers(0, 40, L) + 33).astype(np.uint8)
+        q[0] = ord("@") if i % 2 else ord("+")
+        long_fq += b"@long%d\n" % i + np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, L)].tobytes() + b"\n+\n" + q.tobytes() + b"\n"
+    cases = {"long_fq": long_fq, "fq": text, "fa": fa, "broken": bad_rec[:bad_rec.index(b"\n", 1500000 - 400) + 1] + bad_rec[bad_rec.index(b"\n@", 1500000 - 400) + 1:]}
 
     def run(args, ok=True, **env):
         r = subprocess.run([DUMP] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
@@ -194,7 +203,7 @@ def test_gz_text_is_parsed_in_regions_while_it_arrives(tmp_path):
         plain = tmp_path / f"{name}.txt"
         plain.write_bytes(t)
         want = run([str(plain)])
-        assert want.count(b"\n") > 300
+        assert want.count(b"\n") > (20 if name == "long_fq" else 300)
         for kind, blob in (("gz", member(t)), ("gz1", member(t, deflate_raw(t, 1))), ("bgzf", bgzf(t, 65280)), ("bgzf_small", bgzf(t, 3001))):
             z = tmp_path / f"{name}.{kind}.gz"
             z.write_bytes(blob)
