@@ -359,6 +359,38 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k):
                     "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
             except Exception as e:
                 out["e2e"]["with_report"] = {"value": None, "error": str(e)[:200]}
+            # the same reads as ONE gzip stream (how reads mostly arrive): the executable inflates it with a team of threads
+            # (ku_pgzip.h) and parses the text in regions while it arrives; once with zlib's one inflate beside it
+            try:
+                for fn in ("e2e.tsv", "report.tsv"):
+                    if os.path.exists(f"{tmp}/{fn}"):
+                        os.remove(f"{tmp}/{fn}")
+                t0 = time.time()
+                subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "write_one_stream_gz.py"), f"{tmp}/reads.fq", f"{tmp}/reads.fq.gz"],
+                               check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                t_gz = time.time() - t0
+                os.remove(f"{tmp}/reads.fq")
+                cmd_z = cmd[:-1] + [f"{tmp}/reads.fq.gz"]
+                runs_z = []
+                for rep in range(2):
+                    r = subprocess.run(cmd_z, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_CLI_TIMES="1"), timeout=300)
+                    err_i = r.stderr.decode(errors="replace")
+                    m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", err_i)
+                    if r.returncode != 0 or not m:
+                        raise RuntimeError("classify on the .gz failed: " + err_i[-300:])
+                    runs_z.append(float(m.group(3)))
+                got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
+                gz = {"value": round(n_e / min(runs_z) / 1e6, 2), "unit": "Mreads/s", "seconds": min(runs_z), "seconds_of_both_runs": runs_z,
+                      "file": "one deflate stream in one gzip member (level 6)", "gz_bytes": os.path.getsize(f"{tmp}/reads.fq.gz"),
+                      "written_in_s": round(t_gz, 1), "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
+                if n_e <= 20_000_000:  # (zlib's reader takes ~0.45 s per million reads)
+                    r = subprocess.run(cmd_z, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_NO_PGZIP="1"), timeout=600)
+                    m = re.search(r"(\d+) sequences \(([\d.]+) Mbp\) processed in ([\d.]+)s", r.stderr.decode(errors="replace"))
+                    if r.returncode == 0 and m:
+                        gz["seconds_with_zlib_reader"] = float(m.group(3))
+                out["e2e"]["gz"] = gz
+            except Exception as e:
+                out["e2e"]["gz"] = {"value": None, "error": str(e)[:200]}
         except Exception as e:
             out["e2e"] = {"value": None, "error": str(e)[:200]}
     finally:

@@ -28,30 +28,10 @@ for team in ("12", "16"):  # the parser team's size (default: 8)
 # the same reads as one gzip stream: zlib's single inflate against the gzip team (ku_pgzip.h)
 # (written the way pigz writes: chunks deflated side by side, each closed with a sync flush, concatenated into ONE deflate
 #  stream inside one gzip member -- no member boundaries, no index; `gzip -6` of 3 GB alone would take a minute)
-import multiprocessing, struct, zlib
-CH = 32 << 20
-def _deflate(args):
-    off, last = args
-    with open(path, "rb") as f:
-        f.seek(off)
-        d = f.read(CH)
-    c = zlib.compressobj(6, zlib.DEFLATED, -15)
-    return c.compress(d) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
-size = os.path.getsize(path)
-offs = list(range(0, size, CH))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import write_one_stream_gz
 t = time.time()
-with multiprocessing.Pool(min(32, os.cpu_count() or 1)) as pool, open(path + ".gz", "wb") as g:
-    g.write(b"\x1f\x8b\x08\0\0\0\0\0\0\x03")
-    for comp in pool.imap(_deflate, [(o, o == offs[-1]) for o in offs]):
-        g.write(comp)
-    crc = 0
-    with open(path, "rb") as f:
-        while True:
-            d = f.read(64 << 20)
-            if not d:
-                break
-            crc = zlib.crc32(d, crc)
-    g.write(struct.pack("<II", crc, size & 0xffffffff))
+write_one_stream_gz.write(path)
 print(f"{path}.gz: {os.path.getsize(path + '.gz')} bytes, one deflate stream (level 6), written in {time.time() - t:.1f}s", flush=True)
 for label, env in (("zlib (one inflate, one parser)", {"KU_NO_PGZIP": "1"}), ("gzip team, one parser", {"KU_NO_GZ_REGIONS": "1"}),
                    ("gzip team + parser team", {}), ("gzip team of 16 + parser team", {"KU_PGZIP_TEAM": "16"})):

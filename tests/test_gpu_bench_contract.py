@@ -41,6 +41,8 @@ def test_default_shape_line():
     assert cb["parity_vs_reference_on_sample"] is True
     assert d["device_pipeline"]["calls_match_device_run"] is True and d["device_pipeline"]["value"] > 0
     assert d["e2e"]["calls_match_device_run"] is True and d["e2e"]["value"] > 0
+    gz = d["e2e"]["gz"]  # the same reads as one gzip stream through the gzip team and the region parsers; zlib's reader beside it
+    assert gz["calls_match_device_run"] is True and gz["value"] > 0 and gz["gz_bytes"] > 0 and gz["seconds_with_zlib_reader"] > 0
 
 
 @pytest.mark.parametrize("shape", [("--paired",), ("--read-len", "3000", "--reads", "20000"), ("--nt", "15"), ("--output", "runs")])
