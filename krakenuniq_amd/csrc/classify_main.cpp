@@ -508,7 +508,7 @@ int main(int argc, char **argv) {
     {
       gzFile g = gzopen(path, "rb");
       if (!g) die(EX_NOINPUT, "can't open %s", path);
-      direct = gzdirect(g) != 0;
+      direct = gzdirect(g) != 0 && !ku_seqio::Reader::file_is_bzip2(path);
       gzclose(g);
     }
     ku_seqio::GrowingText gtext;
@@ -610,10 +610,9 @@ int main(int argc, char **argv) {
     }
     if (direct) munmap(map, n);
     else {
-      size_t handed = 0;
-      const bool cut_short = cut.finished(&handed) && cut.stop;
       gz.close();
-      if (!gtext.error.empty() && !cut_short) die(EX_DATAERR, "%s: %s", path, gtext.error.c_str());
+      // damage of the compressed file (a parser that stopped early cancels the producer: that leaves no error behind)
+      if (!gtext.error.empty()) die(EX_DATAERR, "%s: %s", path, gtext.error.c_str());
     }
     busy_reader += now_s() - t_parse;
     return true;

@@ -23,6 +23,7 @@
 
 #include "../../include/krakenuniq_amd.h"
 #include "ku_pgzip.h"
+#include "ku_pbzip2.h"
 
 namespace ku_seqio {
 
@@ -169,6 +170,26 @@ struct Reader {
   std::thread pgz_thread;
   const unsigned char *pgz_map = nullptr;
   size_t pgz_len = 0;
+
+  // .bz2 input: the blocks of the file decoded by a team (ku_pbzip2.h); a pipe is read to its end first (the blocks can
+  // only be found in memory), a regular file is mapped
+  ku_pbzip2::ParallelBunzip2 *pbz = nullptr;
+  const unsigned char *pbz_map = nullptr;
+  size_t pbz_len = 0;
+  std::vector<unsigned char> pbz_mem;
+  static int bzip2_team() {
+    int team = std::max(1, std::min((int)std::thread::hardware_concurrency(), 16));
+    if (const char *e = getenv("KU_PBZIP2_TEAM")) team = std::max(1, std::min(atoi(e), 64));
+    return team;
+  }
+  static bool file_is_bzip2(const char *path) {
+    unsigned char h[14];
+    const int f = ::open(path, O_RDONLY);
+    if (f < 0) return false;
+    const ssize_t got = ::pread(f, h, sizeof h, 0);
+    ::close(f);
+    return got == (ssize_t)sizeof h && ku_pbzip2::ParallelBunzip2::is_bzip2(h, sizeof h);
+  }
 
   Reader() = default;
   Reader(const Reader &) = delete;
@@ -323,6 +344,41 @@ struct Reader {
     pos = len = 0;
     valid = true; eof = false;
     produced_all = stop = false;
+    if (fd >= 0 && file_is_bzip2(path)) {  // a regular .bz2 file: mapped
+      void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (mp == MAP_FAILED) fatal(71, "can't map %s", path);
+      ::close(fd);
+      fd = -1;
+      pbz_map = (const unsigned char *)mp;
+      pbz_len = (size_t)st.st_size;
+      pbz = new ku_pbzip2::ParallelBunzip2;
+      pbz->open(pbz_map, pbz_len, bzip2_team());
+      more();
+      fastq = len > 0 && buf[0] == '@';
+      return;
+    }
+    if (g && gzdirect(g)) {  // uncompressed bytes through a pipe -- or bzip2 ones: the first bytes tell
+      const long got = gzread(g, buf.data(), 14);
+      len = got > 0 ? (size_t)got : 0;
+      if (ku_pbzip2::ParallelBunzip2::is_bzip2((const unsigned char *)buf.data(), len)) {
+        pbz_mem.assign((const unsigned char *)buf.data(), (const unsigned char *)buf.data() + len);
+        len = 0;
+        for (;;) {
+          const size_t at = pbz_mem.size();
+          pbz_mem.resize(at + ((size_t)16 << 20));
+          const long r = gzread(g, pbz_mem.data() + at, (unsigned)((size_t)16 << 20));
+          pbz_mem.resize(at + (r > 0 ? (size_t)r : 0));
+          if (r <= 0) break;
+        }
+        gzclose(g);
+        g = nullptr;
+        pbz = new ku_pbzip2::ParallelBunzip2;
+        pbz->open(pbz_mem.data(), pbz_mem.size(), bzip2_team());
+        more();
+        fastq = len > 0 && buf[0] == '@';
+        return;
+      }
+    }
     if (prefetch && g && S_ISREG(st.st_mode) && !getenv("KU_NO_BGZF") && open_bgzf(path, (size_t)st.st_size)) {
       more();
       fastq = len > 0 && buf[0] == '@';
@@ -373,6 +429,10 @@ struct Reader {
       for (auto &t : bz_team) t.join();
       bz_team.clear();
     }
+    if (pbz) { pbz->close(); delete pbz; pbz = nullptr; }
+    if (pbz_map) munmap((void *)pbz_map, pbz_len);
+    pbz_map = nullptr;
+    std::vector<unsigned char>().swap(pbz_mem);
     if (pgz_thread.joinable()) {
       { std::lock_guard<std::mutex> l(mu); stop = true; }
       cv.notify_all();
@@ -403,6 +463,19 @@ struct Reader {
       if (len > pos) memmove(buf.data(), buf.data() + pos, len - pos);
       len -= pos;
       pos = 0;
+    }
+    if (pbz) {  // the next block's text
+      const uint8_t *blk;
+      size_t nb = 0;
+      if (!pbz->next(blk, nb)) {
+        if (!pbz->error.empty()) fatal(65, "%s", pbz->error.c_str());
+        eof = true;
+        return false;
+      }
+      if (len + nb > buf.size()) buf.resize(std::max(buf.size() * 2, len + nb));
+      memcpy(buf.data() + len, blk, nb);
+      len += nb;
+      return nb > 0 || more();
     }
     if (pgz) {  // the next round's text
       PgzSlot &sl = pgz_slot[pgz_get & 1];
@@ -692,7 +765,7 @@ struct GrowingText {
     cv.notify_all();
   }
   void finish(const std::string &err = std::string()) {
-    { std::lock_guard<std::mutex> l(m); done = true; if (!err.empty()) error = err; }
+    { std::lock_guard<std::mutex> l(m); done = true; if (!err.empty() && !cancelled) error = err; }  // (a cancelled producer's complaint is no error)
     cv.notify_all();
   }
   // consumers: wait until `need` bytes are there or the text is complete; the bytes there now
@@ -723,12 +796,14 @@ struct GrowingText {
   }
 };
 
-// the producer side: a regular .gz file (BGZF, or any gzip stream through ku_pgzip.h) inflated into a GrowingText
+// the producer side: a regular .gz file (BGZF, or any gzip stream through ku_pgzip.h) or .bz2 file (ku_pbzip2.h) inflated
+// into a GrowingText
 struct GzTextStream {
   GrowingText *gt = nullptr;
   const unsigned char *map = nullptr;
   size_t len = 0;
   ku_pgzip::ParallelGunzip *pgz = nullptr;
+  ku_pbzip2::ParallelBunzip2 *pbz = nullptr;
   std::thread coord;
   struct Task { size_t in_lo, in_hi, out_off, out_len; };
   std::vector<Task> tasks;
@@ -799,12 +874,30 @@ struct GzTextStream {
     ::close(f);
     if (mp == MAP_FAILED) return false;
     map = (const unsigned char *)mp;
-    if (map[0] != 0x1f || map[1] != 0x8b || map[2] != 8) { munmap(mp, len); map = nullptr; return false; }
+    const bool bz2 = ku_pbzip2::ParallelBunzip2::is_bzip2(map, len);
+    if (!bz2 && (map[0] != 0x1f || map[1] != 0x8b || map[2] != 8)) { munmap(mp, len); map = nullptr; return false; }
     // virtual room for the text: deflate expands at most 1032-fold; nothing of it is touched before it is written
     const size_t room = std::min((size_t)8 << 40, std::max((size_t)1 << 30, len * 1100));
     if (!text.reserve(room)) { munmap(mp, len); map = nullptr; return false; }
     gt = &text;
     int hw = (int)std::thread::hardware_concurrency();
+    if (bz2) {  // the blocks of a .bz2 file, decoded by a team, copied behind one another in file order
+      pbz = new ku_pbzip2::ParallelBunzip2;
+      pbz->open(map, len, Reader::bzip2_team());
+      coord = std::thread([this] {
+        const uint8_t *blk;
+        size_t nb = 0;
+        std::string err;
+        while (pbz->next(blk, nb)) {
+          char *dst = gt->place(nb);
+          if (!dst) { err = "no room for the text"; break; }
+          memcpy(dst, blk, nb);
+          gt->publish(nb);
+        }
+        gt->finish(err.empty() ? pbz->error : err);
+      });
+      return true;
+    }
     if (!getenv("KU_NO_BGZF") && plan_bgzf()) {
       int n = std::max(1, std::min(hw, 8));
       if (const char *e = getenv("KU_BGZF_TEAM")) n = std::max(1, std::min(atoi(e), 64));
@@ -866,6 +959,7 @@ struct GzTextStream {
     team.clear();
     delete pgz;
     pgz = nullptr;
+    if (pbz) { pbz->close(); delete pbz; pbz = nullptr; }
     if (map) munmap((void *)map, len);
     map = nullptr;
     gt = nullptr;

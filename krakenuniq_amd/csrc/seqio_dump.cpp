@@ -17,6 +17,7 @@
 
 #include "ku_seqio.h"
 #include "ku_pgzip.h"
+#include "ku_pbzip2.h"
 
 // the batches of this tool are plain host memory (Batch::pinned = false); these are never called
 extern "C" int ku_host_alloc(size_t, void **out) { *out = nullptr; return KU_ENOMEM; }
@@ -33,7 +34,7 @@ void ku_seqio::fatal(int code, const char *fmt, ...) {
 
 int main(int argc, char **argv) {
   bool paired = false, quiet = false, prefetch = false, warm = false;
-  int regions = 0, gunzip_team = 0;
+  int regions = 0, gunzip_team = 0, bunzip_team = 0;
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
     if (argv[a][1] == 'P') paired = true;
@@ -41,12 +42,39 @@ int main(int argc, char **argv) {
     else if (argv[a][1] == 'T') prefetch = true;
     else if (argv[a][1] == 'w') warm = true;  // -j: parse every region twice into the same batch, time the second pass (buffers and pages warm)
     else if (argv[a][1] == 'z' && a + 1 < argc) gunzip_team = atoi(argv[++a]);
+    else if (argv[a][1] == 'Z' && a + 1 < argc) bunzip_team = atoi(argv[++a]);  // as -z, for .bz2 (ku_pbzip2.h)
     else if (argv[a][1] == 'j' && a + 1 < argc) regions = atoi(argv[++a]);  // producer thread per file, as the classify executable runs
   }
   timeval t0, t1;
   gettimeofday(&t0, nullptr);
   uint64_t n_reads = 0, n_bytes = 0;
   std::string header, header2;
+  for (; bunzip_team > 0 && a < argc; ++a) {
+    int fd = ::open(argv[a], O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) ku_seqio::fatal(66, "can't open %s", argv[a]);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *data = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : (const uint8_t *)"";
+    ::close(fd);
+    if (!ku_pbzip2::ParallelBunzip2::is_bzip2(data, n)) ku_seqio::fatal(65, "%s: not a bzip2 file", argv[a]);
+    ku_pbzip2::ParallelBunzip2 pb;
+    pb.open(data, n, bunzip_team);
+    const uint8_t *blk;
+    size_t got = 0;
+    uint64_t total = 0;
+    while (pb.next(blk, got)) {
+      total += got;
+      if (!quiet) fwrite(blk, 1, got, stdout);
+    }
+    pb.close();
+    if (!pb.error.empty()) ku_seqio::fatal(65, "%s: %s", argv[a], pb.error.c_str());
+    gettimeofday(&t1, nullptr);
+    const double s = (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_usec - t0.tv_usec) / 1e6;
+    fprintf(stderr, "%llu bytes in %.3f s: %.1f MB/s; %llu blocks, %llu magic numbers inside data\n", (unsigned long long)total, s, total / s / 1e6,
+            (unsigned long long)pb.n_blocks, (unsigned long long)pb.n_skipped);
+    if (n) munmap((void *)data, n);
+    if (a + 1 == argc) return 0;
+  }
   for (; gunzip_team > 0 && a < argc; ++a) {
     int fd = ::open(argv[a], O_RDONLY);
     struct stat st;
@@ -127,7 +155,7 @@ int main(int argc, char **argv) {
     for (auto &t : team) t.join();
     if (growing) {
       gz.close();
-      if (!gt.error.empty() && !broken) ku_seqio::fatal(65, "%s", gt.error.c_str());
+      if (!gt.error.empty()) ku_seqio::fatal(65, "%s", gt.error.c_str());  // (damage of the compressed file, not the parser stopping early)
     }
     for (auto &kv : parsed) {  // (std::map: in region order)
       ku_seqio::Batch &bt = *kv.second.first;

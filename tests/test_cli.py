@@ -324,7 +324,7 @@ def test_uid_mapping_matches_reference(tmp_path, unit, rep):
 
 @pytest.mark.gpu
 def test_gz_input_is_parsed_in_regions_like_the_plain_file(tmp_path):
-    """a regular .gz file (one gzip stream, or BGZF) is inflated by a team into text that the parser team cuts into regions
+    """a regular .gz file (one gzip stream, or BGZF) or .bz2 file is inflated by a team into text that the parser team cuts into regions
     while it arrives (ku_seqio.h GrowingText / RegionCutter, ku_pgzip.h): Kraken output and report identical to the plain
     file's and to the sequential reader's (KU_NO_GZ_REGIONS=1), with small batches / spans / look-ahead (many regions and
     rounds), -C/-U records included; a truncated file is a data error of the run"""
@@ -340,6 +340,9 @@ def test_gz_input_is_parsed_in_regions_like_the_plain_file(tmp_path):
     z.write_bytes(gzip.compress(text, 6))
     b = tmp_path / "big.bgzf.fq.gz"
     b.write_bytes(bgzf(text, 65280))
+    import bz2
+    bz = tmp_path / "big.fq.bz2"
+    bz.write_bytes(bz2.compress(text[:4000000], 2) + bz2.compress(text[4000000:], 9))  # (two streams, blocks of 200 and 900 kB)
 
     def go(path, tag, **env):
         out, rep, c = tmp_path / f"{tag}.tsv", tmp_path / f"{tag}.rep", tmp_path / f"{tag}.c.fq"
@@ -351,7 +354,7 @@ def test_gz_input_is_parsed_in_regions_like_the_plain_file(tmp_path):
     small = {"KU_BATCH_NT": "1000000", "KU_PGZIP_SPAN_KB": "64", "KU_TEXT_AHEAD_MB": "1"}
     want_small = go(plain, "plain_small", **small)  # (the regions are cut by the text alone: the same ones, plain or .gz)
     assert (want_small[0], want_small[2]) == (want[0], want[2])
-    for tag, path in (("gz", z), ("bgzf", b)):
+    for tag, path in (("gz", z), ("bgzf", b), ("bz2", bz)):
         assert go(path, tag) == want, tag
         assert go(path, tag + "_seq", KU_NO_GZ_REGIONS="1") == want, tag
         assert go(path, tag + "_small", **small) == want_small, tag
@@ -360,3 +363,22 @@ def test_gz_input_is_parsed_in_regions_like_the_plain_file(tmp_path):
     cut.write_bytes(blob[:len(blob) // 2])
     r = run(DB + ["-t", "8", "-o", "off", str(cut)])
     assert r.returncode == 65 and b"gzip" in r.stderr
+    cut2 = tmp_path / "cut.fq.bz2"
+    cut2.write_bytes(bz.read_bytes()[:1000000])
+    r = run(DB + ["-t", "8", "-o", "off", str(cut2)])
+    assert r.returncode == 65 and b"bzip2" in r.stderr
+    # mate pairs from compressed files: the sequential readers (each with its team) == the plain files
+    half = len(recs) * 15
+    t1 = b"".join(b"@" + r[0][1:] + b"/1\n" + r[1] + b"\n+\n" + r[3] + b"\n" for rep in range(15) for r in recs)
+    t2 = b"".join(b"@" + r[0][1:] + b"/2\n" + r[1][::-1] + b"\n+\n" + r[3] + b"\n" for rep in range(15) for r in recs)
+    files = {}
+    for nm, t in (("m1", t1), ("m2", t2)):
+        (tmp_path / f"{nm}.fq").write_bytes(t)
+        (tmp_path / f"{nm}.fq.gz").write_bytes(gzip.compress(t, 1))
+        (tmp_path / f"{nm}.fq.bz2").write_bytes(bz2.compress(t, 1))
+    outs = []
+    for ext in ("fq", "fq.gz", "fq.bz2"):
+        r = run(DB + ["-t", "8", "-P", str(tmp_path / f"m1.{ext}"), str(tmp_path / f"m2.{ext}")])
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(r.stdout)
+    assert outs[0].count(b"\n") == half and outs[1] == outs[0] and outs[2] == outs[0]
