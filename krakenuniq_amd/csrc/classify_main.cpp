@@ -59,6 +59,13 @@
 #include "../../include/krakenuniq_amd.h"
 #include "ku_seqio.h"
 
+// Fatal errors are raised by whichever thread meets them (the reader finds a damaged input while the main thread still
+// loads the database): exit() would run the static destructors -- the HIP runtime's among them -- under the feet of the
+// other threads (a truncated .bz2 file ended in SIGSEGV instead of EX_DATAERR).  Flush what is buffered and leave.
+[[noreturn]] static void leave(int code) {
+  fflush(nullptr);
+  _exit(code);
+}
 static void die(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3), noreturn));
 static void die(int code, const char *fmt, ...) {
   va_list ap;
@@ -67,7 +74,7 @@ static void die(int code, const char *fmt, ...) {
   vfprintf(stderr, fmt, ap);
   fprintf(stderr, "\n");
   va_end(ap);
-  exit(code);
+  leave(code);
 }
 void ku_seqio::fatal(int code, const char *fmt, ...) {
   va_list ap;
@@ -76,7 +83,7 @@ void ku_seqio::fatal(int code, const char *fmt, ...) {
   vfprintf(stderr, fmt, ap);
   fprintf(stderr, "\n");
   va_end(ap);
-  exit(code);
+  leave(code);
 }
 
 static int exit_code_of(int st) {
