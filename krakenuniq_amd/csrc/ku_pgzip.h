@@ -485,6 +485,9 @@ template <class T> struct SpanDecoder {
 
   // decode from the reader's position (a member header when at_header, else a block start) until stop(bitpos) says so
   // at a block start, or the stream ends
+  // (and once the span holds more than `soft_cap` elements: a span of highly compressible data -- the N runs of a genome --
+  //  hands over at the next block start instead of growing without bound; the spans behind it are then decoded again)
+  size_t soft_cap = (size_t)256 << 20;
   void run(Bits &b, const uint8_t *m, size_t n, bool at_header, bool check_first, const std::function<bool(size_t)> &stop) {
     bool first = !check_first;
     for (;;) {
@@ -497,7 +500,7 @@ template <class T> struct SpanDecoder {
         floor = pos;
         at_header = false;
       }
-      if (!first && stop(b.bitpos())) { end_bit = b.bitpos(); status = ST_STOP; return; }
+      if (!first && (pos - WIN >= soft_cap || stop(b.bitpos()))) { end_bit = b.bitpos(); status = ST_STOP; return; }
       first = false;
       bool fin = false;
       if (!block(b, m, n, &fin, (size_t)-1 / 4)) { status = ST_ERROR; return; }
@@ -532,6 +535,7 @@ struct ParallelGunzip {
   int team = 1;
   size_t span = (size_t)2 << 20;          // compressed bytes per span
   size_t search_max = (size_t)512 << 10;  // a span gives up looking for its block behind this many bytes
+  size_t span_cap = (size_t)256 << 20;    // bytes of text after which a span hands over at the next block start
   // stream position between rounds (decode side)
   size_t cur_bit = 0;
   bool at_header = true, finished = false;
@@ -569,6 +573,7 @@ struct ParallelGunzip {
     // smaller spans for smaller files: several rounds, so that decoding and emitting overlap and the last round is short
     span = std::min((size_t)2 << 20, std::max((size_t)256 << 10, n / ((size_t)team * 6)));
     if (const char *e = getenv("KU_PGZIP_SPAN_KB")) span = (size_t)atol(e) << 10;
+    if (const char *e = getenv("KU_PGZIP_SPAN_CAP_KB")) span_cap = (size_t)std::max(1L, atol(e)) << 10;  // test hook
     if (span < 4096) span = 4096;
     if (search_max > span) search_max = span;
     cur_bit = 0; at_header = true; finished = false;
@@ -577,7 +582,8 @@ struct ParallelGunzip {
     for (Set &st : sets) {
       st.ds = std::vector<SpanDecoder<uint16_t>>((size_t)team);
       st.d0.tb = &tabs[0];
-      for (int i = 1; i < team; ++i) st.ds[(size_t)i].tb = &tabs[(size_t)i];
+      st.d0.soft_cap = span_cap;
+      for (int i = 1; i < team; ++i) { st.ds[(size_t)i].tb = &tabs[(size_t)i]; st.ds[(size_t)i].soft_cap = span_cap; }
       st.acc.clear();
     }
     primed = false; cur = 0;

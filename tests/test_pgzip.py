@@ -114,6 +114,18 @@ def test_team_inflate_equals_zlib(shape, tmp_path):
             assert r.stdout == want, (shape, team, span_kb, len(r.stdout), len(want))
 
 
+def test_highly_compressible_spans_hand_over_early(tmp_path):
+    """the N runs of a genome FASTA expand a thousandfold: a span that holds more text than its cap stops at the next block
+    start and the next round goes on from there (memory stays bounded); same bytes"""
+    text = b">chr\n" + (b"N" * 60 + b"\n") * 400000 + FA + (b"N" * 60 + b"\n") * 300000 + FA[:100000]
+    p = tmp_path / "n.fa.gz"
+    p.write_bytes(member(text))
+    for cap_kb, span_kb in ((256, 16), (1024, 4), (64, 64)):
+        r = subprocess.run([DUMP, "-z", "4", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, KU_PGZIP_SPAN_CAP_KB=str(cap_kb), KU_PGZIP_SPAN_KB=str(span_kb)))
+        assert r.returncode == 0 and r.stdout == text, (cap_kb, span_kb, r.stderr.decode()[-200:])
+
+
 def test_spans_are_really_decoded_side_by_side(tmp_path):
     """the block search finds the deflate blocks of FASTQ text and the chain of spans holds: with four threads about four
     spans per round, none dropped"""
