@@ -32,6 +32,7 @@
 // broadcast, per-k-mer slots reduce-scattered, per-taxon state reduced at the end; KU_MGPU_MODE=replicas keeps the
 // whole database on every GPU and splits the reads instead).
 #include <fcntl.h>
+#include <malloc.h>
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -206,6 +207,12 @@ int main(int argc, char **argv) {
   uint64_t chunk_bytes = 0;  // -x SIZE: stream the database through HBM in chunks of at most SIZE bytes
   int fmt_threads = 4;  // -t: host threads that format the Kraken lines (the GPU replaces the OpenMP team)
   if (argc > 1 && strcmp(argv[1], "-h") == 0) usage(0);
+  if (const char *e = getenv("KU_MALLOPT")) {  // measurement aid: the formatted lines' buffers (~1 MB each, sixteen per batch) from the heap
+    if (atoi(e)) {                             // instead of one mmap / munmap pair each
+      mallopt(M_MMAP_THRESHOLD, 1 << 30);
+      mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    }
+  }
   int opt;
   while ((opt = getopt(argc, argv, "d:i:t:u:n:m:o:qcC:U:Ma:r:sI:p:x:P")) != -1) {
     long long sig;
