@@ -12,14 +12,21 @@ with open(path, "wb") as f:
     for rep in range(n_m * 1000):
         f.write(block)
 db = f"{ROOT}/tests/golden/f1"
-configs = [("default (-t 16)", "16", {}),
-           ("KU_MALLOPT=1", "16", {"KU_MALLOPT": "1"}),
-           ("batch 128 Mi nt", "16", {"KU_BATCH_NT": str(128 << 20)}),
-           ("batch 128 Mi nt, KU_MALLOPT=1", "16", {"KU_BATCH_NT": str(128 << 20), "KU_MALLOPT": "1"}),
-           ("batch 32 Mi nt", "16", {"KU_BATCH_NT": str(32 << 20)}),
-           ("-t 32", "32", {}),
-           ("-t 8", "8", {}),
-           ("batch 128 Mi nt, 12 parsers", "16", {"KU_BATCH_NT": str(128 << 20), "KU_PARSE_TEAM": "12"})]
+configs = [("batch 32 Mi nt", "16", {"KU_BATCH_NT": str(32 << 20)}),
+           ("batch 24 Mi nt", "16", {"KU_BATCH_NT": str(24 << 20)}),
+           ("batch 16 Mi nt", "16", {"KU_BATCH_NT": str(16 << 20)}),
+           ("batch 12 Mi nt", "16", {"KU_BATCH_NT": str(12 << 20)}),
+           ("batch 8 Mi nt", "16", {"KU_BATCH_NT": str(8 << 20)}),
+           ("batch 16 Mi nt, -t 32", "32", {"KU_BATCH_NT": str(16 << 20)})]
+if os.environ.get("KU_SWEEP") == "knobs":  # the first sweep of round 4 (profiles/r04_e2e_sweep.log, upper half)
+    configs = [("default (-t 16)", "16", {}),
+               ("KU_MALLOPT=1", "16", {"KU_MALLOPT": "1"}),
+               ("batch 128 Mi nt", "16", {"KU_BATCH_NT": str(128 << 20)}),
+               ("batch 128 Mi nt, KU_MALLOPT=1", "16", {"KU_BATCH_NT": str(128 << 20), "KU_MALLOPT": "1"}),
+               ("batch 32 Mi nt", "16", {"KU_BATCH_NT": str(32 << 20)}),
+               ("-t 32", "32", {}),
+               ("-t 8", "8", {}),
+               ("batch 128 Mi nt, 12 parsers", "16", {"KU_BATCH_NT": str(128 << 20), "KU_PARSE_TEAM": "12"})]
 res = {c[0]: [] for c in configs}
 busy = {}
 for rep in range(2):
