@@ -104,3 +104,19 @@ def test_reader_and_region_parsers_take_bz2(tmp_path):
     for args in (["-T", str(bad)], ["-j", "4", str(bad)]):
         r = subprocess.run([DUMP] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 65 and b"bzip2" in r.stderr, args
+
+
+def test_random_damage_never_yields_other_bytes(tmp_path):
+    """as for .gz (tests/test_pgzip.py): the run fails or hands out exactly the original text"""
+    from test_pgzip import corrupt
+    rng = np.random.default_rng(78)
+    src = FQ[:1_200_000]
+    blob = bz2.compress(src, 1)
+    p = tmp_path / "d.bz2"
+    refused = 0
+    for it in range(24):
+        p.write_bytes(corrupt(blob, rng))
+        r = subprocess.run([DUMP, "-Z", "3", str(p)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode != 0 or r.stdout == src, it
+        refused += r.returncode != 0
+    assert refused >= 18
