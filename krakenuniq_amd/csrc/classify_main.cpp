@@ -59,6 +59,7 @@
 
 #include "../../include/krakenuniq_amd.h"
 #include "ku_seqio.h"
+#include "ku_pgzout.h"
 
 // Fatal errors are raised by whichever thread meets them (the reader finds a damaged input while the main thread still
 // loads the database): exit() would run the static destructors -- the HIP runtime's among them -- under the feet of the
@@ -151,18 +152,36 @@ static uint64_t parse_size(const char *s) {
 struct Sink {
   FILE *f = nullptr;
   gzFile g = nullptr;
-  bool open(const std::string &name, bool append = false) {
+  ku_pgzout::Member pg;  // `team`: a .gz file whose parts arrive deflated (ku_pgzout.h: the formatting helpers compress what they
+  bool pgz = false;      // formatted; ogzstream's one deflate on the writing thread would be twenty times slower than the pipeline)
+  bool open(const std::string &name, bool append = false, bool team = false) {
     if (name == "-") { f = stdout; return true; }
-    if (name.size() > 3 && name.compare(name.size() - 3, 3, ".gz") == 0) { g = gzopen(name.c_str(), "wb"); return g != nullptr; }
+    if (name.size() > 3 && name.compare(name.size() - 3, 3, ".gz") == 0) {
+      if (team && !getenv("KU_NO_PGZOUT")) { pgz = pg.open(name.c_str()); return pgz; }
+      g = gzopen(name.c_str(), "wb");
+      return g != nullptr;
+    }
     f = fopen(name.c_str(), append ? "a" : "w");
     return f != nullptr;
   }
   void write(const char *p, size_t n) {
     if (!n) return;
-    if (g) { if (gzwrite(g, p, (unsigned)n) <= 0) die(EX_OSERR, "gz write error"); }
+    if (pgz) {  // (text for a team-written file: deflated here)
+      size_t cl = 0;
+      uLong crc = 0;
+      unsigned char *c = ku_pgzout::deflate_part(p, n, &cl, &crc);
+      if (!c) die(EX_OSERR, "gz write error");
+      write_deflated(c, cl, crc, n);
+      free(c);
+    } else if (g) { if (gzwrite(g, p, (unsigned)n) <= 0) die(EX_OSERR, "gz write error"); }
     else if (f && fwrite(p, 1, n, f) != n) die(EX_OSERR, "write error: %s", strerror(errno));
   }
+  void write_deflated(const unsigned char *c, size_t clen, uLong crc, size_t raw_len) {
+    if (!pg.put(c, clen, crc, raw_len)) die(EX_OSERR, "write error: %s", strerror(errno));
+  }
   void close() {
+    if (pgz && !pg.close()) die(EX_OSERR, "write error: %s", strerror(errno));
+    pgz = false;
     if (g) gzclose(g);
     if (f && f != stdout) fclose(f);
     if (f == stdout) fflush(stdout);
@@ -474,7 +493,7 @@ int main(int argc, char **argv) {
     if (kraken_out == "off" || kraken_out == "-") print_kraken = false;
     else {
       fprintf(stderr, "Writing Kraken output to %s\n", kraken_out.c_str());
-      if (!s_kraken.open(kraken_out)) die(EX_OSERR, "can't open %s", kraken_out.c_str());
+      if (!s_kraken.open(kraken_out, false, /*team=*/true)) die(EX_OSERR, "can't open %s", kraken_out.c_str());
     }
   } else s_kraken.open("-");
   if (print_cls && !s_cls.open(cls_out)) die(EX_OSERR, "can't open %s", cls_out.c_str());
@@ -704,7 +723,7 @@ int main(int argc, char **argv) {
   // `fmt_threads` helpers, disjoint read ranges) while the writer writes those of batch b, in input order.  (One thread
   // doing both, with a team spawned per batch, was the slowest stage of the pipeline: 16 thread starts and a serial
   // 12 MB write per batch.)
-  struct Formatted { Batch *bt; std::vector<char *> parts; std::vector<size_t> len; };
+  struct Formatted { Batch *bt; std::vector<char *> parts; std::vector<size_t> len; std::vector<uLong> crc; std::vector<size_t> raw; };
   struct FQueue {
     std::mutex m; std::condition_variable cv; std::deque<Formatted *> q;
     void push(Formatted *f) { { std::lock_guard<std::mutex> l(m); q.push_back(f); } cv.notify_one(); }
@@ -739,7 +758,8 @@ int main(int argc, char **argv) {
       if (!bt) break;
       const uint64_t n = bt->off.size();
       const double t_fmt = now_s();
-      Formatted *f = new Formatted{bt, std::vector<char *>(fmt_threads, nullptr), std::vector<size_t>(fmt_threads, 0)};
+      Formatted *f = new Formatted{bt, std::vector<char *>(fmt_threads, nullptr), std::vector<size_t>(fmt_threads, 0),
+                                   std::vector<uLong>(fmt_threads, 0), std::vector<size_t>(fmt_threads, 0)};
       if (print_kraken) {
         std::vector<int> status(fmt_threads, KU_OK);
         fmt_team.run([&](int t) {
@@ -749,6 +769,15 @@ int main(int argc, char **argv) {
                                            bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
                                            bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
                                            pflags, &f->parts[t], &f->len[t]);
+          if (status[t] == KU_OK && s_kraken.pgz && f->len[t]) {  // -o x.gz: the helper deflates its own lines
+            size_t cl = 0;
+            unsigned char *c = ku_pgzout::deflate_part(f->parts[t], f->len[t], &cl, &f->crc[t]);
+            if (!c) { status[t] = KU_ENOMEM; return; }
+            ku_free(f->parts[t]);
+            f->parts[t] = (char *)c;  // (malloc'ed like the text: the writer frees either the same way)
+            f->raw[t] = f->len[t];
+            f->len[t] = cl;
+          }
         });
         for (int t = 0; t < fmt_threads; ++t)
           if (status[t] != KU_OK) die(exit_code_of(status[t]), "%s", ku_strerror(status[t]));
@@ -767,7 +796,8 @@ int main(int argc, char **argv) {
       const double t_write = now_s();
       for (int t = 0; t < fmt_threads; ++t)
         if (f->parts[t]) {
-          s_kraken.write(f->parts[t], f->len[t]);
+          if (s_kraken.pgz) s_kraken.write_deflated((const unsigned char *)f->parts[t], f->len[t], f->crc[t], f->raw[t]);
+          else s_kraken.write(f->parts[t], f->len[t]);
           ku_free(f->parts[t]);
         }
       delete f;

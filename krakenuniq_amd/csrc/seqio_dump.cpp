@@ -2,6 +2,8 @@
 // exactly as the reader thread does and prints "id<TAB>sequence" per read, or with -n only the parsing rate.
 // -j N parses N record-aligned regions of each (plain) file independently, as the executable's parser team does.
 // -z J inflates each file with the J-thread gzip team alone (ku_pgzip.h) and writes the bytes (with -n: the rate).
+// -G out.gz: the sequential reader's records go to a gzip file written as the executable writes `-o x.gz` (ku_pgzout.h: parts
+// deflated side by side, one stream).
 // Host-only: does not link the GPU library (pinned allocation is replaced by malloc here), classifies nothing.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -18,6 +20,7 @@
 #include "ku_seqio.h"
 #include "ku_pgzip.h"
 #include "ku_pbzip2.h"
+#include "ku_pgzout.h"
 
 // the batches of this tool are plain host memory (Batch::pinned = false); these are never called
 extern "C" int ku_host_alloc(size_t, void **out) { *out = nullptr; return KU_ENOMEM; }
@@ -35,6 +38,8 @@ void ku_seqio::fatal(int code, const char *fmt, ...) {
 int main(int argc, char **argv) {
   bool paired = false, quiet = false, prefetch = false, warm = false;
   int regions = 0, gunzip_team = 0, bunzip_team = 0;
+  const char *gz_out = nullptr;
+  std::string gz_text;
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
     if (argv[a][1] == 'P') paired = true;
@@ -42,6 +47,7 @@ int main(int argc, char **argv) {
     else if (argv[a][1] == 'T') prefetch = true;
     else if (argv[a][1] == 'w') warm = true;  // -j: parse every region twice into the same batch, time the second pass (buffers and pages warm)
     else if (argv[a][1] == 'z' && a + 1 < argc) gunzip_team = atoi(argv[++a]);
+    else if (argv[a][1] == 'G' && a + 1 < argc) gz_out = argv[++a];
     else if (argv[a][1] == 'Z' && a + 1 < argc) bunzip_team = atoi(argv[++a]);  // as -z, for .bz2 (ku_pbzip2.h)
     else if (argv[a][1] == 'j' && a + 1 < argc) regions = atoi(argv[++a]);  // producer thread per file, as the classify executable runs
   }
@@ -201,7 +207,12 @@ int main(int argc, char **argv) {
         ku_seqio::split_id(header.data(), header.size(), lo, hi);
         if (paired) hi = lo + ku_seqio::strip_mate_suffix(header.data() + lo, hi - lo);
         ++n_reads;
-        if (!quiet) {
+        if (gz_out) {
+          gz_text.append(header.data() + lo, hi - lo);
+          gz_text += '\t';
+          gz_text.append(bt.seqs + bt.off.back(), bt.len.back());
+          gz_text += '\n';
+        } else if (!quiet) {
           fwrite(header.data() + lo, 1, hi - lo, stdout);
           fputc('\t', stdout);
           fwrite(bt.seqs + bt.off.back(), 1, bt.len.back(), stdout);
@@ -214,6 +225,27 @@ int main(int argc, char **argv) {
     bt.release();
     rd.close();
     rd2.close();
+  }
+  if (gz_out) {  // parts of ~200 kB (what a formatting helper of the executable holds), deflated by four threads, written in order
+    const size_t part = getenv("KU_GZ_PART") ? (size_t)atol(getenv("KU_GZ_PART")) : 200000;
+    const size_t n_parts = (gz_text.size() + part - 1) / part;
+    std::vector<unsigned char *> comp(n_parts, nullptr);
+    std::vector<size_t> clen(n_parts, 0);
+    std::vector<uLong> crcs(n_parts, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < 4; ++t)
+      th.emplace_back([&, t] {
+        for (size_t i = (size_t)t; i < n_parts; i += 4)
+          comp[i] = ku_pgzout::deflate_part(gz_text.data() + i * part, std::min(part, gz_text.size() - i * part), &clen[i], &crcs[i]);
+      });
+    for (auto &x : th) x.join();
+    ku_pgzout::Member mem;
+    if (!mem.open(gz_out)) ku_seqio::fatal(73, "can't create %s", gz_out);
+    for (size_t i = 0; i < n_parts; ++i) {
+      if (!comp[i] || !mem.put(comp[i], clen[i], crcs[i], std::min(part, gz_text.size() - i * part))) ku_seqio::fatal(74, "deflate / write error");
+      free(comp[i]);
+    }
+    if (!mem.close()) ku_seqio::fatal(74, "write error");
   }
   gettimeofday(&t1, nullptr);
   const double s = (double)(t1.tv_sec - t0.tv_sec) + (double)(t1.tv_usec - t0.tv_usec) / 1e6;

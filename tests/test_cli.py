@@ -71,6 +71,14 @@ def test_outputs_match_reference(tmp_path):
     gz = tmp_path / "out.tsv.gz"
     assert run(db + ["-o", str(gz), f"{F1}/reads.fq"]).returncode == 0
     assert gzip.open(gz).read() == open(f"{F1}/out.tsv", "rb").read()
+    # (the .gz file is ONE deflate stream whose parts the formatting helpers deflate, ku_pgzout.h: many batches and parts, parts
+    #  without lines, and zlib's own writer beside it)
+    assert run(db + ["-t", "3", "-o", str(gz), f"{F1}/reads.fq"], env={**os.environ, "KU_BATCH_NT": "65536"}).returncode == 0
+    assert gzip.open(gz).read() == open(f"{F1}/out.tsv", "rb").read()
+    assert run(db + ["-t", "16", "-c", "-o", str(gz), f"{F1}/reads.fq"], env={**os.environ, "KU_BATCH_NT": "65536"}).returncode == 0
+    assert gzip.open(gz).read() == open(f"{F1}/out_c.tsv", "rb").read()
+    assert run(db + ["-o", str(gz), f"{F1}/reads.fq"], env={**os.environ, "KU_NO_PGZOUT": "1"}).returncode == 0
+    assert gzip.open(gz).read() == open(f"{F1}/out.tsv", "rb").read()
     r = run(db + ["-o", "off", f"{F1}/reads.fq"])
     assert r.returncode == 0 and r.stdout == b""
     # -u 1000: every per-unit sketch stays sparse (the reference's report_u1000.tsv); small GPU batches on top
