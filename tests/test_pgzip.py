@@ -287,3 +287,25 @@ def test_one_stream_writer_of_the_bench(tmp_path):
     assert gzip.decompress(blob) == FQ and blob.count(b"\x1f\x8b\x08") >= 1
     r = inflate(out, 4, 64)
     assert r.returncode == 0 and r.stdout == FQ
+
+
+def test_gz_output_written_in_parts_is_one_valid_stream(tmp_path):
+    """ku_pgzout.h (how the executable writes `-o x.gz`: every formatting helper deflates its own lines, closed with a sync
+    flush; the writer joins the parts and combines their CRCs): seqio_dump -G writes the parsed records that way -- zlib reads
+    the file back, with parts of 200 kB, of 777 bytes, and for an input without records"""
+    import gzip
+    src = tmp_path / "r.fq"
+    src.write_bytes(FQ[:3_000_000])
+    want = subprocess.run([DUMP, str(src)], stdout=subprocess.PIPE, check=True).stdout
+    for part in ("200000", "777"):
+        out = tmp_path / f"o{part}.gz"
+        subprocess.run([DUMP, "-G", str(out), str(src)], check=True, stderr=subprocess.PIPE, env=dict(os.environ, KU_GZ_PART=part))
+        blob = out.read_bytes()
+        assert zlib_accepts(blob) and gzip.decompress(blob) == want
+        r = inflate(out, 3, 64)  # ... and so does the team
+        assert r.returncode == 0 and r.stdout == want
+    empty = tmp_path / "empty.fq"
+    empty.write_bytes(b"")
+    out = tmp_path / "e.gz"
+    subprocess.run([DUMP, "-G", str(out), str(empty)], check=True, stderr=subprocess.PIPE)
+    assert gzip.decompress(out.read_bytes()) == b""
