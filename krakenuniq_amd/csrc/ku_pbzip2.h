@@ -4,8 +4,8 @@
 //
 // A .bz2 file is a sequence of blocks of at most 900 kB, each compressed on its own (Burrows-Wheeler transform, move to
 // front, run lengths, up to six Huffman tables switched every 50 symbols) and introduced by a 48-bit magic number at ANY
-// bit offset.  A scanner thread finds the magic numbers, the members of the team decode the blocks behind them side by
-// side, and the consumer takes them in file order.  A block counts only where the block before it ended (a magic number
+// bit offset.  The members of a team find the magic numbers (the file in pieces, by whichever member has no block to decode)
+// and decode the blocks behind them side by side; the consumer takes them in file order.  A block counts only where the block before it ended (a magic number
 // inside compressed data is skipped that way), with its CRC right, and every stream's combined CRC is checked at its end
 // marker: what bzip2 -t refuses is refused.  Several streams in one file (pbzip2's output, `cat a.bz2 b.bz2`) follow one
 // another; bytes behind the last stream that do not start a stream are ignored as bzip2 ignores them.

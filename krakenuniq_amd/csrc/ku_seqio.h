@@ -1,4 +1,4 @@
-// Host-side sequence input of the classify executable: FASTA/FASTQ(+gz) records parsed straight into the pinned
+// Host-side sequence input of the classify executable: FASTA/FASTQ records (plain, .gz, .bz2) parsed straight into the pinned
 // read batch the C ABI takes (no per-record std::string round trips), with the record semantics of the reference's
 // readers (src/seqreader.cpp:26-133) and, for mate pairs, of scripts/read_merger.pl:100-197.
 #pragma once
