@@ -267,6 +267,27 @@ int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const
                           const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                           uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs);
 int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs);
+/* The same in two steps, up to TWO batches in flight on a context (round 5; the reference's process_file keeps its team
+ * busy by handing work units out under a critical section, classify.cpp:499-561 -- here the device is kept busy by having
+ * the next batch's upload and the previous batch's copies back run under the current batch's kernels):
+ *   ku_classify_batch_rle_enqueue  plans the batch and starts its upload (in segments, on a copy stream), its kernels and
+ *       the copies back of calls / (run_off, run_cnt); it does not wait for the device.  Every array of the call, inputs
+ *       and outputs, must stay where it is until _finish has returned for the batch; page-locked memory (ku_host_alloc)
+ *       makes the copies asynchronous, pageable memory works but serialises.
+ *   ku_classify_batch_rle_finish   waits for the OLDEST batch in flight (one event), settles the sparse-sketch emulation's
+ *       bookkeeping for it and returns its *n_runs; ku_fetch_runs then copies that batch's runs (valid until the next
+ *       _enqueue or _finish on the context).
+ * Batches are finished in the order they were enqueued.  KU_ESTATE from _enqueue: two batches are in flight already, or
+ * the batch takes a path that cannot overlap (quick mode, several databases, sorted layout, a shard, exact counting, a
+ * read beyond 65535 k-mers, an open work unit left by such a batch) while another is in flight: finish that one, then
+ * enqueue again -- the batch is then classified inside _enqueue and _finish merely hands its totals over.  The entry
+ * points that read or reset the run's state (reports, exports, ku_ctx_reset_counts, ku_sparse_close_unit,
+ * ku_ctx_replace_calls, ku_classify_batch_rle itself) answer KU_ESTATE while batches are in flight. */
+int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                                  const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                                  uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt);
+int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs);
+int ku_classify_batch_rle_in_flight(const ku_ctx *ctx); /* 0 .. 2 */
 
 /* ---- out-of-core run: the database streamed through HBM chunk by chunk (classify -x SIZE; KrakenDB::prepare_chunking /
  * load_chunk / is_minimizer_in_chunk krakendb.cpp:411-526, process_file_with_db_chunk classify.cpp:566-791).  The
@@ -565,6 +586,12 @@ int ku_report_exact(const ku_tax *tax, const char *const *counts_paths, uint32_t
 int ku_report_rows(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint8_t *present,
                    const uint64_t *clade_reads, const uint64_t *tax_reads, const uint64_t *clade_kmers,
                    const uint64_t *clade_uniq, uint64_t n_rows, char **out, size_t *out_len);
+/* ... with a choice of columns.  flags = KU_R_NO_KMER_COLS: "%  reads  taxReads  taxID  rank  taxName", the report of
+ * `classify -p 0` (HLL_PRECISION <= 0, classify.cpp:289,316-323); same rows in the same order, clade_uniq may be NULL. */
+#define KU_R_NO_KMER_COLS 1u
+int ku_report_rows_cols(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint8_t *present,
+                        const uint64_t *clade_reads, const uint64_t *tax_reads, const uint64_t *clade_kmers,
+                        const uint64_t *clade_uniq, uint64_t n_rows, uint32_t flags, char **out, size_t *out_len);
 /* The report straight from the context's device-resident state: the clade roll-up of the TaxReport
  * constructor (taxdb.hpp:928-982: every counted taxon's sketch merged into each of its ancestors') runs on the GPU --
  * one workgroup per counted clade takes the byte-wise maximum over its members' HLL registers and reduces it to the
@@ -575,6 +602,9 @@ int ku_report_rows(const ku_tax *tax, const char *const *counts_paths, uint32_t 
  * sparse-mode emulation on it ends the work unit that is still open, like ku_sparse_export: a call for the end of a run. */
 int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, char **out,
                   size_t *out_len);
+/* ... with the flags of ku_report_rows_cols: KU_R_NO_KMER_COLS needs no sketch at all -- no roll-up runs */
+int ku_ctx_report_cols(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, uint32_t flags,
+                       char **out, size_t *out_len);
 void ku_free(void *p);
 /* Page-locked host memory for batch buffers (fast, truly asynchronous H2D / D2H in ku_classify_batch). */
 int ku_host_alloc(size_t bytes, void **out);

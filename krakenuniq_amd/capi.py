@@ -111,6 +111,10 @@ SIGNATURES = {
     "ku_ctx_disable_sparse": (C.c_int, [C.c_void_p]),
     "ku_ctx_report": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_size_t)]),
+    "ku_ctx_report_cols": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_size_t)]),
+    "ku_report_rows_cols": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_uint32, u8p, u64p, u64p, u64p, u64p, C.c_uint64, C.c_uint32,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "ku_ctx_enable_exact": (C.c_int, [C.c_void_p, C.c_uint32]),
     "ku_counts_export_exact": (C.c_int, [C.c_void_p, u64p]),
     "ku_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts),
@@ -118,6 +122,10 @@ SIGNATURES = {
     "ku_classify_batch_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p, u32p,
                                         u64p, u32p, u64p]),
     "ku_fetch_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "ku_classify_batch_rle_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p, u32p,
+                                                u64p, u32p]),
+    "ku_classify_batch_rle_finish": (C.c_int, [C.c_void_p, u64p]),
+    "ku_classify_batch_rle_in_flight": (C.c_int, [C.c_void_p]),
     "ku_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                            C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ku_classify_batch_device_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -437,11 +445,15 @@ class Ctx:
         """0 = emulation off, 1 = on, 2 = gave up for lack of device memory (ku_ctx_sparse_state)"""
         return lib().ku_ctx_sparse_state(self.h)
 
-    def report(self, tax: "Tax", counts_paths=()):
-        """the report from the device-resident state, clade roll-up on the GPU (ku_ctx_report)"""
+    def report(self, tax: "Tax", counts_paths=(), flags=0):
+        """the report from the device-resident state, clade roll-up on the GPU (ku_ctx_report; flags = 1: the six columns of
+        `classify -p 0`, ku_ctx_report_cols)"""
         out, n = C.c_void_p(), C.c_size_t()
         paths = (C.c_char_p * len(counts_paths))(*[p.encode() for p in counts_paths])
-        _chk(lib().ku_ctx_report(self.h, tax.h, paths, len(counts_paths), C.byref(out), C.byref(n)), "ku_ctx_report")
+        if flags:
+            _chk(lib().ku_ctx_report_cols(self.h, tax.h, paths, len(counts_paths), flags, C.byref(out), C.byref(n)), "ku_ctx_report_cols")
+        else:
+            _chk(lib().ku_ctx_report(self.h, tax.h, paths, len(counts_paths), C.byref(out), C.byref(n)), "ku_ctx_report")
         s = C.string_at(out, n.value).decode()
         lib().ku_free(out)
         return s
@@ -512,6 +524,33 @@ class Ctx:
         o = Opts(flags, min_hits, max_read_len, 0)
         _chk(lib().ku_resolve_device(self.h, d_seqs, d_off, d_len, n_reads, C.byref(o), d_calls, d_taxa, d_hits,
                                      stream), "ku_resolve_device")
+
+    def rle_enqueue(self, buf, off, lens, flags=0, min_hits=1):
+        """First step of a batch through the pipelined form of ku_classify_batch_rle (up to two batches in flight).  Returns the
+        handle rle_finish() takes; the arrays stay alive with it."""
+        arr = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(off)
+        job = {"arr": arr, "off": off, "lens": lens, "calls": np.zeros(n, np.uint32), "hits": np.zeros(n, np.uint32),
+               "run_off": np.zeros(n, np.uint64), "run_cnt": np.zeros(n, np.uint32)}
+        o = Opts(flags, min_hits, 0, 0)
+        _chk(lib().ku_classify_batch_rle_enqueue(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n, C.byref(o),
+                                                 _p(job["calls"], u32p), _p(job["hits"], u32p), _p(job["run_off"], u64p),
+                                                 _p(job["run_cnt"], u32p)), "ku_classify_batch_rle_enqueue")
+        return job
+
+    def rle_finish(self, job):
+        """Second step: waits for the OLDEST batch in flight (which must be `job`), fetches its runs.  Same dictionary as
+        classify_batch_rle."""
+        total = C.c_uint64(0)
+        _chk(lib().ku_classify_batch_rle_finish(self.h, C.byref(total)), "ku_classify_batch_rle_finish")
+        runs = np.zeros((total.value, 2), np.uint32)
+        _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
+        return {"calls": job["calls"], "hits": job["hits"], "run_off": job["run_off"], "run_cnt": job["run_cnt"], "runs": runs}
+
+    def rle_in_flight(self):
+        return lib().ku_classify_batch_rle_in_flight(self.h)
 
     def classify_batch_device(self, d_seqs, n_bytes, d_off, d_len, n_reads, d_calls, d_taxa, d_hits=None, flags=0,
                               min_hits=1, max_read_len=0, stream=None):

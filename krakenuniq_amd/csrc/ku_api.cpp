@@ -383,10 +383,73 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// page-locked host scratch that grows on demand (sources and targets of asynchronous copies must outlive the call that
+// enqueues them and must be page-locked for the copy to be asynchronous at all)
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return KU_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return KU_ENOMEM; }
+    cap = want;
+    return KU_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// One batch on its way through the fused kernel with run-length encoded output (ku_classify_batch_rle_enqueue / _finish,
+// round 5): its own device buffers and page-locked scratch -- two of them alternate, so that the upload of batch b + 1 and
+// the copies back of batch b - 1 run under the kernel of batch b and the host waits for ONE event per batch -- and what
+// _finish needs to know about the batch.
+struct RleJob {
+  DevBuf seqs, off, len, calls, runs, roff, rcnt, ws, unit, u_cnt, u_flag;
+  PinBuf pin;       // [0] extent of the run array, [1] entries of the run-wide set, [2] the emulation's error word; byte 64 on: unit flags
+  PinBuf pin_unit;  // work-unit number of every read (source of an asynchronous upload)
+  unsigned long long *d_counter = nullptr;  // the kernel's bump counter of the run array (2 dwords of the context's scalars)
+  hipEvent_t kernels_done = nullptr, done = nullptr;
+  std::vector<hipEvent_t> seg_events;
+  bool busy = false;
+  bool settled = false;         // classified by a one-step path inside _enqueue: _finish only hands the totals over
+  bool runs_in_ctx = false;     // the runs lie in the context's own run buffer (one-step paths, the overflow redo)
+  uint64_t n_runs = 0;
+  // the batch
+  uint64_t n_bytes = 0, n_reads = 0, runs_cap = 0;
+  uint32_t max_n = 0;
+  ku_opts o{};
+  const uint32_t *h_len = nullptr;
+  uint32_t *h_calls = nullptr, *h_hits = nullptr, *h_rcnt = nullptr;
+  uint64_t *h_roff = nullptr;
+  // sparse-sketch emulation, fast path: the batch's work units
+  bool sparse = false;
+  bool cont_carry = false;      // unit 0 continues a unit whose state sits in the carry buffers (L / U entries; the staged form)
+  bool cont_tail = false;       // unit 0 continues a unit kept as its reads + insert counts (the fast path's own form)
+  bool open_after = false;      // the last unit is still open behind this batch
+  uint32_t n_units = 0;
+  uint64_t kmers = 0;           // upper bound of what the kernel may add to the run-wide set
+  uint64_t acc_after = 0;
+  std::vector<uint64_t> unit_first_read;
+  std::vector<char> tail_text;      // cont_tail: the reads of the open unit BEFORE this batch (bases, each read followed by '\n')
+  std::vector<uint32_t> tail_len;
+  void release() {
+    for (DevBuf *b : {&seqs, &off, &len, &calls, &runs, &roff, &rcnt, &ws, &unit, &u_cnt, &u_flag}) b->release();
+    pin.release();
+    pin_unit.release();
+    if (kernels_done) (void)hipEventDestroy(kernels_done);
+    if (done) (void)hipEventDestroy(done);
+    for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
+    kernels_done = done = nullptr;
+    seg_events.clear();
+  }
+};
+
 // one resident database (shard): the 12-byte pairs until the taxonomy is set, the probe table afterwards
 struct DbStore {
   bool db_owned = false, offsets_owned = false;
   bool hash_layout = true;
+  bool seen_dirty = false;  // SEEN marks of the probe table may be set (ku_device.h; the sparse-sketch emulation's fast path)
   void *d_table = nullptr;
   uint64_t n_dup = 0;
   uint64_t table_lines = 0;
@@ -417,9 +480,14 @@ struct ku_ctx {
   DevBuf b_seqs, b_off, b_len, b_calls, b_taxa, b_hits, b_ws, b_runs, b_roff, b_rcnt;
   // ku_classify_batch_rle through the fused kernel: the batch goes up in segments on a stream of its own while the
   // segments before are classified (one event per segment)
-  hipStream_t h2d_stream = nullptr;
+  hipStream_t h2d_stream = nullptr, d2h_stream = nullptr, fetch_stream = nullptr;
   std::vector<hipEvent_t> seg_events;
   uint32_t *d_scalar = nullptr;
+  // ku_classify_batch_rle in two steps: up to two batches in flight (FIFO: rle_head is the oldest)
+  RleJob rle[2];
+  int rle_head = 0, rle_in_flight = 0;
+  const void *fetch_runs_src = nullptr;  // where the runs of the batch finished last lie (ku_fetch_runs)
+  const void *last_calls_dev = nullptr;  // ... and its calls on the device (ku_ctx_replace_calls)
   // ku_ctx_count_taxons of the store it was computed for (identified by its buffers)
   std::vector<unsigned long long> count_cache;
   const void *count_cache_store = nullptr, *count_cache_pairs = nullptr;
@@ -450,6 +518,17 @@ struct ku_ctx {
     uint64_t n_carry_l = 0, n_carry_u = 0, cap_carry_l = 0, cap_carry_u = 0;
     uint64_t g_count = 0;       // entries of the global set after the last pass (host copy of d_counters[0])
     bool gave_up = false;       // the emulation ran out of device memory during the run and was switched off
+    // The open unit in TAIL form (round 5; the fast path's own): a host copy of its reads so far and its insert counts per
+    // slot.  A unit can only turn a sketch dense when it gave it >= 1025 inserts (hyperloglogplus.cpp:496-498) -- known from
+    // the counts once the unit closes, whichever batches it straddled; only then, and only for such a unit, does the exact
+    // evaluation (L / U tables) run, over these reads + the closing batch's.  Rounds 3-4 ran it for the first and the last
+    // unit of EVERY batch to carry their L / U entries along: two passes, ten launches, two host round trips per batch.
+    // (acc_nt, open, tail_open and the tail describe the state behind the newest ENQUEUED batch.)
+    bool tail_open = false;
+    std::vector<char> tail_text;   // bases of the unit's reads, each read followed by '\n'
+    std::vector<uint32_t> tail_len;
+    DevBuf tail_row;               // inserts of the open unit so far, per slot
+    DevBuf t_seqs, t_off, t_len, t_taxa, t_unit;  // the tail on the device, when it is evaluated
   } sp;
 };
 
@@ -514,7 +593,9 @@ static void ctx_free_sparse(ku_ctx *ctx) {
   for (void *p : {(void *)d.l_key, (void *)d.l_first, (void *)d.u_key, (void *)d.u_distinct, (void *)d.u_last, (void *)d.u_maxfirst,
                   (void *)d.g_key, (void *)d.dense, (void *)d.err, (void *)ctx->sp.d_counters})
     if (p) (void)hipFree(p);
-  for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out, &ctx->sp.u_cnt, &ctx->sp.u_flag, &ctx->sp.list}) b->release();
+  for (DevBuf *b : {&ctx->sp.unit, &ctx->sp.carry_l, &ctx->sp.carry_u, &ctx->sp.out, &ctx->sp.u_cnt, &ctx->sp.u_flag, &ctx->sp.list, &ctx->sp.tail_row,
+                    &ctx->sp.t_seqs, &ctx->sp.t_off, &ctx->sp.t_len, &ctx->sp.t_taxa, &ctx->sp.t_unit})
+    b->release();
   ctx->sp = ku_ctx::Sparse{};
 }
 static void ctx_free_tax(ku_ctx *ctx) {
@@ -550,7 +631,10 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   if (ctx->pf.d_scalar) (void)hipFree(ctx->pf.d_scalar);
   if (ctx->pf.stream) (void)hipStreamDestroy(ctx->pf.stream);
   for (hipEvent_t e : ctx->seg_events) (void)hipEventDestroy(e);
+  for (RleJob &j : ctx->rle) j.release();
   if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
+  if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+  if (ctx->fetch_stream) (void)hipStreamDestroy(ctx->fetch_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -857,6 +941,7 @@ extern "C" int ku_ctx_set_taxonomy(ku_ctx *ctx, const ku_tax *tax, const uint32_
 
 extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
   if (!ctx || !ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  if (ctx->rle_in_flight) return fail(KU_ESTATE, "ku_ctx_reset_counts: batches are in flight (ku_classify_batch_rle_finish first)");
   KU_TRY(ctx_activate(ctx));
   HIP_TRY(hipMemsetAsync(ctx->cnt.registers, 0, (size_t)ctx->tax.n_slots * KU_HLL_M, ctx->stream));
   HIP_TRY(hipMemsetAsync(ctx->cnt.n_kmers, 0, (size_t)ctx->tax.n_slots * 8, ctx->stream));
@@ -865,6 +950,10 @@ extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
     HIP_TRY(hipMemsetAsync(ctx->d_exact_set, 0, (ctx->exact_mask + 1) * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_exact_unique, 0, (size_t)ctx->tax.n_slots * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_scalar + 6, 0, 4, ctx->stream));
+  }
+  if (ctx->m.seen_dirty && ctx->m.d_table) {  // the marks of the run before (sparse-sketch emulation, ku_device.h)
+    KU_TRY(ku_launch_seen(2, ctx->m.d_table, ctx->m.db.n_lines, KuSparseDev{}, nullptr, ctx->stream));
+    ctx->m.seen_dirty = false;
   }
   if (ctx->sp.on) {
     KuSparseDev &d = ctx->sp.dev;
@@ -876,12 +965,18 @@ extern "C" int ku_ctx_reset_counts(ku_ctx *ctx) {
     ctx->sp.open = false;
     ctx->sp.n_carry_l = ctx->sp.n_carry_u = 0;
     ctx->sp.g_count = 0;
+    ctx->sp.tail_open = false;
+    ctx->sp.tail_text.clear();
+    ctx->sp.tail_len.clear();
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return KU_OK;
 }
 
 static int check_ready(ku_ctx *ctx);
+static int rle_idle(const ku_ctx *ctx, const char *who);
+static int sparse_tail_close(ku_ctx *ctx);
+static int sparse_tail_to_carry(ku_ctx *ctx);
 static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, const uint32_t *d_len, const uint64_t *h_off,
                        const uint32_t *h_len, uint64_t n_reads, uint64_t n_bytes, const uint32_t *d_taxa, uint32_t quick_min_hits,
                        hipStream_t s);
@@ -970,6 +1065,7 @@ extern "C" int ku_ctx_count_taxons_db(ku_ctx *ctx, uint32_t db_index, uint32_t *
 // ---------------------------------------------------------------------------- HLL sparse-mode emulation
 extern "C" int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t global_log2) {
   KU_TRY(check_ready(ctx));
+  KU_TRY(rle_idle(ctx, "ku_ctx_enable_sparse"));
   if (ctx->tax.n_slots > KU_SPARSE_MAX_SLOTS) return fail(KU_EUNSUP, "sparse-mode emulation handles up to 2^18 distinct database taxids");
   if (global_log2 == 0) global_log2 = 26;
   if (global_log2 < 10 || global_log2 > 34) return fail(KU_EINVAL, "ku_ctx_enable_sparse: global_log2 out of range (10..34)");
@@ -1064,6 +1160,7 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
                        hipStream_t s) {
   ku_ctx::Sparse &sp = ctx->sp;
   KuSparseDev &d = sp.dev;
+  KU_TRY(sparse_tail_to_carry(ctx));  // (an open unit the fast path left: into the form these passes carry along)
   if (n_bytes + 2 >= (1ull << 32)) return fail(KU_EUNSUP, "sparse-mode emulation: batches of at most 4 G bases");
   for (uint64_t i = 1; i < n_reads; ++i)
     if (h_off[i] < h_off[i - 1]) return fail(KU_EINVAL, "sparse-mode emulation: the reads of a batch must be in buffer order");
@@ -1124,6 +1221,7 @@ static int sparse_pass(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_off, c
 static int sparse_close_open_unit(ku_ctx *ctx) {
   ku_ctx::Sparse &sp = ctx->sp;
   hipStream_t s = ctx->stream;
+  KU_TRY(sparse_tail_close(ctx));  // (a unit the fast path kept as its reads + insert counts)
   if (sp.open) {
     KU_TRY(sparse_reserve_global(ctx, sp.n_carry_l, s));
     KuSparseDev d;
@@ -1141,8 +1239,32 @@ static int sparse_close_open_unit(ku_ctx *ctx) {
   return KU_OK;
 }
 
+// The entries the fused kernel's fast path marked in the probe table (ku_device.h: SEEN bytes) join the run-wide set: for whoever
+// needs the set as such (ku_sparse_export, the union of several ranks' sets, a table that is about to go).  The marks stay.
+static int ctx_seen_harvest(ku_ctx *ctx) {
+  if (!ctx->sp.on || !ctx->m.seen_dirty || !ctx->m.d_table) return KU_OK;
+  hipStream_t s = ctx->stream;
+  unsigned long long *d_n = ctx->sp.d_counters + 3, n = 0;
+  HIP_TRY(hipMemsetAsync(d_n, 0, 8, s));
+  KU_TRY(ku_launch_seen(0, ctx->m.d_table, ctx->m.db.n_lines, ctx->sp.dev, d_n, s));
+  HIP_TRY(hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (n == 0) return KU_OK;
+  KU_TRY(sparse_reserve_global(ctx, n, s));
+  KU_TRY(ku_launch_seen(1, ctx->m.d_table, ctx->m.db.n_lines, ctx->sp.dev, ctx->sp.dev.g_count, s));
+  unsigned long long c = 0;
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(&c, ctx->sp.dev.g_count, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&err, ctx->sp.dev.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  ctx->sp.g_count = c;
+  if (err) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set is full");
+  return KU_OK;
+}
+
 extern "C" int ku_ctx_disable_sparse(ku_ctx *ctx) {
   if (!ctx) return fail(KU_EINVAL, "null context");
+  KU_TRY(rle_idle(ctx, "ku_ctx_disable_sparse"));
   KU_TRY(ctx_activate(ctx));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx_free_sparse(ctx);
@@ -1153,6 +1275,7 @@ extern "C" int ku_ctx_sparse_state(const ku_ctx *ctx) { return !ctx ? 0 : (ctx->
 
 extern "C" int ku_sparse_close_unit(ku_ctx *ctx) {
   KU_TRY(check_ready(ctx));
+  KU_TRY(rle_idle(ctx, "ku_sparse_close_unit"));
   if (!ctx->sp.on) return KU_OK;
   if (ctx->sp.unit_nt == 0) return KU_OK;  // one unit for the whole run
   return sparse_close_open_unit(ctx);
@@ -1160,9 +1283,11 @@ extern "C" int ku_sparse_close_unit(ku_ctx *ctx) {
 
 extern "C" int ku_sparse_export(ku_ctx *ctx, uint8_t *slot_is_sparse, uint64_t *pairs, uint64_t *n_pairs) {
   KU_TRY(check_ready(ctx));
+  KU_TRY(rle_idle(ctx, "ku_sparse_export"));
   if (!ctx->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled (ku_ctx_enable_sparse)");
   if (!n_pairs) return fail(KU_EINVAL, "ku_sparse_export: null argument");
   KU_TRY(sparse_close_open_unit(ctx));
+  KU_TRY(ctx_seen_harvest(ctx));
   ku_ctx::Sparse &sp = ctx->sp;
   KuSparseDev &d = sp.dev;
   hipStream_t s = ctx->stream;  // end of the run: the last, partial work unit closes (classify.cpp:522-523)
@@ -1217,9 +1342,10 @@ int ku_ctx_sparse_pass_slots(ku_ctx *ctx, const void *d_seqs, const uint64_t *d_
 // the unit that is still open on `src` continues on `dst` (same process; the contexts may sit on different devices)
 int ku_ctx_sparse_move_open_unit(ku_ctx *src, ku_ctx *dst) {
   if (!src || !dst || !src->sp.on || !dst->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled on both contexts");
-  if (src == dst || !src->sp.open) return KU_OK;
-  if (dst->sp.open) return fail(KU_ESTATE, "the destination context holds an open work unit of its own");
+  if (src == dst || !(src->sp.open || src->sp.tail_open)) return KU_OK;
+  if (dst->sp.open || dst->sp.tail_open) return fail(KU_ESTATE, "the destination context holds an open work unit of its own");
   KU_TRY(ctx_activate(src));
+  KU_TRY(sparse_tail_to_carry(src));  // (what travels is the staged form: L / U entries)
   HIP_TRY(hipStreamSynchronize(src->stream));
   KU_TRY(ctx_activate(dst));
   HIP_TRY(hipStreamSynchronize(dst->stream));
@@ -1258,6 +1384,7 @@ int ku_ctx_sparse_set_dense(ku_ctx *ctx, const uint32_t *h_dense) {
 int ku_ctx_sparse_absorb(ku_ctx *dst, ku_ctx *src) {
   if (!dst || !src || !dst->sp.on || !src->sp.on) return fail(KU_ESTATE, "sparse-mode emulation is not enabled on both contexts");
   KU_TRY(ctx_activate(src));
+  KU_TRY(ctx_seen_harvest(src));  // (what src's fused kernel marked in its probe table; after the group's dense flags were set)
   HIP_TRY(hipStreamSynchronize(src->stream));
   unsigned long long n_src = 0;
   HIP_TRY(hipMemcpy(&n_src, src->sp.dev.g_count, 8, hipMemcpyDeviceToHost));
@@ -1538,23 +1665,133 @@ static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_
   HIP_TRY(hipStreamSynchronize(s));
   if (total > runs_cap) return fail(KU_EHIP, "run-length encoder overflowed its bound");
   *n_runs = ctx->n_runs = total;
+  ctx->fetch_runs_src = ctx->b_runs.p;
+  ctx->last_calls_dev = ctx->b_calls.p;
   return KU_OK;
 }
 
 // ---- ku_classify_batch_rle through the fused kernel with run-length encoded output (ku_short.hip, OUT >= 1): no
 // per-k-mer array, no second kernel; with the sparse-mode emulation on, its fast path.
-// The exact per-unit evaluation of the emulation for the units the fused kernel could not settle by counting:
-// `flagged` (ascending unit numbers of this batch; bit 31 of the companion = every slot tracked).
-static int sparse_fast_exact(ku_ctx *ctx, const uint32_t *h_len, const std::vector<uint64_t> &unit_first_read,
-                             const std::vector<uint32_t> &flagged, const std::vector<uint8_t> &flag_all, bool last_is_open,
-                             const uint32_t *d_u_cnt, hipStream_t s) {
+
+// The open unit's reads in tail form (bases of each read followed by '\n') go up to the device and through the exact
+// evaluation as local unit `unit` of the pass `d`: a count-less lookup gives their slots (the flat kernel; these reads were
+// classified, booked and marked when their batch went through the fused kernel), ku_sparse_insert_kernel feeds L / U as
+// for any staged batch.  Positions start at 2; *pos_end = the first position the reads behind the tail may use.
+static int sparse_tail_insert(ku_ctx *ctx, const KuSparseDev &d, const std::vector<char> &text, const std::vector<uint32_t> &lens,
+                              uint32_t unit, hipStream_t s, uint32_t *pos_end) {
   ku_ctx::Sparse &sp = ctx->sp;
+  const uint64_t n_reads = lens.size(), n_bytes = text.size();
+  if (pos_end) *pos_end = (uint32_t)n_bytes;
+  if (n_reads == 0) return KU_OK;
+  std::vector<uint64_t> off(n_reads);
+  uint64_t at = 0;
+  for (uint64_t r = 0; r < n_reads; ++r) { off[r] = at; at += (uint64_t)lens[r] + 1; }
+  if (at != n_bytes) return fail(KU_ESTATE, "sparse-mode emulation: the open unit's reads are inconsistent");
+  if (sp.t_seqs.reserve(n_bytes + 16) || sp.t_off.reserve(n_reads * 8) || sp.t_len.reserve(n_reads * 4) || sp.t_taxa.reserve((n_bytes + 16) * 4) ||
+      sp.t_unit.reserve(n_reads * 4))
+    return fail(KU_ENOMEM, "device memory for the open work unit's reads");
+  HIP_TRY(hipMemcpyAsync(sp.t_seqs.p, text.data(), n_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(sp.t_off.p, off.data(), n_reads * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(sp.t_len.p, lens.data(), n_reads * 4, hipMemcpyHostToDevice, s));
+  std::vector<uint32_t> units(n_reads, unit);
+  HIP_TRY(hipMemcpyAsync(sp.t_unit.p, units.data(), n_reads * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // (`off`, `units` go out of scope; this path is rare)
+  int st = ku_launch_lookup(ctx->m.db, ctx->cnt, (const uint8_t *)sp.t_seqs.p, n_bytes, (uint32_t *)sp.t_taxa.p, /*do_counts=*/false, false, false,
+                            ctx->n_cu, s);
+  if (st != KU_OK) return fail(st, "lookup kernel launch failed");
+  return ku_launch_sparse_insert(d, ctx->m.db.k, (const uint8_t *)sp.t_seqs.p, (const uint64_t *)sp.t_off.p, (const uint32_t *)sp.t_len.p,
+                                 (const uint32_t *)sp.t_unit.p, n_reads, (const uint32_t *)sp.t_taxa.p, 0u, ctx->n_cu, s);
+}
+
+// a read of the caller's batch joins the open unit's tail
+static void sparse_tail_append(ku_ctx::Sparse &sp, const char *seqs, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t r0, uint64_t r1) {
+  for (uint64_t r = r0; r < r1; ++r) {
+    sp.tail_text.insert(sp.tail_text.end(), seqs + seq_off[r], seqs + seq_off[r] + seq_len[r]);
+    sp.tail_text.push_back('\n');
+    sp.tail_len.push_back(seq_len[r]);
+  }
+}
+
+// The open unit changes from tail form into the staged form (its L / U entries in the carry buffers): what a staged batch and
+// ku_ctx_sparse_move_open_unit expect.  Every slot that is not dense is tracked, as the staged passes do.
+static int sparse_tail_to_carry(ku_ctx *ctx) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  if (!sp.tail_open) return KU_OK;
+  hipStream_t s = ctx->stream;
+  KU_TRY(sparse_reserve_global(ctx, sp.tail_text.size(), s));
+  KuSparseDev d;
+  KU_TRY(sparse_pass_tables(ctx, sp.tail_text.size(), &d, s));
+  KU_TRY(sparse_tail_insert(ctx, d, sp.tail_text, sp.tail_len, 0u, s, nullptr));
+  KU_TRY(ku_launch_sparse_close(d, 0u, s));  // nothing closes: the largest first positions for the carry
+  HIP_TRY(hipMemsetAsync(sp.d_counters + 1, 0, 16, s));
+  KU_TRY(ku_launch_sparse_carry_out(d, 0u, (unsigned long long *)sp.carry_l.p, (uint32_t *)sp.carry_u.p, sp.d_counters + 1, sp.cap_carry_l,
+                                    sp.cap_carry_u, s));
+  unsigned long long c[3] = {0, 0, 0};
+  uint32_t err = 0;
+  HIP_TRY(hipMemcpyAsync(c, sp.d_counters, 24, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&err, sp.dev.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (err) return fail(KU_ENOMEM, "sparse-mode emulation: a device table is full");
+  sp.g_count = c[0];
+  sp.n_carry_l = std::min<uint64_t>(c[1], sp.cap_carry_l);
+  sp.n_carry_u = std::min<uint64_t>(c[2], sp.cap_carry_u);
+  sp.open = true;
+  sp.tail_open = false;
+  sp.tail_text.clear();
+  sp.tail_len.clear();
+  return KU_OK;
+}
+
+// The open unit in tail form ends here (end of an input file / of the run): it can only have turned a sketch dense if it gave
+// it >= 1025 inserts -- then, and only then, the exact evaluation runs over its reads.
+static int sparse_tail_close(ku_ctx *ctx) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  if (!sp.tail_open) return KU_OK;
+  hipStream_t s = ctx->stream;
+  if (sp.u_flag.reserve(4)) return fail(KU_ENOMEM, "device memory for the work-unit counters");
+  HIP_TRY(hipMemsetAsync(sp.u_flag.p, 0, 4, s));
+  KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)sp.tail_row.p, ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense, (uint8_t *)sp.u_flag.p, s));
+  uint32_t flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, sp.u_flag.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (flag & 0xFFu) {
+    KU_TRY(sparse_reserve_global(ctx, sp.tail_text.size(), s));
+    KuSparseDev d;
+    KU_TRY(sparse_pass_tables(ctx, sp.tail_text.size(), &d, s));
+    KU_TRY(sparse_tail_insert(ctx, d, sp.tail_text, sp.tail_len, 0u, s, nullptr));
+    KU_TRY(ku_launch_sparse_close(d, 1u, s, /*skip_hits=*/true));
+    unsigned long long c = 0;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&c, sp.d_counters, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&err, sp.dev.err, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (err) return fail(KU_ENOMEM, "sparse-mode emulation: a device table is full");
+    sp.g_count = c;
+  }
+  sp.tail_open = false;
+  sp.tail_text.clear();
+  sp.tail_len.clear();
+  return KU_OK;
+}
+
+// The exact per-unit evaluation of the emulation for the units the fused kernel could not settle by counting: `flagged`
+// (ascending unit numbers of the job's batch; flag_all: every slot of the unit is tracked -- a unit in the staged form).
+// last_is_open: the last flagged unit stays open behind the batch (staged form: its entries go into the carry buffers).
+static int sparse_fast_exact(ku_ctx *ctx, RleJob &j, const std::vector<uint32_t> &flagged, const std::vector<uint8_t> &flag_all,
+                             bool last_is_open, hipStream_t s) {
+  ku_ctx::Sparse &sp = ctx->sp;
+  const uint32_t *h_len = j.h_len;
+  const std::vector<uint64_t> &unit_first_read = j.unit_first_read;
+  const uint32_t *d_u_cnt = (const uint32_t *)j.u_cnt.p;
+  // unit 0 continues a unit in tail form: its earlier reads are evaluated with it, and come first in the position space
+  const bool with_tail = j.cont_tail && !flagged.empty() && flagged[0] == 0 && !j.tail_len.empty();
+  const uint64_t tail_bytes = with_tail ? j.tail_text.size() : 0;
   size_t at = 0;
   bool first_pass = true;
   while (at < flagged.size()) {
     // units of this pass: at most 2^25 bases and KU_SPARSE_MAX_UNITS units (the tables of ku_sparse.hip)
     size_t end = at;
-    uint64_t bases = 0, n_list = 0;
+    uint64_t bases = first_pass ? tail_bytes : 0, n_list = 0;
     while (end < flagged.size() && end - at < KU_SPARSE_MAX_UNITS) {
       const uint32_t u = flagged[end];
       uint64_t ub = 0;
@@ -1579,16 +1816,20 @@ static int sparse_fast_exact(ku_ctx *ctx, const uint32_t *h_len, const std::vect
     KU_TRY(sparse_reserve_global(ctx, bases + sp.n_carry_l, s));
     KuSparseDev d;  // this pass's view: the run-wide set as it is now, L / U sized for the pass
     KU_TRY(sparse_pass_tables(ctx, bases + sp.n_carry_l + sp.n_carry_u, &d, s));
-    if (first_pass && sp.open)  // the unit carried over from the batch before is local unit 0 of the first pass
+    if (first_pass && j.cont_carry)  // the unit carried over from the batch before is local unit 0 of the first pass
       KU_TRY(ku_launch_sparse_carry_in(d, (const unsigned long long *)sp.carry_l.p, sp.n_carry_l, (const uint32_t *)sp.carry_u.p, sp.n_carry_u, s));
+    uint32_t pos_base = 0;
+    if (first_pass && with_tail) KU_TRY(sparse_tail_insert(ctx, d, j.tail_text, j.tail_len, 0u, s, &pos_base));
     if (n_list) HIP_TRY(hipMemcpyAsync(sp.list.p, list.data(), n_list * 12, hipMemcpyHostToDevice, s));
     const uint32_t *dl = (const uint32_t *)sp.list.p;
-    KU_TRY(ku_launch_sparse_insert_runs(d, ctx->m.db.k, (const uint8_t *)ctx->b_seqs.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p,
-                                        dl, dl + n_list, dl + 2 * n_list, n_list, ctx->b_runs.p, (const uint64_t *)ctx->b_roff.p,
-                                        (const uint32_t *)ctx->b_rcnt.p, ctx->d_slot_taxid, ctx->tax.n_slots, d_u_cnt, ctx->n_cu, s));
+    KU_TRY(ku_launch_sparse_insert_runs(d, ctx->m.db.k, (const uint8_t *)j.seqs.p, (const uint64_t *)j.off.p, (const uint32_t *)j.len.p,
+                                        dl, dl + n_list, dl + 2 * n_list, n_list, j.runs.p, (const uint64_t *)j.roff.p,
+                                        (const uint32_t *)j.rcnt.p, ctx->d_slot_taxid, ctx->tax.n_slots, d_u_cnt, ctx->n_cu, s, pos_base));
     const uint32_t n_local = (uint32_t)(end - at);
-    KU_TRY(ku_launch_sparse_close(d, has_open ? n_local - 1 : n_local, s));
-    sp.n_carry_l = sp.n_carry_u = 0;
+    // (a unit in the staged form may hold k-mers of a staged batch, which marks nothing in the probe table: its entries all
+    // go into the set; the fast path's own units only contribute their misses)
+    KU_TRY(ku_launch_sparse_close(d, has_open ? n_local - 1 : n_local, s, /*skip_hits=*/!j.cont_carry));
+    if (first_pass && j.cont_carry) sp.n_carry_l = sp.n_carry_u = 0;
     unsigned long long c[3] = {0, 0, 0};
     if (has_open) {
       HIP_TRY(hipMemsetAsync(sp.d_counters + 1, 0, 16, s));
@@ -1597,7 +1838,7 @@ static int sparse_fast_exact(ku_ctx *ctx, const uint32_t *h_len, const std::vect
     }
     HIP_TRY(hipMemcpyAsync(c, sp.d_counters, 24, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));  // `list` goes out of scope
-    sp.g_count = c[0];
+    sp.g_count = std::max<uint64_t>(sp.g_count, c[0]);
     if (has_open) {
       sp.n_carry_l = std::min<uint64_t>(c[1], sp.cap_carry_l);
       sp.n_carry_u = std::min<uint64_t>(c[2], sp.cap_carry_u);
@@ -1620,7 +1861,8 @@ static bool rle_fused_eligible(ku_ctx *ctx, uint32_t flags, uint32_t max_n, uint
   const bool sparse = ctx->sp.on && !(flags & KU_F_NO_COUNTS);
   if (sparse) {
     const ku_ctx::Sparse &sp = ctx->sp;
-    if (getenv("KU_NO_SPARSE_FAST") || !monotonic || sp.unit_nt == 0 || sp.unit_nt > (1ull << 24) || n_bytes + 2 >= (1ull << 32)) return false;
+    // (positions of the exact evaluation are 32-bit: the batch, behind the reads of an open unit of at most 2^24 nt + one read)
+    if (getenv("KU_NO_SPARSE_FAST") || !monotonic || sp.unit_nt == 0 || sp.unit_nt > (1ull << 24) || n_bytes + (1ull << 26) >= (1ull << 32)) return false;
     const uint64_t max_units = n_bytes / sp.unit_nt + 2;
     if (max_units * ctx->tax.n_slots > (1ull << 29)) return false;  // the (unit, slot) counters: at most 2 GiB
   }
@@ -1677,26 +1919,29 @@ extern "C" int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uin
   return st == KU_OK ? KU_OK : fail(st, "fused kernel launch failed");
 }
 
-static int rle_and_fetch(ku_ctx *ctx, const uint32_t *d_taxa, const uint64_t *d_off, const uint32_t *d_len, uint64_t n_reads,
-                         uint64_t runs_cap, bool quick, uint32_t *calls, uint32_t *hits, uint64_t *run_off,
-                         uint32_t *run_cnt, uint64_t *n_runs);
-
-// KU_RLE_TIMES=1: where ku_classify_batch_rle spends its time on the host, summed over the run, printed when the context goes
-static double g_rle_t[9];  // checks, plan + enqueue, wait for the device, after the wait, calls; of the enqueue: H2D calls, launches, D2H calls
+// KU_RLE_TIMES=1: where the batch calls spend their time on the host, summed over the run, printed when the context goes
+static double g_rle_t[6];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls
 static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
 static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void rle_times_print() {
   if (g_rle_times && g_rle_t[4] > 0)
-    fprintf(stderr, "ku_classify_batch_rle over %.0f calls: checks %.3f s, plan + enqueue %.3f s (H2D calls %.3f, launches %.3f, D2H calls %.3f), waiting for the device %.3f s, behind the wait %.3f s\n",
-            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[2], g_rle_t[3]);
+    fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s\n",
+            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3]);
 }
 
-static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
+// no batch may be in flight (entry points that read or change what the batches in flight work on)
+static int rle_idle(const ku_ctx *ctx, const char *who) {
+  if (ctx->rle_in_flight) return fail(KU_ESTATE, std::string(who) + ": batches are in flight (ku_classify_batch_rle_finish first)");
+  return KU_OK;
+}
+
+// ---- step one: plan the batch, start its upload (in segments, on the copy stream), its kernels and the copies back.
+// Nothing here waits for the device.
+static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
                            uint64_t n_reads, const ku_opts &o, uint32_t max_n, bool monotonic, uint32_t *calls, uint32_t *hits,
-                           uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs, bool *classified) {
+                           uint64_t *run_off, uint32_t *run_cnt) {
   hipStream_t s = ctx->stream;
   const double t_in = g_rle_times ? rle_now() : 0.0;
-  *classified = false;
   const bool counts = !(o.flags & KU_F_NO_COUNTS);
   const bool sparse = ctx->sp.on && counts;
   ku_ctx::Sparse &sp = ctx->sp;
@@ -1719,72 +1964,86 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
   // last chunks do not dominate a small batch
   const uint32_t chunk = rle_chunk(n_reads, total_waves);
   // room for ~ one run per 6 bases + the chunk tails; a batch that needs more (many taxa per read) is redone through
-  // the per-k-mer array (below), whose run-length encoder cannot overflow
+  // the per-k-mer array (in _finish), whose run-length encoder cannot overflow
   uint64_t runs_cap = n_bytes / 6 + 4 * n_reads + total_waves * chunk + 4096;
   if (const char *e = getenv("KU_RUNS_CAP")) runs_cap = std::max<uint64_t>(1, (uint64_t)atoll(e));  // test hook
   uint64_t ws = 0;
   if (max_n > ku_short_max_kmers(ctx->m.db)) ws = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, max_seg_reads, ctx->n_cu);
-  if (ws > ctx->b_ws.cap || (n_bytes + 16) > ctx->b_seqs.cap) HIP_TRY(hipStreamSynchronize(s));
-  if (ctx->b_seqs.reserve(n_bytes + 16) || ctx->b_off.reserve(n_reads * 8) || ctx->b_len.reserve(n_reads * 4) ||
-      ctx->b_calls.reserve(n_reads * 4) || ctx->b_runs.reserve(runs_cap * 8) || ctx->b_roff.reserve(n_reads * 8) ||
-      ctx->b_rcnt.reserve(n_reads * 4) || ctx->b_ws.reserve(ws))
+  // (the job's buffers are its own and its previous batch is through: growing them needs no synchronisation of ours)
+  if (j.seqs.reserve(n_bytes + 16) || j.off.reserve(n_reads * 8) || j.len.reserve(n_reads * 4) || j.calls.reserve(n_reads * 4) ||
+      j.runs.reserve(runs_cap * 8) || j.roff.reserve(n_reads * 8) || j.rcnt.reserve(n_reads * 4) || j.ws.reserve(ws))
     return fail(KU_ENOMEM, "device batch buffers");
   if (!ctx->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
-  while (ctx->seg_events.size() < n_seg) {
+  if (!ctx->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+  if (!j.done) HIP_TRY(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+  if (!j.kernels_done) HIP_TRY(hipEventCreateWithFlags(&j.kernels_done, hipEventDisableTiming));
+  while (j.seg_events.size() < n_seg) {
     hipEvent_t e;
     HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ctx->seg_events.push_back(e);
+    j.seg_events.push_back(e);
   }
   // ---- sparse fast path: work-unit plan (the unit closes behind the read that fills it, classify.cpp:510-521)
-  std::vector<uint32_t> unit;
-  std::vector<uint64_t> unit_first_read;
-  uint32_t n_units = 0;
-  bool open_after = false, continuing = false;
-  uint64_t acc_after = 0;
+  j.sparse = sparse;
+  j.cont_carry = j.cont_tail = j.open_after = false;
+  j.n_units = 0;
+  j.kmers = 0;
+  j.unit_first_read.clear();
+  j.tail_text.clear();
+  j.tail_len.clear();
   KuSparseFast sf{};
+  uint32_t *h_unit = nullptr;
+  uint8_t *h_flag = nullptr;
   if (sparse) {
-    unit.resize(n_reads);
+    if (j.pin_unit.reserve(n_reads * 4)) return fail(KU_ENOMEM, "page-locked memory for the work-unit plan");
+    h_unit = (uint32_t *)j.pin_unit.p;
     uint64_t acc = sp.acc_nt;
     uint32_t cur = 0;
-    continuing = sp.open;
-    unit_first_read.push_back(0);
+    j.cont_carry = sp.open;
+    j.cont_tail = sp.tail_open && !sp.open;
+    j.unit_first_read.push_back(0);
     for (uint64_t r = 0; r < n_reads; ++r) {
-      unit[r] = cur;
+      h_unit[r] = cur;
       acc += seq_len[r];
-      if (acc >= sp.unit_nt) { ++cur; acc = 0; unit_first_read.push_back(r + 1); }
+      if (acc >= sp.unit_nt) { ++cur; acc = 0; j.unit_first_read.push_back(r + 1); }
     }
-    open_after = acc > 0;
-    acc_after = acc;
-    n_units = cur + (unit_first_read.back() < n_reads ? 1u : 0u);
-    if (unit_first_read.back() < n_reads) unit_first_read.push_back(n_reads);
-    const uint64_t cells = (uint64_t)n_units * ctx->tax.n_slots;
-    if (sp.unit.reserve(n_reads * 4) || sp.u_cnt.reserve(std::max<uint64_t>(cells, 1) * 4) || sp.u_flag.reserve(((uint64_t)std::max<uint32_t>(n_units, 1) + 3) & ~3ull))
+    j.open_after = acc > 0;
+    j.acc_after = acc;
+    j.n_units = cur + (j.unit_first_read.back() < n_reads ? 1u : 0u);
+    if (j.unit_first_read.back() < n_reads) j.unit_first_read.push_back(n_reads);
+    const uint64_t cells = (uint64_t)j.n_units * ctx->tax.n_slots;
+    if (j.unit.reserve(n_reads * 4) || j.u_cnt.reserve(std::max<uint64_t>(cells, 1) * 4) || j.u_flag.reserve(((uint64_t)std::max<uint32_t>(j.n_units, 1) + 3) & ~3ull) ||
+        sp.tail_row.reserve((size_t)ctx->tax.n_slots * 4))
       return fail(KU_ENOMEM, "device memory for the work-unit counters");
-    uint64_t kmers = 0;  // upper bound of what the fused kernel may add to the run-wide set
-    for (uint64_t r = 0; r < n_reads; ++r) kmers += seq_len[r] >= ctx->m.db.k ? seq_len[r] - ctx->m.db.k + 1 : 0;
-    KU_TRY(sparse_reserve_global(ctx, kmers + sp.n_carry_l, s));
+    for (uint64_t r = 0; r < n_reads; ++r) j.kmers += seq_len[r] >= ctx->m.db.k ? seq_len[r] - ctx->m.db.k + 1 : 0;
+    uint64_t in_flight_kmers = 0;  // what the batches in flight may still add: the host's count of the set lags behind them
+    for (const RleJob &q : ctx->rle) if (q.busy && &q != &j && q.sparse) in_flight_kmers += q.kmers;
+    KU_TRY(sparse_reserve_global(ctx, j.kmers + in_flight_kmers + sp.n_carry_l, s));
     sf.g_key = sp.dev.g_key;
     sf.g_mask = sp.dev.g_mask;
     sf.g_count = sp.dev.g_count;
     sf.dense = sp.dev.dense;
-    sf.u_cnt = (uint32_t *)sp.u_cnt.p;
+    sf.u_cnt = (uint32_t *)j.u_cnt.p;
     sf.err = sp.dev.err;
     sf.n_slots = ctx->tax.n_slots;
     sf.unit_base = 0;
+    ctx->m.seen_dirty = true;  // the kernel books the k-mers the database holds by marking their table entries
   }
-  unsigned long long *d_counter = (unsigned long long *)(ctx->d_scalar + 2);
+  if (j.pin.reserve(64 + (size_t)std::max<uint32_t>(j.n_units, 1) + 8)) return fail(KU_ENOMEM, "page-locked memory for the batch totals");
+  unsigned long long *h_tot = (unsigned long long *)j.pin.p;
+  h_flag = (uint8_t *)j.pin.p + 64;
+  unsigned long long *d_counter = j.d_counter;
   // the run counter and (emulation) the per-(unit, slot) insert counts and the unit flags start at zero: one launch
   if (sparse) {
-    if (ku_launch_zero3(d_counter, 2, sp.u_cnt.p, std::max<uint64_t>((uint64_t)n_units * ctx->tax.n_slots, 1), sp.u_flag.p,
-                        ((uint64_t)std::max<uint32_t>(n_units, 1) + 3) / 4, s) != KU_OK)
+    if (ku_launch_zero3(d_counter, 2, j.u_cnt.p, std::max<uint64_t>((uint64_t)j.n_units * ctx->tax.n_slots, 1), j.u_flag.p,
+                        ((uint64_t)std::max<uint32_t>(j.n_units, 1) + 3) / 4, s) != KU_OK)
       return fail(KU_EHIP, "clearing the batch counters failed");
+    // unit 0 continues the open unit: its row starts from the inserts that unit has had so far
+    if (j.cont_tail && j.n_units) HIP_TRY(hipMemcpyAsync(j.u_cnt.p, sp.tail_row.p, (size_t)ctx->tax.n_slots * 4, hipMemcpyDeviceToDevice, s));
   } else {
     HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
   }
-  HIP_TRY(hipEventRecord(ctx->seg_events[0], s));  // the copy stream starts behind whatever used the buffers before
-  HIP_TRY(hipStreamWaitEvent(ctx->h2d_stream, ctx->seg_events[0], 0));
   KuRunsOut ro{};
-  ro.runs = (uint2 *)ctx->b_runs.p;
+  ro.runs = (uint2 *)j.runs.p;
   ro.counter = d_counter;
   ro.cap = runs_cap;
   ro.chunk = chunk;
@@ -1792,128 +2051,176 @@ static int rle_fused_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, cons
     const uint64_t a = seg[g], b = seg[g + 1];
     const uint64_t lo = g == 0 ? 0 : seq_off[a], hi = g + 1 == n_seg ? n_bytes : seq_off[b];
     hipStream_t cs = n_seg > 1 ? ctx->h2d_stream : s;
-    const double t_h0 = g_rle_times ? rle_now() : 0.0;
-    if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)ctx->b_seqs.p + lo, seqs + lo, hi - lo, hipMemcpyHostToDevice, cs));
+    if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)j.seqs.p + lo, seqs + lo, hi - lo, hipMemcpyHostToDevice, cs));
     if (b > a) {
-      HIP_TRY(hipMemcpyAsync((uint64_t *)ctx->b_off.p + a, seq_off + a, (b - a) * 8, hipMemcpyHostToDevice, cs));
-      HIP_TRY(hipMemcpyAsync((uint32_t *)ctx->b_len.p + a, seq_len + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
-      if (sparse) HIP_TRY(hipMemcpyAsync((uint32_t *)sp.unit.p + a, unit.data() + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
+      HIP_TRY(hipMemcpyAsync((uint64_t *)j.off.p + a, seq_off + a, (b - a) * 8, hipMemcpyHostToDevice, cs));
+      HIP_TRY(hipMemcpyAsync((uint32_t *)j.len.p + a, seq_len + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
+      if (sparse) HIP_TRY(hipMemcpyAsync((uint32_t *)j.unit.p + a, h_unit + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
     }
     if (n_seg > 1) {
-      HIP_TRY(hipEventRecord(ctx->seg_events[g], cs));
-      HIP_TRY(hipStreamWaitEvent(s, ctx->seg_events[g], 0));
+      HIP_TRY(hipEventRecord(j.seg_events[g], cs));
+      HIP_TRY(hipStreamWaitEvent(s, j.seg_events[g], 0));
     }
-    if (g_rle_times) g_rle_t[5] += rle_now() - t_h0;
     if (b == a) continue;
-    ro.run_off = (uint64_t *)ctx->b_roff.p + a;
-    ro.run_cnt = (uint32_t *)ctx->b_rcnt.p + a;
-    sf.unit_of = sparse ? (const uint32_t *)sp.unit.p + a : nullptr;
-    const double t_l0 = g_rle_times ? rle_now() : 0.0;
-    int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p + a,
-                                      (const uint32_t *)ctx->b_len.p + a, b - a, max_n, o.flags, (uint32_t *)ctx->b_calls.p + a, nullptr, nullptr,
-                                      ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
-    if (g_rle_times) g_rle_t[6] += rle_now() - t_l0;
+    ro.run_off = (uint64_t *)j.roff.p + a;
+    ro.run_cnt = (uint32_t *)j.rcnt.p + a;
+    sf.unit_of = sparse ? (const uint32_t *)j.unit.p + a : nullptr;
+    int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)j.seqs.p, n_bytes, (const uint64_t *)j.off.p + a,
+                                      (const uint32_t *)j.len.p + a, b - a, max_n, o.flags, (uint32_t *)j.calls.p + a, nullptr, nullptr,
+                                      j.ws.p, j.ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
     if (st != KU_OK) { (void)hipStreamSynchronize(ctx->h2d_stream); (void)hipStreamSynchronize(s); return fail(st, "fused kernel launch failed"); }
-    const double t_d0 = g_rle_times ? rle_now() : 0.0;
-    HIP_TRY(hipMemcpyAsync(calls + a, (uint32_t *)ctx->b_calls.p + a, (b - a) * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(run_off + a, (uint64_t *)ctx->b_roff.p + a, (b - a) * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(run_cnt + a, (uint32_t *)ctx->b_rcnt.p + a, (b - a) * 4, hipMemcpyDeviceToHost, s));
-    if (g_rle_times) g_rle_t[7] += rle_now() - t_d0;
   }
-  unsigned long long total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, d_counter, 8, hipMemcpyDeviceToHost, s));
-  std::vector<uint8_t> h_flag;
-  unsigned long long g_now = 0;
-  uint32_t sp_err = 0;
   if (sparse) {
-    KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)sp.u_cnt.p, (uint64_t)n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
-                                       (uint8_t *)sp.u_flag.p, s));
-    h_flag.resize(std::max<uint32_t>(n_units, 1));
-    HIP_TRY(hipMemcpyAsync(h_flag.data(), sp.u_flag.p, std::max<uint32_t>(n_units, 1), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&g_now, sp.dev.g_count, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&sp_err, sp.dev.err, 4, hipMemcpyDeviceToHost, s));
+    KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)j.u_cnt.p, (uint64_t)j.n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
+                                       (uint8_t *)j.u_flag.p, s));
+    // the unit that stays open (tail form): its insert counts so far
+    if (j.open_after && !(j.cont_carry && j.n_units == 1))
+      HIP_TRY(hipMemcpyAsync(sp.tail_row.p, (const uint32_t *)j.u_cnt.p + (size_t)(j.n_units - 1) * ctx->tax.n_slots, (size_t)ctx->tax.n_slots * 4,
+                             hipMemcpyDeviceToDevice, s));
   }
-  const double t_enq = g_rle_times ? rle_now() : 0.0;
-  HIP_TRY(hipStreamSynchronize(s));
-  const double t_sync = g_rle_times ? rle_now() : 0.0;
-  struct Lap { double a, b, c; ~Lap() { if (g_rle_times) { g_rle_t[1] += b - a; g_rle_t[2] += c - b; g_rle_t[3] += rle_now() - c; g_rle_t[4] += 1; } } } lap_{t_in, t_enq, t_sync};
-  if (hits) memset(hits, 0, n_reads * 4);  // "Q:n" is quick mode only
-  if (total > runs_cap) {
+  // ---- the copies back run on a stream of their own, behind this batch's kernels -- not in front of the next batch's
+  HIP_TRY(hipEventRecord(j.kernels_done, s));
+  hipStream_t ds = ctx->d2h_stream;
+  HIP_TRY(hipStreamWaitEvent(ds, j.kernels_done, 0));
+  HIP_TRY(hipMemcpyAsync(calls, j.calls.p, n_reads * 4, hipMemcpyDeviceToHost, ds));
+  HIP_TRY(hipMemcpyAsync(run_off, j.roff.p, n_reads * 8, hipMemcpyDeviceToHost, ds));
+  HIP_TRY(hipMemcpyAsync(run_cnt, j.rcnt.p, n_reads * 4, hipMemcpyDeviceToHost, ds));
+  HIP_TRY(hipMemcpyAsync(&h_tot[0], d_counter, 8, hipMemcpyDeviceToHost, ds));
+  if (sparse) {
+    HIP_TRY(hipMemcpyAsync(h_flag, j.u_flag.p, std::max<uint32_t>(j.n_units, 1), hipMemcpyDeviceToHost, ds));
+    HIP_TRY(hipMemcpyAsync(&h_tot[1], sp.dev.g_count, 8, hipMemcpyDeviceToHost, ds));
+    HIP_TRY(hipMemcpyAsync(&h_tot[2], sp.dev.err, 4, hipMemcpyDeviceToHost, ds));
+  }
+  HIP_TRY(hipEventRecord(j.done, ds));
+  // ---- the emulation's state behind this batch (what the next batch's plan starts from)
+  if (sparse && j.n_units) {
+    const bool whole_batch_one_open_unit = j.n_units == 1 && j.open_after;
+    if (j.cont_tail && !whole_batch_one_open_unit) {  // unit 0 closes in this batch: its earlier reads go with the job
+      j.tail_text.swap(sp.tail_text);
+      j.tail_len.swap(sp.tail_len);
+      sp.tail_text.clear();
+      sp.tail_len.clear();
+    }
+    if (j.cont_carry && whole_batch_one_open_unit) {
+      // (staged form, still open: stays in the carry buffers -- _finish writes them)
+    } else if (j.open_after) {
+      if (!(j.cont_tail && whole_batch_one_open_unit)) { sp.tail_text.clear(); sp.tail_len.clear(); }
+      sparse_tail_append(sp, seqs, seq_off, seq_len, j.unit_first_read[j.n_units - 1], n_reads);
+      sp.tail_open = true;
+      sp.open = false;
+    } else {
+      sp.tail_open = false;
+      sp.open = false;
+      sp.tail_text.clear();
+      sp.tail_len.clear();
+    }
+    sp.acc_nt = j.acc_after;
+  }
+  j.n_bytes = n_bytes;
+  j.n_reads = n_reads;
+  j.runs_cap = runs_cap;
+  j.max_n = max_n;
+  j.o = o;
+  j.h_len = seq_len;
+  j.h_calls = calls;
+  j.h_hits = hits;
+  j.h_roff = run_off;
+  j.h_rcnt = run_cnt;
+  j.settled = false;
+  j.runs_in_ctx = false;
+  j.busy = true;
+  if (g_rle_times) g_rle_t[1] += rle_now() - t_in;
+  return KU_OK;
+}
+
+// ---- step two: wait for the batch (one event), settle what the emulation has to settle for it
+static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classified) {
+  hipStream_t s = ctx->stream;
+  *classified = false;
+  if (j.settled) {
+    j.busy = false;
+    *n_runs = ctx->n_runs = j.n_runs;
+    *classified = true;
+    return KU_OK;
+  }
+  const double t_w0 = g_rle_times ? rle_now() : 0.0;
+  HIP_TRY(hipEventSynchronize(j.done));
+  const double t_w1 = g_rle_times ? rle_now() : 0.0;
+  struct Lap { double a, b; ~Lap() { if (g_rle_times) { g_rle_t[2] += b - a; g_rle_t[3] += rle_now() - b; g_rle_t[4] += 1; } } } lap_{t_w0, t_w1};
+  j.busy = false;
+  ku_ctx::Sparse &sp = ctx->sp;
+  const unsigned long long *h_tot = (const unsigned long long *)j.pin.p;
+  const uint8_t *h_flag = (const uint8_t *)j.pin.p + 64;
+  const unsigned long long total = h_tot[0];
+  if (j.h_hits) memset(j.h_hits, 0, j.n_reads * 4);  // "Q:n" is quick mode only
+  ctx->last_calls_dev = j.calls.p;
+  if (total > j.runs_cap) {
     // the run array was too small for this batch (reads that change taxon every few k-mers): the per-k-mer codes once more
-    // without any accounting, through the array parallel to the reads and its own run-length encoder
-    HIP_TRY(hipStreamSynchronize(s));  // (the buffers below may be reallocated)
-    if (ctx->b_taxa.reserve((n_bytes + 16) * 4) || ctx->b_runs.reserve((n_bytes + 1) * 8)) return fail(KU_ENOMEM, "device batch buffers");
-    uint64_t ws2 = ws;
-    if (max_n > ku_short_max_kmers(ctx->m.db)) ws2 = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, n_reads, ctx->n_cu);
+    // without any accounting, through the array parallel to the reads and its own run-length encoder (the context's buffers)
+    if (ctx->b_taxa.reserve((j.n_bytes + 16) * 4) || ctx->b_runs.reserve((j.n_bytes + 1) * 8) || ctx->b_roff.reserve(j.n_reads * 8) ||
+        ctx->b_rcnt.reserve(j.n_reads * 4) || ctx->b_calls.reserve(j.n_reads * 4))
+      return fail(KU_ENOMEM, "device batch buffers");
+    uint64_t ws2 = 0;
+    if (j.max_n > ku_short_max_kmers(ctx->m.db)) ws2 = ku_short_workspace_bytes(j.max_n, ctx->tax.n_slots, j.n_reads, ctx->n_cu);
     if (ctx->b_ws.reserve(ws2)) return fail(KU_ENOMEM, "device batch buffers");
-    int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)ctx->b_seqs.p, n_bytes, (const uint64_t *)ctx->b_off.p,
-                                      (const uint32_t *)ctx->b_len.p, n_reads, max_n, o.flags | KU_F_NO_COUNTS, (uint32_t *)ctx->b_calls.p,
+    int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)j.seqs.p, j.n_bytes, (const uint64_t *)j.off.p,
+                                      (const uint32_t *)j.len.p, j.n_reads, j.max_n, j.o.flags | KU_F_NO_COUNTS, (uint32_t *)ctx->b_calls.p,
                                       (uint32_t *)ctx->b_taxa.p, nullptr, ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s);
     if (st != KU_OK) return fail(st, "fused kernel launch failed");
-    KU_TRY(rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p, n_reads, n_bytes + 1,
-                         false, calls, nullptr, run_off, run_cnt, n_runs));
+    KU_TRY(rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)j.off.p, (const uint32_t *)j.len.p, j.n_reads, j.n_bytes + 1,
+                         false, j.h_calls, nullptr, j.h_roff, j.h_rcnt, n_runs));
+    j.runs_in_ctx = true;
   } else {
     *n_runs = ctx->n_runs = total;
+    ctx->fetch_runs_src = j.runs.p;
   }
   *classified = true;  // what follows only concerns the emulation's state
-  if (sparse) {
-    if (sp_err) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set is full");
-    sp.g_count = g_now;
-    // units the counting could not settle: flagged by the kernel, and the ones that straddle batches
+  if (j.sparse && sp.on) {
+    if ((uint32_t)h_tot[2]) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set is full");
+    sp.g_count = std::max<uint64_t>(sp.g_count, h_tot[1]);
+    if (j.runs_in_ctx) return fail(KU_EUNSUP, "sparse-mode emulation: a batch whose runs overflowed the run array cannot be evaluated");
+    // Units the counting could not settle.  A unit that is still open behind the batch waits (tail form: it is looked at
+    // when it closes, with everything it got); a unit in the staged form (it came from a staged batch) is always tracked.
     std::vector<uint32_t> flagged;
     std::vector<uint8_t> flag_all;
-    for (uint32_t u = 0; u < n_units; ++u) {
-      const bool edge = (u == 0 && continuing) || (u + 1 == n_units && open_after);
-      if (h_flag[u] || edge) { flagged.push_back(u); flag_all.push_back(edge ? 1 : 0); }
+    const bool carry_stays_open = j.cont_carry && j.n_units == 1 && j.open_after;
+    for (uint32_t u = 0; u < j.n_units; ++u) {
+      const bool open = u + 1 == j.n_units && j.open_after;
+      if (u == 0 && j.cont_carry) { flagged.push_back(u); flag_all.push_back(1); }
+      else if (!open && h_flag[u]) { flagged.push_back(u); flag_all.push_back(0); }
     }
-    if (n_units == 0 && continuing) { /* an empty batch leaves the carried unit as it is */ }
-    else KU_TRY(sparse_fast_exact(ctx, seq_len, unit_first_read, flagged, flag_all, open_after, (const uint32_t *)sp.u_cnt.p, s));
-    if (n_units) {
-      sp.open = open_after;
-      sp.acc_nt = acc_after;
-      if (!open_after) sp.n_carry_l = sp.n_carry_u = 0;
-    }
+    if (!flagged.empty()) KU_TRY(sparse_fast_exact(ctx, j, flagged, flag_all, carry_stays_open, s));
   }
   return KU_OK;
 }
 
-extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
-                                     const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
-                                     uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
-  KU_TRY(check_ready(ctx));
-  if ((n_bytes && !seqs) || (n_reads && (!seq_off || !seq_len || !calls || !run_off || !run_cnt)) || !n_runs)
+// which of the two jobs takes the next batch / is the oldest in flight
+static RleJob &rle_next_job(ku_ctx *ctx) {
+  RleJob &j = ctx->rle[(ctx->rle_head + ctx->rle_in_flight) & 1];
+  if (!j.d_counter) j.d_counter = (unsigned long long *)(ctx->d_scalar + ((&j == &ctx->rle[0]) ? 2 : 20));
+  return j;
+}
+
+static int rle_check_batch(const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
+                           uint32_t *calls, uint64_t *run_off, uint32_t *run_cnt, ku_opts &o, bool &monotonic) {
+  if ((n_bytes && !seqs) || (n_reads && (!seq_off || !seq_len || !calls || !run_off || !run_cnt)))
     return fail(KU_EINVAL, "ku_classify_batch_rle: null buffer");
-  *n_runs = 0;
-  ctx->n_runs = 0;
-  if (n_reads == 0) return KU_OK;
-  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   o.flags &= ~KU_F_KEEP_SLOTS;
   const double t_chk = g_rle_times ? rle_now() : 0.0;
   if (o.max_read_len == 0) for (uint64_t i = 0; i < n_reads; ++i) o.max_read_len = std::max(o.max_read_len, seq_len[i]);
-  bool monotonic = true;
+  monotonic = true;
   for (uint64_t i = 0; i < n_reads; ++i) {
     if (seq_off[i] + seq_len[i] > n_bytes) return fail(KU_EINVAL, "read " + std::to_string(i) + " exceeds the sequence buffer");
     if (i && seq_off[i] < seq_off[i - 1] + seq_len[i - 1]) monotonic = false;
   }
   if (g_rle_times) g_rle_t[0] += rle_now() - t_chk;
-  {
-    const uint32_t max_n = o.max_read_len >= ctx->m.db.k ? o.max_read_len - ctx->m.db.k + 1 : 0;
-    if (rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic)) {
-      bool classified = false;
-      int st = rle_fused_batch(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, n_runs, &classified);
-      if (st == KU_ENOMEM && ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {
-        // no room for the emulation's tables: the classification itself does not depend on them (see classify_device_impl):
-        // the run goes on with the dense registers alone; a batch that had not been classified yet is taken again
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipGetLastError();
-        ctx_free_sparse(ctx);
-        ctx->sp.gave_up = true;
-        if (classified) return KU_OK;
-        st = rle_fused_batch(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, n_runs, &classified);
-      }
-      return st;
-    }
-  }
+  return KU_OK;
+}
+
+// the one-step paths (quick mode, several databases, sorted layout, shards, reads beyond 65535 k-mers, ...): through the
+// context's own buffers, synchronously
+static int rle_staged_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len, uint64_t n_reads,
+                            const ku_opts &o, uint32_t *calls, uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
   // a run needs at least one k-mer, so n_bytes bounds the number of runs: the device side cannot overflow
   const uint64_t runs_cap = n_bytes + 1;
   if (ctx->b_seqs.reserve(n_bytes + 16) || ctx->b_off.reserve(n_reads * 8) || ctx->b_len.reserve(n_reads * 4) ||
@@ -1931,20 +2238,121 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
                        runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits, run_off, run_cnt, n_runs);
 }
 
+extern "C" int ku_classify_batch_rle_in_flight(const ku_ctx *ctx) { return ctx ? ctx->rle_in_flight : 0; }
+
+extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                                             const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                                             uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt) {
+  KU_TRY(check_ready(ctx));
+  if (ctx->rle_in_flight >= 2) return fail(KU_ESTATE, "ku_classify_batch_rle_enqueue: two batches are in flight (ku_classify_batch_rle_finish first)");
+  ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
+  bool monotonic = true;
+  KU_TRY(rle_check_batch(seqs, n_bytes, seq_off, seq_len, n_reads, calls, run_off, run_cnt, o, monotonic));
+  RleJob &j = rle_next_job(ctx);
+  const uint32_t max_n = o.max_read_len >= ctx->m.db.k ? o.max_read_len - ctx->m.db.k + 1 : 0;
+  // a unit in the staged form (carry buffers) is settled batch by batch, synchronously: such a batch goes in one step, too
+  const bool in_steps = n_reads && rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic) &&
+                        !(ctx->sp.on && !(o.flags & KU_F_NO_COUNTS) && ctx->sp.open);
+  if (in_steps) {
+    int st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+    if (st == KU_ENOMEM && ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {
+      // no room for the emulation's tables: the classification itself does not depend on them (see classify_device_impl):
+      // the run goes on with the dense registers alone; nothing of this batch had been started
+      (void)hipStreamSynchronize(ctx->stream);
+      if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
+      (void)hipGetLastError();
+      ctx_free_sparse(ctx);
+      ctx->sp.gave_up = true;
+      st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+    }
+    KU_TRY(st);
+    ++ctx->rle_in_flight;
+    return KU_OK;
+  }
+  if (ctx->rle_in_flight) return fail(KU_ESTATE, "ku_classify_batch_rle_enqueue: this batch takes a path that cannot overlap with the batch in flight "
+                                                 "(ku_classify_batch_rle_finish first, then enqueue it again)");
+  // classified here and now; _finish hands the totals over
+  uint64_t nr = 0;
+  ctx->n_runs = 0;
+  if (n_reads) {
+    if (rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic)) {  // (fused, but a unit in the staged form is open)
+      int st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+      bool classified = false;
+      if (st == KU_OK) st = rle_job_finish(ctx, j, &nr, &classified);
+      j.busy = false;
+      if (st == KU_ENOMEM && ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+        ctx_free_sparse(ctx);
+        ctx->sp.gave_up = true;
+        if (!classified) {
+          st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+          if (st == KU_OK) st = rle_job_finish(ctx, j, &nr, &classified);
+          j.busy = false;
+        } else st = KU_OK;
+      }
+      KU_TRY(st);
+    } else {
+      KU_TRY(rle_staged_batch(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, o, calls, hits, run_off, run_cnt, &nr));
+      j.runs_in_ctx = true;
+    }
+  }
+  j.settled = true;
+  j.busy = true;
+  j.n_runs = nr;
+  ++ctx->rle_in_flight;
+  return KU_OK;
+}
+
+extern "C" int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs) {
+  if (!ctx || !n_runs) return fail(KU_EINVAL, "ku_classify_batch_rle_finish: null argument");
+  *n_runs = 0;
+  if (!ctx->rle_in_flight) return fail(KU_ESTATE, "ku_classify_batch_rle_finish: no batch is in flight");
+  KU_TRY(ctx_activate(ctx));
+  RleJob &j = ctx->rle[ctx->rle_head];
+  ctx->rle_head ^= 1;
+  --ctx->rle_in_flight;
+  bool classified = false;
+  int st = rle_job_finish(ctx, j, n_runs, &classified);
+  j.busy = false;
+  if (st == KU_ENOMEM && classified && ctx->sp.on) {
+    // the emulation ran out of room behind the classification: it is given up, the run goes on (ku_ctx_sparse_state says 2)
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->d2h_stream);
+    (void)hipGetLastError();
+    ctx_free_sparse(ctx);
+    ctx->sp.gave_up = true;
+    st = KU_OK;
+  }
+  return st;
+}
+
+extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
+                                     const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
+                                     uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs) {
+  if (!n_runs) return fail(KU_EINVAL, "ku_classify_batch_rle: null buffer");
+  *n_runs = 0;
+  KU_TRY(check_ready(ctx));
+  KU_TRY(rle_idle(ctx, "ku_classify_batch_rle"));
+  KU_TRY(ku_classify_batch_rle_enqueue(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, opts, calls, hits, run_off, run_cnt));
+  return ku_classify_batch_rle_finish(ctx, n_runs);
+}
+
 extern "C" int ku_ctx_replace_calls(ku_ctx *ctx, const uint32_t *new_calls, uint64_t n_reads, uint64_t *n_dropped) {
   KU_TRY(check_ready(ctx));
   if (n_dropped) *n_dropped = 0;
   if (n_reads == 0) return KU_OK;
   if (!new_calls) return fail(KU_EINVAL, "ku_ctx_replace_calls: null argument");
-  if (ctx->b_calls.cap < n_reads * 4) return fail(KU_ESTATE, "ku_ctx_replace_calls: the context holds no batch of that many reads");
+  KU_TRY(rle_idle(ctx, "ku_ctx_replace_calls"));
+  if (!ctx->last_calls_dev) return fail(KU_ESTATE, "ku_ctx_replace_calls: the context holds no batch");
   if (ctx->b_hits.reserve(n_reads * 4) != KU_OK) return fail(KU_ENOMEM, "device batch buffers");
   hipStream_t s = ctx->stream;
   unsigned long long *d_dropped = (unsigned long long *)(ctx->d_scalar + 16);
   HIP_TRY(hipMemsetAsync(d_dropped, 0, 8, s));
   HIP_TRY(hipMemcpyAsync(ctx->b_hits.p, new_calls, n_reads * 4, hipMemcpyHostToDevice, s));
-  KU_TRY(ku_launch_replace_calls((const uint32_t *)ctx->b_calls.p, (const uint32_t *)ctx->b_hits.p, n_reads, ctx->d_node_taxid, ctx->tax.n_nodes,
+  KU_TRY(ku_launch_replace_calls((const uint32_t *)ctx->last_calls_dev, (const uint32_t *)ctx->b_hits.p, n_reads, ctx->d_node_taxid, ctx->tax.n_nodes,
                                  ctx->cnt.n_reads, d_dropped, s));
-  HIP_TRY(hipMemcpyAsync(ctx->b_calls.p, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToDevice, s));  // a second replacement starts from these
+  HIP_TRY(hipMemcpyAsync((void *)ctx->last_calls_dev, ctx->b_hits.p, n_reads * 4, hipMemcpyDeviceToDevice, s));  // a second replacement starts from these
   unsigned long long dropped = 0;
   HIP_TRY(hipMemcpyAsync(&dropped, d_dropped, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1957,8 +2365,13 @@ extern "C" int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs) {
   if (n_runs > ctx->n_runs) return fail(KU_EINVAL, "ku_fetch_runs: the last batch holds " + std::to_string(ctx->n_runs) + " runs");
   if (n_runs == 0) return KU_OK;
   if (!runs) return fail(KU_EINVAL, "ku_fetch_runs: null buffer");
-  HIP_TRY(hipMemcpyAsync(runs, ctx->b_runs.p, n_runs * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (!ctx->fetch_runs_src) return fail(KU_ESTATE, "ku_fetch_runs: no batch was classified");
+  // (a stream of its own: the copy queues neither behind the kernels of the batch in flight nor behind its copies back,
+  // which wait for those kernels)
+  KU_TRY(ctx_activate(ctx));
+  if (!ctx->fetch_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+  HIP_TRY(hipMemcpyAsync(runs, ctx->fetch_runs_src, n_runs * 8, hipMemcpyDeviceToHost, ctx->fetch_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->fetch_stream));
   return KU_OK;
 }
 
@@ -1998,6 +2411,7 @@ extern "C" int ku_ctx_swap_shard(ku_ctx *ctx, const ku_db *db, uint64_t bin_lo, 
   if (!ctx->extra.empty()) return fail(KU_EUNSUP, "chunked runs use one database (as the reference's: classify.cpp:639)");
   if (db->info.k != ctx->m.db.k) return fail(KU_EINVAL, "ku_ctx_swap_shard: k differs from the resident shard's");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  KU_TRY(ctx_seen_harvest(ctx));  // (marks of a fast-path run on the table that is about to go)
   ctx_drop_count_cache(ctx);
   if (ctx->pf.valid && ctx->pf.db == db && ctx->pf.bin_lo == bin_lo && ctx->pf.bin_hi == bin_hi) {
     // the chunk was prefetched (ku_ctx_prefetch_shard): it only has to change places with the resident one
@@ -2242,11 +2656,18 @@ struct DevTmp {  // device scratch of one ku_ctx_report call
 
 extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, char **out,
                              size_t *out_len) {
+  return ku_ctx_report_cols(ctx, tax, counts_paths, n_paths, 0u, out, out_len);
+}
+
+extern "C" int ku_ctx_report_cols(ku_ctx *ctx, const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, uint32_t flags,
+                                  char **out, size_t *out_len) {
   if (!ctx || !tax || !out || !out_len) return fail(KU_EINVAL, "ku_ctx_report: null argument");
   if (!ctx->tax_set) return fail(KU_ESTATE, "taxonomy not set");
+  KU_TRY(rle_idle(ctx, "ku_ctx_report"));
   KU_TRY(ctx_activate(ctx));
   const size_t ns = ctx->tax.n_slots, nn = ctx->tax.n_nodes, nt = tax->ids.size();
-  const bool exact = ctx->d_exact_unique != nullptr, sparse = ctx->sp.on && !exact;
+  const bool six = (flags & KU_R_NO_KMER_COLS) != 0;  // `classify -p 0`: no k-mer columns, so no sketch is looked at
+  const bool exact = ctx->d_exact_unique != nullptr || six, sparse = ctx->sp.on && !exact;
   // KU_REPORT_TIMES=1: where the call spends its time, on stderr
   const bool times = getenv("KU_REPORT_TIMES") != nullptr;
   auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
@@ -2281,8 +2702,8 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
   HIP_TRY(hipMemcpy(nk.data(), ctx->cnt.n_kmers, ns * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(nr.data(), ctx->cnt.n_reads, nn * 8, hipMemcpyDeviceToHost));
   if (exact) {
-    uq.resize(ns);
-    HIP_TRY(hipMemcpy(uq.data(), ctx->d_exact_unique, ns * 8, hipMemcpyDeviceToHost));
+    uq.assign(ns, 0);
+    if (!six) HIP_TRY(hipMemcpy(uq.data(), ctx->d_exact_unique, ns * 8, hipMemcpyDeviceToHost));
   }
   // counted taxa (taxon_counts entries, classify.cpp:939,968) -> every entry of their root paths is a counted clade
   // (taxdb.hpp:928-973); taxa without a taxDB entry are dropped ("No entry for X in database!")
@@ -2341,7 +2762,9 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
     lap("clade lists (host)");
     KU_TRY(ku_launch_rollup_dense(ctx->cnt.registers, d_moff, d_mslot, d_dense, n_clades, d_hist, ctx->stream));
     lap("dense roll-up");
-    if (sparse && n_pairs) {
+    // (entries of sparse sketches lie in the run-wide set G -- n_pairs of them -- and, since round 5, as SEEN marks in the probe
+    // table: what the fused kernel's fast path booked, ku_device.h)
+    if (sparse && (n_pairs || ctx->m.seen_dirty)) {
       // all-sparse clades per slot (its root path up to the first clade with a dense member: density is inherited upwards)
       std::vector<uint32_t> s_off(ns + 1, 0), s_clade;
       for (size_t s = 0; s < ns; ++s) {
@@ -2351,21 +2774,20 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       }
       s_off[ns] = (uint32_t)s_clade.size();
       uint32_t *d_soff = nullptr, *d_sclade = nullptr, *d_err = nullptr, *d_set = nullptr, *d_setcells = nullptr;
-      unsigned long long *d_per_slot = nullptr, *d_setoff = nullptr;
+      unsigned long long *d_setoff = nullptr;
       const KuSparseDev &sd = ctx->sp.dev;
-      st = tmp.zeros(&d_per_slot, ns);
-      if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the clade roll-up");
-      KU_TRY(ku_launch_count_g_slots(sd.g_key, sd.g_mask + 1, sd.dense, d_per_slot, ctx->n_cu, ctx->stream));
-      std::vector<unsigned long long> per_slot(ns);
-      HIP_TRY(hipMemcpyAsync(per_slot.data(), d_per_slot, ns * 8, hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      lap("entries per slot");
+      // What a slot may offer its clades: at most one entry per k-mer booked under it.  (Rounds 2-4 counted the set's entries
+      // per slot first -- a pass over all of G through LDS tables, 25 ms of the report's 83 per 10 M reads; the bound sizes the
+      // union sets generously instead, and the big clades take bitmaps of a fixed size anyway.)
+      std::vector<unsigned long long> per_slot(ns, 0);
+      for (size_t s = 0; s < ns; ++s)
+        if (slot_sparse[s]) per_slot[s] = nk[s];
       std::vector<uint64_t> clade_pairs(n_clades, 0);  // entries each clade's histogram may receive
       for (size_t s = 0; s < ns; ++s)
         for (uint32_t j = s_off[s]; j < s_off[s + 1]; ++j) clade_pairs[s_clade[j]] += per_slot[s];
-      // union sets, one table of 4-byte cells per clade with several members (a clade with one member is that member's
-      // own set, distinct already: histogram only): room for what its members offer -- at most every encoding there is
-      // (2^25 indices; the 2^12 of them whose low 13 bits are zero come with up to 40 ranks) -- at a load of 2/3
+      // union sets, one table of 4-byte cells per clade (also for a clade with one member: the two sources may hold an
+      // encoding twice): room for what its members offer -- at most every encoding there is (2^25 indices; the 2^12 of
+      // them whose low 13 bits are zero come with up to 40 ranks) -- at a load of 2/3
       const uint64_t enc_space = (1ull << 25) + (1ull << 12) * 40;
       const uint64_t flag_space = (1ull << 12) * 40;  // encodings that carry the rank flag
       // BIG clades keep a bitmap over the 2^25 indices instead (4 MiB each; ku_report.hip): every clade that may receive
@@ -2381,7 +2803,7 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       if (const char *e = getenv("KU_ROLLUP_BITMAP_MIN")) bm_min = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
       std::vector<uint32_t> cand;
       for (uint32_t c = 0; c < n_clades; ++c)
-        if (m_off[c + 1] - m_off[c] > 1 && clade_pairs[c] >= bm_min && !clade_dense[c]) cand.push_back(c);
+        if (clade_pairs[c] >= bm_min && !clade_dense[c]) cand.push_back(c);
       std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) {
         return clade_pairs[a] != clade_pairs[b] ? clade_pairs[a] > clade_pairs[b] : (depth[a] != depth[b] ? depth[a] < depth[b] : a < b);
       });
@@ -2426,7 +2848,7 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       std::vector<uint32_t> set_cells(n_clades, 0);
       uint64_t cells = 0;
       for (uint32_t c = 0; c < n_clades; ++c) {
-        if (m_off[c + 1] - m_off[c] <= 1 || !clade_pairs[c]) continue;
+        if (!clade_pairs[c] || clade_dense[c]) continue;
         // a bitmap clade's table only takes the entries with the rank flag (1 in 8192 of what hashes offer)
         const uint64_t bound = bm_of[c] != KU_BM_NONE ? std::min(clade_pairs[c] / 512 + 4096, flag_space) : std::min(clade_pairs[c], enc_space);
         set_off[c] = cells;
@@ -2462,8 +2884,12 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
       if (st == KU_OK) st = tmp.zeros(&d_bm, (size_t)std::max<uint32_t>(n_bm, 1) * (n_bm ? KU_BM_WORDS : 1));
       if (st != KU_OK) return fail(st, "ku_ctx_report: device memory for the union of the sparse sketches");
       lap("union set allocated + cleared");
-      KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, sd.dense, d_soff, d_sclade, d_setoff, d_setcells, d_chot, d_hotc, n_hot, d_set,
-                                     d_hist, d_err, d_bmof, d_bm, ctx->n_cu, ctx->stream));
+      KuRollupPlan plan{};
+      plan.dense = sd.dense; plan.slot_off = d_soff; plan.slot_clade = d_sclade; plan.set_off = d_setoff; plan.set_cells = d_setcells;
+      plan.clade_hot = d_chot; plan.hot_clades = d_hotc; plan.n_hot = n_hot; plan.set = d_set; plan.hist = d_hist; plan.err = d_err;
+      plan.bm_of = d_bmof; plan.bm = d_bm;
+      if (n_pairs) KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, plan, ctx->n_cu, ctx->stream));
+      if (ctx->m.seen_dirty && ctx->m.d_table) KU_TRY(ku_launch_rollup_table(ctx->m.d_table, ctx->m.db.n_lines, plan, ctx->n_cu, ctx->stream));
       for (const auto &lv : level_ranges)  // children into parents, deepest parents first
         KU_TRY(ku_launch_bitmap_or_children(d_bm, d_bmpar + lv.first, lv.second - lv.first, d_choff, d_ch, ctx->stream));
       KU_TRY(ku_launch_bitmap_hist(d_bm, d_bmclade, n_bm, d_hist, ctx->stream));
@@ -2485,8 +2911,8 @@ extern "C" int ku_ctx_report(ku_ctx *ctx, const ku_tax *tax, const char *const *
     }
   }
   lap("estimates (host)");
-  const int rst = ku_report_rows(tax, counts_paths, n_paths, present.data(), c_reads.data(), t_reads.data(), c_kmers.data(), c_uniq.data(), nt,
-                                 out, out_len);
+  const int rst = ku_report_rows_cols(tax, counts_paths, n_paths, present.data(), c_reads.data(), t_reads.data(), c_kmers.data(), c_uniq.data(), nt,
+                                      flags, out, out_len);
   lap("report text");
   return rst;
 }

@@ -210,7 +210,7 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
 //     dwords 0..3   eight 16-bit tag fields, field i in the (i & 1 ? high : low) half of dword i >> 1:
 //                   low 15 bits = tag of entry i (1 .. 0x7FFF; 0 = entry unused); bit 15 of field 0 = the bucket
 //                   received more than eight keys and spilled into the following line(s)
-//     dwords 4..27  eight 12-byte entries {key_lo, key_hi, slot};  dwords 28..31 unused
+//     dwords 4..27  eight 12-byte entries {key_lo, key_hi, slot};  dwords 28..29 eight SEEN bytes (below);  30..31 unused
 // MI355X moves 128 B per L2 miss and sustains ~48 G random line fetches/s whatever the access width
 // (scripts/calib_gather.hip), so a lookup costs the number of distinct lines it touches -- and, per wave, the
 // number of *dependent* round trips of its slowest lane.  The sorted-bin binary search touches ~2.5 lines in ~8
@@ -221,6 +221,16 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
 #define KU_LINE_DWORDS 32
 #define KU_LINE_SLOTS 8
 #define KU_LINE_ENTRY0 4  // first entry dword
+// dwords 28..29: one SEEN byte per entry (byte 112 + i of the line), 0 when the table is built.  The HyperLogLog++ sparse-mode
+// emulation's fast path (ku_short.hip, OUT = 2) sets the byte of every entry a read's k-mer found: the set of (taxon, k-mer)
+// pairs the reference keeps in its sparse sketches (hyperloglogplus.cpp:485-523) is then the set of marked entries --
+// recorded with a plain byte store into a line the probe had fetched anyway instead of a compare-and-swap on a second, random
+// line of a run-wide hash set.  Bytes only ever go 0 -> 1 within a run (monotone: stale reads cost a repeated store, never a
+// lost mark); ku_ctx_reset_counts clears them; the report (ku_report.hip) and ku_sparse_export read them back.
+#define KU_LINE_SEEN0 28
+__device__ __forceinline__ void ku_seen_mark(const uint32_t *line, uint32_t entry) {
+  reinterpret_cast<uint8_t *>(const_cast<uint32_t *>(line) + KU_LINE_SEEN0)[entry] = 1;
+}
 // 15-bit non-zero entry tag from h = fmix64(kmer + 1) (the HLL hash, reused; the HLL consumes bits 63..52 and the
 // leading zeros below them, the tag takes bits 42..28)
 __device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) {

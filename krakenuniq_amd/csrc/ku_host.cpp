@@ -426,9 +426,19 @@ extern "C" int ku_report_exact(const ku_tax *tax, const char *const *counts_path
 extern "C" int ku_report_rows(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint8_t *present,
                               const uint64_t *clade_reads, const uint64_t *tax_reads, const uint64_t *clade_kmers,
                               const uint64_t *clade_uniq, uint64_t n_rows, char **out, size_t *out_len) {
+  return ku_report_rows_cols(tax, counts_paths, n_paths, present, clade_reads, tax_reads, clade_kmers, clade_uniq, n_rows, 0u, out, out_len);
+}
+
+// ... with the reference's other column set: KU_R_NO_KMER_COLS = "% reads taxReads taxID rank taxName", what `classify -p 0`
+// prints (HLL_PRECISION <= 0, classify.cpp:289,316-323); rows and their order are the same (children by reads, then by the
+// number of k-mers: readcounts.hpp:90-98), clade_uniq is not looked at
+extern "C" int ku_report_rows_cols(const ku_tax *tax, const char *const *counts_paths, uint32_t n_paths, const uint8_t *present,
+                                   const uint64_t *clade_reads, const uint64_t *tax_reads, const uint64_t *clade_kmers,
+                                   const uint64_t *clade_uniq, uint64_t n_rows, uint32_t flags, char **out, size_t *out_len) {
   if (!tax || !out || !out_len || (n_paths && !counts_paths)) { ku_set_error("ku_report_rows: null argument"); return KU_EINVAL; }
+  const bool six = (flags & KU_R_NO_KMER_COLS) != 0;
   const size_t nt = tax->ids.size();
-  if (n_rows != nt || (nt && (!present || !clade_reads || !tax_reads || !clade_kmers || !clade_uniq))) {
+  if (n_rows != nt || (nt && (!present || !clade_reads || !tax_reads || !clade_kmers || (!six && !clade_uniq)))) {
     ku_set_error("ku_report_rows: the arrays must have one element per taxDB entry");
     return KU_EINVAL;
   }
@@ -474,7 +484,8 @@ extern "C" int ku_report_rows(const ku_tax *tax, const char *const *counts_paths
   for (uint32_t r : roots) { auto it = tax->row.find(r); if (it != tax->row.end() && present[it->second]) total += clade_reads[it->second]; }
   Sb sb;
   if (total) {
-    sb.s += "%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n";  // classify.cpp:305-314
+    sb.s += six ? "%\treads\ttaxReads\ttaxID\trank\ttaxName\n"                       // classify.cpp:316-323
+                : "%\treads\ttaxReads\tkmers\tdup\tcov\ttaxID\trank\ttaxName\n";  // classify.cpp:305-314
     // iterative DFS (taxdb.hpp:1049-1076)
     struct Frame { uint32_t row; unsigned depth; };
     std::vector<Frame> stack;
@@ -484,13 +495,17 @@ extern "C" int ku_report_rows(const ku_tax *tax, const char *const *counts_paths
       stack.pop_back();
       const uint32_t r = fr.row;
       if (!present[r] || clade_reads[r] == 0) continue;
-      const uint64_t uniq = clade_uniq[r];
-      volatile double gs = double(gsize[r] + gchild[r]);
-      volatile double kc = double(clade_kmers[r]), un = double(uniq);
       sb.printf("%.4g\t", 100.0 * double(clade_reads[r]) / double(total));
-      sb.printf("%llu\t%llu\t%llu\t", (unsigned long long)clade_reads[r], (unsigned long long)tax_reads[r], (unsigned long long)uniq);
-      sb.printf("%.3g\t", kc / un);
-      if (gs == 0) sb.s += "NA\t"; else sb.printf("%.4g\t", un / gs);
+      if (six) {
+        sb.printf("%llu\t%llu\t", (unsigned long long)clade_reads[r], (unsigned long long)tax_reads[r]);
+      } else {
+        const uint64_t uniq = clade_uniq[r];
+        volatile double gs = double(gsize[r] + gchild[r]);
+        volatile double kc = double(clade_kmers[r]), un = double(uniq);
+        sb.printf("%llu\t%llu\t%llu\t", (unsigned long long)clade_reads[r], (unsigned long long)tax_reads[r], (unsigned long long)uniq);
+        sb.printf("%.3g\t", kc / un);
+        if (gs == 0) sb.s += "NA\t"; else sb.printf("%.4g\t", un / gs);
+      }
       if (tax->ids[r] == 0xFFFFFFFFu) sb.s += "-1\t"; else sb.printf("%d\t", (int32_t)tax->ids[r]);
       sb.s += tax->ranks[r];
       sb.s += '\t';

@@ -106,7 +106,7 @@ int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_s
                             uint32_t quick_min_hits, int n_cu, hipStream_t stream);
 int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream);
 int ku_launch_zero3(void *a, uint64_t a_dwords, void *b, uint64_t b_dwords, void *c, uint64_t c_dwords, hipStream_t stream);
-int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream);
+int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream, bool skip_hits = false);
 int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,
                                unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream);
 int ku_launch_sparse_carry_in(const KuSparseDev &s, const unsigned long long *d_carry_l, uint64_t n_l, const uint32_t *d_carry_u,
@@ -116,21 +116,35 @@ int ku_launch_sparse_flag_units(const uint32_t *d_u_cnt, uint64_t n_cells, uint3
 int ku_launch_sparse_insert_runs(const KuSparseDev &s, uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
                                  const uint32_t *d_list_read, const uint32_t *d_list_unit, const uint32_t *d_list_urow, uint64_t n_list,
                                  const void *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt, const uint32_t *d_slot_taxid,
-                                 uint32_t n_slots, const uint32_t *d_u_cnt, int n_cu, hipStream_t stream);
+                                 uint32_t n_slots, const uint32_t *d_u_cnt, int n_cu, hipStream_t stream, uint32_t pos_base = 0);
 // s.g_key / s.g_mask: the new (zeroed) table; s.g_count zeroed by the caller
 int ku_launch_sparse_rehash(const KuSparseDev &s, const unsigned long long *d_old_keys, uint64_t old_cells, hipStream_t stream);
 int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uint64_t cap, unsigned long long *d_counter,
                             hipStream_t stream);
+// the SEEN marks of a probe table (ku_device.h): what = 0 count (entries of slots that are not dense), 1 insert them into the
+// run-wide set, 2 clear all marks
+int ku_launch_seen(int what, void *d_table, uint64_t n_lines, const KuSparseDev &s, unsigned long long *d_count, hipStream_t stream);
 
 // clade roll-up of the report (ku_report.hip): histograms of KU_ROLLUP_BINS bins per clade
 #define KU_ROLLUP_BINS 80
 int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_off, const uint32_t *d_member_slot,
                            const uint8_t *d_clade_dense, uint32_t n_clades, uint32_t *d_hist, hipStream_t stream);
 #define KU_ROLLUP_HOT 48  // clades whose histogram is pre-aggregated in LDS
-int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, const unsigned long long *d_set_off, const uint32_t *d_set_cells,
-                            const uint16_t *d_clade_hot, const uint32_t *d_hot_clades, uint32_t n_hot, uint32_t *d_set, uint32_t *d_hist,
-                            uint32_t *d_err, const uint32_t *d_bm_of, uint32_t *d_bm, int n_cu, hipStream_t stream);
+// the union plan of one ku_ctx_report call (device pointers; ku_api.cpp builds it, ku_report.hip walks it)
+struct KuRollupPlan {
+  const uint32_t *dense;                // per slot
+  const uint32_t *slot_off, *slot_clade;  // CSR: the all-sparse clades on each slot's root path, leaf first
+  const unsigned long long *set_off;    // per clade: its open-addressing table of 4-byte cells within `set` ...
+  const uint32_t *set_cells;            // ... and its size (0: nothing is offered to the clade)
+  const uint16_t *clade_hot;            // per clade: row in the block's LDS histogram (0xFFFF: none)
+  const uint32_t *hot_clades;           // the reverse map
+  uint32_t n_hot, pad;
+  uint32_t *set, *hist, *err;
+  const uint32_t *bm_of;                // per clade: its bitmap (KU_BM_NONE: a table clade)
+  uint32_t *bm;
+};
+int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const KuRollupPlan &plan, int n_cu, hipStream_t stream);
+int ku_launch_rollup_table(const void *d_table, uint64_t n_lines, const KuRollupPlan &plan, int n_cu, hipStream_t stream);
 // union bitmaps of the big all-sparse clades (ku_report.hip): one bit per 25-bit index, KU_BM_WORDS words per clade
 #define KU_BM_WORDS (1u << 20)
 #define KU_BM_NONE 0xFFFFFFFFu
@@ -139,8 +153,6 @@ int ku_launch_bitmap_or_children(uint32_t *d_bm, const uint32_t *d_parents, uint
 int ku_launch_bitmap_hist(const uint32_t *d_bm, const uint32_t *d_bm_clade, uint32_t n_bm, uint32_t *d_hist, hipStream_t stream);
 int ku_launch_replace_calls(const uint32_t *d_old, const uint32_t *d_new, uint64_t n, const uint32_t *d_node_taxid, uint32_t n_nodes,
                             unsigned long long *d_n_reads, unsigned long long *d_dropped, hipStream_t stream);
-int ku_launch_count_g_slots(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, unsigned long long *d_per_slot,
-                            int n_cu, hipStream_t stream);
 
 // host-side view of an opened database for the other translation units (ku_api.cpp owns the struct)
 struct ku_db;

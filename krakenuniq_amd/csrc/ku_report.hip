@@ -14,7 +14,7 @@
 // 80 bins * 4 B per clade go back to the host.
 #include <hip/hip_runtime.h>
 
-#include "ku_internal.h"
+#include "ku_device.h"
 
 namespace {
 
@@ -67,10 +67,10 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
 //
 // Input is the run-wide set G of the sparse-mode emulation where it lies (ku_sparse.hip: cells of (slot + 1) << 32 |
 // encoding, 0 = empty; no compacted copy is made).  An entry walks up its slot's chain of all-sparse clades, leaf first:
-//   * a clade with a single member holds exactly that slot's entries, which are distinct by construction: histogram
-//     only, no set;
-//   * else (clade, encoding) goes into the union set; an entry that is already there stops the walk -- whoever put it
-//     there carries it further up, and the chains of two slots are the same above their first common clade.
+//   * (clade, encoding) goes into the clade's set; an entry that is already there stops the walk -- whoever put it there
+//     carries it further up, and the chains of two slots are the same above their first common clade.  (Rounds 2-4 gave a
+//     clade with a single member no set: its entries came from G alone and were distinct already.  With two sources -- G and
+//     the probe table's SEEN marks, below -- an encoding may arrive twice, and two k-mers may share one; every clade dedups.)
 // So the work is one insert per DISTINCT (clade, encoding) plus one failed probe per duplicate, not entries x depth.
 // The union sets are one open-addressing table PER CLADE of 4-byte cells holding the encoding alone (0 never is one: index
 // 0 carries the rank flag), laid out back to back: set_off[c] / set_cells[c]; half the memory of (clade, encoding) keys --
@@ -83,60 +83,79 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
 // (ku_bitmap_hist) -- one atomic per entry instead of one table insert per entry and level (3 G inserts for 0.6 G entries
 // under a five-level taxonomy were 237 of the report's 290 ms of kernels).  The few entries that carry the flag (index
 // bits p..p' all zero: 1 in 8192) walk on through small per-clade tables as before.
-__global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells,
-                                                                const uint32_t *__restrict__ dense,
-                                                                const uint32_t *__restrict__ slot_off,
-                                                                const uint32_t *__restrict__ slot_clade,
-                                                                const unsigned long long *__restrict__ set_off,
-                                                                const uint32_t *__restrict__ set_cells,
-                                                                const uint16_t *__restrict__ clade_hot,
-                                                                const uint32_t *__restrict__ hot_clades, uint32_t n_hot,
-                                                                uint32_t *set, uint32_t *hist, uint32_t *err,
-                                                                const uint32_t *__restrict__ bm_of, uint32_t *bm) {
+// one entry (slot, encoding) of a sketch that stayed sparse walks up its slot's chain of all-sparse clades, leaf first
+__device__ __forceinline__ void rollup_entry(const KuRollupPlan &p, uint32_t *hot, uint32_t slot, uint32_t enc) {
+  uint32_t r = encoded_rank(enc);
+  if (r > KU_ROLLUP_BINS - 1) r = KU_ROLLUP_BINS - 1;
+  uint32_t g = enc * 0x9E3779B1u;  // (the index sits in the high bits of an encoding: spread it)
+  g ^= g >> 15;
+  g *= 0x85EBCA77u;
+  g ^= g >> 13;
+  for (uint32_t j = p.slot_off[slot]; j < p.slot_off[slot + 1]; ++j) {
+    const uint32_t c = p.slot_clade[j];
+    const uint32_t b = p.bm_of[c];
+    if (b != KU_BM_NONE && !(enc & 1u)) {  // index = enc >> 7: word enc >> 12, bit (enc >> 7) & 31
+      atomicOr(&p.bm[(size_t)b * KU_BM_WORDS + (enc >> 12)], 1u << ((enc >> 7) & 31u));
+      break;
+    }
+    bool fresh = true;
+    const uint32_t cells = p.set_cells[c];  // 0: a clade nothing is offered to
+    if (cells) {
+      uint32_t *tab = p.set + p.set_off[c];
+      uint32_t h = __umulhi(g, cells);
+      bool done = false;
+      for (uint32_t probe = 0; probe < 8192 && !done; ++probe) {
+        const uint32_t old = atomicCAS(&tab[h], 0u, enc);
+        if (old == 0u) done = true;
+        else if (old == enc) { done = true; fresh = false; }
+        h = h + 1 == cells ? 0 : h + 1;
+      }
+      if (!done) { atomicOr(p.err, 1u); fresh = false; }
+    }
+    if (!fresh) break;
+    const uint32_t hi = p.clade_hot[c];
+    if (hi != 0xFFFFu) atomicAdd(&hot[hi * KU_ROLLUP_BINS + r], 1u);
+    else atomicAdd(&p.hist[(size_t)c * KU_ROLLUP_BINS + r], 1u);
+  }
+}
+
+// source 1: the run-wide set G where it lies (cells of (slot + 1) << 32 | encoding, 0 = empty)
+__global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells, KuRollupPlan p) {
   __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
   for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
   __syncthreads();
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < g_cells; i += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long p = g_key[i];
-    if (!p) continue;
-    const uint32_t slot = (uint32_t)(p >> 32) - 1, enc = (uint32_t)p;
-    if (dense[slot]) continue;
-    uint32_t r = encoded_rank(enc);
-    if (r > KU_ROLLUP_BINS - 1) r = KU_ROLLUP_BINS - 1;
-    uint32_t g = enc * 0x9E3779B1u;  // (the index sits in the high bits of an encoding: spread it)
-    g ^= g >> 15;
-    g *= 0x85EBCA77u;
-    g ^= g >> 13;
-    for (uint32_t j = slot_off[slot]; j < slot_off[slot + 1]; ++j) {
-      const uint32_t c = slot_clade[j];
-      const uint32_t b = bm_of[c];
-      if (b != KU_BM_NONE && !(enc & 1u)) {  // index = enc >> 7: word enc >> 12, bit (enc >> 7) & 31
-        atomicOr(&bm[(size_t)b * KU_BM_WORDS + (enc >> 12)], 1u << ((enc >> 7) & 31u));
-        break;
-      }
-      bool fresh = true;
-      const uint32_t cells = set_cells[c];  // 0: a clade with a single member (that member's own, distinct entries)
-      if (cells) {
-        uint32_t *tab = set + set_off[c];
-        uint32_t h = __umulhi(g, cells);
-        bool done = false;
-        for (uint32_t probe = 0; probe < 8192 && !done; ++probe) {
-          const uint32_t old = atomicCAS(&tab[h], 0u, enc);
-          if (old == 0u) done = true;
-          else if (old == enc) { done = true; fresh = false; }
-          h = h + 1 == cells ? 0 : h + 1;
-        }
-        if (!done) { atomicOr(err, 1u); fresh = false; }
-      }
-      if (!fresh) break;
-      const uint32_t hi = clade_hot[c];
-      if (hi != 0xFFFFu) atomicAdd(&hot[hi * KU_ROLLUP_BINS + r], 1u);
-      else atomicAdd(&hist[(size_t)c * KU_ROLLUP_BINS + r], 1u);
-    }
+    const unsigned long long e = g_key[i];
+    if (!e) continue;
+    const uint32_t slot = (uint32_t)(e >> 32) - 1;
+    if (p.dense[slot]) continue;
+    rollup_entry(p, hot, slot, (uint32_t)e);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n_hot * KU_ROLLUP_BINS; i += blockDim.x)
-    if (hot[i]) atomicAdd(&hist[(size_t)hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
+  for (uint32_t i = threadIdx.x; i < p.n_hot * KU_ROLLUP_BINS; i += blockDim.x)
+    if (hot[i]) atomicAdd(&p.hist[(size_t)p.hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
+}
+
+// source 2 (round 5): the probe table's SEEN marks (ku_device.h) -- every marked entry is a k-mer some read held, booked under
+// the entry's slot by the fused kernel's fast path; its encoding is that of the k-mer's hash (hyperloglogplus.cpp:181-204).
+// A thread per (line, entry): the eight lanes of a line read its eight SEEN bytes, the marked ones their 12-byte entry.
+__global__ __launch_bounds__(256) void ku_rollup_table_kernel(const uint32_t *__restrict__ table, uint64_t n_lines, KuRollupPlan p) {
+  __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
+  for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
+  __syncthreads();
+  const uint64_t n_items = n_lines * KU_LINE_SLOTS;
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_items; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t *lp = table + (i >> 3) * KU_LINE_DWORDS;
+    const uint32_t e = (uint32_t)i & 7u;
+    if (!reinterpret_cast<const uint8_t *>(lp + KU_LINE_SEEN0)[e]) continue;
+    const uint32_t slot = lp[KU_LINE_ENTRY0 + 3 * e + 2];
+    if (p.dense[slot]) continue;
+    const uint64_t key = ((uint64_t)lp[KU_LINE_ENTRY0 + 3 * e + 1] << 32) | lp[KU_LINE_ENTRY0 + 3 * e];
+    rollup_entry(p, hot, slot, ks_encode(ku_fmix64(key)));
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < p.n_hot * KU_ROLLUP_BINS; i += blockDim.x)
+    if (hot[i]) atomicAdd(&p.hist[(size_t)p.hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
 }
 
 // bitmap of a parent clade |= the bitmaps of its children (all finished: the launches go level by level, deepest parents
@@ -193,55 +212,6 @@ __global__ __launch_bounds__(256) void ku_bitmap_hist_kernel(const uint32_t *__r
     atomicAdd(&hist[(size_t)bm_clade[blockIdx.y] * KU_ROLLUP_BINS + threadIdx.x], bins[threadIdx.x]);
 }
 
-// entries of G per slot (slots that stayed sparse only): sizes the union set.  Counted in a per-block LDS table keyed by
-// slot (neighbouring cells of a hash table belong to unrelated slots, but a run has far fewer slots than cells)
-__global__ __launch_bounds__(256) void ku_count_g_slots_kernel(const unsigned long long *__restrict__ g_key, uint64_t g_cells,
-                                                                const uint32_t *__restrict__ dense, unsigned long long *per_slot) {
-  constexpr int LOG2 = 11;
-  __shared__ uint32_t s_key[1 << LOG2], s_cnt[1 << LOG2];
-  __shared__ uint32_t s_used;
-  for (uint32_t i = threadIdx.x; i < (1u << LOG2); i += blockDim.x) { s_key[i] = 0; s_cnt[i] = 0; }
-  if (threadIdx.x == 0) s_used = 0;
-  __syncthreads();
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t base = blockIdx.x * (uint64_t)blockDim.x; base < g_cells; base += stride) {  // block-uniform trip count
-    const uint64_t i = base + threadIdx.x;
-    const unsigned long long p = i < g_cells ? g_key[i] : 0ull;
-    if (p) {
-      const uint32_t slot = (uint32_t)(p >> 32) - 1;
-      if (!dense[slot]) {
-        uint32_t h = (slot * 2654435761u) >> (32 - LOG2);
-        bool placed = false;
-        for (int probe = 0; probe < 16 && !placed; ++probe) {
-          uint32_t cur = s_key[h];
-          if (cur == 0) {
-            const uint32_t old = atomicCAS(&s_key[h], 0u, slot + 1);
-            if (old == 0) atomicAdd(&s_used, 1u);
-            cur = old == 0 ? slot + 1 : old;
-          }
-          if (cur == slot + 1) { atomicAdd(&s_cnt[h], 1u); placed = true; }
-          h = (h + 1) & ((1u << LOG2) - 1);
-        }
-        if (!placed) atomicAdd(&per_slot[slot], 1ull);
-      }
-    }
-    __syncthreads();
-    if (s_used > (1u << LOG2) / 2) {  // block-uniform (read behind the barrier)
-      for (uint32_t t = threadIdx.x; t < (1u << LOG2); t += blockDim.x) {
-        if (s_key[t]) atomicAdd(&per_slot[s_key[t] - 1], (unsigned long long)s_cnt[t]);
-        s_key[t] = 0;
-        s_cnt[t] = 0;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) s_used = 0;
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  for (uint32_t t = threadIdx.x; t < (1u << LOG2); t += blockDim.x)
-    if (s_key[t]) atomicAdd(&per_slot[s_key[t] - 1], (unsigned long long)s_cnt[t]);
-}
-
 // classify -I: the reads of the last batch are counted under new calls (ku_ctx_replace_calls).  node_taxid is ascending:
 // a binary search maps a taxid to its node; a taxid outside the node universe cannot be counted.
 __device__ __forceinline__ uint32_t node_of_taxid(const uint32_t *__restrict__ node_taxid, uint32_t n_nodes, uint32_t taxid) {
@@ -282,15 +252,19 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
-int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, const uint32_t *d_slot_off,
-                            const uint32_t *d_slot_clade, const unsigned long long *d_set_off, const uint32_t *d_set_cells,
-                            const uint16_t *d_clade_hot, const uint32_t *d_hot_clades, uint32_t n_hot, uint32_t *d_set, uint32_t *d_hist,
-                            uint32_t *d_err, const uint32_t *d_bm_of, uint32_t *d_bm, int n_cu, hipStream_t stream) {
+int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells, const KuRollupPlan &plan, int n_cu, hipStream_t stream) {
   if (!g_cells) return KU_OK;
   const uint64_t want = (g_cells + 255) / 256;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_slot_off, d_slot_clade, d_set_off, d_set_cells, d_clade_hot,
-                                                       d_hot_clades, n_hot, d_set, d_hist, d_err, d_bm_of, d_bm);
+  ku_rollup_sparse_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, plan);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+
+int ku_launch_rollup_table(const void *d_table, uint64_t n_lines, const KuRollupPlan &plan, int n_cu, hipStream_t stream) {
+  if (!n_lines) return KU_OK;
+  const uint64_t want = (n_lines * KU_LINE_SLOTS + 255) / 256;
+  const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
+  ku_rollup_table_kernel<<<blocks, 256, 0, stream>>>((const uint32_t *)d_table, n_lines, plan);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 
@@ -304,14 +278,5 @@ int ku_launch_bitmap_or_children(uint32_t *d_bm, const uint32_t *d_parents, uint
 int ku_launch_bitmap_hist(const uint32_t *d_bm, const uint32_t *d_bm_clade, uint32_t n_bm, uint32_t *d_hist, hipStream_t stream) {
   if (!n_bm) return KU_OK;
   ku_bitmap_hist_kernel<<<dim3(64, n_bm), 256, 0, stream>>>(d_bm, d_bm_clade, d_hist);
-  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
-}
-
-int ku_launch_count_g_slots(const unsigned long long *d_g_key, uint64_t g_cells, const uint32_t *d_dense, unsigned long long *d_per_slot,
-                            int n_cu, hipStream_t stream) {
-  if (!g_cells) return KU_OK;
-  const uint64_t want = (g_cells + 255) / 256;
-  const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
-  ku_count_g_slots_kernel<<<blocks, 256, 0, stream>>>(d_g_key, g_cells, d_dense, d_per_slot);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

@@ -196,8 +196,17 @@ struct Reader {
   Reader &operator=(const Reader &) = delete;
   ~Reader() { close(); }
 
+  // zlib's reader ends a damaged stream (wrong CRC-32, broken deflate data, a file that stops in mid-member) with -1: that is
+  // no end of file.  (It ended the input silently in rounds 1-4; the team readers have always refused such files.)
+  std::atomic<bool> gz_failed{false};
   long raw_read(char *dst, size_t want) {
-    return fd >= 0 ? (long)::read(fd, dst, want) : (long)gzread(g, dst, (unsigned)want);
+    if (fd >= 0) return (long)::read(fd, dst, want);
+    const long n = (long)gzread(g, dst, (unsigned)want);
+    if (n < 0) gz_failed = true;
+    return n;
+  }
+  void check_gz() {
+    if (gz_failed) fatal(65, "corrupt gzip data in the input (zlib: wrong CRC-32 / length, broken deflate stream or truncated file)");
   }
   // size of the BGZF block at p (0: not one)
   static size_t bgzf_block_size(const unsigned char *p, size_t avail) {
@@ -222,14 +231,18 @@ struct Reader {
       const size_t bs = bgzf_block_size(bz_map + p, bz_len - p);
       if (bs < 26 || p + bs > t.in_hi) { sl.bad = true; break; }
       const size_t xlen = bz_map[p + 10] | ((size_t)bz_map[p + 11] << 8);
+      if (bs < 12 + xlen + 8) { sl.bad = true; break; }  // (an extra field that claims more than the block holds)
       const size_t isize = (size_t)bz_map[p + bs - 4] | ((size_t)bz_map[p + bs - 3] << 8) | ((size_t)bz_map[p + bs - 2] << 16) | ((size_t)bz_map[p + bs - 1] << 24);
+      const uint32_t crc = (uint32_t)bz_map[p + bs - 8] | ((uint32_t)bz_map[p + bs - 7] << 8) | ((uint32_t)bz_map[p + bs - 6] << 16) | ((uint32_t)bz_map[p + bs - 5] << 24);
       if (isize > 65536 || sl.n + isize > sl.out.size()) { sl.bad = true; break; }
       z.next_in = const_cast<unsigned char *>(bz_map + p + 12 + xlen);
       z.avail_in = (unsigned)(bs - 12 - xlen - 8);
       z.next_out = (unsigned char *)sl.out.data() + sl.n;
       z.avail_out = (unsigned)isize;
       const int rc = isize ? inflate(&z, Z_FINISH) : Z_STREAM_END;
-      if (rc != Z_STREAM_END || z.avail_out != 0) { sl.bad = true; break; }
+      // the block's CRC-32, as zlib's gzread checks it (and GzTextStream::inflate_task on the region path): a damaged block
+      // must not be classified silently (a flipped byte in a stored block went through with -P / -t 1)
+      if (rc != Z_STREAM_END || z.avail_out != 0 || (uint32_t)ku_pgzip::crc_of((const uint8_t *)sl.out.data() + sl.n, isize) != crc) { sl.bad = true; break; }
       sl.n += isize;
       inflateReset(&z);
       p += bs;
@@ -250,7 +263,8 @@ struct Reader {
     BgzfTask cur{0, 0};
     while (at < n) {
       const size_t bs = bgzf_block_size(p + at, n - at);
-      if (bs < 26 || at + bs > n) { munmap(m, n); return false; }  // (a plain gzip member in between: not for this path)
+      // (a plain gzip member in between, or an extra field longer than its block: not for this path)
+      if (bs < 26 || at + bs > n || bs < 12 + ((size_t)p[at + 10] | ((size_t)p[at + 11] << 8)) + 8) { munmap(m, n); return false; }
       at += bs;
       if (++in_task == BGZF_TASK || at == n) { cur.in_hi = at; tasks.push_back(cur); cur.in_lo = at; in_task = 0; }
     }
@@ -519,7 +533,7 @@ struct Reader {
         cv.wait(l, [&] { return !ready.empty() || produced_all; });
         if (!ready.empty()) { b = ready.front(); ready.pop_front(); }
       }
-      if (!b) { eof = true; return false; }
+      if (!b) { check_gz(); eof = true; return false; }
       if (len + b->n > buf.size()) buf.resize(std::max(buf.size() * 2, len + b->n));
       memcpy(buf.data() + len, b->data.data(), b->n);
       len += b->n;
@@ -531,7 +545,7 @@ struct Reader {
     const size_t room = buf.size() - len;
     const size_t want = room < ((size_t)1 << 30) ? room : ((size_t)1 << 30);
     long n = raw_read(buf.data() + len, want);
-    if (n <= 0) { eof = true; return false; }
+    if (n <= 0) { check_gz(); eof = true; return false; }
     len += (size_t)n;
     return true;
   }

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   // KS_ABL(bit): measurement knob, compiled in only with -DKU_ABLATION (then env KU_ABLATE selects the bits; the
   // production build has no trace of it -- the flag checks cost scalar registers and branches in the read loop):
   // 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
-  // 32 skip resolve (call 0), 64 skip locus/minimizer stage (bucket 0).  0 in production.
+  // 32 skip resolve (call 0), 64 skip locus/minimizer stage (bucket 0), 128 (OUT = 2) skip the SEEN marks, 256 (OUT = 2) skip
+  // the misses' inserts into the run-wide set.  0 in production.
   using G = KsGeom<ITEMS>;
   constexpr uint32_t TCAP = 1u << G::TCAP_LOG2;
   __shared__ uint32_t s_codes[KS_WAVES][G::NCODES];
@@ -674,10 +675,23 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       }
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) pr[j] = *reinterpret_cast<const KuPair *>(ep[j]);
+      // OUT == 2 (sparse-sketch emulation): the line's SEEN bytes, one per entry (ku_device.h), come with the entry -- same
+      // line, same round trip.  A k-mer the database holds is "inserted into its taxon's sparse sketch" by setting the byte of
+      // its entry: a plain byte store, and only the first time (a stale 0 from this CU's L1 costs a second store, never a
+      // lost one).  The report reads the marks back (ku_report.hip); the run-wide set only takes the misses.
+      uint32_t sb[ITEMS];
+      if (OUT == 2 && DO_COUNTS) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+          sb[j] = reinterpret_cast<const uint8_t *>(lp[j] + KU_LINE_SEEN0)[__builtin_ctz(cand[j] | 0x100u) & 7u];
+      }
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
         const bool hit = cand[j] != 0 && (((uint64_t)pr[j].key_hi << 32) | pr[j].key_lo) == canon[j];
         v[j] = hit ? pr[j].slot : 0u;
+        if (OUT == 2 && DO_COUNTS) {
+          if (hit && !sb[j] && !KS_ABL(128u)) ku_seen_mark(lp[j], (uint32_t)__builtin_ctz(cand[j]));
+        }
         cand[j] &= cand[j] - 1;  // no-op for 0
         act[j] = !hit && (cand[j] != 0 || ovf[j]);
       }
@@ -704,10 +718,12 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         for (int j = 0; j < ITEMS; ++j) {
           if (act[j]) {
             if (cand[j]) {
+              const uint32_t ei = (uint32_t)__builtin_ctz(cand[j]);
               cand[j] &= cand[j] - 1;
               if ((((uint64_t)e[j].key_hi << 32) | e[j].key_lo) == canon[j]) {
                 v[j] = e[j].slot;
                 act[j] = false;
+                if (OUT == 2 && DO_COUNTS && !KS_ABL(128u)) ku_seen_mark(lp[j], ei);  // (rare path: marked without a look)
               }
             } else {
               cand[j] = ku_tag_matches(a4[j], tag[j]);
@@ -821,22 +837,20 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 
     // ---- sparse-mode emulation, fast path (KuSparseFast): inserts per (work unit, slot), and the encoded hash of every
     // k-mer whose slot is not known to be dense into the run-wide set
+    // (round 5: the k-mers the database holds are booked by the SEEN byte of their table entry, stage 4 -- 1.16 G
+    // compare-and-swaps on a 16 GB set per 10 M reads became byte stores into lines the probe had fetched anyway; what is left
+    // for the set are the misses, under taxon 0, until that sketch turns dense, i.e. for about one work unit)
     if (OUT == 2 && DO_COUNTS && n > 0) {
       uint32_t *urow = sf.u_cnt + (size_t)(sf.unit_of[r] - sf.unit_base) * sf.n_slots;
+      bool any_miss;  // uniform
       if (uni) {
         if (lane == 0) {
           if (n_hit) atomicAdd(&urow[uni_slot], n_hit);
           if (n_miss) atomicAdd(&urow[0], n_miss);
         }
-        const bool d_hit = n_hit == 0 || sf.dense[uni_slot] != 0, d_miss = n_miss == 0 || sf.dense[0] != 0;  // uniform
-        if (!(d_hit && d_miss)) {
-          bool want[ITEMS];
-#pragma unroll
-          for (int j = 0; j < ITEMS; ++j) want[j] = j * 64 + lane < n && !amb_k[j] && !(v[j] ? d_hit : d_miss);
-          sp_fresh += ks_g_insert_items<ITEMS>(sf.g_key, sf.g_mask, v, hh, want, sf.err);
-        }
+        any_miss = n_miss != 0;
       } else {
-        bool want[ITEMS];
+        unsigned long long miss_any = 0;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
           const bool okc = j * 64 + lane < n && !amb_k[j];
@@ -851,8 +865,14 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
             if (lane == lead) atomicAdd(&urow[s0], (uint32_t)__popcll(same));
             todo &= ~same;
           }
-          want[j] = okc && !sf.dense[v[j]];
+          miss_any |= __ballot(okc && v[j] == 0);
         }
+        any_miss = miss_any != 0;
+      }
+      if (any_miss && sf.dense[0] == 0 && !KS_ABL(256u)) {
+        bool want[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) want[j] = j * 64 + lane < n && !amb_k[j] && v[j] == 0;
         sp_fresh += ks_g_insert_items<ITEMS>(sf.g_key, sf.g_mask, v, hh, want, sf.err);
       }
     }

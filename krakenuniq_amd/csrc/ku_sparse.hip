@@ -134,7 +134,9 @@ __global__ __launch_bounds__(64) void ku_sparse_insert_runs_kernel(KuSparseDev s
                                                                    const uint2 *__restrict__ runs, const uint64_t *__restrict__ run_off,
                                                                    const uint32_t *__restrict__ run_cnt,
                                                                    const uint32_t *__restrict__ slot_taxid, uint32_t n_slots,
-                                                                   const uint32_t *__restrict__ u_cnt) {
+                                                                   const uint32_t *__restrict__ u_cnt, uint32_t pos_base) {
+  // pos_base: what a unit's inserts BEFORE this buffer took of the position space (a unit whose first reads are evaluated
+  // from the tail buffer, ku_api.cpp: their positions come first)
   const uint32_t lane = threadIdx.x;
   for (uint64_t li = blockIdx.x; li < n_list; li += gridDim.x) {
     const uint32_t r = list_read[li], lu = list_unit[li];
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64) void ku_sparse_insert_runs_kernel(KuSparseDev s
           fwd = (fwd << 2) | (((c >> 1) ^ (c >> 2)) & 3u);
         }
         const uint64_t rc = ku_revcomp64(fwd, k);
-        ks_insert(s, unit, slot, ks_encode(ku_fmix64(fwd < rc ? fwd : rc)), (uint32_t)(off + i) + 2u);
+        ks_insert(s, unit, slot, ks_encode(ku_fmix64(fwd < rc ? fwd : rc)), pos_base + (uint32_t)(off + i) + 2u);
       }
     }
   }
@@ -207,13 +209,15 @@ __global__ void ku_sparse_eval_kernel(KuSparseDev s, uint32_t n_closed) {
 }
 
 // closed units of slots that stayed sparse: their encodings join the run's global set (the sparse + sparse merge)
-__global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed) {
+// skip_hits: the pass belongs to the fused kernel's fast path -- the k-mers the database holds are booked by the SEEN marks of
+// their table entries (ku_device.h), only the misses (slot 0) live in the set
+__global__ void ku_sparse_commit_kernel(KuSparseDev s, uint32_t n_closed, uint32_t skip_hits) {
   unsigned long long n_new = 0;  // one add to the set's size per wave, not per entry (a single hot address otherwise)
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i <= s.l_mask; i += (uint64_t)gridDim.x * blockDim.x) {
     const unsigned long long key = s.l_key[i];
     if (!key) continue;
     const uint32_t unit = (uint32_t)(key >> 50) - 1, slot = (uint32_t)(key >> 32) & 0x3FFFFu, enc = (uint32_t)key;
-    if (unit >= n_closed || s.dense[slot]) continue;
+    if (unit >= n_closed || s.dense[slot] || (skip_hits && slot != 0)) continue;
     const unsigned long long gk = ((unsigned long long)(slot + 1) << 32) | enc;
     uint64_t h = ks_mix(gk) & s.g_mask;
     bool placed = false;
@@ -383,6 +387,36 @@ __global__ void ku_zero3_kernel(uint32_t *a, uint64_t na, uint32_t *b, uint64_t 
   }
 }
 
+// ---- the SEEN marks of the probe table (ku_device.h; set by the fused kernel's fast path, ku_short.hip OUT = 2)
+// A marked entry stands for (slot of the entry, encoding of its k-mer's hash) in the run-wide set.  The report reads the marks
+// where they lie (ku_report.hip); whoever needs the set as such -- ku_sparse_export, the union of several ranks' sets, a
+// table about to be freed -- has them inserted into G first.  A thread per (line, entry).
+template <int WHAT>  // 0: count the marked entries of slots that are not dense; 1: insert them into G; 2: clear all marks
+__global__ __launch_bounds__(256) void ku_seen_kernel(uint32_t *table, uint64_t n_lines, KuSparseDev s, unsigned long long *count) {
+  unsigned long long n = 0;
+  const uint64_t n_items = n_lines * KU_LINE_SLOTS;
+  // (n_items is a multiple of 8 and the stride of 64: the lanes of a wave run the same number of rounds)
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_items; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t *lp = table + (i >> 3) * KU_LINE_DWORDS;
+    const uint32_t e = (uint32_t)i & 7u;
+    if (WHAT == 2) {
+      if (e < 2 && lp[KU_LINE_SEEN0 + e]) lp[KU_LINE_SEEN0 + e] = 0u;
+      continue;
+    }
+    if (!reinterpret_cast<const uint8_t *>(lp + KU_LINE_SEEN0)[e]) continue;
+    const uint32_t slot = lp[KU_LINE_ENTRY0 + 3 * e + 2];
+    if (s.dense[slot]) continue;
+    if (WHAT == 0) { ++n; continue; }
+    const uint64_t key = ((uint64_t)lp[KU_LINE_ENTRY0 + 3 * e + 1] << 32) | lp[KU_LINE_ENTRY0 + 3 * e];
+    if (ks_g_insert(s.g_key, s.g_mask, slot, ks_encode(ku_fmix64(key)), s.err)) ++n;
+  }
+  if (WHAT != 2) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_down(n, d, 64);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(count, n);
+  }
+}
+
 // ---------------------------------------------------------------------------- launch wrappers
 static unsigned ks_grid(uint64_t n) {
   const uint64_t nb = (n + 255) / 256;
@@ -408,10 +442,10 @@ int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream) {
   hipLaunchKernelGGL(ku_sparse_clear_kernel, dim3(ks_grid((n + 3) / 4)), dim3(256), 0, stream, s);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
-int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream) {
+int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream, bool skip_hits) {
   hipLaunchKernelGGL(ku_sparse_maxfirst_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s);
   hipLaunchKernelGGL(ku_sparse_eval_kernel, dim3(ks_grid(s.u_mask + 1)), dim3(256), 0, stream, s, n_closed);
-  hipLaunchKernelGGL(ku_sparse_commit_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s, n_closed);
+  hipLaunchKernelGGL(ku_sparse_commit_kernel, dim3(ks_grid(s.l_mask + 1)), dim3(256), 0, stream, s, n_closed, skip_hits ? 1u : 0u);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 int ku_launch_sparse_rehash(const KuSparseDev &s, const unsigned long long *d_old_keys, uint64_t old_cells, hipStream_t stream) {
@@ -447,16 +481,27 @@ int ku_launch_sparse_flag_units(const uint32_t *d_u_cnt, uint64_t n_cells, uint3
 int ku_launch_sparse_insert_runs(const KuSparseDev &s, uint32_t k, const uint8_t *d_seqs, const uint64_t *d_seq_off, const uint32_t *d_seq_len,
                                  const uint32_t *d_list_read, const uint32_t *d_list_unit, const uint32_t *d_list_urow, uint64_t n_list,
                                  const void *d_runs, const uint64_t *d_run_off, const uint32_t *d_run_cnt, const uint32_t *d_slot_taxid,
-                                 uint32_t n_slots, const uint32_t *d_u_cnt, int n_cu, hipStream_t stream) {
+                                 uint32_t n_slots, const uint32_t *d_u_cnt, int n_cu, hipStream_t stream, uint32_t pos_base) {
   if (n_list == 0) return KU_OK;
   const uint64_t cap = (uint64_t)n_cu * 32;
   hipLaunchKernelGGL(ku_sparse_insert_runs_kernel, dim3((unsigned)(n_list < cap ? n_list : cap)), dim3(64), 0, stream, s, k, d_seqs, d_seq_off,
                      d_seq_len, d_list_read, d_list_unit, d_list_urow, n_list, (const uint2 *)d_runs, d_run_off, d_run_cnt, d_slot_taxid,
-                     n_slots, d_u_cnt);
+                     n_slots, d_u_cnt, pos_base);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
 int ku_launch_sparse_absorb(const KuSparseDev &s, const unsigned long long *d_keys, uint64_t n, hipStream_t stream) {
   if (n == 0) return KU_OK;
   hipLaunchKernelGGL(ku_sparse_absorb_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, s, d_keys, n);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
+// the SEEN marks of a probe table: what = 0 counts the marked entries of slots that are not dense into *d_count, 1 inserts
+// them into the run-wide set (d_count = its size counter), 2 clears every mark
+int ku_launch_seen(int what, void *d_table, uint64_t n_lines, const KuSparseDev &s, unsigned long long *d_count, hipStream_t stream) {
+  if (n_lines == 0) return KU_OK;
+  const uint64_t nb = (n_lines * KU_LINE_SLOTS + 255) / 256;
+  const dim3 grid((unsigned)(nb < 16384 ? nb : 16384)), block(256);
+  if (what == 0) hipLaunchKernelGGL(ku_seen_kernel<0>, grid, block, 0, stream, (uint32_t *)d_table, n_lines, s, d_count);
+  else if (what == 1) hipLaunchKernelGGL(ku_seen_kernel<1>, grid, block, 0, stream, (uint32_t *)d_table, n_lines, s, d_count);
+  else hipLaunchKernelGGL(ku_seen_kernel<2>, grid, block, 0, stream, (uint32_t *)d_table, n_lines, s, d_count);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }

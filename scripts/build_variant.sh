@@ -1,6 +1,8 @@
 #!/bin/bash
 # tuning aid: a variant of the library with extra compile flags for the kernel translation units
 #   scripts/build_variant.sh <name> <flags...>   ->  krakenuniq_amd/variants/libku_<name>.so   (select it with KU_LIB=<path>)
+#   and krakenuniq_amd/variants/<name>/libkrakenuniq_amd.so, the same file under the product's name (for the executables:
+#   LD_LIBRARY_PATH=krakenuniq_amd/variants/<name>, scripts/cli_probe.py LIB=)
 set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../krakenuniq_amd/csrc"
@@ -10,5 +12,6 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include $*"
 /opt/rocm/bin/hipcc $F -c ku_kernels.hip -o /tmp/kuvar_$NAME/ku_kernels.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libku_$NAME.so /tmp/kuvar_$NAME/ku_kernels.o /tmp/kuvar_$NAME/ku_short.o \
-  ku_sparse.o ku_report.o ku_dbsort.o ku_setlcas.o ku_api.o ku_mgpu.o ku_host.o -ldl -lpthread
+  ku_sparse.o ku_report.o ku_route.o ku_dbsort.o ku_setlcas.o ku_api.o ku_mgpu.o ku_host.o -ldl -lpthread
+mkdir -p ../variants/$NAME && cp ../variants/libku_$NAME.so ../variants/$NAME/libkrakenuniq_amd.so
 echo built ../variants/libku_$NAME.so

@@ -17,7 +17,7 @@ Fixtures:
         out_u1000.tsv/report_u1000.tsv (-u 1000: sketches stay sparse),
         out_chunk.tsv/report_chunk.tsv (-x 70K -t 2), out_quick.tsv (-q -m 2),
         out_chunk_quick.tsv/report_chunk_quick.tsv (-x 70K -t 2 -q -m 2),
-        out_c.tsv (-c), database.kdb.counts
+        out_c.tsv (-c), report_p0.tsv (-p 0: six columns), database.kdb.counts
   f2/   edge FASTA (short / N / empty / lower-case / multi-line) + outputs
   f4/   paired FASTQs -> read_merger.pl -> merged.fa + outputs
   f7/   legacy KRAKIDX (type 1) index variant of f1 + outputs
@@ -122,6 +122,10 @@ def make_f1():
     classify(d, ["-x", "70K", "-t", "2", "-q", "-m", "2", "-o", f"{d}/out_chunk_quick.tsv", "-r", f"{d}/report_chunk_quick.tsv"], rd)
     classify(d, ["-c", "-o", f"{d}/out_c.tsv"], rd)
     classify(d, ["-s", "-o", f"{d}/out_s.tsv"], rd)
+    # -p 0: the six-column report without the k-mer columns (classify.cpp:289,316-323); the Kraken file does not change
+    classify(d, ["-p", "0", "-o", f"{d}/out_p0.tsv", "-r", f"{d}/report_p0.tsv"], rd)
+    assert open(f"{d}/out.tsv", "rb").read() == open(f"{d}/out_p0.tsv", "rb").read()
+    os.remove(f"{d}/out_p0.tsv")
     assert open(f"{d}/out.tsv", "rb").read() == open(f"{d}/out_exact.tsv", "rb").read()
     os.remove(f"{d}/out_exact.tsv")
     return d, genomes_for_reads

@@ -68,6 +68,21 @@ def test_outputs_match_reference(tmp_path):
     assert r.stdout == open(f"{F1}/out_quick.tsv", "rb").read()
     assert run(db + ["-c", f"{F1}/reads.fq"]).stdout == open(f"{F1}/out_c.tsv", "rb").read()
     assert run(db + ["-s", f"{F1}/reads.fq"]).stdout == open(f"{F1}/out_s.tsv", "rb").read()
+    # -p 0 (and below): the six-column report, the Kraken file as ever (classify.cpp:289,316-323; golden from _ref/classify -p 0)
+    for p_arg in ("0", "-3"):
+        out0, rep0 = tmp_path / "out_p0.tsv", tmp_path / "report_p0.tsv"
+        if rep0.exists():
+            rep0.unlink()
+        r = run(db + ["-p", p_arg, "-o", str(out0), "-r", str(rep0), f"{F1}/reads.fq"])
+        assert r.returncode == 0, r.stderr.decode()
+        assert out0.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+        assert rep0.read_text().startswith("%\treads\ttaxReads\ttaxID\trank\ttaxName\n")
+        assert rows(rep0.read_text()) == rows(open(f"{F1}/report_p0.tsv").read())
+    assert run(db + ["-p", "x", f"{F1}/reads.fq"]).returncode == 64
+    # one batch at a time (KU_RLE_ONE_STEP: the one-step form of the batch call) == two batches in flight (the default)
+    r = run(db + ["-o", str(out), "-r", str(tmp_path / "rep_one_step.tsv"), f"{F1}/reads.fq"], env=dict(os.environ, KU_RLE_ONE_STEP="1"))
+    assert r.returncode == 0 and out.read_bytes() == open(f"{F1}/out.tsv", "rb").read()
+    assert rows((tmp_path / "rep_one_step.tsv").read_text()) == rows(open(f"{F1}/report.tsv").read())
     gz = tmp_path / "out.tsv.gz"
     assert run(db + ["-o", str(gz), f"{F1}/reads.fq"]).returncode == 0
     assert gzip.open(gz).read() == open(f"{F1}/out.tsv", "rb").read()

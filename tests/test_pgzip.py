@@ -233,6 +233,37 @@ def test_gz_text_is_parsed_in_regions_while_it_arrives(tmp_path):
     assert r.returncode != 0
 
 
+def test_damaged_bgzf_block_is_refused_by_the_sequential_reader_too(tmp_path):
+    """the BGZF path of the sequential reader (mate pairs -P, -T prefetch) did not look at a block's CRC-32: a
+    flipped byte inside a STORED block (which inflates whatever it holds) went through as a wrong base.  Both readers refuse it
+    now; a block whose extra field claims more than the block holds is no BGZF block."""
+    import struct as st
+    from test_seqio import bgzf
+    text = FQ[:600_000]
+    blob = bytearray(bgzf(text, 65280, level=0))  # level 0: stored blocks
+    good = tmp_path / "good.gz"
+    good.write_bytes(bytes(blob))
+    want = subprocess.run([DUMP, "-T", str(good)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0
+    assert subprocess.run([DUMP, "-j", "3", str(good)], stdout=subprocess.PIPE).stdout == want.stdout
+    at = 18 + 5 + 40000  # inside the first block's payload: member header (12 + 6), stored-block header (5), then the text
+    assert blob[at:at + 1] in (b"A", b"C", b"G", b"T", b"I", b"@", b"+", b"\n") or True
+    blob[at] ^= 0x02
+    bad = tmp_path / "bad.gz"
+    bad.write_bytes(bytes(blob))
+    for args in (["-T"], ["-j", "3"], []):
+        r = subprocess.run([DUMP] + args + [str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode != 0 and r.stdout != want.stdout, args
+    r = subprocess.run([DUMP, "-T", "-P", str(bad), str(good)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0
+    # XLEN larger than the block: the file does not qualify as BGZF (zlib's reader takes it and stops at the damage)
+    blob = bytearray(bgzf(text, 65280))
+    st.pack_into("<H", blob, 10, 60000)
+    bad.write_bytes(bytes(blob))
+    for args in (["-T"], ["-j", "3"]):
+        assert subprocess.run([DUMP] + args + [str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode != 0, args
+
+
 def corrupt(blob, rng):
     b = bytearray(blob)
     mode = int(rng.integers(0, 4))
