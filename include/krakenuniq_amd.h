@@ -285,8 +285,13 @@ int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs);
  * ku_ctx_replace_calls, ku_classify_batch_rle itself) answer KU_ESTATE while batches are in flight. */
 int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
                                   const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
-                                  uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt);
+                                  uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, ku_run *runs, uint64_t runs_cap);
+/* runs / runs_cap (optional, NULL / 0): where the batch's runs go.  The first runs_cap entries of the run array are copied there
+ * along with the other results -- the extent in use is only known behind the kernel, a copy of exactly that size would have to
+ * wait for the device.  After _finish, ku_classify_batch_rle_copied() says how many entries are in that buffer (0 when the batch
+ * took a one-step path): when *n_runs is not larger, the runs are all there; else ku_fetch_runs brings them. */
 int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs);
+uint64_t ku_classify_batch_rle_copied(const ku_ctx *ctx); /* entries of the batch finished last that are in its `runs` buffer */
 int ku_classify_batch_rle_in_flight(const ku_ctx *ctx); /* 0 .. 2 */
 
 /* ---- out-of-core run: the database streamed through HBM chunk by chunk (classify -x SIZE; KrakenDB::prepare_chunking /

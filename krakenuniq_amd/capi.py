@@ -123,7 +123,8 @@ SIGNATURES = {
                                         u64p, u32p, u64p]),
     "ku_fetch_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "ku_classify_batch_rle_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p, u32p,
-                                                u64p, u32p]),
+                                                u64p, u32p, C.c_void_p, C.c_uint64]),
+    "ku_classify_batch_rle_copied": (C.c_uint64, [C.c_void_p]),
     "ku_classify_batch_rle_finish": (C.c_int, [C.c_void_p, u64p]),
     "ku_classify_batch_rle_in_flight": (C.c_int, [C.c_void_p]),
     "ku_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -525,7 +526,7 @@ class Ctx:
         _chk(lib().ku_resolve_device(self.h, d_seqs, d_off, d_len, n_reads, C.byref(o), d_calls, d_taxa, d_hits,
                                      stream), "ku_resolve_device")
 
-    def rle_enqueue(self, buf, off, lens, flags=0, min_hits=1):
+    def rle_enqueue(self, buf, off, lens, flags=0, min_hits=1, runs_cap=0):
         """First step of a batch through the pipelined form of ku_classify_batch_rle (up to two batches in flight).  Returns the
         handle rle_finish() takes; the arrays stay alive with it."""
         arr = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf, dtype=np.uint8)
@@ -535,9 +536,11 @@ class Ctx:
         job = {"arr": arr, "off": off, "lens": lens, "calls": np.zeros(n, np.uint32), "hits": np.zeros(n, np.uint32),
                "run_off": np.zeros(n, np.uint64), "run_cnt": np.zeros(n, np.uint32)}
         o = Opts(flags, min_hits, 0, 0)
+        job["runs"] = np.zeros((runs_cap, 2), np.uint32) if runs_cap else None  # (optional: the runs come with the other results)
         _chk(lib().ku_classify_batch_rle_enqueue(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n, C.byref(o),
                                                  _p(job["calls"], u32p), _p(job["hits"], u32p), _p(job["run_off"], u64p),
-                                                 _p(job["run_cnt"], u32p)), "ku_classify_batch_rle_enqueue")
+                                                 _p(job["run_cnt"], u32p), job["runs"].ctypes.data if runs_cap else None, runs_cap),
+             "ku_classify_batch_rle_enqueue")
         return job
 
     def rle_finish(self, job):
@@ -545,8 +548,11 @@ class Ctx:
         classify_batch_rle."""
         total = C.c_uint64(0)
         _chk(lib().ku_classify_batch_rle_finish(self.h, C.byref(total)), "ku_classify_batch_rle_finish")
-        runs = np.zeros((total.value, 2), np.uint32)
-        _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
+        if job.get("runs") is not None and total.value <= lib().ku_classify_batch_rle_copied(self.h):
+            runs = job["runs"][:total.value]  # they came with the other results
+        else:
+            runs = np.zeros((total.value, 2), np.uint32)
+            _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
         return {"calls": job["calls"], "hits": job["hits"], "run_off": job["run_off"], "run_cnt": job["run_cnt"], "runs": runs}
 
     def rle_in_flight(self):

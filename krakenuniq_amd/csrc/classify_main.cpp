@@ -35,6 +35,7 @@
 #include <malloc.h>
 #include <getopt.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <sysexits.h>
@@ -217,6 +218,18 @@ static double now_s() {
   timeval t;
   gettimeofday(&t, nullptr);
   return (double)t.tv_sec + (double)t.tv_usec / 1e6;
+}
+// CPU seconds the calling thread has used (KU_CLI_TIMES: where the cores of a quota-limited host go)
+static double thread_cpu_s() {
+  timespec t;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static double process_cpu_s(double *sys_s) {
+  rusage ru;
+  getrusage(RUSAGE_SELF, &ru);
+  if (sys_s) *sys_s = (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec;
+  return (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec;
 }
 static double seconds_between(const timeval &a, const timeval &b) {
   return (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_usec - a.tv_usec) / 1e6;
@@ -503,6 +516,8 @@ int main(int argc, char **argv) {
   pool_setup.join();
   timeval tv1, tv2;
   gettimeofday(&tv1, nullptr);
+  double cpu_sys0 = 0;
+  const double cpu_user0 = process_cpu_s(&cpu_sys0), cpu_device0 = thread_cpu_s();
   const ku_opts base_opts = {quick ? KU_F_QUICK : 0u, min_hits, 0, 0};
   const uint32_t pflags = (only_classified ? KU_P_ONLY_CLASSIFIED : 0u) | (print_seq ? KU_P_SEQUENCE : 0u) | (quick ? KU_P_QUICK : 0u);
 
@@ -530,6 +545,9 @@ int main(int argc, char **argv) {
   };
   double busy_reader = 0, busy_gpu = 0, busy_writer = 0, busy_format = 0;  // seconds each pipeline stage spent working (KU_CLI_TIMES)
   double busy_gpu_classify = 0, busy_gpu_fetch = 0;                       // ... of the device stage: the batch call, the runs' copy back
+  std::mutex cpu_mu;
+  double cpu_parse = 0, cpu_format = 0, cpu_write = 0, cpu_device = 0;    // CPU seconds of the stages' threads (KU_CLI_TIMES)
+  auto cpu_add = [&](double &acc, double t0) { const double d = thread_cpu_s() - t0; std::lock_guard<std::mutex> l(cpu_mu); acc += d; };
 
   // Regular files, plain or .gz: the text is cut into record-aligned regions of about a quarter work unit and parsed by
   // `parse_team` threads, each into its own batch; the batches go on in file order.  A plain file is mapped; a .gz file
@@ -585,6 +603,7 @@ int main(int argc, char **argv) {
     struct Parsed { Batch *bt; bool whole; size_t hi; };
     std::map<size_t, Parsed> ready;
     auto member = [&] {
+      const double cpu0 = thread_cpu_s();
       for (;;) {
         Batch *bt = chunked ? new Batch() : free_q.pop();
         size_t lo, hi, idx;
@@ -592,6 +611,7 @@ int main(int argc, char **argv) {
           if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
           { std::lock_guard<std::mutex> l(mu); }
           cv.notify_all();
+          cpu_add(cpu_parse, cpu0);
           return;
         }
         bt->clear();
@@ -765,6 +785,8 @@ int main(int argc, char **argv) {
         fmt_team.run([&](int t) {
           const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
           if (hi <= lo) return;
+          const double cpu0 = thread_cpu_s();
+          struct Acc { std::function<void()> f; ~Acc() { f(); } } acc_{[&] { cpu_add(cpu_format, cpu0); }};
           status[t] = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
                                            bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
                                            bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
@@ -788,9 +810,10 @@ int main(int argc, char **argv) {
     write_q.push(nullptr);
   });
   std::thread writer([&] {
+    const double cpu0 = thread_cpu_s();
     for (;;) {
       Formatted *f = write_q.pop();
-      if (!f) break;
+      if (!f) { cpu_add(cpu_write, cpu0); break; }
       Batch *bt = f->bt;
       const uint64_t n = bt->off.size();
       const double t_write = now_s();
@@ -967,6 +990,7 @@ int main(int argc, char **argv) {
   // r04 weak #3).  Groups (KU_DEVICES) and UID mapping (whose calls are replaced batch by batch) go one batch at a time.
   const bool two_step = !mg && !map_uids && !getenv("KU_RLE_ONE_STEP");
   std::deque<Batch *> flying;
+  uint64_t runs_seen_max = 0;  // extent of the largest run array so far: the next batches' buffers take it in one go
   auto finish_oldest = [&] {
     Batch *ft = flying.front();
     flying.pop_front();
@@ -975,10 +999,11 @@ int main(int argc, char **argv) {
     KU_CHECK(ku_classify_batch_rle_finish(ctx, &n_runs));
     const double t1 = now_s();
     busy_gpu_classify += t1 - t0;
-    if (print_kraken && !quick) {  // the runs feed the Kraken lines
-      ft->reserve_runs(n_runs);
-      KU_CHECK(ku_fetch_runs(ctx, ft->runs, n_runs));
+    if (print_kraken && !quick && n_runs > ku_classify_batch_rle_copied(ctx)) {  // the runs feed the Kraken lines: usually they came
+      ft->reserve_runs(n_runs);                                                   // with the calls; a batch with more runs than expected
+      KU_CHECK(ku_fetch_runs(ctx, ft->runs, n_runs));                            // fetches them (the next ones make more room)
     }
+    if (n_runs > runs_seen_max) runs_seen_max = n_runs;
     const double t2 = now_s();
     busy_gpu_fetch += t2 - t1;
     busy_gpu += t2 - t0;
@@ -1008,12 +1033,19 @@ int main(int argc, char **argv) {
     if (two_step) {
       if (flying.size() >= 2) finish_oldest();
       const double t_enq0 = now_s();
+      // the runs come back with the calls when their buffer holds the batch's run array: a quarter more than the largest so far
+      // (the first batches: 3 runs per 100 bases, what the pool's buffers were sized for)
+      const bool want_runs = print_kraken && !quick;
+      const uint64_t r_est = std::max<uint64_t>(runs_seen_max + runs_seen_max / 4, bt->seqs_len / 32);
+      if (want_runs) bt->reserve_runs(r_est);
+      ku_run *rbuf = want_runs ? bt->runs : nullptr;
+      const uint64_t rcap = want_runs ? std::min<uint64_t>(bt->runs_cap, r_est) : 0;  // (what is copied, not what the buffer could hold)
       int st = ku_classify_batch_rle_enqueue(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts, bt->calls.data(),
-                                             bt->hits.data(), bt->run_off.data(), bt->run_cnt.data());
+                                             bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), rbuf, rcap);
       if (st == KU_ESTATE && !flying.empty()) {  // a batch that cannot overlap with the one in flight (quick mode, a very long read, ...)
         while (!flying.empty()) finish_oldest();
         st = ku_classify_batch_rle_enqueue(ctx, bt->seqs, bt->seqs_len, bt->off.data(), bt->len.data(), n, &opts, bt->calls.data(),
-                                           bt->hits.data(), bt->run_off.data(), bt->run_cnt.data());
+                                           bt->hits.data(), bt->run_off.data(), bt->run_cnt.data(), rbuf, rcap);
       }
       KU_CHECK(st);
       flying.push_back(bt);
@@ -1051,6 +1083,7 @@ int main(int argc, char **argv) {
   }
   }
   done_q.push(nullptr);
+  cpu_device = thread_cpu_s() - cpu_device0;
   reader.join();
   formatter.join();
   writer.join();
@@ -1067,9 +1100,14 @@ int main(int argc, char **argv) {
             (total_sequences - total_classified) * 100.0 / total_sequences);
   }
   s_kraken.close(); s_cls.close(); s_ucls.close();
-  if (getenv("KU_CLI_TIMES"))
+  if (getenv("KU_CLI_TIMES")) {
     fprintf(stderr, "stage busy seconds: reader %.3f, device %.3f, writer %.3f (formatting %.3f + writing %.3f; device: batch call %.3f + runs back %.3f)\n",
             busy_reader, busy_gpu, busy_format + busy_writer, busy_format, busy_writer, busy_gpu_classify, busy_gpu_fetch);
+    double sys1 = 0;
+    const double user1 = process_cpu_s(&sys1);
+    fprintf(stderr, "cpu seconds in the window: user %.2f + sys %.2f in all; parser team %.2f, formatting helpers %.2f, writer %.2f, device thread %.2f\n",
+            user1 - cpu_user0, sys1 - cpu_sys0, cpu_parse, cpu_format, cpu_write, cpu_device);
+  }
 
   if (!report_out.empty() && report_out != "off") {
     gettimeofday(&tv1, nullptr);

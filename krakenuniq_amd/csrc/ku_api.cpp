@@ -410,10 +410,12 @@ struct RleJob {
   PinBuf pin_unit;  // work-unit number of every read (source of an asynchronous upload)
   unsigned long long *d_counter = nullptr;  // the kernel's bump counter of the run array (2 dwords of the context's scalars)
   hipEvent_t kernels_done = nullptr, done = nullptr;
+  hipEvent_t t_k0 = nullptr, t_k1 = nullptr;  // KU_RLE_TIMES: around the batch's kernels on the stream they run on
   std::vector<hipEvent_t> seg_events;
   bool busy = false;
   bool settled = false;         // classified by a one-step path inside _enqueue: _finish only hands the totals over
   bool runs_in_ctx = false;     // the runs lie in the context's own run buffer (one-step paths, the overflow redo)
+  uint64_t runs_copied = 0;     // entries of the run array already copied to the caller's buffer (0: ku_fetch_runs does it)
   uint64_t n_runs = 0;
   // the batch
   uint64_t n_bytes = 0, n_reads = 0, runs_cap = 0;
@@ -439,8 +441,10 @@ struct RleJob {
     pin_unit.release();
     if (kernels_done) (void)hipEventDestroy(kernels_done);
     if (done) (void)hipEventDestroy(done);
+    if (t_k0) (void)hipEventDestroy(t_k0);
+    if (t_k1) (void)hipEventDestroy(t_k1);
     for (hipEvent_t e : seg_events) (void)hipEventDestroy(e);
-    kernels_done = done = nullptr;
+    kernels_done = done = t_k0 = t_k1 = nullptr;
     seg_events.clear();
   }
 };
@@ -488,6 +492,7 @@ struct ku_ctx {
   int rle_head = 0, rle_in_flight = 0;
   const void *fetch_runs_src = nullptr;  // where the runs of the batch finished last lie (ku_fetch_runs)
   const void *last_calls_dev = nullptr;  // ... and its calls on the device (ku_ctx_replace_calls)
+  uint64_t last_runs_copied = 0;         // ... and how many of its runs are in the caller's buffer already
   // ku_ctx_count_taxons of the store it was computed for (identified by its buffers)
   std::vector<unsigned long long> count_cache;
   const void *count_cache_store = nullptr, *count_cache_pairs = nullptr;
@@ -1921,12 +1926,15 @@ extern "C" int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uin
 
 // KU_RLE_TIMES=1: where the batch calls spend their time on the host, summed over the run, printed when the context goes
 static double g_rle_t[6];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls
+static double g_rle_kernel_ms = 0;  // HIP events around every batch's kernels (fused kernel + the emulation's flag kernel), summed
+static unsigned long long g_rle_reads = 0;
 static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
 static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void rle_times_print() {
   if (g_rle_times && g_rle_t[4] > 0)
-    fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s\n",
-            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3]);
+    fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s; "
+                    "kernels %.3f ms for %llu reads (HIP events on their stream)\n",
+            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads);
 }
 
 // no batch may be in flight (entry points that read or change what the batches in flight work on)
@@ -1939,7 +1947,7 @@ static int rle_idle(const ku_ctx *ctx, const char *who) {
 // Nothing here waits for the device.
 static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
                            uint64_t n_reads, const ku_opts &o, uint32_t max_n, bool monotonic, uint32_t *calls, uint32_t *hits,
-                           uint64_t *run_off, uint32_t *run_cnt) {
+                           uint64_t *run_off, uint32_t *run_cnt, ku_run *h_runs, uint64_t h_runs_cap) {
   hipStream_t s = ctx->stream;
   const double t_in = g_rle_times ? rle_now() : 0.0;
   const bool counts = !(o.flags & KU_F_NO_COUNTS);
@@ -2047,6 +2055,8 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   ro.counter = d_counter;
   ro.cap = runs_cap;
   ro.chunk = chunk;
+  if (g_rle_times && !j.t_k0) { HIP_TRY(hipEventCreate(&j.t_k0)); HIP_TRY(hipEventCreate(&j.t_k1)); }
+  bool clock_started = false;
   for (uint64_t g = 0; g < n_seg; ++g) {
     const uint64_t a = seg[g], b = seg[g + 1];
     const uint64_t lo = g == 0 ? 0 : seq_off[a], hi = g + 1 == n_seg ? n_bytes : seq_off[b];
@@ -2065,6 +2075,7 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     ro.run_off = (uint64_t *)j.roff.p + a;
     ro.run_cnt = (uint32_t *)j.rcnt.p + a;
     sf.unit_of = sparse ? (const uint32_t *)j.unit.p + a : nullptr;
+    if (g_rle_times && !clock_started) { HIP_TRY(hipEventRecord(j.t_k0, s)); clock_started = true; }  // (behind the first segment's upload)
     int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)j.seqs.p, n_bytes, (const uint64_t *)j.off.p + a,
                                       (const uint32_t *)j.len.p + a, b - a, max_n, o.flags, (uint32_t *)j.calls.p + a, nullptr, nullptr,
                                       j.ws.p, j.ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
@@ -2078,14 +2089,22 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
       HIP_TRY(hipMemcpyAsync(sp.tail_row.p, (const uint32_t *)j.u_cnt.p + (size_t)(j.n_units - 1) * ctx->tax.n_slots, (size_t)ctx->tax.n_slots * 4,
                              hipMemcpyDeviceToDevice, s));
   }
+  if (g_rle_times && clock_started) HIP_TRY(hipEventRecord(j.t_k1, s));
   // ---- the copies back run on a stream of their own, behind this batch's kernels -- not in front of the next batch's
-  HIP_TRY(hipEventRecord(j.kernels_done, s));
-  hipStream_t ds = ctx->d2h_stream;
-  HIP_TRY(hipStreamWaitEvent(ds, j.kernels_done, 0));
+  static const bool own_d2h_stream = !(getenv("KU_RLE_D2H_STREAM") && atoi(getenv("KU_RLE_D2H_STREAM")) == 0);
+  hipStream_t ds = own_d2h_stream ? ctx->d2h_stream : s;
+  if (own_d2h_stream) {
+    HIP_TRY(hipEventRecord(j.kernels_done, s));
+    HIP_TRY(hipStreamWaitEvent(ds, j.kernels_done, 0));
+  }
   HIP_TRY(hipMemcpyAsync(calls, j.calls.p, n_reads * 4, hipMemcpyDeviceToHost, ds));
   HIP_TRY(hipMemcpyAsync(run_off, j.roff.p, n_reads * 8, hipMemcpyDeviceToHost, ds));
   HIP_TRY(hipMemcpyAsync(run_cnt, j.rcnt.p, n_reads * 4, hipMemcpyDeviceToHost, ds));
   HIP_TRY(hipMemcpyAsync(&h_tot[0], d_counter, 8, hipMemcpyDeviceToHost, ds));
+  // the runs themselves, when the caller said where they go: as much of the run array as its buffer holds (the extent in use
+  // is only known behind the kernel; _finish tells whether it fitted -- else ku_fetch_runs, into a larger buffer)
+  j.runs_copied = h_runs ? std::min<uint64_t>(h_runs_cap, runs_cap) : 0;
+  if (j.runs_copied) HIP_TRY(hipMemcpyAsync(h_runs, j.runs.p, j.runs_copied * 8, hipMemcpyDeviceToHost, ds));
   if (sparse) {
     HIP_TRY(hipMemcpyAsync(h_flag, j.u_flag.p, std::max<uint32_t>(j.n_units, 1), hipMemcpyDeviceToHost, ds));
     HIP_TRY(hipMemcpyAsync(&h_tot[1], sp.dev.g_count, 8, hipMemcpyDeviceToHost, ds));
@@ -2137,6 +2156,7 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
 static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classified) {
   hipStream_t s = ctx->stream;
   *classified = false;
+  ctx->last_runs_copied = 0;
   if (j.settled) {
     j.busy = false;
     *n_runs = ctx->n_runs = j.n_runs;
@@ -2146,6 +2166,11 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
   const double t_w0 = g_rle_times ? rle_now() : 0.0;
   HIP_TRY(hipEventSynchronize(j.done));
   const double t_w1 = g_rle_times ? rle_now() : 0.0;
+  if (g_rle_times && j.t_k0 && j.n_reads) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, j.t_k0, j.t_k1) == hipSuccess) { g_rle_kernel_ms += ms; g_rle_reads += j.n_reads; }
+    else (void)hipGetLastError();
+  }
   struct Lap { double a, b; ~Lap() { if (g_rle_times) { g_rle_t[2] += b - a; g_rle_t[3] += rle_now() - b; g_rle_t[4] += 1; } } } lap_{t_w0, t_w1};
   j.busy = false;
   ku_ctx::Sparse &sp = ctx->sp;
@@ -2173,6 +2198,7 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
   } else {
     *n_runs = ctx->n_runs = total;
     ctx->fetch_runs_src = j.runs.p;
+    ctx->last_runs_copied = j.runs_copied;
   }
   *classified = true;  // what follows only concerns the emulation's state
   if (j.sparse && sp.on) {
@@ -2239,10 +2265,11 @@ static int rle_staged_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, con
 }
 
 extern "C" int ku_classify_batch_rle_in_flight(const ku_ctx *ctx) { return ctx ? ctx->rle_in_flight : 0; }
+extern "C" uint64_t ku_classify_batch_rle_copied(const ku_ctx *ctx) { return ctx ? ctx->last_runs_copied : 0; }
 
 extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off,
                                              const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
-                                             uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt) {
+                                             uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, ku_run *runs, uint64_t runs_cap) {
   KU_TRY(check_ready(ctx));
   if (ctx->rle_in_flight >= 2) return fail(KU_ESTATE, "ku_classify_batch_rle_enqueue: two batches are in flight (ku_classify_batch_rle_finish first)");
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
@@ -2254,7 +2281,7 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
   const bool in_steps = n_reads && rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic) &&
                         !(ctx->sp.on && !(o.flags & KU_F_NO_COUNTS) && ctx->sp.open);
   if (in_steps) {
-    int st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+    int st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, runs, runs_cap);
     if (st == KU_ENOMEM && ctx->sp.on && !(o.flags & KU_F_NO_COUNTS)) {
       // no room for the emulation's tables: the classification itself does not depend on them (see classify_device_impl):
       // the run goes on with the dense registers alone; nothing of this batch had been started
@@ -2263,7 +2290,7 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
       (void)hipGetLastError();
       ctx_free_sparse(ctx);
       ctx->sp.gave_up = true;
-      st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+      st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, runs, runs_cap);
     }
     KU_TRY(st);
     ++ctx->rle_in_flight;
@@ -2276,7 +2303,7 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
   ctx->n_runs = 0;
   if (n_reads) {
     if (rle_fused_eligible(ctx, o.flags, max_n, n_bytes, n_reads, monotonic)) {  // (fused, but a unit in the staged form is open)
-      int st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+      int st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, runs, runs_cap);
       bool classified = false;
       if (st == KU_OK) st = rle_job_finish(ctx, j, &nr, &classified);
       j.busy = false;
@@ -2286,7 +2313,7 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
         ctx_free_sparse(ctx);
         ctx->sp.gave_up = true;
         if (!classified) {
-          st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt);
+          st = rle_job_enqueue(ctx, j, seqs, n_bytes, seq_off, seq_len, n_reads, o, max_n, monotonic, calls, hits, run_off, run_cnt, runs, runs_cap);
           if (st == KU_OK) st = rle_job_finish(ctx, j, &nr, &classified);
           j.busy = false;
         } else st = KU_OK;
@@ -2300,6 +2327,7 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
   j.settled = true;
   j.busy = true;
   j.n_runs = nr;
+  j.runs_copied = 0;
   ++ctx->rle_in_flight;
   return KU_OK;
 }
@@ -2334,7 +2362,7 @@ extern "C" int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_b
   *n_runs = 0;
   KU_TRY(check_ready(ctx));
   KU_TRY(rle_idle(ctx, "ku_classify_batch_rle"));
-  KU_TRY(ku_classify_batch_rle_enqueue(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, opts, calls, hits, run_off, run_cnt));
+  KU_TRY(ku_classify_batch_rle_enqueue(ctx, seqs, n_bytes, seq_off, seq_len, n_reads, opts, calls, hits, run_off, run_cnt, nullptr, 0));
   return ku_classify_batch_rle_finish(ctx, n_runs);
 }
 

@@ -8,9 +8,31 @@ table per run.
             REPORT=1 (add -r), PROF=1 (run under rocprofv3 --kernel-trace --stats), LIB=<dir> (a directory that holds another
             build of libkrakenuniq_amd.so, e.g. krakenuniq_amd/variants/abl), THREADS=n, REPEAT=n, GZ=1 (.gz input)
 Prints one block per variant; kernel tables go to gpurun_out/<out_tag>_<label>_kernel_stats.csv."""
-import csv, glob, os, shutil, subprocess, sys, time
+import csv, glob, os, resource, shutil, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def cpu_stat():
+    """CFS throttling counters of this container's cgroup (v2: cpu.stat; v1: cpu/cpu.stat) + its quota"""
+    out = {}
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        if os.path.exists(f):
+            for line in open(f):
+                k, v = line.split()
+                out[k] = int(v)
+            break
+    return out
+
+
+def quota():
+    for f in ("/sys/fs/cgroup/cpu.max",):
+        if os.path.exists(f):
+            return open(f).read().strip()
+    try:
+        return open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read().strip() + " / " + open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+    except OSError:
+        return "?"
 
 
 def main():
@@ -33,7 +55,7 @@ def main():
     bench.write_fastq(f"{tmp}/reads.fq", s.view(n_reads, 151).cpu().numpy(), 150)
     del db, s
     torch.cuda.empty_cache()
-    print(f"database + {n_reads} reads written in {time.time() - t0:.1f}s", flush=True)
+    print(f"database + {n_reads} reads written in {time.time() - t0:.1f}s; cpu quota {quota()}; cpus visible {os.cpu_count()}", flush=True)
     gz_done = False
     for var in variants:
         label, _, kvs = var.partition(":")
@@ -67,12 +89,16 @@ def main():
                 shutil.rmtree(pdir, ignore_errors=True)
                 cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pdir, "--"] + cmd
             t = time.time()
+            ru0, cs0 = resource.getrusage(resource.RUSAGE_CHILDREN), cpu_stat()
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd="/tmp")
             wall = time.time() - t
+            ru1, cs1 = resource.getrusage(resource.RUSAGE_CHILDREN), cpu_stat()
+            cpu_line = (f"cpu user {ru1.ru_utime - ru0.ru_utime:.2f}s sys {ru1.ru_stime - ru0.ru_stime:.2f}s (whole process, load included); throttled "
+                        f"{cs1.get('nr_throttled', 0) - cs0.get('nr_throttled', 0)} periods, {(cs1.get('throttled_usec', cs1.get('throttled_time', 0)) - cs0.get('throttled_usec', cs0.get('throttled_time', 0))) / 1e6:.3f}s")
             err = r.stderr.decode(errors="replace").replace("\r", "\n").split("\n")
             keep = [l.strip()[:260] for l in err if any(w in l for w in ("processed in", "stage busy", "Report finished", "ku_ctx_report:",
-                                                                        "ku_classify_batch_rle over", "error", "Error"))]
-            print(f"== {label} rep {rep} rc {r.returncode} wall {wall:.2f}s")
+                                                                        "ku_classify_batch_rle over", "cpu seconds", "error", "Error"))]
+            print(f"== {label} rep {rep} rc {r.returncode} wall {wall:.2f}s  {cpu_line}")
             print("\n".join("   " + l for l in keep), flush=True)
             if r.returncode != 0:
                 print("\n".join(err[-12:]))

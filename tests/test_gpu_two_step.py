@@ -4,7 +4,7 @@ flight on a context, the upload of the next and the copies back of the previous 
 Checked: the same calls, runs, per-taxon state and Kraken text as the one-step call and as the reference's files, whatever
 the interleaving; with the sparse-sketch emulation on, every taxon's sparse / dense state and encoded set equal the oracle's
 and the report equals the reference's row for row -- the open work unit now travels between batches as its reads + insert
-counts (tail form) and is evaluated when it closes; batches of the staged paths (quick mode) in between go one at a time
+counts (tail form) and is evaluated when it closes; batches of the staged paths in between go one at a time
 and hand the open unit over in the staged form; what cannot overlap is refused with KU_ESTATE while a batch is in flight."""
 import os
 
@@ -33,10 +33,12 @@ def batches_of(buf, off, lens, cuts):
 def run_two_step(ctx, buf, off, lens, cuts, depth=2, **kw):
     """every batch through enqueue / finish with up to `depth` in flight; results in batch order"""
     flying, out = [], []
-    for a, b, bb, bo, bl in batches_of(buf, off, lens, cuts):
+    for i, (a, b, bb, bo, bl) in enumerate(batches_of(buf, off, lens, cuts)):
         if len(flying) >= depth:
             out.append(ctx.rle_finish(flying.pop(0)))
-        flying.append(ctx.rle_enqueue(bb, bo, bl, **kw))
+        # where the runs go: nowhere (ku_fetch_runs brings them), a buffer that is too small (the same), one that holds them
+        # (they come with the calls)
+        flying.append(ctx.rle_enqueue(bb, bo, bl, runs_cap=(0, 3, 1 << 16)[i % 3], **kw))
         assert ctx.rle_in_flight() == len(flying)
     while flying:
         out.append(ctx.rle_finish(flying.pop(0)))
