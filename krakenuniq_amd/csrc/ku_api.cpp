@@ -2040,16 +2040,17 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   unsigned long long *h_tot = (unsigned long long *)j.pin.p;
   h_flag = (uint8_t *)j.pin.p + 64;
   unsigned long long *d_counter = j.d_counter;
-  // the run counter and (emulation) the per-(unit, slot) insert counts and the unit flags start at zero: one launch
+  // (emulation) the per-(unit, slot) insert counts and the unit flags start at zero: one launch
   if (sparse) {
     if (ku_launch_zero3(d_counter, 2, j.u_cnt.p, std::max<uint64_t>((uint64_t)j.n_units * ctx->tax.n_slots, 1), j.u_flag.p,
                         ((uint64_t)std::max<uint32_t>(j.n_units, 1) + 3) / 4, s) != KU_OK)
       return fail(KU_EHIP, "clearing the batch counters failed");
     // unit 0 continues the open unit: its row starts from the inserts that unit has had so far
     if (j.cont_tail && j.n_units) HIP_TRY(hipMemcpyAsync(j.u_cnt.p, sp.tail_row.p, (size_t)ctx->tax.n_slots * 4, hipMemcpyDeviceToDevice, s));
-  } else {
-    HIP_TRY(hipMemsetAsync(d_counter, 0, 8, s));
   }
+  // the run counter starts behind the chunks the waves own from the start (one per wave of every segment's launch)
+  h_tot[3] = total_waves * (unsigned long long)chunk;
+  HIP_TRY(hipMemcpyAsync(d_counter, &h_tot[3], 8, hipMemcpyHostToDevice, s));
   KuRunsOut ro{};
   ro.runs = (uint2 *)j.runs.p;
   ro.counter = d_counter;
@@ -2057,23 +2058,25 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   ro.chunk = chunk;
   if (g_rle_times && !j.t_k0) { HIP_TRY(hipEventCreate(&j.t_k0)); HIP_TRY(hipEventCreate(&j.t_k1)); }
   bool clock_started = false;
+  uint64_t waves_before = 0;
   for (uint64_t g = 0; g < n_seg; ++g) {
     const uint64_t a = seg[g], b = seg[g + 1];
     const uint64_t lo = g == 0 ? 0 : seq_off[a], hi = g + 1 == n_seg ? n_bytes : seq_off[b];
-    hipStream_t cs = n_seg > 1 ? ctx->h2d_stream : s;
+    // (always the copy stream: with a batch in flight, this one's upload runs under that one's kernels)
+    hipStream_t cs = ctx->h2d_stream;
     if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)j.seqs.p + lo, seqs + lo, hi - lo, hipMemcpyHostToDevice, cs));
     if (b > a) {
       HIP_TRY(hipMemcpyAsync((uint64_t *)j.off.p + a, seq_off + a, (b - a) * 8, hipMemcpyHostToDevice, cs));
       HIP_TRY(hipMemcpyAsync((uint32_t *)j.len.p + a, seq_len + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
       if (sparse) HIP_TRY(hipMemcpyAsync((uint32_t *)j.unit.p + a, h_unit + a, (b - a) * 4, hipMemcpyHostToDevice, cs));
     }
-    if (n_seg > 1) {
-      HIP_TRY(hipEventRecord(j.seg_events[g], cs));
-      HIP_TRY(hipStreamWaitEvent(s, j.seg_events[g], 0));
-    }
+    HIP_TRY(hipEventRecord(j.seg_events[g], cs));
+    HIP_TRY(hipStreamWaitEvent(s, j.seg_events[g], 0));
     if (b == a) continue;
     ro.run_off = (uint64_t *)j.roff.p + a;
     ro.run_cnt = (uint32_t *)j.rcnt.p + a;
+    ro.pre_base1 = (uint32_t)(1 + waves_before);
+    waves_before += ku_short_grid_waves(b - a, max_n, ctx->n_cu);
     sf.unit_of = sparse ? (const uint32_t *)j.unit.p + a : nullptr;
     if (g_rle_times && !clock_started) { HIP_TRY(hipEventRecord(j.t_k0, s)); clock_started = true; }  // (behind the first segment's upload)
     int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)j.seqs.p, n_bytes, (const uint64_t *)j.off.p + a,

@@ -225,7 +225,11 @@ struct KuRunsOut {
   uint64_t *run_off;
   uint32_t *run_cnt;
   uint32_t chunk;
-  uint32_t pad;
+  // 0: every chunk is claimed from the counter.  Else the launch's wave w OWNS chunk (pre_base1 - 1 + w) from the start and
+  // only claims from the counter -- which the host then starts at (chunks owned by all launches) * chunk -- when that one is
+  // full.  (Round 5: the batches of the `classify` executable are ~60 k reads = 5 reads per wave; every wave of a launch
+  // claimed its first chunk at the same moment, 12 k adds to one address = ~150 of the launch's 290 microseconds.)
+  uint32_t pre_base1;
 };
 // Sparse-mode emulation inside the fused kernel (fast path): every unambiguous k-mer of a slot whose
 // sketch is not known to be dense goes into the run-wide set G straight away, and the number of inserts per (work unit,

@@ -948,6 +948,51 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
       }
       for (uint32_t i = 1; i < R; ++i)
         if (st == KU_OK && (cut[i] < cut[i - 1] || cut[i] > nb)) st = mfail(KU_EINVAL, "owner routing: the reads of a slice must be in buffer order");
+      // Equal numbers of READS per round are equal numbers of positions only when the reads are about equally long.  With
+      // contigs among short reads a round could hold far more than round_pos positions -- its queues more records than a
+      // ticket can number.  Then the rounds are cut by POSITION: round i starts at the first read at or behind
+      // i / R of the slice (on the host when the offsets are there, else by a bisection over the device array: R - 1 values
+      // per step, one synchronisation per step).
+      uint64_t widest = 0;
+      for (uint32_t i = 0; i < R && st == KU_OK; ++i) widest = std::max(widest, cut[i + 1] - cut[i]);
+      if (st == KU_OK && widest > round_pos + round_pos / 2) {
+        std::vector<uint64_t> lo(R, 0), hi(R, nr);  // first read with offset >= target_i lies in [lo, hi]
+        std::vector<uint64_t> target(R, 0);
+        for (uint32_t i = 1; i < R; ++i) target[i] = p0 + nb / R * i;
+        if (h_off) {
+          for (uint32_t i = 1; i < R; ++i) lo[i] = (uint64_t)(std::lower_bound(h_off + r0, h_off + r0 + nr, target[i]) - (h_off + r0));
+        } else {
+          std::vector<uint64_t> val(R, 0);
+          for (;;) {
+            bool any = false;
+            for (uint32_t i = 1; i < R && st == KU_OK; ++i)
+              if (lo[i] < hi[i]) {
+                any = true;
+                if (hipMemcpyAsync(&val[i], d_off + r0 + (lo[i] + hi[i]) / 2, 8, hipMemcpyDeviceToHost, s) != hipSuccess) st = mfail(KU_EHIP, "read offsets copy failed");
+              }
+            if (!any || st != KU_OK) break;
+            if (hipStreamSynchronize(s) != hipSuccess) { st = mfail(KU_EHIP, "read offsets copy failed"); break; }
+            for (uint32_t i = 1; i < R; ++i)
+              if (lo[i] < hi[i]) {
+                const uint64_t mid = (lo[i] + hi[i]) / 2;
+                if (val[i] < target[i]) lo[i] = mid + 1; else hi[i] = mid;
+              }
+          }
+          if (st == KU_OK) {  // the offsets of the reads found
+            for (uint32_t i = 1; i < R && st == KU_OK; ++i)
+              if (lo[i] < nr && hipMemcpyAsync(&val[i], d_off + r0 + lo[i], 8, hipMemcpyDeviceToHost, s) != hipSuccess) st = mfail(KU_EHIP, "read offsets copy failed");
+            if (st == KU_OK && hipStreamSynchronize(s) != hipSuccess) st = mfail(KU_EHIP, "read offsets copy failed");
+            for (uint32_t i = 1; i < R; ++i) cut[i] = lo[i] < nr ? val[i] - p0 : nb;
+          }
+        }
+        for (uint32_t i = 1; i < R && st == KU_OK; ++i) {
+          lo[i] = std::max(lo[i], lo[i - 1]);
+          rc[i] = lo[i];
+          if (h_off) cut[i] = rc[i] < nr ? h_off[r0 + rc[i]] - p0 : nb;
+        }
+        for (uint32_t i = 1; i < R; ++i)
+          if (st == KU_OK && (cut[i] < cut[i - 1] || cut[i] > nb)) st = mfail(KU_EINVAL, "owner routing: the reads of a slice must be in buffer order");
+      }
     }
     for (uint32_t i = 0; i < R; ++i) {
       rd[i].a = cut[i];

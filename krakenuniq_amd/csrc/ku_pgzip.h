@@ -487,7 +487,7 @@ template <class T> struct SpanDecoder {
   // at a block start, or the stream ends
   // (and once the span holds more than `soft_cap` elements: a span of highly compressible data -- the N runs of a genome --
   //  hands over at the next block start instead of growing without bound; the spans behind it are then decoded again)
-  size_t soft_cap = (size_t)256 << 20;
+  size_t soft_cap = (size_t)48 << 20;
   void run(Bits &b, const uint8_t *m, size_t n, bool at_header, bool check_first, const std::function<bool(size_t)> &stop) {
     bool first = !check_first;
     for (;;) {
@@ -535,7 +535,10 @@ struct ParallelGunzip {
   int team = 1;
   size_t span = (size_t)2 << 20;          // compressed bytes per span
   size_t search_max = (size_t)512 << 10;  // a span gives up looking for its block behind this many bytes
-  size_t span_cap = (size_t)256 << 20;    // bytes of text after which a span hands over at the next block start
+  // bytes of text after which a span hands over at the next block start.  (48 Mi: a span's symbol buffer is 2 bytes per byte
+  // of text and only grows -- 256 Mi let one highly compressible stretch pin 512 MiB per span, times the team, times two sets:
+  // ADVICE r04.  FASTQ spans of 2 MiB compressed hold 8-10 MiB of text: the cap does not touch them.)
+  size_t span_cap = (size_t)48 << 20;
   // stream position between rounds (decode side)
   size_t cur_bit = 0;
   bool at_header = true, finished = false;

@@ -369,8 +369,13 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   uint32_t *g_key = WIN ? spill + ((uint64_t)blockIdx.x * KS_WAVES + wv) * 2ull * spill_cap : nullptr;
   uint32_t *g_cnt = WIN ? g_key + spill_cap : nullptr;
   bool spill_used = false;
-  // OUT >= 1: the part of the run array this wave claimed and has not filled yet (wave-uniform)
+  // OUT >= 1: the part of the run array this wave claimed and has not filled yet (wave-uniform); its first chunk may be its own
+  // from the start (KuRunsOut::pre_base1)
   unsigned long long ch_pos = 0, ch_end = 0;
+  if (OUT != 0 && ro.pre_base1) {
+    ch_pos = ((unsigned long long)(ro.pre_base1 - 1u) + (unsigned long long)blockIdx.x * KS_WAVES + wv) * ro.chunk;
+    ch_end = ch_pos + ro.chunk;
+  }
   // make room for `need` more runs: a new chunk when the current one is too short.  `keep` runs of the read in progress
   // (WIN: a read's runs arrive window by window and must stay contiguous) move along, from `keep_base`.
   auto runs_room = [&](uint32_t need, uint32_t keep, unsigned long long &keep_base) {

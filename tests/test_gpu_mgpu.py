@@ -440,6 +440,72 @@ def test_routed_step_with_windowed_reads_matches_single_context(shape, monkeypat
     mg.close()
 
 
+def test_routed_rounds_are_cut_by_position_when_read_lengths_are_skewed(monkeypatch):
+    """rounds of equal READ counts are not rounds of equal size when contigs are mixed with short reads -- a round
+    could outgrow what a ticket can number.  3 kbp reads first, 150 bp reads behind them, rounds of 2 M positions: the
+    rounds are then cut by position (here by bisection over the device array: the batch is device-resident)"""
+    import torch
+    monkeypatch.setenv("KU_ROUTE_ROUND", "2000003")
+    dev = torch.device("cuda:0")
+    NT, W = 11, 2
+    db = synth_torch.BenchDb(dev, n_species=100, genome_len=60_000, k=K, nt=NT, seed=3)
+    ids, par = db.tax.arrays()
+    ctax = capi.Tax(ids=ids, parents=par)
+    N1, L1, N2, L2 = 3_000, 3000, 40_000, 150
+    s1, o1, l1, _ = db.sample_reads(N1, L1, seed=9)
+    s2, o2, l2, _ = db.sample_reads(N2, L2, seed=10)
+    seqs = torch.cat([s1.reshape(-1), s2.reshape(-1)])
+    nb1 = s1.numel()
+    off = torch.cat([o1, o2 + nb1])
+    lens = torch.cat([l1, l2])
+    N, nb = N1 + N2, seqs.numel()
+    ctx = capi.Ctx(0)
+    ctx.adopt_db(db.pairs.data_ptr(), db.n_pairs, db.offsets.data_ptr(), K, NT, 2, keep=db)
+    ctx.set_taxonomy(ctax)
+    taxa1 = torch.zeros(nb, dtype=torch.int32, device=dev)
+    calls1 = torch.zeros(N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.classify_batch_device(seqs.data_ptr(), nb, off.data_ptr(), lens.data_ptr(), N, calls1.data_ptr(), taxa1.data_ptr(), max_read_len=L1)
+    ctx.synchronize()
+    want = ctx.counts()
+    offs = db.offsets
+    bounds = [0] + [int(torch.searchsorted(offs, offs[-1] * q // W).item()) for q in range(1, W)] + [4 ** NT]
+    mg = capi.Mgpu([0] * W)
+    shards = []
+    for r in range(W):
+        sh = synth_torch.BenchDb(dev, n_species=100, genome_len=60_000, k=K, nt=NT, seed=3, bin_lo=bounds[r], bin_hi=bounds[r + 1])
+        mg.ctx(r).adopt_db(sh.pairs.data_ptr(), sh.n_pairs, sh.offsets.data_ptr(), K, NT, 2, bounds[r], bounds[r + 1])
+        shards.append(sh)
+    mg.set_taxonomy(ctax)
+    assert mg.uses_routing()
+    rb = [0, N1 + 2_000, N]  # rank 0: every contig and a few short reads (9.3 M positions), rank 1: short reads only (5.7 M)
+    off_h = off.cpu().numpy()
+    pb = [0, int(off_h[rb[1]]), nb]
+    bufs = []
+    for r in range(W):
+        bufs.append({"seqs": torch.cat([seqs, torch.zeros(16, dtype=torch.uint8, device=dev)]) if r == 0 else torch.zeros(nb + 16, dtype=torch.uint8, device=dev),
+                     "off": off if r == 0 else torch.zeros(N, dtype=torch.int64, device=dev),
+                     "len": lens if r == 0 else torch.zeros(N, dtype=torch.int32, device=dev),
+                     "calls": torch.zeros(N, dtype=torch.int32, device=dev), "taxa": torch.zeros(nb + 16, dtype=torch.int32, device=dev)})
+    torch.cuda.synchronize()
+    mg.step_device([{"d_seqs": b["seqs"].data_ptr(), "d_seq_off": b["off"].data_ptr(), "d_seq_len": b["len"].data_ptr(),
+                     "d_calls": b["calls"].data_ptr(), "d_taxa": b["taxa"].data_ptr()} for b in bufs], nb, N, rb, pb, max_read_len=L1)
+    for r in range(W):
+        mg.ctx(r).synchronize()
+    valid = torch.zeros(nb, dtype=torch.bool, device=dev)  # positions that carry a k-mer code
+    pos = torch.arange(nb, device=dev)
+    rid = torch.searchsorted(off, pos, right=True) - 1
+    valid = (pos - off[rid]) < (lens[rid].to(torch.int64) - K + 1)
+    for r in range(W):
+        lo, hi = rb[r], rb[r + 1]
+        assert torch.equal(bufs[r]["calls"][lo:hi], calls1[lo:hi]), r
+        m = valid & (pos >= pb[r]) & (pos < pb[r + 1])
+        assert torch.equal(bufs[r]["taxa"][:nb][m], taxa1[m]), r
+    mg.reduce_state()
+    assert same_counts(mg.ctx(1).counts(), want)
+    mg.close()
+
+
 def test_routed_step_of_eight_ranks_on_the_bench_database_matches_one_context():
     """owner routing at size: the 8 GB bench database in eight minimizer-range shards, eight ranks on
     the one device, 2 M reads per step -- calls, per-k-mer codes and the reduced per-taxon state equal one context that
