@@ -267,7 +267,8 @@ int ku_classify_batch_rle(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, const
                           const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                           uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, uint64_t *n_runs);
 int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs);
-/* The same in two steps, up to TWO batches in flight on a context (round 5; the reference's process_file keeps its team
+#define KU_RLE_MAX_IN_FLIGHT 4
+/* The same in two steps, up to KU_RLE_MAX_IN_FLIGHT batches in flight on a context (round 5; the reference's process_file keeps its team
  * busy by handing work units out under a critical section, classify.cpp:499-561 -- here the device is kept busy by having
  * the next batch's upload and the previous batch's copies back run under the current batch's kernels):
  *   ku_classify_batch_rle_enqueue  plans the batch and starts its upload (in segments, on a copy stream), its kernels and
@@ -277,7 +278,9 @@ int ku_fetch_runs(ku_ctx *ctx, ku_run *runs, uint64_t n_runs);
  *   ku_classify_batch_rle_finish   waits for the OLDEST batch in flight (one event), settles the sparse-sketch emulation's
  *       bookkeeping for it and returns its *n_runs; ku_fetch_runs then copies that batch's runs (valid until the next
  *       _enqueue or _finish on the context).
- * Batches are finished in the order they were enqueued.  KU_ESTATE from _enqueue: two batches are in flight already, or
+ * Batches are finished in the order they were enqueued.  (A batch's way through the device is a chain of dependent steps --
+ * upload, kernel, copies back, each with tens of microseconds of latency -- about 1 ms for a 60 k-read batch whose kernel takes 0.2 ms:
+ * several batches in flight hide it.)  KU_ESTATE from _enqueue: KU_RLE_MAX_IN_FLIGHT batches are in flight already, or
  * the batch takes a path that cannot overlap (quick mode, several databases, sorted layout, a shard, exact counting, a
  * read beyond 65535 k-mers, an open work unit left by such a batch) while another is in flight: finish that one, then
  * enqueue again -- the batch is then classified inside _enqueue and _finish merely hands its totals over.  The entry
@@ -292,7 +295,7 @@ int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint64_t n_byte
  * took a one-step path): when *n_runs is not larger, the runs are all there; else ku_fetch_runs brings them. */
 int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs);
 uint64_t ku_classify_batch_rle_copied(const ku_ctx *ctx); /* entries of the batch finished last that are in its `runs` buffer */
-int ku_classify_batch_rle_in_flight(const ku_ctx *ctx); /* 0 .. 2 */
+int ku_classify_batch_rle_in_flight(const ku_ctx *ctx); /* 0 .. KU_RLE_MAX_IN_FLIGHT */
 
 /* ---- out-of-core run: the database streamed through HBM chunk by chunk (classify -x SIZE; KrakenDB::prepare_chunking /
  * load_chunk / is_minimizer_in_chunk krakendb.cpp:411-526, process_file_with_db_chunk classify.cpp:566-791).  The

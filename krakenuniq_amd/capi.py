@@ -526,20 +526,26 @@ class Ctx:
         _chk(lib().ku_resolve_device(self.h, d_seqs, d_off, d_len, n_reads, C.byref(o), d_calls, d_taxa, d_hits,
                                      stream), "ku_resolve_device")
 
-    def rle_enqueue(self, buf, off, lens, flags=0, min_hits=1, runs_cap=0):
-        """First step of a batch through the pipelined form of ku_classify_batch_rle (up to two batches in flight).  Returns the
-        handle rle_finish() takes; the arrays stay alive with it."""
+    def rle_enqueue(self, buf, off, lens, flags=0, min_hits=1, runs_cap=0, out=None):
+        """First step of a batch through the two-step form of ku_classify_batch_rle (up to two batches in flight).  Returns the
+        handle rle_finish() takes; the arrays stay alive with it.  out: caller-owned result arrays as for classify_batch_rle
+        (page-locked ones make the copies asynchronous); out["runs"] / runs_cap: where the runs go with the other results."""
         arr = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         n = len(off)
-        job = {"arr": arr, "off": off, "lens": lens, "calls": np.zeros(n, np.uint32), "hits": np.zeros(n, np.uint32),
-               "run_off": np.zeros(n, np.uint64), "run_cnt": np.zeros(n, np.uint32)}
+        out = out or {}
+        job = {"arr": arr, "off": off, "lens": lens, "n": n,
+               "calls": out["calls"] if "calls" in out else np.zeros(max(n, 1), np.uint32),
+               "hits": out["hits"] if "hits" in out else np.zeros(max(n, 1), np.uint32),
+               "run_off": out["run_off"] if "run_off" in out else np.zeros(max(n, 1), np.uint64),
+               "run_cnt": out["run_cnt"] if "run_cnt" in out else np.zeros(max(n, 1), np.uint32)}
         o = Opts(flags, min_hits, 0, 0)
-        job["runs"] = np.zeros((runs_cap, 2), np.uint32) if runs_cap else None  # (optional: the runs come with the other results)
+        job["runs"] = out["runs"] if "runs" in out else (np.zeros((runs_cap, 2), np.uint32) if runs_cap else None)
+        rc = len(job["runs"]) if job["runs"] is not None else 0
         _chk(lib().ku_classify_batch_rle_enqueue(self.h, arr.ctypes.data, len(arr), _p(off, u64p), _p(lens, u32p), n, C.byref(o),
                                                  _p(job["calls"], u32p), _p(job["hits"], u32p), _p(job["run_off"], u64p),
-                                                 _p(job["run_cnt"], u32p), job["runs"].ctypes.data if runs_cap else None, runs_cap),
+                                                 _p(job["run_cnt"], u32p), job["runs"].ctypes.data if rc else None, rc),
              "ku_classify_batch_rle_enqueue")
         return job
 
@@ -553,7 +559,8 @@ class Ctx:
         else:
             runs = np.zeros((total.value, 2), np.uint32)
             _chk(lib().ku_fetch_runs(self.h, runs.ctypes.data, total.value), "ku_fetch_runs")
-        return {"calls": job["calls"], "hits": job["hits"], "run_off": job["run_off"], "run_cnt": job["run_cnt"], "runs": runs}
+        n = job.get("n", len(job.get("calls", ())))
+        return {"calls": job["calls"][:n], "hits": job["hits"][:n], "run_off": job["run_off"][:n], "run_cnt": job["run_cnt"][:n], "runs": runs}
 
     def rle_in_flight(self):
         return lib().ku_classify_batch_rle_in_flight(self.h)

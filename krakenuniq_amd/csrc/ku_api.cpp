@@ -401,8 +401,9 @@ struct PinBuf {
 };
 
 // One batch on its way through the fused kernel with run-length encoded output (ku_classify_batch_rle_enqueue / _finish,
-// round 5): its own device buffers and page-locked scratch -- two of them alternate, so that the upload of batch b + 1 and
-// the copies back of batch b - 1 run under the kernel of batch b and the host waits for ONE event per batch -- and what
+// round 5): its own device buffers and page-locked scratch -- KU_RLE_MAX_IN_FLIGHT of them take turns, so that the uploads of
+// the next batches and the copies back of the previous ones run under the kernel of batch b and the host waits for ONE event
+// per batch -- and what
 // _finish needs to know about the batch.
 struct RleJob {
   DevBuf seqs, off, len, calls, runs, roff, rcnt, ws, unit, u_cnt, u_flag;
@@ -488,7 +489,7 @@ struct ku_ctx {
   std::vector<hipEvent_t> seg_events;
   uint32_t *d_scalar = nullptr;
   // ku_classify_batch_rle in two steps: up to two batches in flight (FIFO: rle_head is the oldest)
-  RleJob rle[2];
+  RleJob rle[KU_RLE_MAX_IN_FLIGHT];
   int rle_head = 0, rle_in_flight = 0;
   const void *fetch_runs_src = nullptr;  // where the runs of the batch finished last lie (ku_fetch_runs)
   const void *last_calls_dev = nullptr;  // ... and its calls on the device (ku_ctx_replace_calls)
@@ -2225,8 +2226,9 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
 
 // which of the two jobs takes the next batch / is the oldest in flight
 static RleJob &rle_next_job(ku_ctx *ctx) {
-  RleJob &j = ctx->rle[(ctx->rle_head + ctx->rle_in_flight) & 1];
-  if (!j.d_counter) j.d_counter = (unsigned long long *)(ctx->d_scalar + ((&j == &ctx->rle[0]) ? 2 : 20));
+  RleJob &j = ctx->rle[(ctx->rle_head + ctx->rle_in_flight) % KU_RLE_MAX_IN_FLIGHT];
+  static const int counter_at[KU_RLE_MAX_IN_FLIGHT] = {2, 20, 22, 24};  // (dwords of the context's 32 scalars nobody else uses)
+  if (!j.d_counter) j.d_counter = (unsigned long long *)(ctx->d_scalar + counter_at[&j - &ctx->rle[0]]);
   return j;
 }
 
@@ -2274,7 +2276,8 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
                                              const uint32_t *seq_len, uint64_t n_reads, const ku_opts *opts, uint32_t *calls,
                                              uint32_t *hits, uint64_t *run_off, uint32_t *run_cnt, ku_run *runs, uint64_t runs_cap) {
   KU_TRY(check_ready(ctx));
-  if (ctx->rle_in_flight >= 2) return fail(KU_ESTATE, "ku_classify_batch_rle_enqueue: two batches are in flight (ku_classify_batch_rle_finish first)");
+  if (ctx->rle_in_flight >= KU_RLE_MAX_IN_FLIGHT)
+    return fail(KU_ESTATE, "ku_classify_batch_rle_enqueue: " + std::to_string(KU_RLE_MAX_IN_FLIGHT) + " batches are in flight (ku_classify_batch_rle_finish first)");
   ku_opts o = opts ? *opts : ku_opts{0, 1, 0, 0};
   bool monotonic = true;
   KU_TRY(rle_check_batch(seqs, n_bytes, seq_off, seq_len, n_reads, calls, run_off, run_cnt, o, monotonic));
@@ -2341,7 +2344,7 @@ extern "C" int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs) {
   if (!ctx->rle_in_flight) return fail(KU_ESTATE, "ku_classify_batch_rle_finish: no batch is in flight");
   KU_TRY(ctx_activate(ctx));
   RleJob &j = ctx->rle[ctx->rle_head];
-  ctx->rle_head ^= 1;
+  ctx->rle_head = (ctx->rle_head + 1) % KU_RLE_MAX_IN_FLIGHT;
   --ctx->rle_in_flight;
   bool classified = false;
   int st = rle_job_finish(ctx, j, n_runs, &classified);

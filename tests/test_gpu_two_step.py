@@ -1,4 +1,4 @@
-"""-m gpu: ku_classify_batch_rle in two steps (ku_classify_batch_rle_enqueue / _finish, round 5): up to two batches in
+"""-m gpu: ku_classify_batch_rle in two steps (ku_classify_batch_rle_enqueue / _finish, round 5): up to four batches in
 flight on a context, the upload of the next and the copies back of the previous under the kernels of the current one.
 
 Checked: the same calls, runs, per-taxon state and Kraken text as the one-step call and as the reference's files, whatever
@@ -30,7 +30,7 @@ def batches_of(buf, off, lens, cuts):
         yield a, b, buf[lo:hi], off[a:b] - lo, lens[a:b]
 
 
-def run_two_step(ctx, buf, off, lens, cuts, depth=2, **kw):
+def run_two_step(ctx, buf, off, lens, cuts, depth=3, **kw):
     """every batch through enqueue / finish with up to `depth` in flight; results in batch order"""
     flying, out = [], []
     for i, (a, b, bb, bo, bl) in enumerate(batches_of(buf, off, lens, cuts)):
@@ -53,7 +53,7 @@ def kraken_text(buf, off, lens, ids, cuts, results):
     return text
 
 
-@pytest.mark.parametrize("n_batches,depth", [(1, 2), (6, 2), (6, 1), (17, 2)])
+@pytest.mark.parametrize("n_batches,depth", [(1, 2), (6, 2), (6, 1), (17, 4), (17, 3)])
 def test_two_step_equals_the_reference_files(n_batches, depth):
     ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
     buf, off, lens = ko.pack_reads(seqs)
@@ -142,17 +142,16 @@ def test_what_cannot_be_in_flight_is_refused():
     ctx, cdb, ctax = gc.make_ctx(F1)
     with pytest.raises(capi.KuError):
         ctx.rle_finish({})  # nothing in flight
-    j1 = ctx.rle_enqueue(buf, off, lens)
-    j2 = ctx.rle_enqueue(buf, off, lens)
+    jobs = [ctx.rle_enqueue(buf, off, lens) for _ in range(4)]  # KU_RLE_MAX_IN_FLIGHT
     with pytest.raises(capi.KuError):
-        ctx.rle_enqueue(buf, off, lens)  # two in flight already
+        ctx.rle_enqueue(buf, off, lens)  # four in flight already
     with pytest.raises(capi.KuError):
         ctx.classify_batch_rle(buf, off, lens)
     with pytest.raises(capi.KuError):
         ctx.reset_counts()
-    r1 = ctx.rle_finish(j1)
-    r2 = ctx.rle_finish(j2)
-    assert np.array_equal(r1["calls"], r2["calls"])
+    res = [ctx.rle_finish(j) for j in jobs]
+    r1, r2 = res[0], res[3]
+    assert all(np.array_equal(r1["calls"], r["calls"]) for r in res)
     want = ctx.classify_batch_rle(buf, off, lens)
     assert np.array_equal(want["calls"], r1["calls"])
     assert capi.format_kraken_rle(buf, off, lens, ids[:300], K, r2) == capi.format_kraken_rle(buf, off, lens, ids[:300], K, want)
