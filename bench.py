@@ -628,6 +628,13 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
               "traffic": traffic, "traffic_source": tnote,
               "kernel_ms": round(t_equiv, 3), "stage_ms_measured": {kk: round(v, 3) for kk, v in tm.items() if kk.endswith("_ms")},
               "stage_share_of_the_full_layout": {"scan": share, "resolve": share, "owner": 1.0},
+              #  with fewer ranks than shards achieved / frac / kernel_ms price the rank's step IN THE FULL LAYOUT from the
+              # measured stages (scan and resolve scaled by the share of the reads the rank has there): a model of a layout that
+              # did not run, not a measured time.  The measured sum of this run's stages and its own fraction are given beside it.
+              "modelled": share != 1.0,
+              "measured_stage_sum_ms": round(tm["scan_ms"] + tm["owner_ms"] + tm["resolve_ms"], 3),
+              "measured_frac_model_of_this_run": round((a.reads / ws * (L + 4.0) + st["lookups"] * 20 + 12 * st["sum_ceil_log2"]) /
+                                                       ((tm["scan_ms"] + tm["owner_ms"] + tm["resolve_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
               "rounds": tm["rounds"], "records_received": int(tm["records_received"]), "kmers_received": int(tm["kmers_received"]),
               "kmers_per_record": round(tm["kmers_received"] / max(tm["records_received"], 1), 2),
               "owned_lookups_per_step": int(st["lookups"]), "owned_fraction_of_kmers": round(st["lookups"] / max(1.0, a.reads * nk), 4),

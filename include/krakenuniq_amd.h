@@ -296,6 +296,9 @@ int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint64_t n_byte
 int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs);
 uint64_t ku_classify_batch_rle_copied(const ku_ctx *ctx); /* entries of the batch finished last that are in its `runs` buffer */
 int ku_classify_batch_rle_in_flight(const ku_ctx *ctx); /* 0 .. KU_RLE_MAX_IN_FLIGHT */
+/* optional: the buffers of n_jobs batches of up to n_bytes / n_reads (longest read max_read_len) ahead of the first batch --
+ * device memory, page-locked scratch, streams and events that _enqueue would otherwise set up on first use */
+int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint64_t n_reads, uint32_t max_read_len, uint32_t n_jobs);
 
 /* ---- out-of-core run: the database streamed through HBM chunk by chunk (classify -x SIZE; KrakenDB::prepare_chunking /
  * load_chunk / is_minimizer_in_chunk krakendb.cpp:411-526, process_file_with_db_chunk classify.cpp:566-791).  The

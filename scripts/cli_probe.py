@@ -5,7 +5,7 @@ table per run.
 
   python scripts/cli_probe.py <species> <reads> <out_tag> VARIANT [VARIANT ...]
   VARIANT = label[:key=value[,key=value...]]      keys: any environment variable, or
-            REPORT=1 (add -r), PROF=1 (run under rocprofv3 --kernel-trace --stats), LIB=<dir> (a directory that holds another
+            REPORT=1 (add -r), PROF=1 (run under rocprofv3 --kernel-trace --stats), CPULIST=0-31 (taskset), LIB=<dir> (a directory that holds another
             build of libkrakenuniq_amd.so, e.g. krakenuniq_amd/variants/abl), THREADS=n, REPEAT=n, GZ=1 (.gz input)
 Prints one block per variant; kernel tables go to gpurun_out/<out_tag>_<label>_kernel_stats.csv."""
 import csv, glob, os, resource, shutil, subprocess, sys, time
@@ -61,7 +61,7 @@ def main():
         label, _, kvs = var.partition(":")
         env = dict(os.environ, KU_CLI_TIMES="1", KU_REPORT_TIMES="1")
         report = prof = gz = False
-        threads, repeat = "16", 1
+        threads, repeat, cpulist = "16", 1, None
         for kv in [x for x in kvs.split(",") if x]:
             k, v = kv.split("=", 1)
             if k == "REPORT": report = v != "0"
@@ -69,6 +69,7 @@ def main():
             elif k == "GZ": gz = v != "0"
             elif k == "THREADS": threads = v
             elif k == "REPEAT": repeat = int(v)
+            elif k == "CPULIST": cpulist = v.replace("+", ",")  # taskset -c (a+b for a,b)
             elif k == "LIB": env["LD_LIBRARY_PATH"] = os.path.join(ROOT, v) + ":" + env.get("LD_LIBRARY_PATH", "")
             else: env[k] = v
         reads = f"{tmp}/reads.fq"
@@ -84,6 +85,8 @@ def main():
                 if os.path.exists(f): os.remove(f)
             cmd = [f"{ROOT}/krakenuniq_amd/bin/classify", "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB",
                    "-t", threads, "-o", f"{tmp}/out.tsv"] + (["-r", f"{tmp}/report.tsv"] if report else []) + [reads]
+            if cpulist:
+                cmd = ["taskset", "-c", cpulist] + cmd
             pdir = f"/tmp/prof_{tag}_{label}"
             if prof:
                 shutil.rmtree(pdir, ignore_errors=True)
@@ -96,7 +99,7 @@ def main():
             cpu_line = (f"cpu user {ru1.ru_utime - ru0.ru_utime:.2f}s sys {ru1.ru_stime - ru0.ru_stime:.2f}s (whole process, load included); throttled "
                         f"{cs1.get('nr_throttled', 0) - cs0.get('nr_throttled', 0)} periods, {(cs1.get('throttled_usec', cs1.get('throttled_time', 0)) - cs0.get('throttled_usec', cs0.get('throttled_time', 0))) / 1e6:.3f}s")
             err = r.stderr.decode(errors="replace").replace("\r", "\n").split("\n")
-            keep = [l.strip()[:260] for l in err if any(w in l for w in ("processed in", "stage busy", "Report finished", "ku_ctx_report:",
+            keep = [l.strip()[:520] for l in err if any(w in l for w in ("processed in", "stage busy", "Report finished", "ku_ctx_report:",
                                                                         "ku_classify_batch_rle over", "cpu seconds", "error", "Error"))]
             print(f"== {label} rep {rep} rc {r.returncode} wall {wall:.2f}s  {cpu_line}")
             print("\n".join("   " + l for l in keep), flush=True)
