@@ -15,7 +15,7 @@
 //   -u N                                work unit size in nt as in the reference (default 500000, src/classify.cpp:38): it decides
 //                                       which per-taxon sketches stay sparse, i.e. which `kmers` of the report are near
 //                                       exact (HLL sparse-mode emulation; KU_NO_SPARSE=1 switches it off: dense estimates).
-//                                       The GPU batch size is separate: KU_BATCH_NT (default 32 Mi nt)
+//                                       The GPU batch size is separate: KU_BATCH_NT (default 48 Mi nt)
 //   -M                                  accepted: the database is always preloaded (into HBM)
 //   -x SIZE                             the database is streamed through HBM in minimizer-range chunks of at most SIZE
 //                                       bytes (src/krakendb.cpp:463-522) when that yields more than one chunk
@@ -241,7 +241,7 @@ int main(int argc, char **argv) {
   bool paired = false, warned_pairs = false, warned_uid_calls = false;
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
-  uint64_t unit_nt = 32ull << 20;    // GPU batch size in nt (KU_BATCH_NT); plain and .gz files travel in regions of a quarter of it.
+  uint64_t unit_nt = 48ull << 20;    // GPU batch size in nt (KU_BATCH_NT; round 5: 48 Mi, with the batch call in two steps the optimum moved up from 32 Mi); plain and .gz files travel in regions of a quarter of it.
                                      // 10 M x 150 bp end to end (scripts/e2e_sweep.py, profiles/r04_e2e_sweep.log): 128 Mi 0.53 s, 64 Mi 0.44,
                                      // 32 Mi 0.29, 24 Mi 0.31, 16 Mi 0.36, 8 Mi 0.46 -- larger batches fill and drain the three stages slowly,
                                      // smaller ones pay the device stage's ~1 ms per call too often
@@ -407,7 +407,9 @@ int main(int argc, char **argv) {
   // The batch buffers of the host pipeline (below) are page-locked memory, which is slow to allocate (a few hundred MB
   // take longer than classifying the first millions of reads).  A helper sizes the pool's buffers for plain-text
   // regions while this thread loads the database; it is joined before the first read is looked at.
-  const int team_cap = getenv("KU_PARSE_TEAM") ? std::max(1, atoi(getenv("KU_PARSE_TEAM"))) : 8;
+  // (round 5: up to 12 parsers -- with the device stage out of the way the reader is the longest stage: 8 -> 12 members took the
+  // 10 M-read window from 0.17 to 0.15 s, 16 bought nothing more; profiles/r05_e2e_sweep.log)
+  const int team_cap = getenv("KU_PARSE_TEAM") ? std::max(1, atoi(getenv("KU_PARSE_TEAM"))) : 12;
   const int parse_team = paired ? 1 : (fmt_threads < team_cap ? fmt_threads : team_cap);
   const int n_batches = 7 + (parse_team > 1 ? parse_team : 0);  // one per team member + up to four on the device, formatter, writer and one queued
   ku_seqio::PinSwitch::enabled = !chunk_bytes;  // per-read arrays of the batches page-locked too (before any batch exists)
@@ -607,7 +609,7 @@ int main(int argc, char **argv) {
     // a quarter of a work unit per region: the team's batches are pinned memory, smaller ones are quicker to set up
     // and keep the three stages busier.  FASTQ text is ~2.2 bytes per base (header, '+', qualities), FASTA ~1.05
     cut.region_bytes = std::max<size_t>((size_t)1 << 16, (size_t)((double)(unit_nt / 4) * (fastq ? 2.3 : 1.05)));
-    cut.ramp = getenv("KU_REGION_RAMP") ? (size_t)atoi(getenv("KU_REGION_RAMP")) : (size_t)parse_team;
+    cut.ramp = getenv("KU_REGION_RAMP") ? (size_t)atoi(getenv("KU_REGION_RAMP")) : 0;  // (smaller first regions: measured, no gain)
     std::mutex mu;
     std::condition_variable cv;
     size_t next_out = 0;
