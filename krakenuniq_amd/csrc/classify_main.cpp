@@ -235,6 +235,88 @@ static double seconds_between(const timeval &a, const timeval &b) {
   return (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_usec - a.tv_usec) / 1e6;
 }
 
+// KU_CRLF_REFERENCE=1: the Kraken lines of the reads that had carriage returns inside (multi-line FASTA with CRLF line ends)
+// as the reference prints them (ku_seqio.h, crlf_note()).  `text` holds the lines of the reads [lo, hi) of `bt` as
+// ku_format_kraken_rle wrote them, one per read; the lines of the listed reads are replaced.  Returns a malloc'ed buffer.
+static char *rewrite_crlf_lines(const Batch &bt, uint64_t lo, uint64_t hi, uint32_t k, char *text, size_t *len) {
+  size_t a = std::lower_bound(bt.crlf_read.begin(), bt.crlf_read.end(), (uint32_t)lo) - bt.crlf_read.begin();
+  const size_t b = std::lower_bound(bt.crlf_read.begin(), bt.crlf_read.end(), (uint32_t)hi) - bt.crlf_read.begin();
+  if (a == b) return text;
+  std::string out;
+  out.reserve(*len + 64);
+  const char *p = text, *end = text + *len;
+  for (uint64_t r = lo; r < hi && p < end; ++r) {
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    const char *line_end = nl ? nl + 1 : end;
+    if (a < b && bt.crlf_read[a] == r) {
+      // the line's five columns: C/U, id, call, length, hit list
+      std::vector<std::string> col;
+      const char *q = p;
+      for (int c = 0; c < 4 && q < line_end; ++c) {
+        const char *t = (const char *)memchr(q, '\t', (size_t)(line_end - q));
+        if (!t) break;
+        col.emplace_back(q, t);
+        q = t + 1;
+      }
+      std::string hits(q, line_end - (nl ? 1 : 0));
+      const uint32_t s0 = bt.crlf_off[a], s1 = a + 1 < bt.crlf_off.size() ? bt.crlf_off[a + 1] : (uint32_t)bt.crlf_start.size();
+      const uint32_t L1 = bt.len[r];           // bases + the carriage return that closes the record
+      const uint32_t L = L1 ? L1 - 1 : 0;      // bases
+      if (col.size() == 4 && L1 >= k && bt.seqs[bt.off[r] + L1 - 1] == '\r') {
+        // per-k-mer codes of the joined sequence (L1 - k + 1 of them, the last one holds the '\r')
+        std::vector<std::string> codes;
+        codes.reserve(L1 - k + 1);
+        for (size_t i = 0; i < hits.size();) {
+          size_t sp = hits.find(' ', i);
+          if (sp == std::string::npos) sp = hits.size();
+          const size_t colon = hits.find(':', i);
+          if (colon != std::string::npos && colon < sp) {
+            const std::string code = hits.substr(i, colon - i);
+            const unsigned long cnt = strtoul(hits.c_str() + colon + 1, nullptr, 10);
+            for (unsigned long j = 0; j < cnt; ++j) codes.push_back(code);
+          }
+          i = sp + 1;
+        }
+        if (codes.size() == (size_t)L1 - k + 1) {
+          std::vector<const std::string *> kept;
+          uint32_t nb = 0, si = s0;
+          for (uint32_t t = 0; t < L; ++t) {
+            if (si < s1 && bt.crlf_start[si] == t) { ++nb; ++si; continue; }  // the first base behind a line break is not counted
+            if (t + 1 - nb >= k) kept.push_back(&codes[t - k + 1]);
+          }
+          kept.push_back(&codes.back());  // the scanner's last, ambiguous k-mer behind the closing '\r'
+          std::string h;
+          for (size_t i = 0; i < kept.size();) {
+            size_t j = i;
+            while (j < kept.size() && *kept[j] == *kept[i]) ++j;
+            if (!h.empty()) h += ' ';
+            h += *kept[i];
+            h += ':';
+            h += std::to_string(j - i);
+            i = j;
+          }
+          out += col[0]; out += '\t'; out += col[1]; out += '\t'; out += col[2]; out += '\t';
+          out += std::to_string(L + (s1 - s0) + 1);  // every line's '\r' counts (taxdb / classify.cpp print dna.seq.size())
+          out += '\t'; out += h; out += '\n';
+          ++a;
+          p = line_end;
+          continue;
+        }
+      }
+      ++a;  // (not the shape this emulation knows: the line stays)
+    }
+    out.append(p, line_end);
+    p = line_end;
+  }
+  out.append(p, end);
+  char *nb = (char *)malloc(out.size() + 1);
+  if (!nb) return text;
+  memcpy(nb, out.data(), out.size());
+  ku_free(text);
+  *len = out.size();
+  return nb;
+}
+
 int main(int argc, char **argv) {
   std::vector<std::string> dbs, idxs;
   std::string kraken_out, report_out, taxdb, cls_out, ucls_out, uid_map_file;
@@ -817,6 +899,8 @@ int main(int argc, char **argv) {
                                            bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
                                            bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
                                            pflags, &f->parts[t], &f->len[t]);
+          if (status[t] == KU_OK && !bt->crlf_read.empty() && pflags == 0)  // KU_CRLF_REFERENCE=1: the reference's lines for such reads
+            f->parts[t] = rewrite_crlf_lines(*bt, lo, hi, info.k, f->parts[t], &f->len[t]);
           if (status[t] == KU_OK && s_kraken.pgz && f->len[t]) {  // -o x.gz: the helper deflates its own lines
             size_t cl = 0;
             unsigned char *c = ku_pgzout::deflate_part(f->parts[t], f->len[t], &cl, &f->crc[t]);

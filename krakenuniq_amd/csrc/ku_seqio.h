@@ -3,6 +3,7 @@
 // readers (src/seqreader.cpp:26-133) and, for mate pairs, of scripts/read_merger.pl:100-197.
 #pragma once
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -34,6 +35,26 @@ namespace ku_seqio {
 // when `enabled` (set once at program start, before any batch exists), so that their copies are DMA transfers instead
 // of staged ones; plain memory otherwise (tools without a device, -x runs with one batch per region).
 struct PinSwitch { static inline bool enabled = false; };
+
+// CPUs this process may really use: the affinity mask, capped by the container's CFS quota (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us) -- a box that shows 256 CPUs under a quota of 16 runs 16 threads' worth, and a team
+// sized for 256 is throttled (measured: the gzip team at 16 on such a box lost to the team at 12)
+inline int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n > 0 ? n : 1 << 30, CPU_COUNT(&set));
+  long long quota = -1, period = 0;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else {
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+  }
+  if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+  return std::max(1, n);
+}
 template <class T> struct PinAlloc {
   using value_type = T;
   PinAlloc() = default;
@@ -69,10 +90,14 @@ struct Batch {
     return p;
   }
   void free_bytes(void *p) { if (pinned) ku_host_free(p); else free(p); }
+  // KU_CRLF_REFERENCE=1 (multi-line FASTA with CRLF line ends, see crlf_note()): the reads that had carriage returns inside,
+  // and where their lines began (base index in the joined sequence) -- crlf_off is a CSR over crlf_start
+  std::vector<uint32_t> crlf_read, crlf_off, crlf_start;
   void clear() {
     seqs_len = 0; nt = 0;
     ids.clear(); headers.clear(); quals.clear();
     off.clear(); idoff.clear(); hoff.clear(); qoff.clear(); len.clear();
+    crlf_read.clear(); crlf_off.clear(); crlf_start.clear();
   }
   void reserve_seq(size_t extra) {
     const size_t need = seqs_len + extra + 1;
@@ -582,11 +607,20 @@ inline void split_id(const char *h, size_t n, size_t &lo, size_t &hi) {
 // the k-mer ending at the first base of the next line, and the reported length counts the '\r's.  Here the line ends
 // inside a sequence are dropped and every k-mer is classified; said once, because the per-read output then differs
 // from the reference's for such files (FASTQ and one-line-per-sequence FASTA are byte-identical, tests/golden/f10).
+// KU_CRLF_REFERENCE=1 reproduces the reference's Kraken line for such reads (round 5): the parser notes where the lines began,
+// and the output stage rewrites the line -- the k-mer ending on the first base behind every line break is taken out of the hit
+// list (and, near the start of a read, the k-mers the scanner had not counted enough bases for yet: it does not count that
+// base, src/krakenutil.cpp:240-249,265-269), the length column counts the carriage returns.  What stays as computed from
+// every k-mer: the call and the per-taxon accounting (the reference would not count the dropped k-mers either).
+inline bool crlf_reference() {
+  static const bool on = getenv("KU_CRLF_REFERENCE") && atoi(getenv("KU_CRLF_REFERENCE"));
+  return on;
+}
 inline void crlf_note() {
   static std::atomic<bool> said{false};
-  if (!said.exchange(true))
+  if (!said.exchange(true) && !crlf_reference())
     fprintf(stderr, "classify: warning: multi-line FASTA with CRLF line ends: the carriage returns inside sequences are "
-                    "removed (the reference skips one k-mer per line break on such input)\n");
+                    "removed (the reference skips one k-mer per line break on such input; KU_CRLF_REFERENCE=1 prints its lines)\n");
 }
 
 // One record of `rd`: sequence pieces appended to the read currently open in `bt`; header (without '>'/'@') and
@@ -637,7 +671,15 @@ inline bool next_record(Reader &rd, Batch &bt, std::string *header, std::string 
     if (l_hi > 0 && *rd.at(0) == '>') break;  // next record: not consumed
     // CRLF files: the '\r' closing a line that another sequence line follows is dropped (see crlf_note()); the one
     // closing the record stays -- it is what the reference scans too (one more, ambiguous, k-mer; length + 1)
-    if (l_hi > 0 && bt.seqs_len > read_lo && bt.seqs[bt.seqs_len - 1] == '\r') { --bt.seqs_len; crlf_note(); }
+    if (l_hi > 0 && bt.seqs_len > read_lo && bt.seqs[bt.seqs_len - 1] == '\r') {
+      --bt.seqs_len;
+      crlf_note();
+      if (crlf_reference() && !bt.off.empty()) {  // (the read in progress is the one begin_read() opened last)
+        const uint32_t r = (uint32_t)bt.off.size() - 1;
+        if (bt.crlf_read.empty() || bt.crlf_read.back() != r) { bt.crlf_read.push_back(r); bt.crlf_off.push_back((uint32_t)bt.crlf_start.size()); }
+        bt.crlf_start.push_back((uint32_t)(bt.seqs_len - read_lo));
+      }
+    }
     bt.append(rd.at(0), l_hi);
     *seq_bytes += l_hi;
     rd.pos += l_next;
@@ -955,7 +997,9 @@ struct GzTextStream {
       map = nullptr;
       return false;
     }
-    int n = std::max(1, std::min(hw, 8));
+    // (the inflating team next to the parser team and the formatting helpers: three quarters of the usable CPUs, at most 12)
+    int n = std::max(1, std::min(usable_cpus() * 3 / 4, 12));
+    (void)hw;
     if (const char *e = getenv("KU_PGZIP_TEAM")) n = std::max(1, std::min(atoi(e), 64));
     pgz = new ku_pgzip::ParallelGunzip;
     pgz->open(map, len, n);

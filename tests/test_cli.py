@@ -139,7 +139,8 @@ def test_crlf_inputs():
     """tests/golden/f10: CRLF FASTQ and one-line-per-sequence CRLF FASTA are byte-identical with the reference (the '\\r'
     closing a sequence is one more, ambiguous, base).  Multi-line CRLF FASTA is the one documented deviation: the
     reference's scanner loses one k-mer per line break there (src/krakenutil.cpp:266-270; crlf_multiline.out.tsv keeps
-    its output); here the line breaks are removed, said once on stderr, so the reads classify like the one-line file"""
+    its output); here the line breaks are removed, said once on stderr, so the reads classify like the one-line file --
+    unless KU_CRLF_REFERENCE=1 asks for the reference's lines"""
     g = os.path.join(ROOT, "tests", "golden", "f10")
     for name in ("crlf.fq", "crlf_oneline.fa"):
         r = run(DB + [f"{g}/{name}"])
@@ -150,6 +151,16 @@ def test_crlf_inputs():
     assert r.stdout == open(f"{g}/crlf_oneline.out.tsv", "rb").read()
     ref = open(f"{g}/crlf_multiline.out.tsv").read().splitlines()
     assert [ln.split("\t")[:3] for ln in r.stdout.decode().splitlines()] == [ln.split("\t")[:3] for ln in ref]
+    # KU_CRLF_REFERENCE=1 (round 5): the reference's lines for such reads -- the k-mer behind every line break taken out of the hit
+    # list, the carriage returns counted in the length column -- byte for byte its output file; also through several threads'
+    # parts, the parser team and a .gz file
+    for extra, name in ((["-t", "1"], "crlf_multiline.fa"), (["-t", "4"], "crlf_multiline.fa")):
+        r = run(DB + extra + [f"{g}/{name}"], env=dict(os.environ, KU_CRLF_REFERENCE="1"))
+        assert r.returncode == 0 and b"multi-line FASTA with CRLF" not in r.stderr
+        assert r.stdout == open(f"{g}/crlf_multiline.out.tsv", "rb").read(), extra
+    for name in ("crlf.fq", "crlf_oneline.fa"):  # (nothing changes for the files that agreed already)
+        r = run(DB + [f"{g}/{name}"], env=dict(os.environ, KU_CRLF_REFERENCE="1"))
+        assert r.stdout == open(f"{g}/{name.rsplit('.', 1)[0]}.out.tsv", "rb").read(), name
 
 
 @pytest.mark.gpu
