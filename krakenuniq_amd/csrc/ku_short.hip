@@ -365,6 +365,19 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   ks_wave_sync();
 
   const uint64_t n_waves = (uint64_t)gridDim.x * KS_WAVES;
+#ifdef KS_STAGGER
+  // experiment of round 5 (scripts/build_variant.sh stg -DKS_STAGGER; scripts/rle_depth_probe.py): a launch of the executable's
+  // batch size (61 k reads = 5 per wave) costs 3.6 us per thousand reads against 1.9 for the 10 M-read launch of the bench.
+  // Were the waves of a SIMD held back by marching in step (all in the same stage, waiting for memory together), starting them
+  // (ablate >> 16) * 64 cycles apart would help: measured 4 .. 256 steps, no change (110 ms per 30 M reads every time).  What is
+  // left as an explanation is what a wave pays ONCE -- instruction cache and TLB misses of a kernel of this size on its first
+  // read, the counter tables' flush -- spread over 5 reads instead of 800.
+  {
+    const uint32_t steps = ablate >> 16;
+    const uint32_t slot = ((uint32_t)blockIdx.x / 256u) % 6u;
+    for (uint32_t i = 0; i < slot * steps; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
   // WIN: this wave's region of the spill workspace (keys, then values), wiped on first use
   uint32_t *g_key = WIN ? spill + ((uint64_t)blockIdx.x * KS_WAVES + wv) * 2ull * spill_cap : nullptr;
   uint32_t *g_cnt = WIN ? g_key + spill_cap : nullptr;

@@ -42,7 +42,7 @@ def child(per_batch, n_batches):
             o2 = pin(per_batch, torch.int64).view(np.uint64); o2[:] = off
             l2 = pin(per_batch, torch.int32).view(np.uint32); l2[:] = lens
             pool.append((sq, o2, l2))
-    for depth in (1, 2, 3, 4):
+    for depth in ((3,) if os.environ.get("KU_PROBE_STAGGER") else (1, 2, 3, 4)):
         best = None
         for rep in range(3):
             ctx.reset_counts()
@@ -92,7 +92,12 @@ def main():
     s.reshape(-1).cpu().numpy().tofile(f"{TMP}/reads.bin")
     del db, s
     torch.cuda.empty_cache()
-    variants = [("default", {}), ("sixteen page-locked buffer sets in turn, as the executable's pool", {"KU_PROBE_POOL": "16"})]
+    variants = [("default", {})]
+    if os.environ.get("KU_PROBE_STAGGER"):  # the -DKS_STAGGER variant of the library: waves that share a SIMD start apart
+        lib = os.path.join(ROOT, "krakenuniq_amd", "variants", "libku_stg.so")
+        variants = [("default", {}), ("variant build, no stagger", {"KU_LIB": lib, "KU_ABLATE": "0"})]
+        for steps in os.environ["KU_PROBE_STAGGER"].split(","):
+            variants.append((f"waves of a SIMD {steps} x 64 cycles apart", {"KU_LIB": lib, "KU_ABLATE": str(int(steps) << 16)}))
     for name, env in variants:
         print(f"== {name}", flush=True)
         r = subprocess.run([sys.executable, __file__, str(per_batch), str(n_batches)], env=dict(os.environ, KU_DEPTH_PROBE_CHILD="1", KU_RLE_TIMES="1", **env),
