@@ -15,7 +15,7 @@
 //   -u N                                work unit size in nt as in the reference (default 500000, src/classify.cpp:38): it decides
 //                                       which per-taxon sketches stay sparse, i.e. which `kmers` of the report are near
 //                                       exact (HLL sparse-mode emulation; KU_NO_SPARSE=1 switches it off: dense estimates).
-//                                       The GPU batch size is separate: KU_BATCH_NT (default 48 Mi nt)
+//                                       The GPU batch size is separate: KU_BATCH_NT (default 64 Mi nt)
 //   -M                                  accepted: the database is always preloaded (into HBM)
 //   -x SIZE                             the database is streamed through HBM in minimizer-range chunks of at most SIZE
 //                                       bytes (src/krakendb.cpp:463-522) when that yields more than one chunk
@@ -323,7 +323,8 @@ int main(int argc, char **argv) {
   bool paired = false, warned_pairs = false, warned_uid_calls = false;
   bool quick = false, only_classified = false, print_seq = false, print_cls = false, print_ucls = false, populate = false;
   uint32_t min_hits = 1;
-  uint64_t unit_nt = 48ull << 20;    // GPU batch size in nt (KU_BATCH_NT; round 5: 48 Mi, with the batch call in two steps the optimum moved up from 32 Mi); plain and .gz files travel in regions of a quarter of it.
+  uint64_t unit_nt = 64ull << 20;    // GPU batch size in nt (KU_BATCH_NT; round 5: 64 Mi = regions of 16 Mi nt, one launch of ~120 k reads each -- with the
+                                     // batch call in two steps the window is flat from 40 to 96 Mi and the kernel's cost per read falls with the launch size); plain and .gz files travel in regions of a quarter of it.
                                      // 10 M x 150 bp end to end (scripts/e2e_sweep.py, profiles/r04_e2e_sweep.log): 128 Mi 0.53 s, 64 Mi 0.44,
                                      // 32 Mi 0.29, 24 Mi 0.31, 16 Mi 0.36, 8 Mi 0.46 -- larger batches fill and drain the three stages slowly,
                                      // smaller ones pay the device stage's ~1 ms per call too often

@@ -1958,7 +1958,9 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   // ---- segments of the batch: cut at read boundaries, uploaded one after the other on the copy stream while the
   // compute stream classifies the ones before
   uint64_t n_seg = 1;
-  static const uint64_t seg_bytes = (uint64_t)std::max(1, getenv("KU_RLE_SEG_MB") ? atoi(getenv("KU_RLE_SEG_MB")) : 8) << 20;
+  // (16 MiB per segment since round 5 -- was 8: with several batches in flight the overlap of upload and kernels comes from the
+  // OTHER batches, and a launch of 120 k reads costs 3.0 us per thousand reads where two of 60 k cost 3.8, ku_short.hip)
+  static const uint64_t seg_bytes = (uint64_t)std::max(1, getenv("KU_RLE_SEG_MB") ? atoi(getenv("KU_RLE_SEG_MB")) : 16) << 20;
   if (monotonic && !getenv("KU_NO_H2D_OVERLAP")) n_seg = std::min<uint64_t>(8, std::max<uint64_t>(1, n_bytes / seg_bytes));
   std::vector<uint64_t> seg(n_seg + 1, 0);
   for (uint64_t g = 1; g < n_seg; ++g) {
