@@ -1780,6 +1780,24 @@ static int sparse_tail_close(ku_ctx *ctx) {
   return KU_OK;
 }
 
+// KU_RLE_TIMES=1: where the batch calls spend their time on the host, summed over the run, printed when the context goes
+static double g_rle_t[10];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls; of the enqueue: [5] buffers + plan ([9]: sparse_reserve_global in it), [6] uploads, [7] launches, [8] copies back + events
+static double g_rle_x[6];  // of 'behind the wait': [0] flagging again, [1] exact passes, [2] their number, [3] units they evaluated, [4] reads in them
+static double g_rle_kernel_ms = 0;  // HIP events around every batch's kernels (fused kernel + the emulation's flag kernel), summed
+static unsigned long long g_rle_reads = 0;
+static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
+static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static void rle_times_print() {
+  if (g_rle_times && g_rle_t[4] > 0)
+    fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s; "
+                    "kernels %.3f ms for %llu reads (HIP events on their stream); of the enqueue: buffers + plan %.3f s, uploads %.3f s, launches %.3f s, "
+                    "copies back + events %.3f s; of buffers + plan: room in the emulation's run-wide set %.3f s\n",
+            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads, g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[8], g_rle_t[9]);
+  if (g_rle_times && g_rle_x[2] > 0)
+    fprintf(stderr, "ku_classify_batch_rle, behind the wait: flagging again %.3f s, %.0f exact passes over %.0f work units (%.0f reads) %.3f s, of it %.3f s waiting for their kernels\n", g_rle_x[0], g_rle_x[2],
+            g_rle_x[3], g_rle_x[4], g_rle_x[1], g_rle_x[5]);
+}
+
 // The exact per-unit evaluation of the emulation for the units the fused kernel could not settle by counting: `flagged`
 // (ascending unit numbers of the job's batch; flag_all: every slot of the unit is tracked -- a unit in the staged form).
 // last_is_open: the last flagged unit stays open behind the batch (staged form: its entries go into the carry buffers).
@@ -1843,7 +1861,9 @@ static int sparse_fast_exact(ku_ctx *ctx, RleJob &j, const std::vector<uint32_t>
                                         sp.cap_carry_l, sp.cap_carry_u, s));
     }
     HIP_TRY(hipMemcpyAsync(c, sp.d_counters, 24, hipMemcpyDeviceToHost, s));
+    const double t_sy0 = g_rle_times ? rle_now() : 0.0;
     HIP_TRY(hipStreamSynchronize(s));  // `list` goes out of scope
+    if (g_rle_times) g_rle_x[5] += rle_now() - t_sy0;
     sp.g_count = std::max<uint64_t>(sp.g_count, c[0]);
     if (has_open) {
       sp.n_carry_l = std::min<uint64_t>(c[1], sp.cap_carry_l);
@@ -1923,20 +1943,6 @@ extern "C" int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uin
   int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len, n_reads, max_n, o.flags,
                                     d_calls, nullptr, nullptr, ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s, &ro, nullptr);
   return st == KU_OK ? KU_OK : fail(st, "fused kernel launch failed");
-}
-
-// KU_RLE_TIMES=1: where the batch calls spend their time on the host, summed over the run, printed when the context goes
-static double g_rle_t[10];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls; of the enqueue: [5] buffers + plan, [6] uploads, [7] launches, [8] copies back + events
-static double g_rle_kernel_ms = 0;  // HIP events around every batch's kernels (fused kernel + the emulation's flag kernel), summed
-static unsigned long long g_rle_reads = 0;
-static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
-static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
-static void rle_times_print() {
-  if (g_rle_times && g_rle_t[4] > 0)
-    fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s; "
-                    "kernels %.3f ms for %llu reads (HIP events on their stream); of the enqueue: buffers + plan %.3f s, uploads %.3f s, launches %.3f s, "
-                    "copies back + events %.3f s\n",
-            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads, g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[8]);
 }
 
 // no batch may be in flight (entry points that read or change what the batches in flight work on)
@@ -2030,7 +2036,9 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     for (uint64_t r = 0; r < n_reads; ++r) j.kmers += seq_len[r] >= ctx->m.db.k ? seq_len[r] - ctx->m.db.k + 1 : 0;
     uint64_t in_flight_kmers = 0;  // what the batches in flight may still add: the host's count of the set lags behind them
     for (const RleJob &q : ctx->rle) if (q.busy && &q != &j && q.sparse) in_flight_kmers += q.kmers;
+    const double t_g0 = g_rle_times ? rle_now() : 0.0;
     KU_TRY(sparse_reserve_global(ctx, j.kmers + in_flight_kmers + sp.n_carry_l, s));
+    if (g_rle_times) g_rle_t[9] += rle_now() - t_g0;
     sf.g_key = sp.dev.g_key;
     sf.g_mask = sp.dev.g_mask;
     sf.g_count = sp.dev.g_count;
@@ -2225,12 +2233,38 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
     std::vector<uint32_t> flagged;
     std::vector<uint8_t> flag_all;
     const bool carry_stays_open = j.cont_carry && j.n_units == 1 && j.open_after;
+    // The flags are from when the batch's kernels ran -- with several batches in flight, before the exact pass of a batch AHEAD
+    // of this one turned dense the very sketch that flags these units (the first units of a run: taxon 0's; without this, every
+    // unit of the two batches behind went through the exact evaluation for nothing, 25-75 ms per 10 M reads).  Sketches only ever
+    // turn dense, so flagging once more with the state as it is now can only take flags away; the counts are complete (the
+    // batch's event), the state is at rest (exact passes end synchronised), and a stream of its own does not queue behind the
+    // kernels of the batches in flight.
+    bool any_flag = false;
+    for (uint32_t u = 0; u < j.n_units; ++u) any_flag |= !(u + 1 == j.n_units && j.open_after) && h_flag[u];
+    const double t_rf0 = g_rle_times ? rle_now() : 0.0;
+    if (any_flag && !getenv("KU_NO_REFLAG")) {  // (test hook: the flags as the kernels left them)
+      hipStream_t fs = ctx->d2h_stream;
+      const size_t fb = ((size_t)j.n_units + 3) & ~(size_t)3;
+      HIP_TRY(hipMemsetAsync(j.u_flag.p, 0, fb, fs));
+      KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)j.u_cnt.p, (uint64_t)j.n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
+                                         (uint8_t *)j.u_flag.p, fs));
+      HIP_TRY(hipMemcpyAsync((uint8_t *)j.pin.p + 64, j.u_flag.p, j.n_units, hipMemcpyDeviceToHost, fs));
+      HIP_TRY(hipStreamSynchronize(fs));
+    }
     for (uint32_t u = 0; u < j.n_units; ++u) {
       const bool open = u + 1 == j.n_units && j.open_after;
       if (u == 0 && j.cont_carry) { flagged.push_back(u); flag_all.push_back(1); }
       else if (!open && h_flag[u]) { flagged.push_back(u); flag_all.push_back(0); }
     }
+    const double t_ex0 = g_rle_times ? rle_now() : 0.0;
+    if (g_rle_times) g_rle_x[0] += t_ex0 - t_rf0;
     if (!flagged.empty()) KU_TRY(sparse_fast_exact(ctx, j, flagged, flag_all, carry_stays_open, s));
+    if (g_rle_times && !flagged.empty()) {
+      g_rle_x[1] += rle_now() - t_ex0;
+      g_rle_x[2] += 1;
+      g_rle_x[3] += (double)flagged.size();
+      for (uint32_t u : flagged) g_rle_x[4] += (double)(j.unit_first_read[u + 1] - j.unit_first_read[u]);
+    }
   }
   return KU_OK;
 }
@@ -2315,6 +2349,54 @@ extern "C" int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint
     }
   }
   if (sparse && ctx->sp.tail_row.reserve((size_t)ctx->tax.n_slots * 4)) return fail(KU_ENOMEM, "device memory for the work-unit counters");
+  // One read through the whole path, count-less (no state changes): the fused kernel's code object is loaded, the copy streams get
+  // their queues, the events exist -- here rather than under the caller's first batch, whose enqueue took 22 ms of a 10 M-read
+  // `classify` run's 0.19 s window (profiles/r05_e2e_sweep.log, the pipeline trace).  Failure is harmless.
+  if (!getenv("KU_NO_WARMUP")) {
+    // A dozen batches of the caller's size class through the whole path, count-less (no state changes), three in flight, from and
+    // into page-locked memory like the executable's.  What a run's first batches otherwise pay for, as the pipeline trace of
+    // `classify` showed it one by one (profiles/r05_e2e_sweep.log): the fused kernel's code object; the copy streams' queues (the
+    // first copy of some hundred KB from the device into page-locked memory on a stream: 23.5 ms -- 4-byte copies go another
+    // way); each job's events and scratch; scratch memory for the counting instances (they spill a few bytes per lane); and a
+    // 13 ms ioctl of the runtime's under the first enqueue that follows a finished batch.  Failure is harmless.
+    (void)ku_launch_warm_scratch(ctx->n_cu, ctx->stream);
+    const uint64_t wn = (std::min<uint64_t>(std::max<uint64_t>(n_reads, 1), 65536) + 1) & ~1ull, stride = 101;  // (even: the arrays behind stay 8-byte aligned)
+    const size_t per_slot = (size_t)wn * (4 + 4 + 4 + 8) + (size_t)wn * 8 * 8;
+    PinBuf w;
+    if (w.reserve((size_t)wn * (stride + 12) + KU_RLE_MAX_IN_FLIGHT * per_slot + 4096) == 0) {
+      memset(w.p, 0, w.cap);
+      char *text = (char *)w.p;
+      uint64_t *w_off = (uint64_t *)(text + ((wn * stride + 63) & ~63ull));
+      uint32_t *w_len = (uint32_t *)(w_off + wn);
+      char *slots = (char *)(w_len + wn);
+      for (uint64_t r = 0; r < wn; ++r) {
+        char *t = text + r * stride;
+        for (int i = 0; i < 100; ++i) t[i] = "ACGTTGCAAGCTTCGA"[(i * 7 + i / 16 + r) & 15];
+        t[100] = '\n';
+        w_off[r] = r * stride;
+        w_len[r] = 100;
+      }
+      const ku_opts wo = {KU_F_NO_COUNTS, 1, 100, 0};
+      uint64_t w_runs = 0;
+      int flying = 0;
+      for (int rep = 0; rep < 12; ++rep) {
+        if (flying == 3) { (void)ku_classify_batch_rle_finish(ctx, &w_runs); --flying; }
+        char *sl = slots + (size_t)(rep % KU_RLE_MAX_IN_FLIGHT) * per_slot;
+        uint64_t *roff = (uint64_t *)sl;
+        uint32_t *calls = (uint32_t *)(roff + wn), *hits = calls + wn, *rcnt = hits + wn;
+        ku_run *runs = (ku_run *)(rcnt + wn);
+        if (ku_classify_batch_rle_enqueue(ctx, text, wn * stride, w_off, w_len, wn, &wo, calls, hits, roff, rcnt, runs, wn * 8) == KU_OK) ++flying;
+      }
+      while (flying-- > 0) (void)ku_classify_batch_rle_finish(ctx, &w_runs);
+      if (ctx->fetch_stream) {  // (ku_fetch_runs' stream)
+        (void)hipMemcpyAsync(w.p, ctx->rle[0].seqs.p, std::min<size_t>(ctx->rle[0].seqs.cap, 1u << 20), hipMemcpyDeviceToHost, ctx->fetch_stream);
+        (void)hipStreamSynchronize(ctx->fetch_stream);
+      }
+      (void)hipDeviceSynchronize();
+      w.release();
+    }
+    (void)hipGetLastError();
+  }
   return KU_OK;
 }
 

@@ -123,6 +123,7 @@ int ku_launch_sparse_export(const KuSparseDev &s, unsigned long long *d_out, uin
                             hipStream_t stream);
 // the SEEN marks of a probe table (ku_device.h): what = 0 count (entries of slots that are not dense), 1 insert them into the
 // run-wide set, 2 clear all marks
+int ku_launch_warm_scratch(int n_cu, hipStream_t stream);  // (a scratch-using kernel over every wave slot: see ku_sparse.hip)
 int ku_launch_seen(int what, void *d_table, uint64_t n_lines, const KuSparseDev &s, unsigned long long *d_count, hipStream_t stream);
 
 // clade roll-up of the report (ku_report.hip): histograms of KU_ROLLUP_BINS bins per clade

@@ -82,6 +82,7 @@ struct Batch {
   bool fastq = false;
   bool first_of_file = false;  // the batch opens an input file (the reference's work units do not span files)
   uint64_t nt = 0;
+  double trace[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // KU_CLI_TRACE=1: when the batch reached each step of classify's pipeline
   ku_batch *dev = nullptr;    // -x runs: the batch stays on the device across the chunk passes
   bool pinned = true;         // page-locked buffers for the copies to the device; false: plain host memory
   void *alloc_bytes(size_t n) {

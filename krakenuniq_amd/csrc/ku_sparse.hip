@@ -505,3 +505,19 @@ int ku_launch_seen(int what, void *d_table, uint64_t n_lines, const KuSparseDev 
   else hipLaunchKernelGGL(ku_seen_kernel<2>, grid, block, 0, stream, (uint32_t *)d_table, n_lines, s, d_count);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
+
+// Warm-up aid (ku_classify_batch_rle_reserve): a kernel that needs scratch memory, over the whole device.  The instances of the
+// fused kernel that count spill 8-12 bytes per lane; the first dispatch on a queue that needs scratch makes the runtime allocate
+// it for every wave slot of the device -- ~20 ms, which used to fall under the first batch of a run.  128 bytes per lane here, so
+// that whichever instance follows finds enough.
+__global__ __launch_bounds__(64) void ku_warm_scratch_kernel(uint32_t *out, uint32_t n) {
+  volatile uint32_t a[32];
+  for (uint32_t i = 0; i < 32; ++i) a[i] = i * n + threadIdx.x;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < 32; ++i) sum += a[(i * 7 + n) & 31];
+  if (n == 0xFFFFFFFFu && out) out[0] = sum;  // (never: the caller passes n = 1)
+}
+int ku_launch_warm_scratch(int n_cu, hipStream_t stream) {
+  hipLaunchKernelGGL(ku_warm_scratch_kernel, dim3((unsigned)(n_cu > 0 ? n_cu : 256) * 32), dim3(64), 0, stream, (uint32_t *)nullptr, 1u);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}

@@ -100,7 +100,7 @@ def main():
                         f"{cs1.get('nr_throttled', 0) - cs0.get('nr_throttled', 0)} periods, {(cs1.get('throttled_usec', cs1.get('throttled_time', 0)) - cs0.get('throttled_usec', cs0.get('throttled_time', 0))) / 1e6:.3f}s")
             err = r.stderr.decode(errors="replace").replace("\r", "\n").split("\n")
             keep = [l.strip()[:520] for l in err if any(w in l for w in ("processed in", "stage busy", "Report finished", "ku_ctx_report:",
-                                                                        "ku_classify_batch_rle over", "cpu seconds", "error", "Error"))]
+                                                                        "ku_classify_batch_rle over", "ku_classify_batch_rle, behind", "rle_first:", "stacks:", "trace:", "cpu seconds", "error", "Error"))]
             print(f"== {label} rep {rep} rc {r.returncode} wall {wall:.2f}s  {cpu_line}")
             print("\n".join("   " + l for l in keep), flush=True)
             if r.returncode != 0:
