@@ -566,6 +566,10 @@ class Ctx:
     def rle_in_flight(self):
         return lib().ku_classify_batch_rle_in_flight(self.h)
 
+    def rle_reserve(self, n_bytes, n_reads, max_read_len, n_jobs=4):
+        """ku_classify_batch_rle_reserve: buffers for n_jobs batches + the warm-up (count-less synthetic batches)"""
+        _chk(lib().ku_classify_batch_rle_reserve(self.h, n_bytes, n_reads, max_read_len, n_jobs), "ku_classify_batch_rle_reserve")
+
     def classify_batch_device(self, d_seqs, n_bytes, d_off, d_len, n_reads, d_calls, d_taxa, d_hits=None, flags=0,
                               min_hits=1, max_read_len=0, stream=None):
         o = Opts(flags, min_hits, max_read_len, 0)

@@ -2360,6 +2360,11 @@ extern "C" int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint
     // way); each job's events and scratch; scratch memory for the counting instances (they spill a few bytes per lane); and a
     // 13 ms ioctl of the runtime's under the first enqueue that follows a finished batch.  Failure is harmless.
     (void)ku_launch_warm_scratch(ctx->n_cu, ctx->stream);
+    double keep_t[10], keep_x[6];  // (KU_RLE_TIMES: the warm-up's batches are none of the caller's)
+    memcpy(keep_t, g_rle_t, sizeof keep_t);
+    memcpy(keep_x, g_rle_x, sizeof keep_x);
+    const double keep_ms = g_rle_kernel_ms;
+    const unsigned long long keep_reads = g_rle_reads;
     const uint64_t wn = (std::min<uint64_t>(std::max<uint64_t>(n_reads, 1), 65536) + 1) & ~1ull, stride = 101;  // (even: the arrays behind stay 8-byte aligned)
     const size_t per_slot = (size_t)wn * (4 + 4 + 4 + 8) + (size_t)wn * 8 * 8;
     PinBuf w;
@@ -2396,6 +2401,10 @@ extern "C" int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint
       w.release();
     }
     (void)hipGetLastError();
+    memcpy(g_rle_t, keep_t, sizeof keep_t);
+    memcpy(g_rle_x, keep_x, sizeof keep_x);
+    g_rle_kernel_ms = keep_ms;
+    g_rle_reads = keep_reads;
   }
   return KU_OK;
 }

@@ -155,3 +155,31 @@ def test_what_cannot_be_in_flight_is_refused():
     want = ctx.classify_batch_rle(buf, off, lens)
     assert np.array_equal(want["calls"], r1["calls"])
     assert capi.format_kraken_rle(buf, off, lens, ids[:300], K, r2) == capi.format_kraken_rle(buf, off, lens, ids[:300], K, want)
+
+
+def test_reserve_and_its_warm_up_change_nothing(monkeypatch):
+    """ku_classify_batch_rle_reserve sends synthetic batches through the path (count-less) so that the first real batch finds
+    the runtime set up: the run's state -- counts, registers, the emulation's sets, the table's marks -- is as without it; and the
+    flags the emulation takes again at _finish (the state may have moved on since the kernels ran) only ever spare work:
+    KU_NO_REFLAG=1 gives the same result"""
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    cuts = split_points(len(seqs), 11, 3)
+    states = []
+    for variant in ("plain", "reserve", "no_reflag"):
+        if variant == "no_reflag":
+            monkeypatch.setenv("KU_NO_REFLAG", "1")
+        ctx, cdb, ctax = gc.make_ctx(F1)
+        ctx.enable_sparse(1000)
+        if variant != "plain":
+            ctx.rle_reserve(len(buf) // 4, len(seqs) // 4, int(lens.max()), 4)
+            c0 = ctx.counts()
+            assert not c0["n_reads"].any() and not c0["n_kmers"].any() and not c0["registers"].any()
+        res = run_two_step(ctx, buf, off, lens, cuts, depth=3)
+        assert kraken_text(buf, off, lens, ids, cuts, res) == open(f"{F1}/out.tsv").read()
+        text = ctx.report(ctax, [f"{F1}/database.kdb.counts"])
+        assert rows(text) == rows(open(f"{F1}/report_u1000.tsv").read())
+        c = ctx.counts()
+        states.append((text, c["n_reads"].copy(), c["n_kmers"].copy(), c["registers"].copy()))
+    for t, a, b, r in states[1:]:
+        assert t == states[0][0] and np.array_equal(a, states[0][1]) and np.array_equal(b, states[0][2]) and np.array_equal(r, states[0][3])
