@@ -395,7 +395,17 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
                               "bookkeeping), as the executable launches it: one launch per batch of ~120 k reads",
                               "kernel_ms": round(k_ms, 3), "launch_ms_source": "HIP events around every batch's kernels on their stream, summed "
                               "(KU_RLE_TIMES; includes the per-batch flag kernel)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(algo_bytes0), "traffic": None}
+                              "frac": round(ach / HBM_PEAK_GBS, 5), "frac_model": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(algo_bytes0),
+                              "traffic": None, "frac_hw": None}
+                    try:  # counter-measured HBM bytes of this instance over a 10 M-read run of the executable (scripts/summarize_cli_pmc.py)
+                        tj = json.load(open(os.path.join(ROOT, "profiles", "lookup_traffic.json")))
+                        ent = tj.get("cli", {}).get("report") if tj.get("kernel_rev") == capi.kernel_rev() else None
+                        if ent and ent.get("reads") == n_e:
+                            rf_rep["traffic"] = ent["hbm_bytes_per_run"]
+                            rf_rep["frac_hw"] = round(ent["hbm_bytes_per_run"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                            rf_rep["traffic_source"] = ent["source"]
+                    except (OSError, ValueError, KeyError):
+                        pass
                 got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
                 n_rows = sum(1 for _ in open(f"{tmp}/report.tsv"))
                 out["e2e"]["with_report"] = {

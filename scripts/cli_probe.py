@@ -5,7 +5,8 @@ table per run.
 
   python scripts/cli_probe.py <species> <reads> <out_tag> VARIANT [VARIANT ...]
   VARIANT = label[:key=value[,key=value...]]      keys: any environment variable, or
-            REPORT=1 (add -r), PROF=1 (run under rocprofv3 --kernel-trace --stats), CPULIST=0-31 (taskset), LIB=<dir> (a directory that holds another
+            REPORT=1 (add -r), PROF=1 (run under rocprofv3 --kernel-trace --stats), PMC=<counter> (run under rocprofv3 --pmc <counter>, the
+            fused kernel's launches only: their sum goes to gpurun_out/<out_tag>_<label>_pmc.json), CPULIST=0-31 (taskset), LIB=<dir> (a directory that holds another
             build of libkrakenuniq_amd.so, e.g. krakenuniq_amd/variants/abl), THREADS=n, REPEAT=n, GZ=1 (.gz input)
 Prints one block per variant; kernel tables go to gpurun_out/<out_tag>_<label>_kernel_stats.csv."""
 import csv, glob, os, resource, shutil, subprocess, sys, time
@@ -61,11 +62,13 @@ def main():
         label, _, kvs = var.partition(":")
         env = dict(os.environ, KU_CLI_TIMES="1", KU_REPORT_TIMES="1")
         report = prof = gz = False
+        pmc = None
         threads, repeat, cpulist = "16", 1, None
         for kv in [x for x in kvs.split(",") if x]:
             k, v = kv.split("=", 1)
             if k == "REPORT": report = v != "0"
             elif k == "PROF": prof = v != "0"
+            elif k == "PMC": pmc = v
             elif k == "GZ": gz = v != "0"
             elif k == "THREADS": threads = v
             elif k == "REPEAT": repeat = int(v)
@@ -91,6 +94,9 @@ def main():
             if prof:
                 shutil.rmtree(pdir, ignore_errors=True)
                 cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", pdir, "--"] + cmd
+            if pmc:
+                shutil.rmtree(pdir, ignore_errors=True)
+                cmd = ["rocprofv3", "--pmc", pmc, "--kernel-include-regex", "ku_classify_short_kernel", "--output-format", "csv", "-d", pdir, "--"] + cmd
             t = time.time()
             ru0, cs0 = resource.getrusage(resource.RUSAGE_CHILDREN), cpu_stat()
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd="/tmp")
@@ -105,6 +111,20 @@ def main():
             print("\n".join("   " + l for l in keep), flush=True)
             if r.returncode != 0:
                 print("\n".join(err[-12:]))
+            if pmc:
+                import json
+                tot = {}
+                for f in glob.glob(f"{pdir}/**/*counter_collection.csv", recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row["Counter_Name"] != pmc or "ku_classify_short_kernel" not in row["Kernel_Name"]:
+                            continue
+                        kn = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                        e = tot.setdefault(kn, {"sum": 0.0, "launches": 0})
+                        e["sum"] += float(row["Counter_Value"])
+                        e["launches"] += 1
+                json.dump({"counter": pmc, "reads": n_reads, "report": report, "kernels": tot}, open(f"{out_dir}/{tag}_{label}_pmc.json", "w"), indent=1)
+                print("   " + pmc + ": " + "; ".join(f"{k}: {v['sum']:.4g} over {v['launches']} launches" for k, v in tot.items()))
+                shutil.rmtree(pdir, ignore_errors=True)
             if prof:
                 files = [f for f in glob.glob(f"{pdir}/**/*kernel_stats.csv", recursive=True) if "ku_" in open(f).read()]
                 if files:
