@@ -610,32 +610,32 @@ int main(int argc, char **argv) {
   if (print_cls && !s_cls.open(cls_out)) die(EX_OSERR, "can't open %s", cls_out.c_str());
   if (print_ucls && !s_ucls.open(ucls_out)) die(EX_OSERR, "can't open %s", ucls_out.c_str());
 
-  struct FmtTeam {  // the helpers: run(job) calls job(t) on every member and returns when all are done
-    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
-    uint64_t gen = 0; int pending = 0; bool quit = false; std::function<void(int)> job;
+  struct FmtTeam {  // the helpers: they take tasks -- a slice of a batch each -- from one queue, across batches (a team that ran
+                    // one batch at a time behind a barrier was busy 0.63 ms of every 0.93: the batch waited for its slowest slice)
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv;
+    std::deque<std::function<void()>> tasks; bool quit = false;
     void start(int n) {
-      for (int t = 0; t < n; ++t) th.emplace_back([this, t] {
+      for (int t = 0; t < n; ++t) th.emplace_back([this] {
         prctl(PR_SET_NAME, "ku-fmt");
         // (the member's part of the heap, touched once: its first buffers for formatted lines -- ~1 MB each -- then come without
         // page faults; sixteen members faulting 12 MB in while the parser team maps the input made the first batch's
         // formatting take 6-19 ms instead of 1.4)
         if (void *w = malloc((size_t)3 << 20)) { memset(w, 1, (size_t)3 << 20); free(w); }
-        uint64_t seen = 0;
         for (;;) {
-          std::function<void(int)> j;
-          { std::unique_lock<std::mutex> l(m); cv_go.wait(l, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; j = job; }
-          j(t);
-          { std::lock_guard<std::mutex> l(m); if (--pending == 0) cv_done.notify_one(); }
+          std::function<void()> task;
+          {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return quit || !tasks.empty(); });
+            if (tasks.empty()) return;  // (quit, and nothing left)
+            task = std::move(tasks.front());
+            tasks.pop_front();
+          }
+          task();
         }
       });
     }
-    void run(const std::function<void(int)> &j) {
-      std::unique_lock<std::mutex> l(m);
-      job = j; pending = (int)th.size(); ++gen;
-      cv_go.notify_all();
-      cv_done.wait(l, [&] { return pending == 0; });
-    }
-    void stop() { { std::lock_guard<std::mutex> l(m); quit = true; } cv_go.notify_all(); for (auto &x : th) x.join(); th.clear(); }
+    void submit(std::function<void()> f) { { std::lock_guard<std::mutex> l(m); tasks.push_back(std::move(f)); } cv.notify_one(); }
+    void stop() { { std::lock_guard<std::mutex> l(m); quit = true; } cv.notify_all(); for (auto &x : th) x.join(); th.clear(); }
   } fmt_team;
   if (print_kraken) fmt_team.start(fmt_threads);  // (ahead of the timing window, like the batch pool)
   unsigned long long total_sequences = 0, total_classified = 0, total_bases = 0;
@@ -961,11 +961,19 @@ int main(int argc, char **argv) {
     parsed_q.push(nullptr);
   });
 
-  // Output stage in two steps that overlap: the formatter formats the Kraken lines of batch b + 1 (a standing team of
-  // `fmt_threads` helpers, disjoint read ranges) while the writer writes those of batch b, in input order.  (One thread
-  // doing both, with a team spawned per batch, was the slowest stage of the pipeline: 16 thread starts and a serial
-  // 12 MB write per batch.)
-  struct Formatted { Batch *bt; std::vector<char *> parts; std::vector<size_t> len; std::vector<uLong> crc; std::vector<size_t> raw; };
+  // Output stage in two steps that overlap: the formatting helpers (a standing team of `fmt_threads`) take slices of the
+  // finished batches from one queue -- `fmt_threads` slices per batch, disjoint read ranges, across batch borders -- while the
+  // writer writes the batches in input order, each as soon as its slices are through.  (One thread doing both, with a team
+  // spawned per batch, was the slowest stage of the pipeline in round 1: 16 thread starts and a serial 12 MB write per batch;
+  // a team behind a barrier per batch left its members idle a third of the time in round 5.)
+  struct Formatted {
+    Batch *bt; std::vector<char *> parts; std::vector<size_t> len; std::vector<uLong> crc; std::vector<size_t> raw;
+    std::vector<double> t_end;     // when each slice was done (the writer takes the latest for the trace)
+    std::atomic<int> pending{0};   // slices still being formatted: the writer waits for 0 (fmt_done_cv)
+    double t0 = 0;
+  };
+  std::mutex fmt_done_mu;
+  std::condition_variable fmt_done_cv;
   struct FQueue {
     std::mutex m; std::condition_variable cv; std::deque<Formatted *> q;
     void push(Formatted *f) { { std::lock_guard<std::mutex> l(m); q.push_back(f); } cv.notify_one(); }
@@ -977,39 +985,45 @@ int main(int argc, char **argv) {
       Batch *bt = done_q.pop();
       if (!bt) break;
       const uint64_t n = bt->off.size();
-      const double t_fmt = now_s();
-      Formatted *f = new Formatted{bt, std::vector<char *>(fmt_threads, nullptr), std::vector<size_t>(fmt_threads, 0),
-                                   std::vector<uLong>(fmt_threads, 0), std::vector<size_t>(fmt_threads, 0)};
-      if (print_kraken) {
-        std::vector<int> status(fmt_threads, KU_OK);
-        fmt_team.run([&](int t) {
-          const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
-          if (hi <= lo) return;
-          const double cpu0 = thread_cpu_s();
-          struct Acc { std::function<void()> f; ~Acc() { f(); } } acc_{[&] { cpu_add(cpu_format, cpu0); }};
-          status[t] = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo,
-                                           bt->ids.data() + bt->idoff[lo], info.k, bt->calls.data() + lo, bt->runs,
-                                           bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
-                                           pflags, &f->parts[t], &f->len[t]);
-          if (status[t] == KU_OK && !bt->crlf_read.empty() && pflags == 0)  // KU_CRLF_REFERENCE=1: the reference's lines for such reads
-            f->parts[t] = rewrite_crlf_lines(*bt, lo, hi, info.k, f->parts[t], &f->len[t]);
-          if (status[t] == KU_OK && s_kraken.pgz && f->len[t]) {  // -o x.gz: the helper deflates its own lines
-            size_t cl = 0;
-            unsigned char *c = ku_pgzout::deflate_part(f->parts[t], f->len[t], &cl, &f->crc[t]);
-            if (!c) { status[t] = KU_ENOMEM; return; }
-            ku_free(f->parts[t]);
-            f->parts[t] = (char *)c;  // (malloc'ed like the text: the writer frees either the same way)
-            f->raw[t] = f->len[t];
-            f->len[t] = cl;
+      Formatted *f = new Formatted;
+      f->bt = bt;
+      f->parts.assign(fmt_threads, nullptr); f->len.assign(fmt_threads, 0); f->crc.assign(fmt_threads, 0); f->raw.assign(fmt_threads, 0);
+      f->t_end.assign(fmt_threads, 0.0);
+      f->t0 = now_s();
+      f->pending.store(print_kraken ? fmt_threads : 0);
+      write_q.push(f);  // (in batch order; the writer waits until the batch's slices are through)
+      if (!print_kraken) continue;
+      for (int t = 0; t < fmt_threads; ++t)
+        fmt_team.submit([&, f, bt, n, t] {
+          {
+            const uint64_t lo = n * t / fmt_threads, hi = n * (t + 1) / fmt_threads;
+            const double cpu0 = thread_cpu_s();
+            int status = KU_OK;
+            if (hi > lo) {
+              status = ku_format_kraken_rle(bt->seqs, bt->off.data() + lo, bt->len.data() + lo, hi - lo, bt->ids.data() + bt->idoff[lo], info.k,
+                                            bt->calls.data() + lo, bt->runs, bt->run_off.data() + lo, bt->run_cnt.data() + lo, bt->hits.data() + lo,
+                                            pflags, &f->parts[t], &f->len[t]);
+              if (status == KU_OK && !bt->crlf_read.empty() && pflags == 0)  // KU_CRLF_REFERENCE=1: the reference's lines for such reads
+                f->parts[t] = rewrite_crlf_lines(*bt, lo, hi, info.k, f->parts[t], &f->len[t]);
+              if (status == KU_OK && s_kraken.pgz && f->len[t]) {  // -o x.gz: the helper deflates its own lines
+                size_t cl = 0;
+                unsigned char *c = ku_pgzout::deflate_part(f->parts[t], f->len[t], &cl, &f->crc[t]);
+                if (!c) status = KU_ENOMEM;
+                else {
+                  ku_free(f->parts[t]);
+                  f->parts[t] = (char *)c;  // (malloc'ed like the text: the writer frees either the same way)
+                  f->raw[t] = f->len[t];
+                  f->len[t] = cl;
+                }
+              }
+            }
+            if (status != KU_OK) die(exit_code_of(status), "%s", ku_strerror(status));
+            cpu_add(cpu_format, cpu0);
+            f->t_end[t] = now_s();
           }
+          // (nothing of f or bt is touched behind this line: the writer may take them the moment the count reaches 0)
+          if (f->pending.fetch_sub(1) == 1) { { std::lock_guard<std::mutex> l(fmt_done_mu); } fmt_done_cv.notify_all(); }
         });
-        for (int t = 0; t < fmt_threads; ++t)
-          if (status[t] != KU_OK) die(exit_code_of(status[t]), "%s", ku_strerror(status[t]));
-      }
-      bt->trace[6] = t_fmt;
-      bt->trace[7] = now_s();
-      busy_format += bt->trace[7] - t_fmt;
-      write_q.push(f);
     }
     write_q.push(nullptr);
   });
@@ -1019,7 +1033,15 @@ int main(int argc, char **argv) {
     for (;;) {
       Formatted *f = write_q.pop();
       if (!f) { cpu_add(cpu_write, cpu0); break; }
+      if (f->pending.load() != 0) {
+        std::unique_lock<std::mutex> l(fmt_done_mu);
+        fmt_done_cv.wait(l, [&] { return f->pending.load() == 0; });
+      }
       Batch *bt = f->bt;
+      bt->trace[6] = f->t0;
+      bt->trace[7] = f->t0;
+      for (double e : f->t_end) if (e > bt->trace[7]) bt->trace[7] = e;
+      busy_format += bt->trace[7] - f->t0;
       const uint64_t n = bt->off.size();
       const double t_write = now_s();
       // (one thread, one write after the other: ~1.2 ms per 12 MB batch into a tmpfs file, the pipeline's slowest step since round 5;
