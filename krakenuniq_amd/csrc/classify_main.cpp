@@ -1045,7 +1045,9 @@ int main(int argc, char **argv) {
       const uint64_t n = bt->off.size();
       const double t_write = now_s();
       // (one thread, one write after the other: ~1.2 ms per 12 MB batch into a tmpfs file, the pipeline's slowest step since round 5;
-      // a team of four pwrite()-ing a batch's parts side by side took 1.9 ms -- the file's pages are allocated under one lock)
+      // a team of four pwrite()-ing a batch's parts side by side took 1.9 ms -- the file's pages are allocated under one lock;
+      // a second thread allocating them ahead of the writer, fallocate(KEEP_SIZE) 32-512 MB ahead, made the writer slower
+      // as well: 0.102-0.115 s of writing per run instead of 0.086)
       for (int t = 0; t < fmt_threads; ++t)
         if (f->parts[t]) {
           if (s_kraken.pgz) s_kraken.write_deflated((const unsigned char *)f->parts[t], f->len[t], f->crc[t], f->raw[t]);
