@@ -134,6 +134,7 @@ int main(int argc, char **argv) {
       cut.region_bytes = std::max<size_t>(1, (n + (size_t)regions - 1) / (size_t)regions);
     }
     cut.fastq = growing ? gt.base[0] == '@' : (n && data[0] == '@');
+    if (const char *e = getenv("KU_REGION_RAMP")) cut.ramp = (size_t)atoi(e);  // smaller first regions, as the classify executable cuts them
     std::mutex rm;
     std::map<size_t, std::pair<ku_seqio::Batch *, size_t>> parsed;  // region -> (batch, end of the region)
     size_t first_broken = (size_t)-1;  // the stream ends inside this region: what was parsed behind it does not count

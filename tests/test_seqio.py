@@ -95,6 +95,17 @@ def test_region_parallel_parse_equals_sequential(tmp_path):
         assert dump(["-j", str(j), str(fq)])[:2] == want, j
     for fn in ("f1/reads.fq", "f2/edge.fa", "f4/merged.fa"):
         assert dump(["-j", "6", os.path.join(G, fn)])[:2] == dump([os.path.join(G, fn)])[:2], fn
+    # smaller first regions (what the classify executable does since round 5: KU_REGION_RAMP regions of a quarter, as many of half
+    # the size, then full ones): the same records in the same order -- plain, and from a one-stream .gz file whose text grows
+    # while it is cut
+    import gzip
+    gzf = tmp_path / "tricky.fq.gz"
+    gzf.write_bytes(gzip.compress(b"".join(recs), 6))
+    for ramp in (1, 3, 12, 40):
+        env = dict(os.environ, KU_REGION_RAMP=str(ramp), KU_REGION_KB="16")
+        for j in (5, 64):
+            assert dump(["-j", str(j), str(fq)], env=env)[:2] == want, (ramp, j)
+        assert dump(["-j", "4", str(gzf)], env=env)[:2] == want, ramp
     # an empty line after record 1500 ends the stream in both modes
     bad = tmp_path / "bad.fq"
     bad.write_bytes(b"".join(recs[:1500]) + b"\n" + b"".join(recs[1500:]))
