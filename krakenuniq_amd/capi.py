@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("KU_LIB") or os.path.join(_HERE, "libkrakenuniq_amd.so")  # KU_LIB: tuning experiments only
+LIB_PATH = os.environ.get("KU_LIB") or os.path.join(_HERE, "libkrakenuniq_amd.so")  # KU_LIB: tuning experiments, and the tests' -DKU_TEST_HOOKS build
 
 KU_AMBIG = 0xFFFFFFFF
 KU_HLL_M = 4096
@@ -528,7 +528,7 @@ class Ctx:
                                      stream), "ku_resolve_device")
 
     def rle_enqueue(self, buf, off, lens, flags=0, min_hits=1, runs_cap=0, out=None):
-        """First step of a batch through the two-step form of ku_classify_batch_rle (up to two batches in flight).  Returns the
+        """First step of a batch through the two-step form of ku_classify_batch_rle (up to KU_RLE_MAX_IN_FLIGHT = four batches in flight).  Returns the
         handle rle_finish() takes; the arrays stay alive with it.  out: caller-owned result arrays as for classify_batch_rle
         (page-locked ones make the copies asynchronous); out["runs"] / runs_cap: where the runs go with the other results."""
         arr = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else buf, dtype=np.uint8)

@@ -654,6 +654,8 @@ int main(int argc, char **argv) {
   // (team and pool are set up above, next to the database load)
   Queue free_q, parsed_q, done_q;
   for (auto &bt : pool) free_q.push(&bt);
+  ku_seqio::UnitGate gate;  // (reader thread only)
+  gate.unit_nt = work_unit_nt;
   const bool keep_records = print_cls || print_ucls;
   // -x runs allocate a batch per region instead of recycling a pool: the nucleotides between reader and writer are
   // bounded instead (set once the device budget is known)
@@ -761,17 +763,12 @@ int main(int argc, char **argv) {
     ku_seqio::RegionCutter cut;
     void *map = MAP_FAILED;
     const size_t n = (size_t)st.st_size;
-    // KU_REGION_READ=1: the regions are READ (pread into a buffer of the member's own) rather than parsed out of the mapping --
-    // no page-table work under the address space's locks, but a copy of every byte.  Measured on the GPU box (10 M reads,
-    // profiles/r05_e2e_sweep.log): the mapping wins (0.21 s against 0.20-0.35 s, half the parser CPU), so it stays the default.
-    static const bool region_read = getenv("KU_REGION_READ") && atoi(getenv("KU_REGION_READ"));
-    int region_fd = -1;
     if (direct) {
       int fd = ::open(path, O_RDONLY);
       if (fd < 0) return false;
       map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-      if (region_read) region_fd = fd; else ::close(fd);
-      if (map == MAP_FAILED) { if (region_fd >= 0) ::close(region_fd); return false; }
+      ::close(fd);
+      if (map == MAP_FAILED) return false;
       cut.data = (const char *)map;
       cut.n = n;
     } else {
@@ -796,9 +793,9 @@ int main(int argc, char **argv) {
     std::mutex mu;
     std::condition_variable cv;
     size_t next_out = 0;
-    bool file_start_pending = false;  // the file's first region held no bases: the next batch that goes on opens the file
-    struct Parsed { Batch *bt; bool whole; size_t hi; };
+    struct Parsed { Batch *bt; size_t lo, hi; ku_seqio::RegionParse res; };
     std::map<size_t, Parsed> ready;
+    ku_seqio::GrowingText *const gtp = direct ? nullptr : &gtext;
     auto member = [&] {
       prctl(PR_SET_NAME, "ku-parse");
       const double cpu0 = thread_cpu_s();
@@ -815,22 +812,10 @@ int main(int argc, char **argv) {
         bt->clear();
         bt->trace[0] = now_s();
         bt->fastq = fastq;
-        bt->first_of_file = lo == 0;
+        bt->first_of_file = false;  // (set where the batches go on in file order)
         bt->reserve_seq(fastq ? (hi - lo) / 2 + 4096 : hi - lo);  // one allocation: the sequences are at most that long
-        const char *region = data + lo;
-        if (direct && region_fd >= 0) {
-          static thread_local std::vector<char> rbuf;
-          if (rbuf.size() < hi - lo) rbuf.resize(hi - lo + (hi - lo) / 8);
-          size_t got = 0;
-          while (got < hi - lo) {
-            const ssize_t r = pread(region_fd, rbuf.data() + got, hi - lo - got, (off_t)(lo + got));
-            if (r <= 0) break;
-            got += (size_t)r;
-          }
-          if (got == hi - lo) region = rbuf.data();  // (a short read -- the file shrank? -- leaves the mapping to say so)
-        }
 #ifdef MADV_POPULATE_READ
-        if (direct && region == data + lo) {  // the region's pages into this process's page table with one call instead of one fault per 4 KiB (eight
+        if (direct) {  // the region's pages into this process's page table with one call instead of one fault per 4 KiB (eight
                        // threads faulting in one address space queue on its locks: a third of the team's time); failure is harmless
           static const bool populate = !(getenv("KU_NO_POPULATE") && atoi(getenv("KU_NO_POPULATE")));
           // (2 MiB per call: the call holds the address space's lock shared for as long as it runs, and a thread that wants it
@@ -843,9 +828,10 @@ int main(int argc, char **argv) {
             for (size_t a = a0; a < hi; a += step) (void)madvise((void *)(data + a), std::min(step, hi - a), MADV_POPULATE_READ);
         }
 #endif
-        const bool whole = ku_seqio::parse_region(region, hi - lo, fastq, *bt, keep_records);
+        // (the records that START in the region, each read to its end wherever that lies: ku_seqio::parse_region)
+        const ku_seqio::RegionParse res = ku_seqio::parse_region(data, n, gtp, lo, hi, fastq, *bt, keep_records);
         bt->trace[1] = now_s();
-        { std::lock_guard<std::mutex> l(mu); ready[idx] = Parsed{bt, whole, hi}; }
+        { std::lock_guard<std::mutex> l(mu); ready[idx] = Parsed{bt, lo, hi, res}; }
         cv.notify_all();
       }
     };
@@ -854,33 +840,44 @@ int main(int argc, char **argv) {
     // on the 16-CPU quota of the GPU box, 10 M reads from one gzip stream: 0.368-0.372 s with 6, 0.381-0.412 with 12)
     const int members = direct ? parse_team : std::min(parse_team, getenv("KU_PARSE_TEAM_GZ") ? std::max(1, atoi(getenv("KU_PARSE_TEAM_GZ"))) : 6);
     for (int t = 0; t < members; ++t) team.emplace_back(member);
-    for (;;) {  // forward the batches in file order
+    // The batches go on in file order.  A region counts iff the parse of the region before it stopped exactly at its start
+    // (ku_seqio::RegionChain: a region cut inside a record -- damaged FASTQ -- is parsed again from there, by this thread); the
+    // reference's "a work unit without nucleotides ends the file" is applied to work units, not to batches (ku_seqio::UnitGate).
+    ku_seqio::RegionChain chain;
+    gate.begin_file();
+    bool file_start_pending = true;  // the next batch that goes on opens the file (work units do not span files)
+    auto recycle = [&](Batch *bt) { if (chunked) { bt->release(); delete bt; } else free_q.push(bt); };
+    auto forward = [&](Batch *bt) {
+      if (bt->off.empty()) { recycle(bt); return; }
+      bt->first_of_file = file_start_pending;
+      file_start_pending = false;
+      if (chunked) inflight_add(bt->nt);
+      bt->trace[2] = now_s();
+      parsed_q.push(bt);
+    };
+    for (;;) {
       std::unique_lock<std::mutex> l(mu);
       size_t handed = 0;
       cv.wait(l, [&] { return ready.count(next_out) || (cut.finished(&handed) && next_out == handed); });
       auto it = ready.find(next_out);
       if (it == ready.end()) break;  // every region handed out and forwarded
-      Batch *bt = it->second.bt;
-      const bool whole = it->second.whole;
-      const size_t region_end = it->second.hi;
+      const Parsed p = it->second;
       ready.erase(it);
       ++next_out;
-      const bool ends = !whole || bt->nt == 0;  // malformed record, or a unit without nucleotides (src/classify.cpp:522-523)
       l.unlock();
-      if (ends) { cut.halt(); if (!direct) gtext.cancel(); }
-      else if (!direct) gtext.release_before(region_end);  // (its sequences are in the batch: the text's pages go back)
-      if (bt->nt == 0) {
-        file_start_pending |= bt->first_of_file;
-        if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
-      } else {
-        bt->first_of_file |= file_start_pending;
-        file_start_pending = false;
-        if (chunked) inflight_add(bt->nt);
-        bt->trace[2] = now_s();
-        parsed_q.push(bt);
+      switch (chain.judge(p.lo, p.hi, p.res)) {
+        case ku_seqio::RegionChain::REPARSE:
+          p.bt->clear();
+          chain.accept(ku_seqio::parse_region(data, n, gtp, chain.expect, p.hi, fastq, *p.bt, keep_records));
+          gate.push(p.bt, forward, recycle);
+          break;
+        case ku_seqio::RegionChain::ACCEPT: gate.push(p.bt, forward, recycle); break;
+        case ku_seqio::RegionChain::SKIP: recycle(p.bt); break;
       }
-      if (ends) break;
+      if (chain.ended) { cut.halt(); if (!direct) gtext.cancel(); break; }  // malformed record / end of the file: nothing behind it counts
+      if (!direct) gtext.release_before(std::min(p.hi, chain.expect));  // (its sequences are in the batch: the text's pages go back)
     }
+    gate.finish(forward, recycle);
     for (auto &t : team) t.join();
     {  // batches parsed behind the end of the stream are dropped
       std::lock_guard<std::mutex> l(mu);
@@ -888,7 +885,7 @@ int main(int argc, char **argv) {
     }
     // (the mapping is taken down behind the timing window: unmapping 3 GB of populated pages took the reader 30 ms AFTER the last
     // line was written -- giving memory back is no part of classifying, as for the pool below)
-    if (direct) { input_maps.emplace_back(map, n); if (region_fd >= 0) ::close(region_fd); }
+    if (direct) input_maps.emplace_back(map, n);
     else {
       gz.close();
       // damage of the compressed file (a parser that stopped early cancels the producer: that leaves no error behind)
@@ -909,13 +906,21 @@ int main(int argc, char **argv) {
       Reader rd, rd2;
       rd.open(argv[fi], /*prefetch=*/true);
       if (paired) rd2.open(argv[fi + 1], /*prefetch=*/true);
-      bool more = true, first = true;
+      bool more = true, file_start_pending = true;
+      gate.begin_file();
+      auto recycle = [&](Batch *b) { if (chunked) { b->release(); delete b; } else free_q.push(b); };
+      auto forward = [&](Batch *b) {
+        if (b->off.empty()) { recycle(b); return; }
+        b->first_of_file = file_start_pending;
+        file_start_pending = false;
+        if (chunked) inflight_add(b->nt);
+        parsed_q.push(b);
+      };
       while (more) {
         Batch *bt = chunked ? new Batch() : free_q.pop();  // -x: every batch stays alive until the last chunk
         const double t_parse = now_s();
         bt->clear();
-        bt->first_of_file = first;
-        first = false;
+        bt->first_of_file = false;
         bt->fastq = paired ? false : rd.fastq;  // mate pairs travel as merged FASTA records (read_merger.pl:187-197)
         while (bt->nt < unit_nt) {
           size_t n1 = 0, n2 = 0, lo, hi;
@@ -951,13 +956,9 @@ int main(int argc, char **argv) {
           add_record_meta(bt, header, 0, header.size(), quals);
         }
         busy_reader += now_s() - t_parse;
-        if (bt->nt == 0) {  // a unit without nucleotides ends processing (src/classify.cpp:522-523)
-          if (chunked) { bt->release(); delete bt; } else free_q.push(bt);
-          break;
-        }
-        if (chunked) inflight_add(bt->nt);
-        parsed_q.push(bt);
+        gate.push(bt, forward, recycle);
       }
+      gate.finish(forward, recycle);  // a work unit without nucleotides ends the file, its reads are dropped (src/classify.cpp:522-523)
       rd.close();
       rd2.close();
     }

@@ -1807,6 +1807,11 @@ static int sparse_fast_exact(ku_ctx *ctx, RleJob &j, const std::vector<uint32_t>
   const uint32_t *h_len = j.h_len;
   const std::vector<uint64_t> &unit_first_read = j.unit_first_read;
   const uint32_t *d_u_cnt = (const uint32_t *)j.u_cnt.p;
+  // the batch's runs: its own run array -- or, when that overflowed, the context's buffers, where rle_job_finish's redo (per-k-mer
+  // codes + ku_rle_kernel, whose bound cannot overflow) left them; counts, SEEN marks and u_cnt are the fused kernel's either way
+  const void *d_runs = j.runs_in_ctx ? ctx->b_runs.p : j.runs.p;
+  const uint64_t *d_roff = (const uint64_t *)(j.runs_in_ctx ? ctx->b_roff.p : j.roff.p);
+  const uint32_t *d_rcnt = (const uint32_t *)(j.runs_in_ctx ? ctx->b_rcnt.p : j.rcnt.p);
   // unit 0 continues a unit in tail form: its earlier reads are evaluated with it, and come first in the position space
   const bool with_tail = j.cont_tail && !flagged.empty() && flagged[0] == 0 && !j.tail_len.empty();
   const uint64_t tail_bytes = with_tail ? j.tail_text.size() : 0;
@@ -1847,8 +1852,8 @@ static int sparse_fast_exact(ku_ctx *ctx, RleJob &j, const std::vector<uint32_t>
     if (n_list) HIP_TRY(hipMemcpyAsync(sp.list.p, list.data(), n_list * 12, hipMemcpyHostToDevice, s));
     const uint32_t *dl = (const uint32_t *)sp.list.p;
     KU_TRY(ku_launch_sparse_insert_runs(d, ctx->m.db.k, (const uint8_t *)j.seqs.p, (const uint64_t *)j.off.p, (const uint32_t *)j.len.p,
-                                        dl, dl + n_list, dl + 2 * n_list, n_list, j.runs.p, (const uint64_t *)j.roff.p,
-                                        (const uint32_t *)j.rcnt.p, ctx->d_slot_taxid, ctx->tax.n_slots, d_u_cnt, ctx->n_cu, s, pos_base));
+                                        dl, dl + n_list, dl + 2 * n_list, n_list, d_runs, d_roff, d_rcnt, ctx->d_slot_taxid, ctx->tax.n_slots,
+                                        d_u_cnt, ctx->n_cu, s, pos_base));
     const uint32_t n_local = (uint32_t)(end - at);
     // (a unit in the staged form may hold k-mers of a staged batch, which marks nothing in the probe table: its entries all
     // go into the set; the fast path's own units only contribute their misses)
@@ -1940,6 +1945,11 @@ extern "C" int ku_classify_batch_device_rle(ku_ctx *ctx, const void *d_seqs, uin
   ro.chunk = rle_chunk(n_reads, waves);
   ro.run_off = d_run_off;
   ro.run_cnt = d_run_cnt;
+  // every wave owns its first chunk, the counter starts behind those (as in rle_job_enqueue: no claim storm at the launch's start)
+  if (waves * ro.chunk <= runs_cap && waves * ro.chunk < (1ull << 31)) {
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_n_runs, (int)(waves * ro.chunk), 1, s));
+    ro.pre_base1 = 1;
+  }
   int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)d_seqs, n_bytes, d_seq_off, d_seq_len, n_reads, max_n, o.flags,
                                     d_calls, nullptr, nullptr, ctx->b_ws.p, ctx->b_ws.cap, ctx->n_cu, s, &ro, nullptr);
   return st == KU_OK ? KU_OK : fail(st, "fused kernel launch failed");
@@ -2227,7 +2237,6 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
   if (j.sparse && sp.on) {
     if ((uint32_t)h_tot[2]) return fail(KU_ENOMEM, "sparse-mode emulation: the run-wide set is full");
     sp.g_count = std::max<uint64_t>(sp.g_count, h_tot[1]);
-    if (j.runs_in_ctx) return fail(KU_EUNSUP, "sparse-mode emulation: a batch whose runs overflowed the run array cannot be evaluated");
     // Units the counting could not settle.  A unit that is still open behind the batch waits (tail form: it is looked at
     // when it closes, with everything it got); a unit in the staged form (it came from a staged batch) is always tracked.
     std::vector<uint32_t> flagged;
@@ -2243,7 +2252,9 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
     for (uint32_t u = 0; u < j.n_units; ++u) any_flag |= !(u + 1 == j.n_units && j.open_after) && h_flag[u];
     const double t_rf0 = g_rle_times ? rle_now() : 0.0;
     if (any_flag && !getenv("KU_NO_REFLAG")) {  // (test hook: the flags as the kernels left them)
-      hipStream_t fs = ctx->d2h_stream;
+      // (its own stream: d2h_stream holds the waits for the kernels and the copies back of the batches in flight)
+      if (!ctx->fetch_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fetch_stream, hipStreamNonBlocking));
+      hipStream_t fs = ctx->fetch_stream;
       const size_t fb = ((size_t)j.n_units + 3) & ~(size_t)3;
       HIP_TRY(hipMemsetAsync(j.u_flag.p, 0, fb, fs));
       KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)j.u_cnt.p, (uint64_t)j.n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
@@ -2272,7 +2283,8 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
 // which of the two jobs takes the next batch / is the oldest in flight
 static RleJob &rle_next_job(ku_ctx *ctx) {
   RleJob &j = ctx->rle[(ctx->rle_head + ctx->rle_in_flight) % KU_RLE_MAX_IN_FLIGHT];
-  static const int counter_at[KU_RLE_MAX_IN_FLIGHT] = {2, 20, 22, 24};  // (dwords of the context's 32 scalars nobody else uses)
+  static const int counter_at[KU_RLE_MAX_IN_FLIGHT] = {26, 20, 22, 24};  // (dwords of the context's 32 scalars nobody else uses: dword 2 is
+                                                                          // rle_and_fetch's counter, which an overflow redo launches on while batches are in flight)
   if (!j.d_counter) j.d_counter = (unsigned long long *)(ctx->d_scalar + counter_at[&j - &ctx->rle[0]]);
   return j;
 }
@@ -2492,7 +2504,7 @@ extern "C" int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs) {
   if (st == KU_ENOMEM && classified && ctx->sp.on) {
     // the emulation ran out of room behind the classification: it is given up, the run goes on (ku_ctx_sparse_state says 2)
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->d2h_stream);
+    if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     (void)hipGetLastError();
     ctx_free_sparse(ctx);
     ctx->sp.gave_up = true;

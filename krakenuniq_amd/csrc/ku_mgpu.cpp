@@ -68,8 +68,10 @@ pthread_once_t g_rccl_once = PTHREAD_ONCE_INIT;
 std::string g_rccl_err;
 
 void rccl_load() {
-  // KU_RCCL_LIB=<path>: bind that library instead (tests/rccl_shim: the peer paths between processes on a 1-GPU box;
-  // RTLD_LOCAL + the handle-first lookup of dlsym keep it apart from an RCCL the process already holds)
+#ifdef KU_TEST_HOOKS
+  // Test builds only (tests/rccl_shim/Makefile links libkrakenuniq_amd_testhooks.so with -DKU_TEST_HOOKS; the product library does
+  // not look at the variable): KU_RCCL_LIB=<path> binds that library instead -- the peer paths between processes on a 1-GPU box;
+  // RTLD_LOCAL + the handle-first lookup of dlsym keep it apart from an RCCL the process already holds
   if (const char *over = getenv("KU_RCCL_LIB")) {
     g_rccl.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
     if (!g_rccl.h) {
@@ -77,6 +79,7 @@ void rccl_load() {
       return;
     }
   }
+#endif
   for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
     if (g_rccl.h) break;
     g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -1193,9 +1196,13 @@ int rank_step_routed(ku_mgpu *m, ku_mgpu::Rank &r, int st, void *d_seqs, uint64_
   }
   // the caller's stream takes over again
   if (str[1] != s && r.ev_b) {
-    // (KU_TEST_DROP_STREAM_JOIN: a test hook -- the join is left out, i.e. the bug an asynchronous collective library exposes
+    // (KU_TEST_DROP_STREAM_JOIN, test builds only (-DKU_TEST_HOOKS): the join is left out, i.e. the bug an asynchronous collective library exposes
     // and a synchronous stand-in hides; tests/test_gpu_rccl_shim.py checks that the stand-in of round 5 makes the step fail)
+#ifdef KU_TEST_HOOKS
     static const bool drop_join = std::getenv("KU_TEST_DROP_STREAM_JOIN") != nullptr;
+#else
+    constexpr bool drop_join = false;
+#endif
     if (hipEventRecord(r.ev_b, str[1]) != hipSuccess || (!drop_join && hipStreamWaitEvent(s, r.ev_b, 0) != hipSuccess))
       st = st == KU_OK ? mfail(KU_EHIP, "stream join failed") : st;
   }

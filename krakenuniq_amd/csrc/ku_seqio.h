@@ -151,6 +151,77 @@ struct Batch {
   }
 };
 
+// ---- compressed input parsed in regions: the text of a .gz file arrives in one contiguous (virtual) range, written front
+// to back by the inflating team while the parser team already cuts and parses record-aligned regions of it, exactly as it
+// does with a mapped plain file.  Pages behind the parsed regions go back to the system (MADV_DONTNEED), the producer
+// stays at most `max_ahead` bytes in front of them.
+struct GrowingText {
+  char *base = nullptr;
+  size_t reserved = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  size_t avail = 0, freed = 0, max_ahead = (size_t)1 << 30;
+  int starving = 0;  // consumers waiting for more text: the producer may then run further ahead than max_ahead
+  bool done = false, cancelled = false;
+  std::string error;
+  GrowingText() = default;
+  GrowingText(const GrowingText &) = delete;
+  GrowingText &operator=(const GrowingText &) = delete;
+  ~GrowingText() { if (base) munmap(base, reserved); }
+  bool reserve(size_t bytes) {
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) return false;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(p, bytes, MADV_HUGEPAGE);  // 2 MiB faults where the system allows them
+#endif
+    base = (char *)p;
+    reserved = bytes;
+    if (const char *e = getenv("KU_TEXT_AHEAD_MB")) max_ahead = (size_t)std::max(1L, atol(e)) << 20;
+    return true;
+  }
+  // producer: where the next n bytes go (nullptr: cancelled, or the reservation is used up)
+  char *place(size_t n) {
+    std::unique_lock<std::mutex> l(m);
+    cv.wait(l, [&] { return cancelled || starving > 0 || avail == freed || avail + n - freed <= max_ahead; });
+    if (cancelled || avail + n > reserved) return nullptr;
+    return base + avail;
+  }
+  void publish(size_t n) {
+    { std::lock_guard<std::mutex> l(m); avail += n; }
+    cv.notify_all();
+  }
+  void finish(const std::string &err = std::string()) {
+    { std::lock_guard<std::mutex> l(m); done = true; if (!err.empty() && !cancelled) error = err; }  // (a cancelled producer's complaint is no error)
+    cv.notify_all();
+  }
+  // consumers: wait until `need` bytes are there or the text is complete; the bytes there now
+  size_t wait_for(size_t need, bool *complete) {
+    std::unique_lock<std::mutex> l(m);
+    if (avail < need && !done && !cancelled) {
+      ++starving;
+      cv.notify_all();
+      cv.wait(l, [&] { return avail >= need || done || cancelled; });
+      --starving;
+    }
+    *complete = done || cancelled;
+    return avail;
+  }
+  void release_before(size_t pos) {
+    pos &= ~(size_t)((2u << 20) - 1);
+    std::unique_lock<std::mutex> l(m);
+    if (pos <= freed) return;
+    const size_t lo = freed;
+    freed = pos;
+    l.unlock();
+    (void)madvise(base + lo, pos - lo, MADV_DONTNEED);
+    cv.notify_all();
+  }
+  void cancel() {
+    { std::lock_guard<std::mutex> l(m); cancelled = true; }
+    cv.notify_all();
+  }
+};
+
 // ---- FASTA/FASTQ reader (gz transparently via zlib).  Lines are handed out as ranges of one large buffer.  With
 // prefetch on, a producer thread per file does the read(2) / inflate into a small ring of blocks, so decompression
 // overlaps with parsing and the two files of a mate pair are inflated concurrently.
@@ -158,8 +229,15 @@ struct Reader {
   gzFile g = nullptr;
   int fd = -1;  // plain (uncompressed) files are read with read(2): one copy less than through zlib
   bool fastq = false, valid = true, eof = false;
+  // no record of this file has been handed out yet.  The reference's FASTA reader takes the header of every record but the
+  // first from the loop that read the record before it (its `linebuffer`, src/seqreader.cpp:62-71): a header line that ends the
+  // file WITHOUT a line end leaves that loop with the stream at its end, and the next call returns "no more sequences"
+  // (:37-40) -- the record is dropped.  The first header of a file is read by the call itself and goes through.
+  bool first_record = true;
   std::vector<char> buf;
-  const char *mem = nullptr;  // memory mode: parse [mem, mem + len) in place (a record-aligned region of a mapped file)
+  const char *mem = nullptr;  // memory mode: parse [mem, mem + len) in place (the text of a file from a record start on)
+  GrowingText *grow = nullptr;  // memory mode over text that is still being written: [mem, mem + len) is what has arrived,
+  size_t grow_base = 0;         // mem = grow->base + grow_base; more() waits for the producer
   size_t pos = 0, len = 0;  // unconsumed bytes: buf[pos, len)
   // producer side (prefetch)
   static constexpr size_t BLOCK = (size_t)4 << 20;
@@ -229,6 +307,11 @@ struct Reader {
     if (fd >= 0) return (long)::read(fd, dst, want);
     const long n = (long)gzread(g, dst, (unsigned)want);
     if (n < 0) gz_failed = true;
+    else if (n == 0) {  // zlib reports a file that stops in mid-member as a plain 0 with Z_BUF_ERROR pending: no end of file either
+      int e = Z_OK;
+      (void)gzerror(g, &e);
+      if (e != Z_OK && e != Z_STREAM_END) gz_failed = true;
+    }
     return n;
   }
   void check_gz() {
@@ -383,6 +466,7 @@ struct Reader {
     buf.resize((size_t)1 << 24);
     pos = len = 0;
     valid = true; eof = false;
+    first_record = true;
     produced_all = stop = false;
     if (fd >= 0 && file_is_bzip2(path)) {  // a regular .bz2 file: mapped
       void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
@@ -454,15 +538,24 @@ struct Reader {
     more();
     fastq = len > 0 && buf[0] == '@';  // determine_input_file_type (src/classify.cpp:377-388)
   }
-  // parse a region that already sits in memory (no file behind it)
-  void open_memory(const char *p, size_t n, bool is_fastq) {
+  // parse text that already sits in memory, from a record start to the end of the file: [p, p + n)
+  void open_memory(const char *p, size_t n, bool is_fastq, bool file_start = true) {
     mem = p;
     pos = 0; len = n;
     valid = true; eof = true;
     fastq = is_fastq;
+    first_record = file_start;
+  }
+  // the same over a text that is still growing: from offset `at` of gt, of which `have` bytes (absolute) are known to be there
+  void open_growing(GrowingText *gt, size_t at, size_t have, bool is_fastq, bool file_start) {
+    open_memory(gt->base + at, have > at ? have - at : 0, is_fastq, file_start);
+    grow = gt;
+    grow_base = at;
+    eof = false;
   }
   void close() {
     mem = nullptr;
+    grow = nullptr;
     if (!bz_team.empty()) {
       { std::lock_guard<std::mutex> l(mu); stop = true; }
       cv.notify_all();
@@ -499,6 +592,13 @@ struct Reader {
   // append file data behind the unconsumed bytes (which move to the front); false at end of file
   bool more() {
     if (eof) return false;
+    if (grow) {  // memory mode over growing text: nothing moves, the window's end does
+      bool complete = false;
+      const size_t avail = grow->wait_for(grow_base + len + 1, &complete);
+      if (avail > grow_base + len) { len = avail - grow_base; return true; }
+      eof = true;
+      return false;
+    }
     if (pos > 0) {
       if (len > pos) memmove(buf.data(), buf.data() + pos, len - pos);
       len -= pos;
@@ -664,6 +764,9 @@ inline bool next_record(Reader &rd, Batch &bt, std::string *header, std::string 
     rd.valid = false;
     return false;
   }
+  // a header line the file ends in, without a line end: only the first record of a file survives that (see first_record)
+  if (h_next == h_hi && !rd.first_record) { rd.valid = false; return false; }
+  rd.first_record = false;
   if (header) header->assign(rd.at(1), h_hi - 1);
   rd.pos += h_next;
   size_t l_hi, l_next;
@@ -761,96 +864,126 @@ inline size_t parse_fastq_fast(const char *data, size_t n, Batch &bt, bool keep_
   return (size_t)(p - data);
 }
 
-inline bool parse_region(const char *data, size_t n, bool fastq, Batch &bt, bool keep_records) {
-  if (fastq && !getenv("KU_SEQIO_GENERAL")) {
-    const size_t done = parse_fastq_fast(data, n, bt, keep_records);
-    data += done;
-    n -= done;
-    if (n == 0) return true;
+// The records that START inside [lo, hi) of a text, parsed as the sequential reader would parse them from `lo` on -- `lo` must be
+// a position that reader reaches as a record start; `hi` is where the next region was cut, a record start by the cutter's
+// judgement (find_record_start) -- exact for FASTA, a heuristic for FASTQ that damaged files defeat.  So the parser is not
+// confined to the region: the text is visible to its end (`text_n` bytes of `text`, or all that `gt` will ever deliver), a record
+// that starts before `hi` is read to ITS end wherever that lies, and the caller learns where the parse stopped.  Regions chain:
+// region i + 1 counts iff region i stopped exactly at its start (RegionChain below); otherwise the stretch is parsed again from
+// where region i stopped.  (Round 5 handed the parser [lo, hi) alone: a region cut inside a record then produced records the
+// reference never sees -- `seqio_dump -j 3` on a FASTQ file with a deleted sequence line printed a quality string as an id.)
+struct RegionParse {
+  bool ended = false;  // the stream ended inside the region (malformed record, an empty FASTQ line, the end of the file):
+                       // nothing behind `end` is ever read by the reference (src/seqreader.cpp:51-55,103-112)
+  size_t end = 0;      // where the parse stopped (absolute offset in the text; >= hi unless `ended`)
+};
+inline RegionParse parse_region(const char *text, size_t text_n, GrowingText *gt, size_t lo, size_t hi, bool fastq, Batch &bt,
+                                bool keep_records) {
+  RegionParse res;
+  size_t at = lo;
+  if (fastq && !getenv("KU_SEQIO_GENERAL")) {  // whole four-line records inside [lo, hi): the fast path
+    at += parse_fastq_fast(text + lo, hi - lo, bt, keep_records);
+    if (at == hi) { res.end = hi; return res; }
   }
   Reader rd;
-  rd.open_memory(data, n, fastq);
+  if (gt) rd.open_growing(gt, at, hi, fastq, at == 0);
+  else rd.open_memory(text + at, text_n - at, fastq, at == 0);
   std::string header, quals;
-  size_t nb, lo, hi;
-  for (;;) {
+  size_t nb, id_lo, id_hi;
+  while (at + rd.pos < hi) {
     bt.begin_read();
-    if (!next_record(rd, bt, &header, keep_records ? &quals : nullptr, &nb)) { bt.off.pop_back(); break; }
+    if (!next_record(rd, bt, &header, keep_records ? &quals : nullptr, &nb)) { bt.off.pop_back(); res.ended = true; break; }
     bt.end_read();
-    split_id(header.data(), header.size(), lo, hi);
-    bt.add_meta(header, lo, hi, quals, keep_records);
+    split_id(header.data(), header.size(), id_lo, id_hi);
+    bt.add_meta(header, id_lo, id_hi, quals, keep_records);
   }
-  return rd.pos == rd.len;
+  res.end = at + rd.pos;
+  return res;
 }
 
-// ---- compressed input parsed in regions: the text of a .gz file arrives in one contiguous (virtual) range, written front
-// to back by the inflating team while the parser team already cuts and parses record-aligned regions of it, exactly as it
-// does with a mapped plain file.  Pages behind the parsed regions go back to the system (MADV_DONTNEED), the producer
-// stays at most `max_ahead` bytes in front of them.
-struct GrowingText {
-  char *base = nullptr;
-  size_t reserved = 0;
-  std::mutex m;
-  std::condition_variable cv;
-  size_t avail = 0, freed = 0, max_ahead = (size_t)1 << 30;
-  int starving = 0;  // consumers waiting for more text: the producer may then run further ahead than max_ahead
-  bool done = false, cancelled = false;
-  std::string error;
-  GrowingText() = default;
-  GrowingText(const GrowingText &) = delete;
-  GrowingText &operator=(const GrowingText &) = delete;
-  ~GrowingText() { if (base) munmap(base, reserved); }
-  bool reserve(size_t bytes) {
-    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    if (p == MAP_FAILED) return false;
-#ifdef MADV_HUGEPAGE
-    (void)madvise(p, bytes, MADV_HUGEPAGE);  // 2 MiB faults where the system allows them
-#endif
-    base = (char *)p;
-    reserved = bytes;
-    if (const char *e = getenv("KU_TEXT_AHEAD_MB")) max_ahead = (size_t)std::max(1L, atol(e)) << 20;
-    return true;
-  }
-  // producer: where the next n bytes go (nullptr: cancelled, or the reservation is used up)
-  char *place(size_t n) {
-    std::unique_lock<std::mutex> l(m);
-    cv.wait(l, [&] { return cancelled || starving > 0 || avail == freed || avail + n - freed <= max_ahead; });
-    if (cancelled || avail + n > reserved) return nullptr;
-    return base + avail;
-  }
-  void publish(size_t n) {
-    { std::lock_guard<std::mutex> l(m); avail += n; }
-    cv.notify_all();
-  }
-  void finish(const std::string &err = std::string()) {
-    { std::lock_guard<std::mutex> l(m); done = true; if (!err.empty() && !cancelled) error = err; }  // (a cancelled producer's complaint is no error)
-    cv.notify_all();
-  }
-  // consumers: wait until `need` bytes are there or the text is complete; the bytes there now
-  size_t wait_for(size_t need, bool *complete) {
-    std::unique_lock<std::mutex> l(m);
-    if (avail < need && !done && !cancelled) {
-      ++starving;
-      cv.notify_all();
-      cv.wait(l, [&] { return avail >= need || done || cancelled; });
-      --starving;
+// Work units at the reference's granularity (src/classify.cpp:510-523): a unit takes reads until it holds Work_unit_size
+// nucleotides; a unit WITHOUT nucleotides ends the file's processing and its reads are never classified or printed -- it can
+// only be the file's last unit, made of empty records.  Batches of one file pass through in order; a batch whose tail is such a
+// run of empty reads in a unit that holds no nucleotide yet is held back until the next batch (or the end of the file) decides.
+struct UnitGate {
+  uint64_t unit_nt = 500000;  // Work_unit_size (-u)
+  uint64_t acc = 0;           // nucleotides of the open unit
+  struct Held { Batch *bt; size_t keep; };  // reads [keep, n) of bt are empty and belong to the open unit, which holds no nucleotide
+  std::vector<Held> held;     // (non-empty only while acc == 0)
+  void begin_file() { acc = 0; held.clear(); }
+  // `out(bt)`: the batch goes on as it is; `recycle(bt)`: its reads went into a batch that is held already (so that a long
+  // stretch of empty records cannot take every batch of a caller's pool out of circulation)
+  template <class Out, class Recycle> void push(Batch *bt, Out &&out, Recycle &&recycle) {
+    const size_t n = bt->off.size();
+    if (bt->nt == 0) {  // empty reads only: they join the open unit
+      if (acc > 0 || n == 0) out(bt);
+      else if (held.empty()) held.push_back(Held{bt, 0});
+      else {
+        Batch *dst = held.back().bt;
+        const bool records = !dst->hoff.empty() || !bt->hoff.empty();
+        const std::string none;
+        for (size_t i = 0; i < n; ++i) {
+          dst->begin_read();
+          dst->end_read();
+          const std::string id(bt->ids.c_str() + bt->idoff[i]);
+          if (records) {
+            const std::string hdr(bt->headers.c_str() + bt->hoff[i]), q(bt->quals.c_str() + bt->qoff[i]);
+            dst->idoff.push_back(dst->ids.size());
+            dst->ids += id; dst->ids.push_back('\0');
+            dst->hoff.push_back(dst->headers.size()); dst->headers += hdr; dst->headers.push_back('\0');
+            dst->qoff.push_back(dst->quals.size()); dst->quals += q; dst->quals.push_back('\0');
+          } else dst->add_meta(id, 0, id.size(), none, false);
+        }
+        recycle(bt);
+      }
+      return;
     }
-    *complete = done || cancelled;
-    return avail;
+    // these nucleotides share a unit with the reads held so far
+    for (Held &h : held) out(h.bt);
+    held.clear();
+    size_t last_close = 0;
+    uint64_t a = acc;
+    const uint32_t *len = bt->len.data();
+    for (size_t i = 0; i < n; ++i) {
+      a += len[i];
+      if (a >= unit_nt) { a = 0; last_close = i + 1; }
+    }
+    acc = a;
+    if (a == 0 && last_close < n) held.push_back(Held{bt, last_close});  // a unit closed, empty reads follow it
+    else out(bt);
   }
-  void release_before(size_t pos) {
-    pos &= ~(size_t)((2u << 20) - 1);
-    std::unique_lock<std::mutex> l(m);
-    if (pos <= freed) return;
-    const size_t lo = freed;
-    freed = pos;
-    l.unlock();
-    (void)madvise(base + lo, pos - lo, MADV_DONTNEED);
-    cv.notify_all();
+  // end of the file's stream: the held reads are a unit without nucleotides -- never classified, never printed.  `out(bt)` for a
+  // batch that keeps its front part, `drop(bt)` for one that is left with no reads
+  template <class Out, class Drop> void finish(Out &&out, Drop &&drop) {
+    for (Held &h : held) {
+      if (h.keep == 0) { drop(h.bt); continue; }
+      Batch *bt = h.bt;
+      bt->seqs_len = bt->off[h.keep];  // (the dropped reads are empty: only their separators go)
+      bt->off.resize(h.keep); bt->len.resize(h.keep); bt->idoff.resize(h.keep);
+      if (!bt->hoff.empty()) { bt->hoff.resize(h.keep); bt->qoff.resize(h.keep); }
+      out(bt);
+    }
+    held.clear();
+    acc = 0;
   }
-  void cancel() {
-    { std::lock_guard<std::mutex> l(m); cancelled = true; }
-    cv.notify_all();
+};
+
+// The chain of regions of one file, in order: region i + 1 counts iff the parse of region i stopped exactly at its start.
+struct RegionChain {
+  size_t expect = 0;   // where the sequential parse stands
+  bool ended = false;  // the stream has ended: nothing behind counts
+  // what to do with the region [lo, hi) whose parse (started at lo) gave `r`:
+  enum Verdict { ACCEPT, REPARSE, SKIP };
+  //   ACCEPT  -- its records count;  REPARSE -- it was cut inside a record: parse [expect, hi) again, then call accept() with that
+  //   result;  SKIP -- the record before it ran past its end (or the stream has ended): its records do not exist
+  Verdict judge(size_t lo, size_t hi, const RegionParse &r) {
+    static const bool say = getenv("KU_SEQIO_DEBUG") != nullptr;
+    if (ended || expect >= hi) { if (say) fprintf(stderr, "regions: [%zu, %zu) skipped (the parse stands at %zu%s)\n", lo, hi, expect, ended ? ", ended" : ""); return SKIP; }
+    if (lo != expect) { if (say) fprintf(stderr, "regions: [%zu, %zu) was cut inside a record: parsed again from %zu\n", lo, hi, expect); return REPARSE; }
+    accept(r);
+    return ACCEPT;
   }
+  void accept(const RegionParse &r) { expect = r.end; ended |= r.ended; }
 };
 
 // the producer side: a regular .gz file (BGZF, or any gzip stream through ku_pgzip.h) or .bz2 file (ku_pbzip2.h) inflated

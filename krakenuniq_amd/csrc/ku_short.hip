@@ -1008,10 +1008,12 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       ks_wave_sync();
     }
   }
+#ifndef KS_DIAG_NOFLUSH  // (diagnostic builds: what do the waves' last flushes cost a small launch?  scripts/launch_shape_probe.py)
   if (DO_COUNTS) {
     if (!ROUTE) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
     ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
   }
+#endif
   if (OUT == 2 && lane == 0 && sp_fresh) atomicAdd(sf.g_count, (unsigned long long)sp_fresh);
 }
 

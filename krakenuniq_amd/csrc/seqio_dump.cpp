@@ -40,6 +40,7 @@ int main(int argc, char **argv) {
   int regions = 0, gunzip_team = 0, bunzip_team = 0;
   const char *gz_out = nullptr;
   std::string gz_text;
+  ku_seqio::UnitGate gate;  // -u N: the reference's work unit size (a unit without nucleotides ends a file, src/classify.cpp:522-523)
   int a = 1;
   for (; a < argc && argv[a][0] == '-' && argv[a][1]; ++a) {
     if (argv[a][1] == 'P') paired = true;
@@ -49,6 +50,7 @@ int main(int argc, char **argv) {
     else if (argv[a][1] == 'z' && a + 1 < argc) gunzip_team = atoi(argv[++a]);
     else if (argv[a][1] == 'G' && a + 1 < argc) gz_out = argv[++a];
     else if (argv[a][1] == 'Z' && a + 1 < argc) bunzip_team = atoi(argv[++a]);  // as -z, for .bz2 (ku_pbzip2.h)
+    else if (argv[a][1] == 'u' && a + 1 < argc) gate.unit_nt = (uint64_t)std::max(1LL, atoll(argv[++a]));
     else if (argv[a][1] == 'j' && a + 1 < argc) regions = atoi(argv[++a]);  // producer thread per file, as the classify executable runs
   }
   timeval t0, t1;
@@ -136,24 +138,36 @@ int main(int argc, char **argv) {
     cut.fastq = growing ? gt.base[0] == '@' : (n && data[0] == '@');
     if (const char *e = getenv("KU_REGION_RAMP")) cut.ramp = (size_t)atoi(e);  // smaller first regions, as the classify executable cuts them
     std::mutex rm;
-    std::map<size_t, std::pair<ku_seqio::Batch *, size_t>> parsed;  // region -> (batch, end of the region)
-    size_t first_broken = (size_t)-1;  // the stream ends inside this region: what was parsed behind it does not count
+    struct Parsed { ku_seqio::Batch *bt; size_t lo, hi; ku_seqio::RegionParse res; };
+    std::map<size_t, Parsed> parsed;
+    std::vector<ku_seqio::Batch *> ordered;  // the batches whose records count, in file order
+    ku_seqio::RegionChain chain;
     size_t next_out = 0;
-    bool broken = false;
+    ku_seqio::GrowingText *gtp = growing ? &gt : nullptr;
     auto member = [&] {
       size_t lo, hi, idx;
       while (cut.claim(lo, hi, idx)) {
         ku_seqio::Batch *bt = new ku_seqio::Batch;
         bt->pinned = false;
-        const bool whole = ku_seqio::parse_region(cut.data + lo, hi - lo, cut.fastq, *bt, false);
-        if (warm && !growing) { bt->clear(); ku_seqio::parse_region(cut.data + lo, hi - lo, cut.fastq, *bt, false); }
+        ku_seqio::RegionParse res = ku_seqio::parse_region(cut.data, n, gtp, lo, hi, cut.fastq, *bt, false);
+        if (warm && !growing) { bt->clear(); res = ku_seqio::parse_region(cut.data, n, gtp, lo, hi, cut.fastq, *bt, false); }
         std::lock_guard<std::mutex> l(rm);
-        parsed[idx] = {bt, hi};
-        if (!whole) { broken = true; first_broken = std::min(first_broken, idx); cut.halt(); }
-        if (growing) {  // the text behind the regions parsed so far (in order) is not needed any more
-          size_t upto = 0;
-          for (size_t i = next_out; parsed.count(i); ++i) { upto = parsed[i].second; next_out = i + 1; }
-          if (upto) gt.release_before(upto);
+        parsed[idx] = Parsed{bt, lo, hi, res};
+        for (auto it = parsed.find(next_out); it != parsed.end(); it = parsed.find(next_out)) {  // in file order: does the region count?
+          Parsed &p = it->second;
+          switch (chain.judge(p.lo, p.hi, p.res)) {
+            case ku_seqio::RegionChain::REPARSE:  // cut inside a record: again from where the region before it stopped
+              p.bt->clear();
+              chain.accept(ku_seqio::parse_region(cut.data, n, gtp, chain.expect, p.hi, cut.fastq, *p.bt, false));
+              ordered.push_back(p.bt);
+              break;
+            case ku_seqio::RegionChain::ACCEPT: ordered.push_back(p.bt); break;
+            case ku_seqio::RegionChain::SKIP: p.bt->release(); delete p.bt; break;
+          }
+          if (chain.ended) cut.halt();
+          else if (growing) gt.release_before(std::min(p.hi, chain.expect));  // the text behind the regions parsed so far is not needed any more
+          parsed.erase(it);
+          ++next_out;
         }
       }
     };
@@ -164,9 +178,10 @@ int main(int argc, char **argv) {
       gz.close();
       if (!gt.error.empty()) ku_seqio::fatal(65, "%s", gt.error.c_str());  // (damage of the compressed file, not the parser stopping early)
     }
-    for (auto &kv : parsed) {  // (std::map: in region order)
-      ku_seqio::Batch &bt = *kv.second.first;
-      for (size_t i = 0; i < bt.off.size() && kv.first <= first_broken; ++i) {
+    for (auto &kv : parsed) { kv.second.bt->release(); delete kv.second.bt; }  // (parsed behind the end of the stream)
+    auto print = [&](ku_seqio::Batch *btp) {
+      ku_seqio::Batch &bt = *btp;
+      for (size_t i = 0; i < bt.off.size(); ++i) {
         ++n_reads;
         n_bytes += bt.len[i];
         if (!quiet) {
@@ -177,8 +192,12 @@ int main(int argc, char **argv) {
         }
       }
       bt.release();
-      delete kv.second.first;
-    }
+      delete btp;
+    };
+    auto drop = [&](ku_seqio::Batch *btp) { btp->release(); delete btp; };
+    gate.begin_file();
+    for (ku_seqio::Batch *bt : ordered) gate.push(bt, print, drop);
+    gate.finish(print, drop);
     if (!growing && n) munmap((void *)data, n);
   }
   for (; a < argc; a += paired ? 2 : 1) {
@@ -188,10 +207,34 @@ int main(int argc, char **argv) {
       if (a + 1 >= argc) ku_seqio::fatal(64, "-P needs the files in pairs");
       rd2.open(argv[a + 1], prefetch);
     }
-    ku_seqio::Batch bt;
-    bt.pinned = false;
+    auto emit = [&](ku_seqio::Batch *btp) {
+      ku_seqio::Batch &bt = *btp;
+      for (size_t i = 0; i < bt.off.size(); ++i) {
+        ++n_reads;
+        const char *id = bt.ids.c_str() + bt.idoff[i];
+        if (gz_out) {
+          gz_text.append(id);
+          gz_text += '\t';
+          gz_text.append(bt.seqs + bt.off[i], bt.len[i]);
+          gz_text += '\n';
+        } else if (!quiet) {
+          fputs(id, stdout);
+          fputc('\t', stdout);
+          fwrite(bt.seqs + bt.off[i], 1, bt.len[i], stdout);
+          fputc('\n', stdout);
+        }
+      }
+      n_bytes += bt.nt;
+      bt.release();
+      delete btp;
+    };
+    auto drop = [&](ku_seqio::Batch *btp) { btp->release(); delete btp; };
+    gate.begin_file();
+    const std::string no_quals;
     for (bool more = true; more;) {
-      bt.clear();
+      ku_seqio::Batch *btp = new ku_seqio::Batch;
+      ku_seqio::Batch &bt = *btp;
+      bt.pinned = false;
       while (bt.nt < (64u << 20)) {
         size_t n1, n2, lo, hi;
         bt.begin_read();
@@ -207,23 +250,11 @@ int main(int argc, char **argv) {
         bt.end_read();
         ku_seqio::split_id(header.data(), header.size(), lo, hi);
         if (paired) hi = lo + ku_seqio::strip_mate_suffix(header.data() + lo, hi - lo);
-        ++n_reads;
-        if (gz_out) {
-          gz_text.append(header.data() + lo, hi - lo);
-          gz_text += '\t';
-          gz_text.append(bt.seqs + bt.off.back(), bt.len.back());
-          gz_text += '\n';
-        } else if (!quiet) {
-          fwrite(header.data() + lo, 1, hi - lo, stdout);
-          fputc('\t', stdout);
-          fwrite(bt.seqs + bt.off.back(), 1, bt.len.back(), stdout);
-          fputc('\n', stdout);
-        }
+        bt.add_meta(header, lo, hi, no_quals, false);
       }
-      n_bytes += bt.nt;
-      if (bt.nt == 0) break;
+      gate.push(btp, emit, drop);  // (a unit without nucleotides ends the file: decided at work-unit granularity)
     }
-    bt.release();
+    gate.finish(emit, drop);
     rd.close();
     rd2.close();
   }

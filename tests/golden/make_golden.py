@@ -26,6 +26,9 @@ Fixtures:
         known answers of resolve_uids3 and of std::unordered_map's iteration order
   f8/   second database + reads for hierarchical multi-database runs (both orders, quick mode)
   f10/  CRLF inputs (FASTQ, one-line-per-sequence FASTA, multi-line FASTA) of f1 reads + outputs
+  f12/  how a file's input ENDS (src/seqreader.cpp:37-40,62-71, src/classify.cpp:510-523): a FASTA header as the last line
+        without a line end, trailing empty records that form a work unit of their own / that share one with nucleotides, a FASTQ
+        file with a deleted sequence line, quality lines that start with '@'; cases.json lists (input, flags, output)
   kat.json  per-function known-answer vectors from ref_kat
 """
 import json
@@ -329,6 +332,48 @@ def make_f10(f1):
         classify(f1, ["-o", f"{d}/{name.rsplit('.', 1)[0]}.out.tsv"], [f"{d}/{name}"])
 
 
+def make_f12(f1):
+    """end-of-input rules of the reference's readers and of process_file's work units (outputs with -s: id AND sequence)"""
+    d = os.path.join(HERE, "f12")
+    os.makedirs(d, exist_ok=True)
+    ids, seqs = synth.read_seqfile(f"{f1}/reads.fq")
+    fa = lambda lo, hi: b"".join(b">" + i.encode() + b"\n" + s + b"\n" for i, s in zip(ids[lo:hi], seqs[lo:hi]))
+    fq = lambda lo, hi, q=b"I": b"".join(b"@" + i.encode() + b"\n" + s + b"\n+\n" + q * len(s) + b"\n" for i, s in zip(ids[lo:hi], seqs[lo:hi]))
+    empties_fa = b">e1\n>e2 with a description\n\n>e3\n"
+    files = {
+        # the last line is a header without a line end: dropped (the first record of a file would go through: lone_header.fa)
+        "hdr_at_eof.fa": fa(0, 30) + b">tail",
+        "lone_header.fa": b">only",
+        # 20 reads x 150 nt with -u 1500: the units close behind reads 10 and 20 -- the empty records behind them are a unit
+        # without nucleotides: never printed; with -u 1400 the same (a unit closes at 1500 >= 1400)
+        "empty_unit.fa": fa(0, 20) + empties_fa,
+        # 21 reads: the third unit holds read 21 AND the empty records: all printed
+        "empty_shared_unit.fa": fa(0, 21) + empties_fa,
+        # empty records in the middle of the file share a unit with what follows
+        "empty_inside.fa": fa(0, 20) + empties_fa + fa(20, 25),
+        "only_empties.fa": empties_fa,
+        "empty_unit.fq": fq(0, 20) + b"@e1\n\n+\n\n@e2\n\n+\n\n",
+        # record 120 of 200 lost its sequence line: the stream ends there (malformed quality header)
+        "deleted_seq_line.fq": fq(0, 120) + b"@" + ids[120].encode() + b"\n+\n" + b"I" * 150 + b"\n" + fq(121, 200),
+        # quality lines that start with '@' (and one '+' line carrying the id): every record start must be found all the same
+        "at_quals.fq": fq(0, 100, b"@") + fq(100, 200),
+        # a deleted quality line AND '@' qualities: what follows the damage looks like records at the wrong line offsets
+        "deleted_qual_line.fq": fq(0, 60, b"@") + b"@" + ids[60].encode() + b"\n" + seqs[60] + b"\n+\n" + fq(61, 200, b"@"),
+    }
+    # sequences that start with '+' (any byte is a base to the reference: an ambiguous one) behind quality lines that start with
+    # '@': "a line starting with '@' whose second successor starts with '+'" then holds for every QUALITY line as well -- three of
+    # four cuts of a region parser land inside a record
+    files["plus_seqs.fq"] = b"".join(b"@" + i.encode() + b"\n+" + s[1:] + b"\n+\n" + b"@" * len(s) + b"\n" for i, s in zip(ids[:200], seqs[:200]))
+    cases = []
+    for name, data in files.items():
+        open(f"{d}/{name}", "wb").write(data)
+        for flags in (["-u", "1500"], ["-u", "1400"]) if name.startswith("empty") or name.startswith("only") else ([],):
+            out = f"{name}{'.u' + flags[1] if flags else ''}.out.tsv"
+            classify(f1, ["-s", "-t", "1", "-o", f"{d}/{out}"] + flags, [f"{d}/{name}"])
+            cases.append({"input": name, "flags": flags, "output": out})
+    json.dump(cases, open(f"{d}/cases.json", "w"), indent=1)
+
+
 def make_kat(f1):
     rng = np.random.default_rng(3)
     kat = {"k": K}
@@ -562,6 +607,9 @@ def main():
     if sys.argv[1:] == ["f10"]:
         make_f10(os.path.join(HERE, "f1"))
         return
+    if sys.argv[1:] == ["f12"]:
+        make_f12(os.path.join(HERE, "f1"))
+        return
     if sys.argv[1:] == ["f1x"]:
         make_f1_exact_variants()
         return
@@ -576,6 +624,7 @@ def main():
     make_f4(f1, genomes)
     make_f7(f1)
     make_f10(f1)
+    make_f12(f1)
     make_f11(f1, genomes)
     make_kat(f1)
     make_kat_uid()

@@ -135,6 +135,48 @@ def test_fasta_paired_edge_and_read_files(tmp_path):
 
 
 @pytest.mark.gpu
+def test_end_of_input_rules_equal_the_reference(tmp_path):
+    """tests/golden/f12 (make_golden.py f12): how a file's input ends -- a FASTA header as the last line without a line end, a
+    work unit without nucleotides (src/classify.cpp:510-523, decided per WORK UNIT, not per GPU batch), damaged FASTQ files whose
+    regions the cutter gets wrong -- byte for byte the reference's `classify -s` output, with the parser team, with one reader
+    thread, from .gz, and with GPU batches so small that the files span several"""
+    import json
+    d = os.path.join(ROOT, "tests", "golden", "f12")
+    for case in json.load(open(f"{d}/cases.json")):
+        want = open(f"{d}/{case['output']}", "rb").read()
+        path = f"{d}/{case['input']}"
+        gz = tmp_path / (case["input"] + ".gz")
+        with gzip.open(gz, "wb") as f:
+            f.write(open(path, "rb").read())
+        for threads, src, env in (("4", path, {}), ("1", path, {}), ("4", path, {"KU_BATCH_NT": "65536", "KU_REGION_RAMP": "0"}),
+                                  ("4", str(gz), {}), ("1", str(gz), {})):
+            r = run(DB + ["-s", "-t", threads] + case["flags"] + [src], env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout == want, (case, threads, src, env)
+    # a stretch of empty records longer than a GPU batch in the middle of a file: batches without a nucleotide travel through the
+    # device like any other (they share a work unit with the reads that follow), at the end of a file they are a unit of their own
+    head = open(f"{d}/empty_inside.fa", "rb").read().split(b">e1\n")[0]
+    lines = open(f"{d}/empty_inside.fa.u1500.out.tsv", "rb").read().split(b"\n")[:-1]
+    tail = b"".join(b">" + ln.split(b"\t")[1] + b"\n" + ln.split(b"\t")[5] + b"\n" for ln in lines[23:])
+    empties = b"".join(b">x%d\n" % j for j in range(6000))
+    want_empties = b"".join(b"U\tx%d\t0\t0\t0:0\t\n" % j for j in range(6000))
+    for name, data, want in (("inside.fa", head + empties + tail, b"\n".join(lines[:20]) + b"\n" + want_empties + b"\n".join(lines[23:]) + b"\n"),
+                             ("behind.fa", head + empties, b"\n".join(lines[:20]) + b"\n")):
+        f = tmp_path / name
+        f.write_bytes(data)
+        for threads, env in (("4", {"KU_BATCH_NT": "65536", "KU_REGION_RAMP": "0"}), ("1", {"KU_BATCH_NT": "65536"}), ("4", {})):
+            r = run(DB + ["-s", "-u", "1500", "-t", threads, str(f)], env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout == want, (name, threads, env)
+            # and with a report: the sparse-sketch emulation's unit plan sees the same reads
+            rep = tmp_path / "rep.tsv"
+            if rep.exists():
+                rep.unlink()
+            r = run(DB + ["-s", "-u", "1500", "-t", threads, "-r", str(rep), str(f)], env=dict(os.environ, **env))
+            assert r.returncode == 0 and r.stdout == want, r.stderr.decode()
+
+
+@pytest.mark.gpu
 def test_crlf_inputs():
     """tests/golden/f10: CRLF FASTQ and one-line-per-sequence CRLF FASTA are byte-identical with the reference (the '\\r'
     closing a sequence is one more, ambiguous, base).  Multi-line CRLF FASTA is the one documented deviation: the

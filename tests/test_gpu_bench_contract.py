@@ -57,7 +57,7 @@ def run_bench_world(n, *extra):
     stand-in for RCCL (tests/rccl_shim), which moves the ranks' messages between the processes"""
     shim = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
     assert os.path.exists(shim)
-    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_SHIM_TIMEOUT="120")
+    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_LIB=os.path.join(ROOT, "tests", "rccl_shim", "libkrakenuniq_amd_testhooks.so"), KU_SHIM_TIMEOUT="120")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--reads", "120000",
                         "--species", "60", "--genome-len", "60000", "--cpu-sample", "0", *extra], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, cwd=ROOT, timeout=900, env=env)
@@ -88,7 +88,7 @@ def test_two_ranks_plain_line_has_the_sharded_layout_as_its_headline():
     """`bench.py --gpus 2` without --mode / --config: both legs run, the line is the sharded layout's (configs[2] scaled to the
     world -- here at a size two ranks on one GPU hold), the replicas are the second leg"""
     shim = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
-    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_SHIM_TIMEOUT="120", KU_BENCH_SHARD_SPECIES="40",
+    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_LIB=os.path.join(ROOT, "tests", "rccl_shim", "libkrakenuniq_amd_testhooks.so"), KU_SHIM_TIMEOUT="120", KU_BENCH_SHARD_SPECIES="40",
                KU_BENCH_SHARD_GENOME_LEN="50000", KU_BENCH_SHARD_READS="100000", KU_BENCH_SHARD_NT="11")  # (nt = 15: 8.6 GB of index per rank, minutes)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "100000",
                         "--species", "60", "--genome-len", "60000", "--cpu-sample", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,

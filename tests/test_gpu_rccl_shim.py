@@ -1,5 +1,5 @@
 """The multi-GPU driver's RCCL paths with REAL PEERS on a 1-GPU box: `world` processes, one rank each, all on cuda:0,
-bound (KU_RCCL_LIB) to tests/rccl_shim/libku_rccl_shim.so instead of RCCL, which refuses two ranks on one device.  The shim
+bound (KU_RCCL_LIB, honoured by the test build of the library only) to tests/rccl_shim/libku_rccl_shim.so instead of RCCL, which refuses two ranks on one device.  The shim
 is test infrastructure: the same entry points between processes through files in /dev/shm.  What runs here is the product's
 own code: ncclCommInitRank per process, comm_scatter_slices / comm_alltoallv / comm_allgather_u64_dev (owner routing),
 comm_broadcast + the grouped send / receive all-to-all or the grouped ncclReduce (position-wise exchange), the all-gather of
@@ -15,6 +15,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
+# the product library does not look at KU_RCCL_LIB / KU_TEST_DROP_STREAM_JOIN: the test build of it does (-DKU_TEST_HOOKS, the same
+# objects with ku_mgpu.cpp compiled once more; tests/rccl_shim/Makefile)
+HOOKS_LIB = os.path.join(ROOT, "tests", "rccl_shim", "libkrakenuniq_amd_testhooks.so")
 WORKER = os.path.join(ROOT, "tests", "rccl_shim", "worker.py")
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +25,8 @@ pytestmark = pytest.mark.gpu
 def run_world(world, mode, extra_env=None, expect_failure=False):
     assert os.path.exists(SHIM), "tests/rccl_shim/libku_rccl_shim.so is not built (make -C tests/rccl_shim)"
     scratch = tempfile.mkdtemp(prefix="ku_shim_test_")
-    env = dict(os.environ, KU_RCCL_LIB=SHIM, KU_SHIM_TIMEOUT="90", **(extra_env or {}))
+    assert os.path.exists(HOOKS_LIB), "tests/rccl_shim/libkrakenuniq_amd_testhooks.so is not built (make -C tests/rccl_shim)"
+    env = dict(os.environ, KU_LIB=HOOKS_LIB, KU_RCCL_LIB=SHIM, KU_SHIM_TIMEOUT="90", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), mode, scratch], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []

@@ -183,3 +183,26 @@ def test_reserve_and_its_warm_up_change_nothing(monkeypatch):
         states.append((text, c["n_reads"].copy(), c["n_kmers"].copy(), c["registers"].copy()))
     for t, a, b, r in states[1:]:
         assert t == states[0][0] and np.array_equal(a, states[0][1]) and np.array_equal(b, states[0][2]) and np.array_equal(r, states[0][3])
+
+
+@pytest.mark.parametrize("unit,report,n_batches", [(1000, "report_u1000.tsv", 9), (500000, "report.tsv", 7), (7000, None, 12)])
+def test_run_array_overflow_with_the_emulation_on(unit, report, n_batches, monkeypatch):
+    """a batch whose runs outgrow the run array (KU_RUNS_CAP forces it) is redone through the per-k-mer array --
+    and the sparse-sketch emulation, on by default under `classify -r`, evaluates its flagged work units from THAT redo's runs
+    (round 5 ended the run with KU_EUNSUP there).  Batches in flight; state and report equal the oracle's / the reference's."""
+    ids, seqs = synth.read_seqfile(f"{F1}/reads.fq")
+    buf, off, lens = ko.pack_reads(seqs)
+    cuts = split_points(len(seqs), n_batches, 23)
+    monkeypatch.setenv("KU_RUNS_CAP", "40")
+    ctx, cdb, ctax = gc.make_ctx(F1)
+    ctx.enable_sparse(unit)
+    res = run_two_step(ctx, buf, off, lens, cuts)
+    assert kraken_text(buf, off, lens, ids, cuts, res) == open(f"{F1}/out.tsv").read()
+    run = ko.Run(ko.Db(f"{F1}/database.kdb", f"{F1}/database.idx"), ko.Tax(f"{F1}/taxDB"), work_unit_nt=unit)
+    run.classify(seqs)
+    text = ctx.report(ctax, [f"{F1}/database.kdb.counts"])
+    counts, flags, pairs, n_sparse, n_dense = assert_sparse_state_equals_oracle(ctx, run)
+    gc.assert_same_counts(counts, run)
+    assert ctx.sparse_state() == 1  # (not given up)
+    if report:
+        assert rows(text) == rows(open(os.path.join(F1, report)).read())

@@ -185,6 +185,11 @@ def test_reader_takes_plain_gz_through_the_team(tmp_path):
     bad.write_bytes(blob[:len(blob) // 2])
     r = subprocess.run([DUMP, "-T", str(bad)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 65 and b"gzip" in r.stderr
+    # ... through zlib's reader too (a file that stops in mid-member makes gzread return 0 with Z_BUF_ERROR pending,
+    # not -1 -- the sequential reader took that for the end of the input): the plain reader, the producer side, mate pairs
+    for args in ([str(bad)], ["-T", str(bad)], ["-P", "-T", str(bad), str(z2)], ["-P", str(z1), str(bad)]):
+        r = subprocess.run([DUMP] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_NO_PGZIP="1"))
+        assert r.returncode == 65 and b"gzip" in r.stderr, args
 
 
 def test_gz_text_is_parsed_in_regions_while_it_arrives(tmp_path):

@@ -159,3 +159,55 @@ def test_bgzf_input_is_inflated_by_a_team_and_parses_like_the_text(tmp_path):
     mixed = tmp_path / "mixed.fq.gz"
     mixed.write_bytes(bgzf(text[:len(text) // 2])[:-28] + gzip.compress(text[len(text) // 2:]))
     assert dump(["-T", str(mixed)])[:2] == want
+
+
+def _golden_records(path):
+    """(id, sequence) of the reference's Kraken lines printed with -s (columns 2 and 6)"""
+    out = []
+    for ln in open(path, "rb").read().split(b"\n")[:-1]:
+        c = ln.split(b"\t", 5)
+        out.append((c[1].decode(), c[5]))
+    return out
+
+
+def test_end_of_input_rules_equal_the_reference(tmp_path):
+    """tests/golden/f12 (outputs of the compiled reference, make_golden.py f12): a FASTA header as the last line without
+    a line end is no record unless it is the file's first (seqreader.cpp:37-40,62-71); a work unit without nucleotides ends
+    the file and is never printed -- at WORK-UNIT granularity (classify.cpp:510-523); a damaged FASTQ file ends where the
+    sequential reader ends, whatever the number of region parsers"""
+    import json
+    d = f"{G}/f12"
+    for case in json.load(open(f"{d}/cases.json")):
+        want = _golden_records(f"{d}/{case['output']}")
+        path = f"{d}/{case['input']}"
+        gz = tmp_path / (case["input"] + ".gz")
+        with gzip.open(gz, "wb") as f:
+            f.write(open(path, "rb").read())
+        for extra, env in (([], None), (["-j", "2"], None), (["-j", "3"], None), (["-j", "5"], None), (["-j", "6"], None), (["-j", "7"], None), (["-j", "11"], None),
+                           (["-j", "3"], {"KU_REGION_RAMP": "2"}),
+                           (["-T"], None), ("gz", None), ("gz-j", {"KU_REGION_KB": "1"})):
+            if extra == "gz":
+                args = case["flags"] + [str(gz)]
+            elif extra == "gz-j":
+                if os.path.getsize(gz) < 20:
+                    continue
+                args = case["flags"] + ["-j", "3", str(gz)]
+            else:
+                args = case["flags"] + extra + [path]
+            ids, seqs, _ = dump(args, env=dict(os.environ, **env) if env else None)
+            assert list(zip(ids, seqs)) == want, (case, extra)
+    # the adversarial file really has its regions cut inside records (and parsed again from where the region before stopped)
+    r = subprocess.run([DUMP, "-j", "6", "-n", f"{d}/plus_seqs.fq"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_SEQIO_DEBUG="1"))
+    assert r.stderr.count(b"was cut inside a record") >= 2
+
+
+def test_fuzz_against_reference():
+    """differential fuzzing against the compiled reference's reader (tests/fuzz_seqio.py; build container only)"""
+    import pytest
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fuzz_seqio
+    if not os.path.exists(fuzz_seqio.REF):
+        pytest.skip("oracle/_ref/classify is built in the build container only")
+    failures = fuzz_seqio.fuzz(120, seed=20261001)
+    assert not failures, failures[:3]
