@@ -339,7 +339,21 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
             cmd = [cli_bin, "-d", f"{tmp}/database.kdb", "-i", f"{tmp}/database.idx", "-a", f"{tmp}/taxDB", "-t", thr,
                    "-o", f"{tmp}/e2e.tsv", f"{tmp}/reads.fq"]
             runs_s, errs = [], []
-            for rep in range(3):  # three runs, the median counts (the host side -- 16 CPUs of quota on a 256-CPU box -- varies from run to run)
+            N_E2E = 5  # five runs, every one of them listed, the median counts -- the first (cold) one included (the host side -- 16 CPUs of
+                       # quota on a 256-CPU box -- varies from run to run; round 5 took the median of three and the cold run never counted)
+
+            def cpu_in_window(err_text):
+                """the executable's own account of the window (KU_CLI_TIMES): CPU seconds by stage, thread counts"""
+                mc = re.search(r"cpu seconds in the window: user ([\d.]+) \+ sys ([\d.]+) in all; parser team ([\d.]+), formatting helpers ([\d.]+), writer ([\d.]+), device thread ([\d.]+)", err_text)
+                mt = re.search(r"threads in the window: parser team (\d+), formatting helpers (\d+), others (\d+)", err_text)
+                if not mc:
+                    return None
+                d = {"user": float(mc.group(1)), "sys": float(mc.group(2)), "parser_team": float(mc.group(3)), "formatting_helpers": float(mc.group(4)),
+                     "writer": float(mc.group(5)), "device_thread": float(mc.group(6))}
+                if mt:
+                    d["threads"] = {"parser_team": int(mt.group(1)), "formatting_helpers": int(mt.group(2)), "others": int(mt.group(3))}
+                return d
+            for rep in range(N_E2E):
                 t0 = time.time()
                 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KU_CLI_TIMES="1"))
                 wall = time.time() - t0
@@ -349,7 +363,7 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
                     raise RuntimeError("classify failed: " + err_i[-300:])
                 runs_s.append(float(m.group(3)))
                 errs.append(err_i)
-            secs = sorted(runs_s)[1]
+            secs = sorted(runs_s)[N_E2E // 2]
             err = errs[runs_s.index(secs)]
             mb = re.search(r"stage busy seconds: reader ([\d.]+), device ([\d.]+), writer ([\d.]+)", err)
             busy_plain = float(mb.group(2)) if mb else None
@@ -357,8 +371,9 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
             got = pd.read_csv(f"{tmp}/e2e.tsv", sep="\t", header=None, usecols=[2], dtype=np.uint32)[2].to_numpy()
             out["e2e"] = {"value": round(n_e / secs / 1e6, 2), "unit": "Mreads/s", "reads": n_e, "threads": int(thr),
                           "window": "the executable's report_stats window (classify.cpp:248-258): FASTQ parse -> GPU -> Kraken file",
-                          "seconds": secs, "seconds_of_the_runs": runs_s, "value_is": "the median of three runs",
-                          "wall_incl_db_load_s": round(wall, 1),
+                          "seconds": secs, "seconds_of_the_runs": runs_s, "value_is": f"the median of {N_E2E} runs, the first (cold) one included",
+                          "first_run_seconds": runs_s[0], "cpu_seconds_in_the_window_of_the_median_run": cpu_in_window(err),
+                          "cpu_quota": cgroup_quota(), "wall_incl_db_load_s": round(wall, 1),
                           "calls_match_device_run": bool(len(got) == n_e and (got == calls_gpu[:n_e]).all())}
             # the same run as scripts/krakenuniq starts it: with a report (-r), i.e. with the HyperLogLog++ sparse-sketch
             # emulation inside the timing window and the clade roll-up behind it
@@ -367,7 +382,7 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
                 env = dict(os.environ, KU_CLI_TIMES="1", KU_REPORT_TIMES="1", KU_RLE_TIMES="1")
                 cmd_r = cmd[:-1] + ["-r", f"{tmp}/report.tsv", cmd[-1]]
                 runs_r, errs_r = [], []
-                for rep in range(3):
+                for rep in range(N_E2E):
                     for fn in ("e2e.tsv", "report.tsv"):
                         if os.path.exists(f"{tmp}/{fn}"):
                             os.remove(f"{tmp}/{fn}")
@@ -380,21 +395,25 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
                         raise RuntimeError("classify -r failed: " + err_i[-300:])
                     runs_r.append(float(m.group(3)))
                     errs_r.append(err_i)
-                err = errs_r[runs_r.index(sorted(runs_r)[1])]
+                secs_r = sorted(runs_r)[N_E2E // 2]
+                err = errs_r[runs_r.index(secs_r)]
                 m2 = re.search(r"Report finished in ([\d.]+) seconds", err)
                 m3 = re.search(r"stage busy seconds: reader ([\d.]+), device ([\d.]+), writer ([\d.]+)", err)
-                secs_r = sorted(runs_r)[1]
                 # the fused kernel's emulation instance (OUT = 2: SEEN marks, insert counts, misses into the set) on the stream it
                 # runs on, summed over the run's batches by HIP events (KU_RLE_TIMES), against batch 0's algorithmic bytes
                 mk = re.search(r"kernels ([\d.]+) ms for (\d+) reads", err)
+                mks = re.search(r"their sum is ([\d.]+) ms", err)
                 rf_rep = None
                 if mk and algo_bytes0 and int(mk.group(2)) == n_e:
                     k_ms = float(mk.group(1))
                     ach = algo_bytes0 / (k_ms * 1e-3) / 1e9
                     rf_rep = {"bound": "hbm", "kernel": "ku_classify_short_kernel<..., OUT = 2> (fused lookup + resolve + runs + sparse-sketch "
-                              "bookkeeping), as the executable launches it: one launch per batch of ~120 k reads",
-                              "kernel_ms": round(k_ms, 3), "launch_ms_source": "HIP events around every batch's kernels on their stream, summed "
-                              "(KU_RLE_TIMES; includes the per-batch flag kernel)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "bookkeeping), as the executable launches it: one launch per batch of ~120 k reads, the kernels of consecutive "
+                              "batches on two streams in turn (one launch's tail under the next one's start)",
+                              "kernel_ms": round(k_ms, 3), "launch_ms_source": "HIP events around every batch's kernels on the stream they run on: the time "
+                              "the batches' intervals COVER (they overlap; KU_RLE_TIMES; includes the per-batch flag kernel)",
+                              "kernel_ms_sum_of_the_intervals": float(mks.group(1)) if mks else None,
+                              "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(ach / HBM_PEAK_GBS, 5), "frac_model": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(algo_bytes0),
                               "traffic": None, "frac_hw": None}
                     try:  # counter-measured HBM bytes of this instance over a 10 M-read run of the executable (scripts/summarize_cli_pmc.py)
@@ -410,6 +429,7 @@ def host_legs(a, db, ctx, batch, read_len, calls_gpu, taxa_gpu, k, algo_bytes0=N
                 n_rows = sum(1 for _ in open(f"{tmp}/report.tsv"))
                 out["e2e"]["with_report"] = {
                     "value": round(n_e / secs_r / 1e6, 2), "unit": "Mreads/s", "seconds": secs_r, "seconds_of_the_runs": runs_r,
+                    "value_is": f"the median of {N_E2E} runs, the first one included", "cpu_seconds_in_the_window_of_the_median_run": cpu_in_window(err),
                     "roofline": rf_rep,
                     "report_seconds": float(m2.group(1)), "report_rows": n_rows,
                     "report_stages_ms": {mm.group(1).strip(): float(mm.group(2)) for mm in re.finditer(r"ku_ctx_report: (.+?) +([\d.]+) ms", err)},
@@ -695,7 +715,65 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
             "n_shards": n_shards, "read_len": L, "build": build}
 
 
+# ---- N > 1: what the run is about to do, said before it does it, and a bound on how long it may take -----------------------------
+# The driver gives `bench.py --gpus N` 1800 s.  KU_BENCH_BUDGET_S (default 1500) is this script's own bound on the whole run: the
+# sharded leg gets what the replicas leg left of it (KU_BENCH_SHARDED_LEG_LIMIT fixes it instead), and a rendezvous or a
+# collective that never returns ends the run with ONE line that says so instead of the driver's kill.
+BUDGET_S = float(os.environ.get("KU_BENCH_BUDGET_S", "1500"))
+SYNTH_PAIRS_PER_S = 3.4e7   # shard synthesis on one MI355X (profiles/README.md: 3.1 G pairs in ~90 s)
+TABLE_PAIRS_PER_S = 3.8e9   # slot table + probe table behind it (0.61 G pairs in 0.16 s)
+
+
+def planned_table_bytes(n_pairs, free_hbm):
+    """the probe table ku_ctx_set_taxonomy will lay out: 128-byte lines of 8 entries at load 0.2 when that takes at
+    most 40 % of the free HBM, else 0.3, 0.45, 0.6, 0.8; the sorted layout (12 B per pair) when none fits"""
+    for lf in (0.2, 0.3, 0.45, 0.6, 0.8):
+        b = int(n_pairs / (8 * lf)) * 128
+        if b <= (0.4 if lf == 0.2 else 0.85) * free_hbm:
+            return b, lf
+    return n_pairs * 12, None
+
+
+def preflight(a, rank, ws, local_rank, dev, leg, species, genome_len, nt, shards, reads, t_start):
+    """one stderr line per rank + (rank 0) the plan of the leg: devices, free HBM, bytes to synthesise and to lay out, ETA, limits"""
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    # distinct canonical k-mers of the synthetic genomes: ~ species x genome_len (3 % substitutions between siblings keep most apart)
+    pairs_all = species * genome_len
+    pairs_rank = pairs_all // max(shards, 1)
+    idx_bytes = 8 * (4 ** nt // max(shards, 1) + 1)  # (quantile shard bounds: about 1 / shards of the bins each)
+    table_b, lf = planned_table_bytes(pairs_rank, free_b - pairs_rank * 12 - idx_bytes)
+    eta = pairs_rank / SYNTH_PAIRS_PER_S + pairs_rank / TABLE_PAIRS_PER_S + 15
+    info = {"leg": leg, "rank": rank, "world": ws, "device": local_rank, "device_name": torch.cuda.get_device_name(dev),
+            "visible_devices": torch.cuda.device_count(), "hbm_free_gb": round(free_b / 1e9, 1), "hbm_total_gb": round(total_b / 1e9, 1),
+            "pairs_this_rank": pairs_rank, "pair_bytes_gb": round(pairs_rank * 12 / 1e9, 1), "index_bytes_gb": round(idx_bytes / 1e9, 2),
+            "planned_table_gb": round(table_b / 1e9, 1), "planned_load_factor": lf, "reads_per_step": reads,
+            "build_eta_s": round(eta), "elapsed_s": round(time.time() - t_start), "budget_s": BUDGET_S}
+    if table_b + pairs_rank * 12 + idx_bytes > free_b:
+        info["warning"] = "pairs + index + table exceed the free HBM of this device: the library will fall back to a denser layout or fail"
+    sys.stderr.write("[bench preflight] " + json.dumps(info) + "\n")
+    sys.stderr.flush()
+    return info
+
+
+def start_budget_watchdog(rank, ws, t_start, state):
+    """rank 0 prints one JSON line with what there is when the budget runs out (state["result"], or a line that names the step that
+    did not return); every rank leaves.  Cancelled by main() when the run is through."""
+    def expire():
+        if rank == 0:
+            r = state.get("result") or {"metric": "Mreads/s (150 bp)", "value": None, "unit": "Mreads/s", "n_gpus": ws,
+                                        "higher_is_better": True, "data": "synthetic"}
+            r["error"] = (f"bench.py gave up after its own budget of {BUDGET_S:.0f} s (KU_BENCH_BUDGET_S) while: {state.get('doing', '?')}; "
+                          f"started {time.time() - t_start:.0f} s ago")
+            print(json.dumps(r), flush=True)
+        os._exit(3)
+    w = threading.Timer(max(30.0, BUDGET_S - (time.time() - t_start)), expire)
+    w.daemon = True
+    w.start()
+    return w
+
+
 def main():
+    t_start = time.time()
     a = parse()
     self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -725,12 +803,15 @@ def main():
         dist.broadcast(t, 0)
         return t.cpu().numpy()
 
+    run_state = {"doing": "torch.distributed rendezvous (init_process_group)"}
+    budget_watchdog = start_budget_watchdog(rank, ws, t_start, run_state) if ws > 1 else None
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_dev:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    run_state["doing"] = "the RCCL id of the C++ driver's communicator (broadcast)"
     uid = fresh_uid()
 
     k = 31
@@ -743,6 +824,8 @@ def main():
 
     if sharded:
         t_build = time.time()
+        run_state["doing"] = "the sharded run (shard synthesis, probe table, routed steps)"
+        pf = preflight(a, rank, ws, local_rank, dev, "sharded", a.species, a.genome_len, a.nt, max(a.db_shards or ws, ws), a.reads, t_start) if ws > 1 or a.config != 1 else None
         sr = sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, a.steps, a.warmup, stream)
         elapsed, mg, db, L = sr["elapsed"], sr["mg"], sr["db"], sr["read_len"]
         value = a.reads * a.steps / elapsed / 1e6
@@ -764,6 +847,10 @@ def main():
                        "db_build_split": sr["build"]},
             "roofline": sr["roofline"], "wire": sr["wire"],
         }
+        if pf:
+            result["config"]["preflight"] = pf
+        if budget_watchdog:
+            budget_watchdog.cancel()
         if rank == 0:
             print(json.dumps(result), flush=True)
         mg.close()
@@ -773,6 +860,8 @@ def main():
 
     # ---------------------------------------------------------------- replicas (N = 1: the plain single-GPU run)
     t_build = time.time()
+    run_state["doing"] = "the replicas leg (database synthesis, probe table, steps, end-of-run reduce)"
+    pf_rep = preflight(a, rank, ws, local_rank, dev, "replicas", a.species, a.genome_len, a.nt, 1, a.reads, t_start) if ws > 1 else None
     db = synth_torch.BenchDb(dev, n_species=a.species, genome_len=a.genome_len, k=k, nt=a.nt, seed=7)
     db.kmers = db.vals = None
     torch.cuda.empty_cache()
@@ -989,7 +1078,11 @@ def main():
                 result["sharded"] = {"value": None, "error": "the sharded leg did not finish within its time limit"}
                 print(json.dumps(result), flush=True)
             os._exit(0)
-        watchdog = threading.Timer(float(os.environ.get("KU_BENCH_SHARDED_LEG_LIMIT", "900")), give_up)
+        # the leg's limit: what the replicas leg left of the run's budget, less a minute for the line (KU_BENCH_SHARDED_LEG_LIMIT fixes it)
+        leg_limit = float(os.environ.get("KU_BENCH_SHARDED_LEG_LIMIT", "0")) or max(120.0, BUDGET_S - (time.time() - t_start) - 60.0)
+        run_state["doing"] = f"the sharded leg (limit {leg_limit:.0f} s)"
+        run_state["result"] = result
+        watchdog = threading.Timer(leg_limit, give_up)
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -1005,19 +1098,24 @@ def main():
                 # configs[2] scaled to this world: the standard geometry, one ~37 GB minimizer-range shard (12 000 species) per GPU
                 # -- at N = 8 the ~300 GB database of BASELINE.json --, 10 M x 150 bp reads per step over all ranks
                 # (KU_BENCH_SHARD_SPECIES / _GENOME_LEN / _READS / _NT: the same flow at a size a test box holds N times)
+                # KU_BENCH_SCALE_DIV=d: the rehearsal of exactly this flow on a test box -- the preset's sizes divided by d (species per
+                # shard, reads per step), everything else as the driver runs it (tests/test_gpu_bench_contract.py)
+                div = max(1, int(os.environ.get("KU_BENCH_SCALE_DIV", "1")))
                 a2.nt, a2.db_shards = int(os.environ.get("KU_BENCH_SHARD_NT", "15")), ws
-                a2.species = int(os.environ.get("KU_BENCH_SHARD_SPECIES", "12000")) * ws
+                a2.species = max(4, int(os.environ.get("KU_BENCH_SHARD_SPECIES", "12000")) // div) * ws
                 a2.genome_len = int(os.environ.get("KU_BENCH_SHARD_GENOME_LEN", "310000"))
-                a2.reads, a2.read_len, a2.paired, a2.batches = int(os.environ.get("KU_BENCH_SHARD_READS", "10000000")), 150, False, 2
+                a2.reads, a2.read_len, a2.paired, a2.batches = max(1000, int(os.environ.get("KU_BENCH_SHARD_READS", "10000000")) // div), 150, False, 2
             s_steps = a.steps if headline else max(2, min(a.steps, 4))
             s_warm = a.warmup if headline else 1
+            pf_sh = preflight(a2, rank, ws, local_rank, dev, "sharded", a2.species, a2.genome_len, a2.nt, max(a2.db_shards or ws, ws), a2.reads, t_start)
+            pf_sh["leg_limit_s"] = round(leg_limit)
             sr = sharded_run(a2, capi, synth_torch, dev, rank, local_rank, ws, fresh_uid(), k, s_steps, s_warm, stream)
             el = sr["elapsed"]
             result["sharded"] = {"value": round(a2.reads * s_steps / el / 1e6, 3), "unit": "Mreads/s", "scaling": "strong",
                                  "steps": s_steps, "warmup": s_warm, "ms_per_step": round(el / s_steps * 1e3, 3), "db_pairs_per_gpu": sr["db"].n_pairs,
                                  "headline": headline, "reads_per_step": a2.reads, "nt": a2.nt, "taxa": a2.species, "db_shards": sr["n_shards"],
                                  "db_build_split": sr["build"], "hbm_layout": sr["mg"].ctx(0).db_layout(),
-                                 "every_read_resolved_once": sr["ok"], "roofline": sr["roofline"], "wire": sr["wire"],
+                                 "every_read_resolved_once": sr["ok"], "roofline": sr["roofline"], "wire": sr["wire"], "preflight": pf_sh,
                                  "path": "ku_mgpu_step_device: " + ("scatter of the read slices -> scan of the own slice -> one 16-byte record per run of k-mers to the owner of its bin (all-to-all) -> probe + accounting at the owner -> 4-byte slots back -> per-slice resolve" if sr["wire"].get("exchange", "").startswith("owner routing") else "ncclBroadcast -> owner lookup -> all-to-all (grouped ncclSend/ncclRecv) + max-merge -> per-slice resolve")}
             sr["mg"].close()
         except Exception as e:
@@ -1036,8 +1134,11 @@ def main():
                                          "scattered from rank 0, owner-routed over RCCL",
                              "db_pairs_per_gpu": sh["db_pairs_per_gpu"], "hbm_layout": sh["hbm_layout"], "k": k, "nt": sh["nt"], "taxa": sh["taxa"],
                              "reads_per_step": sh["reads_per_step"], "read_len": 150, "parallelism": f"sharded{ws}", "db_shards": sh["db_shards"],
-                             "every_read_resolved_once": sh["every_read_resolved_once"], "db_build_split": sh["db_build_split"], "path": sh["path"]},
+                             "every_read_resolved_once": sh["every_read_resolved_once"], "db_build_split": sh["db_build_split"], "path": sh["path"],
+                             "preflight": sh.get("preflight"), "budget_s": BUDGET_S, "elapsed_s": round(time.time() - t_start)},
                   "roofline": sh["roofline"], "wire": sh["wire"], "replicas": rep}
+    if budget_watchdog:
+        budget_watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if mg:

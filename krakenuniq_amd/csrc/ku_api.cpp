@@ -486,6 +486,14 @@ struct ku_ctx {
   // ku_classify_batch_rle through the fused kernel: the batch goes up in segments on a stream of its own while the
   // segments before are classified (one event per segment)
   hipStream_t h2d_stream = nullptr, d2h_stream = nullptr, fetch_stream = nullptr;
+  // Round 6: the kernels of consecutive batches in flight run on TWO streams in turn, so that the tail of one batch's launch --
+  // its last waves, their counter flushes -- lies under the start of the next one's: launches of ~120 k reads then cost what the
+  // bench's 10 M-read launch costs per read (scripts/launch_shape_probe.py: 30.3 -> 19.5 ms per 10 M reads; 19.8 in one launch).
+  // What orders the batches: main_ev (work queued on the context's own stream before the batch), tail_ready (the open work unit's
+  // insert counts travel from batch to batch), and the host, which waits for a batch's event before it settles it.
+  hipStream_t k_streams[2] = {nullptr, nullptr};
+  hipEvent_t main_ev = nullptr, tail_ready = nullptr;
+  bool tail_ready_set = false;
   std::vector<hipEvent_t> seg_events;
   uint32_t *d_scalar = nullptr;
   // ku_classify_batch_rle in two steps: up to two batches in flight (FIFO: rle_head is the oldest)
@@ -640,6 +648,9 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   for (RleJob &j : ctx->rle) j.release();
   if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+  for (hipStream_t &ks : ctx->k_streams) if (ks) { (void)hipStreamDestroy(ks); ks = nullptr; }
+  if (ctx->main_ev) (void)hipEventDestroy(ctx->main_ev);
+  if (ctx->tail_ready) (void)hipEventDestroy(ctx->tail_ready);
   if (ctx->fetch_stream) (void)hipStreamDestroy(ctx->fetch_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1116,11 +1127,16 @@ extern "C" int ku_ctx_enable_sparse(ku_ctx *ctx, uint64_t work_unit_nt, uint32_t
 // room in the run-wide (slot, encoding) set for `incoming` more entries at load <= 1/2: a larger table takes over when
 // the current one could fill (the set only grows with the distinct k-mers of the taxa that stay sparse -- on a run of
 // many taxa that is most of what the reads hold)
+// the kernels of every batch in flight are through (they run on streams of their own: what is about to replace a table they
+// write to -- the run-wide set growing -- waits for them on the host; rare)
+static int rle_drain_kernels(ku_ctx *ctx);
+
 static int sparse_reserve_global(ku_ctx *ctx, uint64_t incoming, hipStream_t s) {
   ku_ctx::Sparse &sp = ctx->sp;
   KuSparseDev &d = sp.dev;
   const uint64_t need = 2 * (sp.g_count + incoming);
   if (need <= d.g_mask + 1) return KU_OK;
+  KU_TRY(rle_drain_kernels(ctx));
   uint64_t cells = (d.g_mask + 1) * 2;
   while (cells < need) cells *= 2;
   const char *cap_env = getenv("KU_SPARSE_MAX_LOG2");  // test hook: a small ceiling stands in for a full device
@@ -1783,16 +1799,19 @@ static int sparse_tail_close(ku_ctx *ctx) {
 // KU_RLE_TIMES=1: where the batch calls spend their time on the host, summed over the run, printed when the context goes
 static double g_rle_t[10];  // checks, plan + enqueue, waiting for the device in _finish, behind the wait, calls; of the enqueue: [5] buffers + plan ([9]: sparse_reserve_global in it), [6] uploads, [7] launches, [8] copies back + events
 static double g_rle_x[6];  // of 'behind the wait': [0] flagging again, [1] exact passes, [2] their number, [3] units they evaluated, [4] reads in them
-static double g_rle_kernel_ms = 0;  // HIP events around every batch's kernels (fused kernel + the emulation's flag kernel), summed
+static double g_rle_kernel_ms = 0;  // HIP events around every batch's kernels (fused kernel + the emulation's flag kernel): the time
+                                    // covered by the batches' intervals -- they overlap since the batches' kernels run on two streams --
+static double g_rle_kernel_sum_ms = 0, g_rle_cover_end = 0;  // ... their plain sum, and where the covered time ends (ms behind g_rle_ref)
+static hipEvent_t g_rle_ref = nullptr;
 static unsigned long long g_rle_reads = 0;
 static const bool g_rle_times = getenv("KU_RLE_TIMES") != nullptr;
 static double rle_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void rle_times_print() {
   if (g_rle_times && g_rle_t[4] > 0)
     fprintf(stderr, "ku_classify_batch_rle over %.0f batches: checks %.3f s, plan + enqueue %.3f s, waiting for the device %.3f s, behind the wait %.3f s; "
-                    "kernels %.3f ms for %llu reads (HIP events on their stream); of the enqueue: buffers + plan %.3f s, uploads %.3f s, launches %.3f s, "
+                    "kernels %.3f ms for %llu reads (HIP events on their streams: the time the batches' intervals cover; their sum is %.3f ms); of the enqueue: buffers + plan %.3f s, uploads %.3f s, launches %.3f s, "
                     "copies back + events %.3f s; of buffers + plan: room in the emulation's run-wide set %.3f s\n",
-            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads, g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[8], g_rle_t[9]);
+            g_rle_t[4], g_rle_t[0], g_rle_t[1], g_rle_t[2], g_rle_t[3], g_rle_kernel_ms, g_rle_reads, g_rle_kernel_sum_ms, g_rle_t[5], g_rle_t[6], g_rle_t[7], g_rle_t[8], g_rle_t[9]);
   if (g_rle_times && g_rle_x[2] > 0)
     fprintf(stderr, "ku_classify_batch_rle, behind the wait: flagging again %.3f s, %.0f exact passes over %.0f work units (%.0f reads) %.3f s, of it %.3f s waiting for their kernels\n", g_rle_x[0], g_rle_x[2],
             g_rle_x[3], g_rle_x[4], g_rle_x[1], g_rle_x[5]);
@@ -1966,7 +1985,15 @@ static int rle_idle(const ku_ctx *ctx, const char *who) {
 static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
                            uint64_t n_reads, const ku_opts &o, uint32_t max_n, bool monotonic, uint32_t *calls, uint32_t *hits,
                            uint64_t *run_off, uint32_t *run_cnt, ku_run *h_runs, uint64_t h_runs_cap) {
+  // the batch's kernels: consecutive batches take the two kernel streams in turn (KU_RLE_KERNEL_STREAMS=1: the context's one stream)
+  static const bool one_kernel_stream = getenv("KU_RLE_KERNEL_STREAMS") && atoi(getenv("KU_RLE_KERNEL_STREAMS")) == 1;
   hipStream_t s = ctx->stream;
+  if (!one_kernel_stream) {
+    hipStream_t &ks = ctx->k_streams[(&j - &ctx->rle[0]) & 1];
+    if (!ks) HIP_TRY(hipStreamCreateWithFlags(&ks, hipStreamNonBlocking));
+    if (!ctx->main_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->main_ev, hipEventDisableTiming));
+    s = ks;
+  }
   const double t_in = g_rle_times ? rle_now() : 0.0;
   const bool counts = !(o.flags & KU_F_NO_COUNTS);
   const bool sparse = ctx->sp.on && counts;
@@ -2047,7 +2074,7 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     uint64_t in_flight_kmers = 0;  // what the batches in flight may still add: the host's count of the set lags behind them
     for (const RleJob &q : ctx->rle) if (q.busy && &q != &j && q.sparse) in_flight_kmers += q.kmers;
     const double t_g0 = g_rle_times ? rle_now() : 0.0;
-    KU_TRY(sparse_reserve_global(ctx, j.kmers + in_flight_kmers + sp.n_carry_l, s));
+    KU_TRY(sparse_reserve_global(ctx, j.kmers + in_flight_kmers + sp.n_carry_l, ctx->stream));  // (drains the batches in flight when it grows the set)
     if (g_rle_times) g_rle_t[9] += rle_now() - t_g0;
     sf.g_key = sp.dev.g_key;
     sf.g_mask = sp.dev.g_mask;
@@ -2063,14 +2090,17 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   unsigned long long *h_tot = (unsigned long long *)j.pin.p;
   h_flag = (uint8_t *)j.pin.p + 64;
   if (g_rle_times) g_rle_t[5] += rle_now() - t_in;
+  if (s != ctx->stream) {  // whatever was queued on the context's own stream before this batch comes first
+    HIP_TRY(hipEventRecord(ctx->main_ev, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(s, ctx->main_ev, 0));
+  }
   unsigned long long *d_counter = j.d_counter;
   // (emulation) the per-(unit, slot) insert counts and the unit flags start at zero: one launch
   if (sparse) {
     if (ku_launch_zero3(d_counter, 2, j.u_cnt.p, std::max<uint64_t>((uint64_t)j.n_units * ctx->tax.n_slots, 1), j.u_flag.p,
                         ((uint64_t)std::max<uint32_t>(j.n_units, 1) + 3) / 4, s) != KU_OK)
       return fail(KU_EHIP, "clearing the batch counters failed");
-    // unit 0 continues the open unit: its row starts from the inserts that unit has had so far
-    if (j.cont_tail && j.n_units) HIP_TRY(hipMemcpyAsync(j.u_cnt.p, sp.tail_row.p, (size_t)ctx->tax.n_slots * 4, hipMemcpyDeviceToDevice, s));
+    // (unit 0 continues the open unit: the inserts that unit has had so far join its row BEHIND the kernels, below)
   }
   // the run counter starts behind the chunks the waves own from the start (one per wave of every segment's launch)
   h_tot[3] = total_waves * (unsigned long long)chunk;
@@ -2105,7 +2135,11 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
     ro.pre_base1 = (uint32_t)(1 + waves_before);
     waves_before += ku_short_grid_waves(b - a, max_n, ctx->n_cu);
     sf.unit_of = sparse ? (const uint32_t *)j.unit.p + a : nullptr;
-    if (g_rle_times && !clock_started) { HIP_TRY(hipEventRecord(j.t_k0, s)); clock_started = true; }  // (behind the first segment's upload)
+    if (g_rle_times && !clock_started) {  // (behind the first segment's upload)
+      if (!g_rle_ref) { HIP_TRY(hipEventCreate(&g_rle_ref)); HIP_TRY(hipEventRecord(g_rle_ref, s)); }
+      HIP_TRY(hipEventRecord(j.t_k0, s));
+      clock_started = true;
+    }
     int st = ku_launch_classify_short(ctx->m.db, ctx->tax, ctx->cnt, (const uint8_t *)j.seqs.p, n_bytes, (const uint64_t *)j.off.p + a,
                                       (const uint32_t *)j.len.p + a, b - a, max_n, o.flags, (uint32_t *)j.calls.p + a, nullptr, nullptr,
                                       j.ws.p, j.ws.cap, ctx->n_cu, s, &ro, sparse ? &sf : nullptr);
@@ -2114,19 +2148,31 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   }
   const double t_c0 = g_rle_times ? rle_now() : 0.0;
   if (sparse) {
+    // unit 0 continues the open unit: the inserts that unit had before this batch join its row here, behind the kernels -- the
+    // batch before this one writes them behind ITS kernels, on the other stream (tail_ready), and only this small step waits
+    if (j.cont_tail && j.n_units) {
+      if (ctx->tail_ready_set && s != ctx->stream) HIP_TRY(hipStreamWaitEvent(s, ctx->tail_ready, 0));
+      KU_TRY(ku_launch_add_u32((uint32_t *)j.u_cnt.p, (const uint32_t *)sp.tail_row.p, ctx->tax.n_slots, s));
+    }
     KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)j.u_cnt.p, (uint64_t)j.n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
                                        (uint8_t *)j.u_flag.p, s));
     // the unit that stays open (tail form): its insert counts so far
-    if (j.open_after && !(j.cont_carry && j.n_units == 1))
+    if (j.open_after && !(j.cont_carry && j.n_units == 1)) {
       HIP_TRY(hipMemcpyAsync(sp.tail_row.p, (const uint32_t *)j.u_cnt.p + (size_t)(j.n_units - 1) * ctx->tax.n_slots, (size_t)ctx->tax.n_slots * 4,
                              hipMemcpyDeviceToDevice, s));
+      if (s != ctx->stream) {
+        if (!ctx->tail_ready) HIP_TRY(hipEventCreateWithFlags(&ctx->tail_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->tail_ready, s));
+        ctx->tail_ready_set = true;
+      }
+    }
   }
   if (g_rle_times && clock_started) HIP_TRY(hipEventRecord(j.t_k1, s));
   // ---- the copies back run on a stream of their own, behind this batch's kernels -- not in front of the next batch's
   static const bool own_d2h_stream = !(getenv("KU_RLE_D2H_STREAM") && atoi(getenv("KU_RLE_D2H_STREAM")) == 0);
   hipStream_t ds = own_d2h_stream ? ctx->d2h_stream : s;
+  HIP_TRY(hipEventRecord(j.kernels_done, s));
   if (own_d2h_stream) {
-    HIP_TRY(hipEventRecord(j.kernels_done, s));
     HIP_TRY(hipStreamWaitEvent(ds, j.kernels_done, 0));
   }
   HIP_TRY(hipMemcpyAsync(calls, j.calls.p, n_reads * 4, hipMemcpyDeviceToHost, ds));
@@ -2201,8 +2247,14 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
   const double t_w1 = g_rle_times ? rle_now() : 0.0;
   if (g_rle_times && j.t_k0 && j.n_reads) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, j.t_k0, j.t_k1) == hipSuccess) { g_rle_kernel_ms += ms; g_rle_reads += j.n_reads; }
-    else (void)hipGetLastError();
+    float a = 0, b = 0;
+    if (g_rle_ref && hipEventElapsedTime(&ms, j.t_k0, j.t_k1) == hipSuccess && hipEventElapsedTime(&a, g_rle_ref, j.t_k0) == hipSuccess &&
+        hipEventElapsedTime(&b, g_rle_ref, j.t_k1) == hipSuccess) {
+      g_rle_kernel_sum_ms += ms;
+      g_rle_kernel_ms += std::max(0.0, (double)b - std::max((double)a, g_rle_cover_end));  // (the batches come in the order of their starts)
+      g_rle_cover_end = std::max(g_rle_cover_end, (double)b);
+      g_rle_reads += j.n_reads;
+    } else (void)hipGetLastError();
   }
   struct Lap { double a, b; ~Lap() { if (g_rle_times) { g_rle_t[2] += b - a; g_rle_t[3] += rle_now() - b; g_rle_t[4] += 1; } } } lap_{t_w0, t_w1};
   j.busy = false;
@@ -2277,6 +2329,12 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
       for (uint32_t u : flagged) g_rle_x[4] += (double)(j.unit_first_read[u + 1] - j.unit_first_read[u]);
     }
   }
+  return KU_OK;
+}
+
+static int rle_drain_kernels(ku_ctx *ctx) {
+  for (RleJob &q : ctx->rle)
+    if (q.busy && q.kernels_done) HIP_TRY(hipEventSynchronize(q.kernels_done));
   return KU_OK;
 }
 
@@ -2375,7 +2433,7 @@ extern "C" int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint
     double keep_t[10], keep_x[6];  // (KU_RLE_TIMES: the warm-up's batches are none of the caller's)
     memcpy(keep_t, g_rle_t, sizeof keep_t);
     memcpy(keep_x, g_rle_x, sizeof keep_x);
-    const double keep_ms = g_rle_kernel_ms;
+    const double keep_ms = g_rle_kernel_ms, keep_sum = g_rle_kernel_sum_ms;
     const unsigned long long keep_reads = g_rle_reads;
     const uint64_t wn = (std::min<uint64_t>(std::max<uint64_t>(n_reads, 1), 65536) + 1) & ~1ull, stride = 101;  // (even: the arrays behind stay 8-byte aligned)
     const size_t per_slot = (size_t)wn * (4 + 4 + 4 + 8) + (size_t)wn * 8 * 8;
@@ -2416,6 +2474,7 @@ extern "C" int ku_classify_batch_rle_reserve(ku_ctx *ctx, uint64_t n_bytes, uint
     memcpy(g_rle_t, keep_t, sizeof keep_t);
     memcpy(g_rle_x, keep_x, sizeof keep_x);
     g_rle_kernel_ms = keep_ms;
+    g_rle_kernel_sum_ms = keep_sum;
     g_rle_reads = keep_reads;
   }
   return KU_OK;
@@ -2444,6 +2503,7 @@ extern "C" int ku_classify_batch_rle_enqueue(ku_ctx *ctx, const char *seqs, uint
       // no room for the emulation's tables: the classification itself does not depend on them (see classify_device_impl):
       // the run goes on with the dense registers alone; nothing of this batch had been started
       (void)hipStreamSynchronize(ctx->stream);
+      for (hipStream_t ks : ctx->k_streams) if (ks) (void)hipStreamSynchronize(ks);
       if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
       (void)hipGetLastError();
       ctx_free_sparse(ctx);
@@ -2504,6 +2564,7 @@ extern "C" int ku_classify_batch_rle_finish(ku_ctx *ctx, uint64_t *n_runs) {
   if (st == KU_ENOMEM && classified && ctx->sp.on) {
     // the emulation ran out of room behind the classification: it is given up, the run goes on (ku_ctx_sparse_state says 2)
     (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t ks : ctx->k_streams) if (ks) (void)hipStreamSynchronize(ks);
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     (void)hipGetLastError();
     ctx_free_sparse(ctx);

@@ -106,6 +106,8 @@ int ku_launch_sparse_insert(const KuSparseDev &s, uint32_t k, const uint8_t *d_s
                             uint32_t quick_min_hits, int n_cu, hipStream_t stream);
 int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream);
 int ku_launch_zero3(void *a, uint64_t a_dwords, void *b, uint64_t b_dwords, void *c, uint64_t c_dwords, hipStream_t stream);
+// dst[i] += src[i], i < n (the open work unit's insert counts joining a batch's first row)
+int ku_launch_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream);
 int ku_launch_sparse_close(const KuSparseDev &s, uint32_t n_closed, hipStream_t stream, bool skip_hits = false);
 int ku_launch_sparse_carry_out(const KuSparseDev &s, uint32_t unit, unsigned long long *d_carry_l, uint32_t *d_carry_u,
                                unsigned long long *d_counters, uint64_t cap_l, uint64_t cap_u, hipStream_t stream);

@@ -1028,9 +1028,12 @@ uint32_t ku_short_max_kmers_windowed(const KuDbDev &db) {
 }
 
 static unsigned ks_grid(uint64_t n_reads, int items, int n_cu) {
-  // persistent grid: two rounds of the blocks a CU holds at once (KS_OCC blocks of KS_WAVES = 4 waves per CU)
+  // persistent grid: two rounds of the blocks a CU holds at once (KS_OCC blocks of KS_WAVES = 4 waves per CU) -- one round for the
+  // launches of the `classify` executable's size, where a second round's waves would start up (LDS tables, first chunk) and flush
+  // their counters for a handful of reads each (scripts/launch_shape_probe.py, launches of 120 k reads: 30.3 -> 24.9 ms per 10 M reads
+  // on one stream; from 1 M reads per launch on two rounds are the better: 19.95 against 20.32)
   const char *oe = getenv("KU_SHORT_BLOCKS_PER_CU");
-  const uint64_t per_cu = oe ? (uint64_t)atoi(oe) : 2ull * KS_OCC(items);
+  const uint64_t per_cu = oe ? (uint64_t)atoi(oe) : (n_reads < 500000 ? 1ull : 2ull) * KS_OCC(items);
   const uint64_t want = (n_reads + KS_WAVES - 1) / KS_WAVES, cap = (uint64_t)n_cu * per_cu;
   return (unsigned)(want < cap ? want : cap);
 }

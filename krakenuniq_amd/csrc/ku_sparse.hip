@@ -437,6 +437,14 @@ int ku_launch_zero3(void *a, uint64_t a_dwords, void *b, uint64_t b_dwords, void
   hipLaunchKernelGGL(ku_zero3_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, (uint32_t *)a, a_dwords, (uint32_t *)b, b_dwords, (uint32_t *)c, c_dwords);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
 }
+__global__ void ku_add_u32_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+int ku_launch_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t stream) {
+  if (n == 0) return KU_OK;
+  hipLaunchKernelGGL(ku_add_u32_kernel, dim3(ks_grid(n)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;
+}
 int ku_launch_sparse_clear(const KuSparseDev &s, hipStream_t stream) {
   const uint64_t n = (s.l_mask > s.u_mask ? s.l_mask : s.u_mask) + 1;
   hipLaunchKernelGGL(ku_sparse_clear_kernel, dim3(ks_grid((n + 3) / 4)), dim3(256), 0, stream, s);
