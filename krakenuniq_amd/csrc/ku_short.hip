@@ -59,6 +59,9 @@ __device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32
   ks_wave_sync();
   for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
     uint32_t kk = key[i];
+#ifdef KS_DIAG_NOHOT  // (diagnostic builds: is it the ONE address every wave adds to -- the misses' counter -- that the flushes cost?)
+    if (kk == 1) kk = 0;
+#endif
     if (kk) atomicAdd(&global[kk - 1], (unsigned long long)cnt[i]);
     key[i] = 0;
     cnt[i] = 0;
@@ -92,6 +95,9 @@ __device__ __forceinline__ void ks_rct_flush(uint32_t *key, uint32_t *cnt, uint3
   ks_wave_sync();
   for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
     uint32_t kk = key[i];
+#ifdef KS_DIAG_NOHOT
+    if (kk - 1 == KS_RCT_SLOT) kk = 0;  // (the unclassified reads' counter)
+#endif
     if (kk) atomicAdd(&global[ks_rct_node(kk - 1, tax)], (unsigned long long)cnt[i]);
     key[i] = 0;
     cnt[i] = 0;
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   // production build has no trace of it -- the flag checks cost scalar registers and branches in the read loop):
   // 1 skip probe, 2 skip HLL, 4 skip n_kmers, 8 skip taxa store,
   // 32 skip resolve (call 0), 64 skip locus/minimizer stage (bucket 0), 128 (OUT = 2) skip the SEEN marks, 256 (OUT = 2) skip
-  // the misses' inserts into the run-wide set.  0 in production.
+  // the misses' inserts into the run-wide set, 512 (OUT = 2) skip the insert counts per (unit, slot).  0 in production.
   using G = KsGeom<ITEMS>;
   constexpr uint32_t TCAP = 1u << G::TCAP_LOG2;
   __shared__ uint32_t s_codes[KS_WAVES][G::NCODES];
@@ -861,7 +867,9 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
     if (OUT == 2 && DO_COUNTS && n > 0) {
       uint32_t *urow = sf.u_cnt + (size_t)(sf.unit_of[r] - sf.unit_base) * sf.n_slots;
       bool any_miss;  // uniform
-      if (uni) {
+      if (KS_ABL(512u)) {  // (measurement: without the insert counts per (unit, slot))
+        any_miss = false;
+      } else if (uni) {
         if (lane == 0) {
           if (n_hit) atomicAdd(&urow[uni_slot], n_hit);
           if (n_miss) atomicAdd(&urow[0], n_miss);

@@ -74,10 +74,57 @@ def child(n_total):
     del ctx
 
 
+def child_host(n_total):
+    """the host-buffer boundary as the executable uses it: batches of n reads through ku_classify_batch_rle_enqueue / _finish, ONE in
+    flight (every launch alone on the device, as in a run whose parser cannot keep the device busy) or three; with and without the
+    sparse-sketch emulation (OUT = 2 / OUT = 1).  Kernel time: the library's HIP events (KU_RLE_TIMES), printed when the context goes."""
+    import numpy as np
+    import torch
+    from krakenuniq_amd import capi
+    stride = 151
+    reads = np.fromfile(f"{TMP}/reads.bin", dtype=np.uint8)
+    n_all = len(reads) // stride
+    n_total = min(n_total, n_all)
+    pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory().numpy()
+    host = pin(len(reads), torch.uint8)
+    host[:] = reads
+    per = int(os.environ.get("KU_PROBE_HOST_READS", "111000"))
+    sparse = os.environ.get("KU_PROBE_SPARSE") == "1"
+    depth = int(os.environ.get("KU_PROBE_DEPTH", "1"))
+    cdb = capi.Db(f"{TMP}/database.kdb", f"{TMP}/database.idx")
+    ctax = capi.Tax(f"{TMP}/taxDB")
+    ctx = capi.Ctx(0)
+    ctx.load_db(cdb)
+    ctx.set_taxonomy(ctax)
+    if sparse:
+        ctx.enable_sparse(500000)
+    ctx.rle_reserve(per * stride, per, 150, 4)
+    off = pin(per, torch.int64).view(np.uint64)
+    lens = pin(per, torch.int32).view(np.uint32)
+    off[:] = np.arange(per, dtype=np.uint64) * stride
+    lens[:] = 150
+    mk = lambda: {"calls": pin(per, torch.int32).view(np.uint32), "hits": pin(per, torch.int32).view(np.uint32),
+                  "run_cnt": pin(per, torch.int32).view(np.uint32), "run_off": pin(per, torch.int64).view(np.uint64),
+                  "runs": pin((per * 6 + (1 << 16), 2), torch.int32).view(np.uint32)}
+    outs = [mk() for _ in range(4)]
+    n_b = n_total // per
+    t0 = time.perf_counter()
+    flying = []
+    for i in range(n_b):
+        if len(flying) >= depth:
+            ctx.rle_finish(flying.pop(0))
+        flying.append(ctx.rle_enqueue(host[i * per * stride:(i + 1) * per * stride], off, lens, out=outs[i % 4]))
+    while flying:
+        ctx.rle_finish(flying.pop(0))
+    dt = time.perf_counter() - t0
+    print(f"   host batches of {per} reads x {n_b}, depth {depth}, sparse emulation {'on' if sparse else 'off'}: {dt * 1e3:.1f} ms wall for {n_b * per} reads", flush=True)
+    del ctx  # (prints the library's timers)
+
+
 def main():
     n_total = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10_000_000
     if os.environ.get("KU_LAUNCH_PROBE_CHILD"):
-        return child(n_total)
+        return child_host(n_total) if os.environ.get("KU_PROBE_HOST") == "1" else child(n_total)
     import shutil
     import torch
     from krakenuniq_amd import synth_torch
@@ -91,16 +138,21 @@ def main():
     s.reshape(-1).cpu().numpy().tofile(f"{TMP}/reads.bin")
     del db, s
     torch.cuda.empty_cache()
-    variants = [("default", {})]
+    variants = [] if os.environ.get("KU_PROBE_NO_DEFAULT") else [("default", {})]
     for spec in sys.argv[2:]:
         name, _, envs = spec.partition(":")
         variants.append((name, dict(kv.split("=", 1) for kv in envs.split(",") if kv)))
     for name, env in variants:
         print(f"== {name} {env}", flush=True)
         t0 = time.time()
-        r = subprocess.run([sys.executable, __file__, str(n_total)], env=dict(os.environ, KU_LAUNCH_PROBE_CHILD="1", **env),
+        r = subprocess.run([sys.executable, __file__, str(n_total)], env=dict(os.environ, KU_LAUNCH_PROBE_CHILD="1", KU_RLE_TIMES="1", **env),
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         print(r.stdout if r.returncode == 0 else f"   rc {r.returncode}: {r.stderr[-600:]}", flush=True)
+        for line in r.stderr.split("\n"):
+            if "ku_classify_batch_rle over" in line:
+                m = __import__("re").search(r"kernels ([\d.]+) ms for (\d+) reads.*?their sum is ([\d.]+) ms", line)
+                if m:
+                    print(f"   kernels: {float(m.group(1)) * 1e7 / int(m.group(2)):.2f} ms per 10 M reads covered, {float(m.group(3)) * 1e7 / int(m.group(2)):.2f} summed", flush=True)
         print(f"   ({time.time() - t0:.0f} s)", flush=True)
     shutil.rmtree(TMP, ignore_errors=True)
 

@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -102,3 +103,33 @@ def test_two_ranks_plain_line_has_the_sharded_layout_as_its_headline():
     assert d["roofline"]["stage_ms_measured"]["owner_ms"] > 0 and d["wire"]["exchange"].startswith("owner routing")
     rep = d["replicas"]
     assert rep["scaling"] == "weak" and rep["value"] > 0 and rep["config"]["merged_read_count_ok"] is True
+
+
+def test_plain_gpus_2_rehearsal_at_the_presets_shape():
+    """the driver's own `python bench.py --gpus 2 --steps K --warmup W` flow, end to end, at the preset's geometry
+    (nt = 15: the 8.6 GB index per world, standard k) with its sizes divided by KU_BENCH_SCALE_DIV -- nothing else overridden: the
+    pre-flight lines, both legs, the sharded layout as the headline, inside the run's own budget.  Two processes on one device
+    through the asynchronous stand-in for librccl (the only thing a 1-GPU box cannot do is RCCL between two devices)."""
+    shim = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
+    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_LIB=os.path.join(ROOT, "tests", "rccl_shim", "libkrakenuniq_amd_testhooks.so"),
+               KU_SHIM_TIMEOUT="300", KU_BENCH_SCALE_DIV="100", KU_BENCH_BUDGET_S="1200")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "200000",
+                        "--species", "100", "--cpu-sample", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=1300, env=env)
+    wall = time.time() - t0
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "error" not in d, d.get("error")
+    # the pre-flight lines of both legs, from both ranks, before the builds
+    pf = [json.loads(ln.split("[bench preflight] ", 1)[1]) for ln in err.split("\n") if "[bench preflight] " in ln]
+    assert sorted((p["leg"], p["rank"]) for p in pf) == [("replicas", 0), ("replicas", 1), ("sharded", 0), ("sharded", 1)]
+    assert all(p["hbm_free_gb"] > 0 and p["planned_table_gb"] > 0 and p["budget_s"] == 1200 for p in pf)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    c = d["config"]
+    assert c["parallelism"] == "sharded2" and c["nt"] == 15 and c["taxa"] == 240 and c["reads_per_step"] == 100000
+    assert c["every_read_resolved_once"] is True and c["preflight"]["leg"] == "sharded" and c["preflight"]["leg_limit_s"] > 0
+    assert d["replicas"]["value"] > 0 and d["replicas"]["config"]["merged_read_count_ok"] is True
+    assert wall < 1200, wall
