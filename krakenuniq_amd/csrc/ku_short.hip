@@ -53,15 +53,20 @@ __device__ __forceinline__ void ks_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// `hot`: the wave's LAST flush -- the count under key 0 (the misses' counter, which every wave of a launch holds) goes to this LDS
+// word instead of global memory; the block adds its waves' words up and issues one atomic (the end of the kernel).  A launch of the
+// `classify` executable's size has 6 144 waves that all end within microseconds of each other: their adds to that ONE address
+// queued for ~35 us of a 275 us launch (scripts/launch_shape_probe.py: 25.0 -> 22.1 ms per 10 M reads without them).
 template <int LOG2>
 __device__ __forceinline__ void ks_ct_flush(uint32_t *key, uint32_t *cnt, uint32_t *used, unsigned long long *global,
-                                            uint32_t lane) {
+                                            uint32_t lane, uint32_t *hot = nullptr) {
   ks_wave_sync();
   for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
     uint32_t kk = key[i];
 #ifdef KS_DIAG_NOHOT  // (diagnostic builds: is it the ONE address every wave adds to -- the misses' counter -- that the flushes cost?)
     if (kk == 1) kk = 0;
 #endif
+    if (hot && kk == 1) { *hot = cnt[i]; kk = 0; }
     if (kk) atomicAdd(&global[kk - 1], (unsigned long long)cnt[i]);
     key[i] = 0;
     cnt[i] = 0;
@@ -91,13 +96,14 @@ __device__ __forceinline__ void ks_rct_add(uint32_t *key, uint32_t *cnt, uint32_
 }
 template <int LOG2>
 __device__ __forceinline__ void ks_rct_flush(uint32_t *key, uint32_t *cnt, uint32_t *used, const KuTaxDev &tax,
-                                             unsigned long long *global, uint32_t lane) {
+                                             unsigned long long *global, uint32_t lane, uint32_t *hot = nullptr) {
   ks_wave_sync();
   for (uint32_t i = lane; i < (1u << LOG2); i += 64) {
     uint32_t kk = key[i];
 #ifdef KS_DIAG_NOHOT
     if (kk - 1 == KS_RCT_SLOT) kk = 0;  // (the unclassified reads' counter)
 #endif
+    if (hot && kk - 1 == KS_RCT_SLOT) { *hot = cnt[i]; kk = 0; }  // (reads without a hit: node 0, see ks_ct_flush)
     if (kk) atomicAdd(&global[ks_rct_node(kk - 1, tax)], (unsigned long long)cnt[i]);
     key[i] = 0;
     cnt[i] = 0;
@@ -1018,8 +1024,18 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
   }
 #ifndef KS_DIAG_NOFLUSH  // (diagnostic builds: what do the waves' last flushes cost a small launch?  scripts/launch_shape_probe.py)
   if (DO_COUNTS) {
-    if (!ROUTE) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane);
-    ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane);
+    // the counters every wave holds -- misses (slot 0), reads without a hit (node 0) -- leave the block as ONE add each
+    __shared__ uint32_t s_hot[KS_WAVES][2];
+    if (lane < 2) s_hot[wv][lane] = 0;
+    if (!ROUTE) ks_ct_flush<G::KCT_LOG2>(s_kk[wv], s_kc[wv], &misc[0], cnt.n_kmers, lane, &s_hot[wv][0]);
+    ks_rct_flush<G::RCT_LOG2>(s_rk[wv], s_rc[wv], &misc[1], tax, cnt.n_reads, lane, &s_hot[wv][1]);
+    __syncthreads();  // (every wave of the block reaches the end of the kernel: the only block barrier in it)
+    if (wv == 0 && lane < 2) {
+      unsigned long long sum = 0;
+#pragma unroll
+      for (int q = 0; q < KS_WAVES; ++q) sum += s_hot[q][lane];
+      if (sum) atomicAdd(lane == 0 ? &cnt.n_kmers[0] : &cnt.n_reads[0], sum);
+    }
   }
 #endif
   if (OUT == 2 && lane == 0 && sp_fresh) atomicAdd(sf.g_count, (unsigned long long)sp_fresh);
