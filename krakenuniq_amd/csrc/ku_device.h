@@ -116,8 +116,10 @@ __device__ __forceinline__ void ku_ct_maybe_flush(uint32_t *ct_key, uint32_t *ct
 __device__ __forceinline__ uint8_t *ku_hll_locate(uint8_t *registers, uint32_t slot, uint64_t h, uint32_t &rank) {
   // h = ku_fmix64(canonical k-mer)
   const uint32_t idx = (uint32_t)(h >> (64 - KU_HLL_P));
-  const uint64_t rest = h << KU_HLL_P;
-  rank = rest ? (uint32_t)__builtin_clzll(rest) + 1 : (64 - KU_HLL_P + 1);
+  // (clz of the bits behind the index, + 1; all of them zero: 64 - p + 1 -- bit p - 1, set below the hash's bits, stops the
+  // count there without a compare and select)
+  const uint64_t rest = (h << KU_HLL_P) | (1ull << (KU_HLL_P - 1));
+  rank = (uint32_t)__builtin_clzll(rest) + 1;
   return registers + (size_t)slot * KU_HLL_M + idx;
 }
 __device__ __forceinline__ void ku_hll_raise(uint8_t *r, uint32_t seen, uint32_t rank) {
@@ -207,9 +209,10 @@ __device__ __forceinline__ void ku_pack_byte(uint32_t b, uint32_t j, uint32_t &w
 
 // Hash layout (LAYOUT 1, default): at upload time the shard's pairs are re-laid out as a bucketised hash table,
 // one bucket per 128-byte line:
-//     dwords 0..3   eight 16-bit tag fields, field i in the (i & 1 ? high : low) half of dword i >> 1:
-//                   low 15 bits = tag of entry i (1 .. 0x7FFF; 0 = entry unused); bit 15 of field 0 = the bucket
-//                   received more than eight keys and spilled into the following line(s)
+//     dwords 0..3   eight 16-bit tag fields, the field of entry i in the (i >> 2 ? high : low) half of dword i & 3 (round 6: entries
+//                   0..3 in the low halves, 4..7 in the high ones, so that the packed compare below yields the candidate
+//                   mask with three shifts): low 15 bits = tag of entry i (1 .. 0x7FFF; 0 = entry unused); bit 15 of entry 0's
+//                   field (bit 15 of dword 0) = the bucket received more than eight keys and spilled into the following line(s)
 //     dwords 4..27  eight 12-byte entries {key_lo, key_hi, slot};  dwords 28..29 eight SEEN bytes (below);  30..31 unused
 // MI355X moves 128 B per L2 miss and sustains ~48 G random line fetches/s whatever the access width
 // (scripts/calib_gather.hip), so a lookup costs the number of distinct lines it touches -- and, per wave, the
@@ -237,10 +240,12 @@ __device__ __forceinline__ uint32_t ku_table_tag(uint64_t h) {
   const uint32_t t = (uint32_t)(h >> 28) & 0x7FFFu;
   return t ? t : 1u;
 }
-// bit i set <=> tag field i of the header equals `tag` (unused fields are 0, tags are not)
+#ifdef KU_TAG_FIELDWISE  // (A/B builds: round 5's header -- field i in the (i & 1 ? high : low) half of dword i >> 1, compared field by field)
+__device__ __forceinline__ uint32_t ku_tag_dword(uint32_t i) { return i >> 1; }
+__device__ __forceinline__ uint32_t ku_tag_shift(uint32_t i) { return (i & 1u) * 16u; }
 __device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t tag) {
   uint32_t m = 0;
-  m |= ((h4.x & 0x7FFFu) == tag) << 0;  // field 0 carries the spill flag in bit 15
+  m |= ((h4.x & 0x7FFFu) == tag) << 0;
   m |= ((h4.x >> 16) == tag) << 1;
   m |= ((h4.y & 0xFFFFu) == tag) << 2;
   m |= ((h4.y >> 16) == tag) << 3;
@@ -250,6 +255,30 @@ __device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t tag) {
   m |= ((h4.w >> 16) == tag) << 7;
   return m;
 }
+#else
+// where the tag field of entry i lies: dword, shift
+__device__ __forceinline__ uint32_t ku_tag_dword(uint32_t i) { return i & 3u; }
+__device__ __forceinline__ uint32_t ku_tag_shift(uint32_t i) { return (i >> 2) * 16u; }
+// both 16-bit halves of a dword at once: min(half, 1) -- 0 where the half is 0, else 1 (v_pk_min_u16; the compiler turns the
+// portable form into two compares, two selects and a permute)
+__device__ __forceinline__ uint32_t ku_pk_min_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// bit i set <=> the tag field of entry i equals `tag` (unused fields are 0, tags are not).  Packed 16-bit arithmetic on the four
+// header dwords: XOR with the tag in both halves, min(half, 1) leaves 0 exactly where a field matched, the four dwords' flags are
+// interleaved into bits 0..3 (low halves: entries 0..3) and 16..19 (entries 4..7).  16 vector instructions per header where the
+// field-by-field compare took 43 (round 6; the kernel is bound by instruction issue).
+__device__ __forceinline__ uint32_t ku_tag_matches(uint4 h4, uint32_t tag) {
+  const uint32_t t2 = tag | (tag << 16), one = 0x00010001u;
+  const uint32_t e0 = ku_pk_min_u16((h4.x & 0xFFFF7FFFu) ^ t2, one);  // (entry 0's field carries the spill flag in bit 15)
+  const uint32_t e1 = ku_pk_min_u16(h4.y ^ t2, one), e2 = ku_pk_min_u16(h4.z ^ t2, one), e3 = ku_pk_min_u16(h4.w ^ t2, one);
+  const uint32_t differ = ((((e3 << 1) | e2) << 1 | e1) << 1) | e0;  // bit i / 16 + i: entry i / 4 + i does NOT match
+  const uint32_t m = ~differ & 0x000F000Fu;
+  return (m | (m >> 12)) & 0xFFu;
+}
+#endif
 __device__ __forceinline__ bool ku_line_spilled(uint4 h4) { return (h4.x & 0x8000u) != 0; }
 
 // Locality-aware bucket choice.  Consecutive k-mers of a read share their minimizer *occurrence* ~(k-nt+1)/2

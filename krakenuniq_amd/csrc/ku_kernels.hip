@@ -657,8 +657,8 @@ __global__ void ku_build_table_kernel(const uint32_t *__restrict__ pairs, uint64
       // dword that holds it (the neighbour field and the spill flag may change under it: retry on the fresh value)
       int got = -1;
       for (int i = 0; i < KU_LINE_SLOTS && got < 0; ++i) {
-        uint32_t *w = lp + (i >> 1);
-        const uint32_t sh = (i & 1) * 16;
+        uint32_t *w = lp + ku_tag_dword((uint32_t)i);
+        const uint32_t sh = ku_tag_shift((uint32_t)i);
         uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (((cur >> sh) & 0x7FFFu) == 0) {
           const uint32_t prev = atomicCAS(w, cur, cur | (tag << sh));
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void ku_count_table_kernel(const uint32_t *__r
     if (l < n_lines) {
       const uint32_t *lp = table + l * KU_LINE_DWORDS;
       for (uint32_t i = 0; i < KU_LINE_SLOTS; ++i)
-        if ((lp[i >> 1] >> ((i & 1) * 16)) & 0x7FFFu) ku_ct_add(s_ctk, s_ctc, &s_ctu, lp[KU_LINE_ENTRY0 + 3 * i + 2], 1, counts);
+        if ((lp[ku_tag_dword(i)] >> ku_tag_shift(i)) & 0x7FFFu) ku_ct_add(s_ctk, s_ctc, &s_ctu, lp[KU_LINE_ENTRY0 + 3 * i + 2], 1, counts);
     }
     __syncthreads();
     ku_ct_maybe_flush(s_ctk, s_ctc, &s_ctu, counts);
