@@ -211,3 +211,22 @@ def test_fuzz_against_reference():
         pytest.skip("oracle/_ref/classify is built in the build container only")
     failures = fuzz_seqio.fuzz(120, seed=20261001)
     assert not failures, failures[:3]
+
+
+def test_long_stretches_of_empty_records_between_region_parsers(tmp_path):
+    """whole regions of empty records: they share a work unit with the nucleotides that follow (printed), or form the file's last,
+    nucleotide-free unit (never printed) -- whatever the number of region parsers; the held batches are folded into one
+    (UnitGate), so a pool of batches cannot run dry"""
+    d = f"{G}/f12"
+    head = open(f"{d}/empty_inside.fa", "rb").read().split(b">e1\n")[0]          # 20 reads of 150 nt
+    tail = b">t1\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>t2\nTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT\n"
+    empties = b"".join(b">x%d\n" % j for j in range(5000))
+    for name, data, n_want in (("inside.fa", head + empties + tail, 20 + 5000 + 2), ("behind.fa", head + empties, 20),
+                               ("front.fa", empties + tail, 5002), ("all.fa", empties, 0)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        want = dump(["-u", "1500", str(p)])[:2]
+        assert len(want[0]) == n_want, name
+        for j in ("2", "5", "13"):
+            got = dump(["-u", "1500", "-j", j, str(p)])[:2]
+            assert got == want, (name, j)
