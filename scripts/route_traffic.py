@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/route_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_config_evidence.sh: HBM bytes per step
+"""profiles/route_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_r06.sh configN pmcN: HBM bytes per step
 of the stages of an owner-routed step (scan, owner, resolve; the prefix-sum kernels count with the owner), per workload,
 with the hash of the kernel sources they were measured on (bench.py refuses the file for any other source).
    usage: scripts/route_traffic.py <tag> <workload key> <steps in the profiled run> [<tag> <key> <steps> ...]

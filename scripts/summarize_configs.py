@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>_config{2,3,4}_{line.json,stats/} (scripts/profile_r05.sh configN) -> profiles/<tag>_configN_line.json and
+"""gpurun_out/<tag>_config{2,3,4}_{line.json,stats/} (scripts/profile_r06.sh configN) -> profiles/<tag>_configN_line.json and
 profiles/<tag>_configN_kernel_stats.csv (our kernels + every kernel >= 1 % of GPU time), and the check VERDICT r04 #4 asks
 for: the stage kernels' durations in the rocprofv3 table (rounds on ONE stream: they do not overlap), per step, against the
 stage times the bench line measured with HIP events.      usage: scripts/summarize_configs.py <tag>"""
