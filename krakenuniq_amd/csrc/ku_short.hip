@@ -20,6 +20,7 @@
 // every second k-mer, only two lanes instead of four share a bucket line per instruction, and the number of line
 // requests, the scarce resource of the probe, doubles.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ku_device.h"
 
@@ -134,9 +135,12 @@ __device__ __forceinline__ void ks_tab_add(uint32_t *t_key, uint32_t *t_cnt, uin
 
 // resolve_tree (krakenutil.cpp:149-200) over the wave's table: score(t) = sum of the hit counts on t's root path, the
 // best score wins, ties fold lca() in ascending taxid (= slot) order.  Leaves the table empty.  Returns the node.
+// `urow` (sparse-sketch emulation, OUT = 2): the read's hit counts are its inserts per slot -- booked into the work unit's row of
+// insert counts from here, one add per DISTINCT taxon of the read by the lane that owns the table entry (round 6; a ballot loop
+// over the lanes' slots did it before: 5 of the instance's 37 ms per 10 M reads)
 template <int LOG2>
 __device__ __forceinline__ uint32_t ks_tab_resolve(uint32_t *t_key, uint32_t *t_cnt, uint16_t *t_list, uint32_t *list_len,
-                                                   const KuTaxDev &tax, uint32_t lane) {
+                                                   const KuTaxDev &tax, uint32_t lane, uint32_t *urow = nullptr) {
   constexpr uint32_t TCAP = 1u << LOG2;
   if (lane == 0) *list_len = 0;
   ks_wave_sync();
@@ -148,6 +152,7 @@ __device__ __forceinline__ uint32_t ks_tab_resolve(uint32_t *t_key, uint32_t *t_
   for (uint32_t e = lane; e < n_list; e += 64) {
     const uint32_t pos = t_list[e];
     const uint32_t sl = t_key[pos] - 1;
+    if (urow) atomicAdd(&urow[sl], t_cnt[pos] & 0xffffu);  // (the scores are added into the high halves further down)
     uint32_t score = 0;
     for (uint32_t i = tax.slot_anc_off[sl], i_end = tax.slot_anc_off[sl + 1]; i < i_end; ++i) {
       const uint32_t s = tax.slot_anc[i];
@@ -569,8 +574,15 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
       uint32_t tacc = 0xFFFFFFFFu;  // min over the steps of (own ^ neighbour) - 2: < 62 <=> equal keys at two positions
       bool tie = false;             // ... somewhere in the read -> exact scan below
       if (lane < KS_PAD) mmv[P + lane] = (0x03FFFFFFu - lane) << KU_PK_KEYSHIFT;
+      // The k-mers take ITEMS rounds of 64 lanes, the m-mer positions w - 1 more than that: a round of their own when they do not
+      // fit ITEMS rounds (a 150 bp read: 138 positions) -- and none when they do (reads up to 140 bp at ITEMS = 2, up to 204 bp at
+      // ITEMS = 3: round 6; measured on 100 bp reads: 14.4 -> 14.1 ms per 10 M).
+      const bool tail_round = P > (uint32_t)ITEMS * 64u;  // (wave-uniform)
+      pk[ITEMS] = 0;
+      wr[ITEMS] = (uint32_t)G::NMM - 1u;
 #pragma unroll
       for (int j = 0; j <= ITEMS; ++j) {
+        if (j == ITEMS && !tail_round) break;
         const uint32_t p = j * 64 + lane;
         wr[j] = p < P ? p : (uint32_t)G::NMM - 1u;
         const uint32_t wi = p >> 4, sh = (p & 15u) * 2;
@@ -608,23 +620,30 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
         uint32_t tj[ITEMS + 1];
 #pragma unroll
         for (int j = 0; j <= ITEMS; ++j) tj[j] = 0xFFFFFFFFu;
+        // the doubling steps over NR rounds of positions (ITEMS + 1 with the tail round, else ITEMS: the positions behind the
+        // last round that takes part are sentinels nobody updates)
+        auto doubling = [&](auto nr_c) {
+          constexpr int NR = decltype(nr_c)::value;
 #pragma unroll
-        for (uint32_t sft = 0; sft < 5; ++sft) {
-          const uint32_t st = 1u << sft;
-          if (2 * st > w) break;
-          uint32_t nb[ITEMS + 1];
+          for (uint32_t sft = 0; sft < 5; ++sft) {
+            const uint32_t st = 1u << sft;
+            if (2 * st > w) break;
+            uint32_t nb[NR];
 #pragma unroll
-          for (int j = 0; j <= ITEMS; ++j) nb[j] = mmv[j * 64 + lane + st] + (st << 1);
-          ks_wave_sync();  // every read of this step before any write (in-place update)
+            for (int j = 0; j < NR; ++j) nb[j] = mmv[j * 64 + lane + st] + (st << 1);
+            ks_wave_sync();  // every read of this step before any write (in-place update)
 #pragma unroll
-          for (int j = 0; j <= ITEMS; ++j) {
-            tj[j] = min(tj[j], (pk[j] ^ nb[j]) - 2u);
-            pk[j] = min(pk[j], nb[j]);
-            mmv[wr[j]] = pk[j];
+            for (int j = 0; j < NR; ++j) {
+              tj[j] = min(tj[j], (pk[j] ^ nb[j]) - 2u);
+              pk[j] = min(pk[j], nb[j]);
+              mmv[wr[j]] = pk[j];
+            }
+            ks_wave_sync();
+            blk = 2 * st;
           }
-          ks_wave_sync();
-          blk = 2 * st;
-        }
+        };
+        if (tail_round) doubling(std::integral_constant<int, ITEMS + 1>{});
+        else doubling(std::integral_constant<int, ITEMS>{});
         if (w > blk) {
 #pragma unroll
           for (int j = 0; j < ITEMS; ++j) {
@@ -789,7 +808,9 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
 #pragma unroll
           for (int j = 0; j < ITEMS; ++j)
             if (v[j] != 0) ks_tab_add<G::TCAP_LOG2, false>(t_key, t_cnt, nullptr, v[j], 1u);
-          call_node = ks_tab_resolve<G::TCAP_LOG2>(t_key, t_cnt, t_list, &misc[2], tax, lane);
+          uint32_t *urow_hits = nullptr;  // OUT = 2: the read's hits are booked per (work unit, slot) from the table
+          if (OUT == 2 && DO_COUNTS && !KS_ABL(512u)) urow_hits = sf.u_cnt + (size_t)(sf.unit_of[r] - sf.unit_base) * sf.n_slots;
+          call_node = ks_tab_resolve<G::TCAP_LOG2>(t_key, t_cnt, t_list, &misc[2], tax, lane, urow_hits);
         }
       } else if (bal) {
         // the window's hits join the read's: (rd_first, rd_cnt) while a single taxon has been met, the table from the
@@ -881,6 +902,13 @@ __global__ __launch_bounds__(64 * KS_WAVES, KS_OCC(ITEMS)) void ku_classify_shor
           if (n_miss) atomicAdd(&urow[0], n_miss);
         }
         any_miss = n_miss != 0;
+      } else if (!WIN && !KS_ABL(32u)) {
+        // several taxa, one pass: the hits went into the unit's row with the resolve table (ks_tab_resolve); the misses here
+        uint32_t nm = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) nm += (uint32_t)__popcll(__ballot(j * 64 + lane < n && !amb_k[j] && v[j] == 0));
+        if (lane == 0 && nm) atomicAdd(&urow[0], nm);
+        any_miss = nm != 0;
       } else {
         unsigned long long miss_any = 0;
 #pragma unroll
