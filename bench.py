@@ -1044,6 +1044,10 @@ def main():
                      "frac": round(frac_model, 5), "frac_model": round(frac_model, 5),
                      "frac_hw": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and kernel_ms else None,
                      "traffic": traffic, "traffic_source": traffic_note,
+                     "which_fraction_is_which": "frac (= frac_model) prices the REFERENCE algorithm's bytes (SURVEY 8d: a comparison search of 12-byte pairs) "
+                                                "against the kernel's time, as the contract defines `achieved`; the bucket probe moves fewer bytes -- "
+                                                "frac_hw (counter-measured FETCH_SIZE x 2 + WRITE_SIZE per launch) is the HBM utilisation; the kernel is "
+                                                "bound by instruction issue, not by HBM (DESIGN 3.2, 4)",
                      "algorithmic_bytes_per_launch": int(bytes_algo), "lookups_per_launch": int(lookups),
                      "mean_ceil_log2_bin": round(sum_log / max(lookups, 1), 3), "kernel_ms": round(kernel_ms, 3)},
     }
