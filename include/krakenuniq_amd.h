@@ -3,7 +3,7 @@
  * The reference (fbreitwieser/krakenuniq v1.0.4) has no library API: the
  * boundary is the `classify` executable (src/classify.cpp) that
  * scripts/krakenuniq:248 spawns.  This header is the thin C layer between that
- * executable's host code (this repo's krakenuniq_amd/csrc/classify_main.cpp,
+ * executable's host code (this repo's krakenuniq_amd/csrc/classify_{main,input,device,output}.cpp,
  * flag-compatible with src/classify.cpp:1074) and the HIP kernels.  Every entry
  * point names the reference code it replaces (file:line under the reference's
  * src/).  Conventions: extern "C", opaque handles, plain pointers + sizes, int
