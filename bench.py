@@ -1089,7 +1089,30 @@ def main():
         watchdog = threading.Timer(leg_limit, give_up)
         watchdog.daemon = True
         watchdog.start()
+        # a rank that fails in this leg (an allocation, say) leaves the others waiting in an exchange: it says so in the rendezvous
+        # store, everybody looks there every two seconds, and the run ends with the line measured above instead of at the limit
+        leg_store, leg_over, fail_key = dist.distributed_c10d._get_default_store(), threading.Event(), "ku_bench/sharded_leg_failed"
+
+        def watch_the_others():
+            while not leg_over.wait(2.0):
+                try:
+                    if not leg_store.check([fail_key]):
+                        continue
+                    why = leg_store.get(fail_key).decode(errors="replace")
+                except Exception:
+                    if rank != 0 and not leg_over.is_set():
+                        os._exit(0)  # the store went with rank 0 (or the launcher): nobody is left to exchange with
+                    return
+                if leg_over.is_set():
+                    return
+                if rank == 0:
+                    result["sharded"] = {"value": None, "error": why[:300]}
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+        threading.Thread(target=watch_the_others, daemon=True).start()
         try:
+            if os.environ.get("KU_BENCH_TEST_FAIL_SHARDED_RANK") == str(rank):
+                raise RuntimeError("injected by KU_BENCH_TEST_FAIL_SHARDED_RANK (tests/test_gpu_bench_contract.py)")
             del batches, d_taxa, d_calls
             mg.close()
             mg = None
@@ -1123,7 +1146,19 @@ def main():
                                  "path": "ku_mgpu_step_device: " + ("scatter of the read slices -> scan of the own slice -> one 16-byte record per run of k-mers to the owner of its bin (all-to-all) -> probe + accounting at the owner -> 4-byte slots back -> per-slice resolve" if sr["wire"].get("exchange", "").startswith("owner routing") else "ncclBroadcast -> owner lookup -> all-to-all (grouped ncclSend/ncclRecv) + max-merge -> per-slice resolve")}
             sr["mg"].close()
         except Exception as e:
-            result["sharded"] = {"value": None, "error": str(e)[:300]}
+            import traceback
+            why = f"rank {rank} failed in the sharded leg: {type(e).__name__}: {e}"
+            sys.stderr.write(f"[bench] {why}\n{traceback.format_exc()}")
+            sys.stderr.flush()
+            try:  # the first failure is the cause; a rank that fell over the first one's departure reports that one
+                if leg_store.check([fail_key]):
+                    why = leg_store.get(fail_key).decode(errors="replace")
+                else:
+                    leg_store.set(fail_key, why[:300])
+            except Exception:
+                pass
+            result["sharded"] = {"value": None, "error": why[:300]}
+        leg_over.set()
         watchdog.cancel()
     sh = result.get("sharded") if ws > 1 else None
     if sh and sh.get("headline") and sh.get("value"):
@@ -1145,6 +1180,8 @@ def main():
         budget_watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if ws > 1 and (result.get("sharded") or {}).get("error"):
+        os._exit(0)  # the other ranks left from inside an exchange: nothing orderly remains to be taken down
     if mg:
         mg.close()
     if ws > 1:

@@ -133,3 +133,24 @@ def test_plain_gpus_2_rehearsal_at_the_presets_shape():
     assert c["every_read_resolved_once"] is True and c["preflight"]["leg"] == "sharded" and c["preflight"]["leg_limit_s"] > 0
     assert d["replicas"]["value"] > 0 and d["replicas"]["config"]["merged_read_count_ok"] is True
     assert wall < 1200, wall
+
+
+def test_a_rank_failing_in_the_sharded_leg_ends_the_run_with_the_replicas_line():
+    """one rank raising in the second leg (an allocation failure, say) leaves the others inside an exchange; the run must not sit
+    there until its limit: the failing rank says so in the rendezvous store, and rank 0 prints the line it has at once"""
+    shim = os.path.join(ROOT, "tests", "rccl_shim", "libku_rccl_shim.so")
+    env = dict(os.environ, KU_BENCH_ONE_DEVICE="1", KU_RCCL_LIB=shim, KU_LIB=os.path.join(ROOT, "tests", "rccl_shim", "libkrakenuniq_amd_testhooks.so"),
+               KU_SHIM_TIMEOUT="300", KU_BENCH_SCALE_DIV="100", KU_BENCH_BUDGET_S="1200", KU_BENCH_TEST_FAIL_SHARDED_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "200000",
+                        "--species", "100", "--cpu-sample", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=1300, env=env)
+    wall = time.time() - t0
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    lines = [ln for ln in r.stdout.decode().split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["config"]["merged_read_count_ok"] is True
+    assert d["sharded"]["value"] is None and "rank 1 failed in the sharded leg" in d["sharded"]["error"]
+    assert "[bench] rank 1 failed in the sharded leg" in err
+    assert wall < 400, wall
