@@ -273,6 +273,11 @@ extern "C" int ku_ctx_report_cols(ku_ctx *ctx, const ku_tax *tax, const char *co
       if (st == KU_OK) st = tmp.put(&d_choff, ch_off);
       if (st == KU_OK) st = tmp.put(&d_ch, ch);
       if (st == KU_OK) st = tmp.put(&d_bmpar, bm_parents_by_level);
+      std::vector<uint32_t> slot_fast(ns, KU_FAST_SKIP);
+      for (size_t s = 0; s < ns; ++s)
+        if (s_off[s + 1] > s_off[s]) slot_fast[s] = bm_of[s_clade[s_off[s]]] != KU_BM_NONE ? bm_of[s_clade[s_off[s]]] : KU_FAST_WALK;
+      uint32_t *d_sfast = nullptr;
+      if (st == KU_OK) st = tmp.put(&d_sfast, slot_fast);
       lap("union plan (host)");
       if (st == KU_OK) st = tmp.zeros(&d_set, cells);
       if (st == KU_OK) st = tmp.zeros(&d_bm, (size_t)std::max<uint32_t>(n_bm, 1) * (n_bm ? KU_BM_WORDS : 1));
@@ -281,7 +286,7 @@ extern "C" int ku_ctx_report_cols(ku_ctx *ctx, const ku_tax *tax, const char *co
       KuRollupPlan plan{};
       plan.dense = sd.dense; plan.slot_off = d_soff; plan.slot_clade = d_sclade; plan.set_off = d_setoff; plan.set_cells = d_setcells;
       plan.clade_hot = d_chot; plan.hot_clades = d_hotc; plan.n_hot = n_hot; plan.set = d_set; plan.hist = d_hist; plan.err = d_err;
-      plan.bm_of = d_bmof; plan.bm = d_bm;
+      plan.bm_of = d_bmof; plan.bm = d_bm; plan.slot_fast = d_sfast;
       if (n_pairs) KU_TRY(ku_launch_rollup_sparse(sd.g_key, sd.g_mask + 1, plan, ctx->n_cu, ctx->stream));
       if (ctx->m.seen_dirty && ctx->m.d_table) KU_TRY(ku_launch_rollup_table(ctx->m.d_table, ctx->m.db.n_lines, plan, ctx->n_cu, ctx->stream));
       for (const auto &lv : level_ranges)  // children into parents, deepest parents first

@@ -136,6 +136,7 @@ int ku_launch_rollup_dense(const uint8_t *d_registers, const uint32_t *d_member_
 // the union plan of one ku_ctx_report call (device pointers; ku_api.cpp builds it, ku_report.hip walks it)
 struct KuRollupPlan {
   const uint32_t *dense;                // per slot
+  const uint32_t *slot_fast;            // per slot: the bitmap its entries go to first, or KU_FAST_SKIP / KU_FAST_WALK (ku_report.hip)
   const uint32_t *slot_off, *slot_clade;  // CSR: the all-sparse clades on each slot's root path, leaf first
   const unsigned long long *set_off;    // per clade: its open-addressing table of 4-byte cells within `set` ...
   const uint32_t *set_cells;            // ... and its size (0: nothing is offered to the clade)
@@ -151,6 +152,8 @@ int ku_launch_rollup_table(const void *d_table, uint64_t n_lines, const KuRollup
 // union bitmaps of the big all-sparse clades (ku_report.hip): one bit per 25-bit index, KU_BM_WORDS words per clade
 #define KU_BM_WORDS (1u << 20)
 #define KU_BM_NONE 0xFFFFFFFFu
+#define KU_FAST_SKIP 0xFFFFFFFFu                 // KuRollupPlan::slot_fast: nothing of this slot is offered to anybody
+#define KU_FAST_WALK 0xFFFFFFFEu                 //                          the slot's first clade keeps a table: the general walk
 int ku_launch_bitmap_or_children(uint32_t *d_bm, const uint32_t *d_parents, uint32_t n_parents, const uint32_t *d_child_off,
                                  const uint32_t *d_child, hipStream_t stream);
 int ku_launch_bitmap_hist(const uint32_t *d_bm, const uint32_t *d_bm_clade, uint32_t n_bm, uint32_t *d_hist, hipStream_t stream);

@@ -83,6 +83,7 @@ __device__ __forceinline__ uint32_t encoded_rank(uint32_t e) {
 // (ku_bitmap_hist) -- one atomic per entry instead of one table insert per entry and level (3 G inserts for 0.6 G entries
 // under a five-level taxonomy were 237 of the report's 290 ms of kernels).  The few entries that carry the flag (index
 // bits p..p' all zero: 1 in 8192) walk on through small per-clade tables as before.
+__device__ __forceinline__ void rollup_to_bitmap(const KuRollupPlan &p, uint32_t b, uint32_t enc);
 // one entry (slot, encoding) of a sketch that stayed sparse walks up its slot's chain of all-sparse clades, leaf first
 __device__ __forceinline__ void rollup_entry(const KuRollupPlan &p, uint32_t *hot, uint32_t slot, uint32_t enc) {
   uint32_t r = encoded_rank(enc);
@@ -95,7 +96,7 @@ __device__ __forceinline__ void rollup_entry(const KuRollupPlan &p, uint32_t *ho
     const uint32_t c = p.slot_clade[j];
     const uint32_t b = p.bm_of[c];
     if (b != KU_BM_NONE && !(enc & 1u)) {  // index = enc >> 7: word enc >> 12, bit (enc >> 7) & 31
-      atomicOr(&p.bm[(size_t)b * KU_BM_WORDS + (enc >> 12)], 1u << ((enc >> 7) & 31u));
+      rollup_to_bitmap(p, b, enc);
       break;
     }
     bool fresh = true;
@@ -136,22 +137,50 @@ __global__ __launch_bounds__(256) void ku_rollup_sparse_kernel(const unsigned lo
     if (hot[i]) atomicAdd(&p.hist[(size_t)p.hot_clades[i / KU_ROLLUP_BINS] * KU_ROLLUP_BINS + i % KU_ROLLUP_BINS], hot[i]);
 }
 
+// an entry bound for bitmap b (its encoding carries no rank flag): index = enc >> 7 -> word enc >> 12, bit (enc >> 7) & 31.
+// (Round 6 tried buckets per (bitmap, 2^18-index segment) filled through an L2-resident cursor, their bits then set in LDS and
+// written once: the cursor's round trip and the scattered 4-byte stores cost what the read-modify-writes of random HBM lines
+// cost -- 23 against 21 ms for 0.55 G entries -- plus 4 B of scratch per entry; not kept.)
+__device__ __forceinline__ void rollup_to_bitmap(const KuRollupPlan &p, uint32_t b, uint32_t enc) {
+  atomicOr(&p.bm[(size_t)b * KU_BM_WORDS + (enc >> 12)], 1u << ((enc >> 7) & 31u));
+}
+
 // source 2 (round 5): the probe table's SEEN marks (ku_device.h) -- every marked entry is a k-mer some read held, booked under
 // the entry's slot by the fused kernel's fast path; its encoding is that of the k-mer's hash (hyperloglogplus.cpp:181-204).
-// A thread per (line, entry): the eight lanes of a line read its eight SEEN bytes, the marked ones their 12-byte entry.
+// A thread per LINE and two lines per thread and turn: the eight SEEN bytes of each as one 8-byte load (a wave has 128 line
+// requests in flight; a thread per entry -- rounds 5/6 -- had eight lanes wait for one line and every wave turn for the whole
+// chain entry -> slot -> chain of clades -> bit: 44.6 ms for the 49 GB table of the bench database after a 10 M-read run; now
+// 31.3 ms: 8.1 the scan, 1.9 the chain, 21 the 0.55 G read-modify-writes of random bitmap lines), then the marked entries from
+// the same lines.  `slot_fast` shortens the chain for what nearly every entry is: the slot's first all-sparse clade
+// keeps a bitmap (its number), the slot is dense or offers nothing (KU_FAST_SKIP), or the general walk (KU_FAST_WALK).
 __global__ __launch_bounds__(256) void ku_rollup_table_kernel(const uint32_t *__restrict__ table, uint64_t n_lines, KuRollupPlan p) {
   __shared__ uint32_t hot[KU_ROLLUP_HOT * KU_ROLLUP_BINS];
   for (uint32_t i = threadIdx.x; i < KU_ROLLUP_HOT * KU_ROLLUP_BINS; i += blockDim.x) hot[i] = 0;
   __syncthreads();
-  const uint64_t n_items = n_lines * KU_LINE_SLOTS;
-  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_items; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t *lp = table + (i >> 3) * KU_LINE_DWORDS;
-    const uint32_t e = (uint32_t)i & 7u;
-    if (!reinterpret_cast<const uint8_t *>(lp + KU_LINE_SEEN0)[e]) continue;
-    const uint32_t slot = lp[KU_LINE_ENTRY0 + 3 * e + 2];
-    if (p.dense[slot]) continue;
-    const uint64_t key = ((uint64_t)lp[KU_LINE_ENTRY0 + 3 * e + 1] << 32) | lp[KU_LINE_ENTRY0 + 3 * e];
-    rollup_entry(p, hot, slot, ks_encode(ku_fmix64(key)));
+  constexpr int LINES = 2;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i0 = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i0 < n_lines; i0 += LINES * stride) {
+    unsigned long long seen[LINES];
+#pragma unroll
+    for (int u = 0; u < LINES; ++u) {
+      const uint64_t i = i0 + (uint64_t)u * stride;
+      seen[u] = i < n_lines ? *reinterpret_cast<const unsigned long long *>(table + i * KU_LINE_DWORDS + KU_LINE_SEEN0) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < LINES; ++u) {
+      const uint32_t *lp = table + (i0 + (uint64_t)u * stride) * KU_LINE_DWORDS;
+      unsigned long long sm = seen[u];
+      while (sm) {
+        const uint32_t e = (uint32_t)__builtin_ctzll(sm) >> 3;
+        sm &= ~(0xFFull << (8 * e));
+        const uint32_t k_lo = lp[KU_LINE_ENTRY0 + 3 * e], k_hi = lp[KU_LINE_ENTRY0 + 3 * e + 1], slot = lp[KU_LINE_ENTRY0 + 3 * e + 2];
+        const uint32_t f = p.slot_fast[slot];
+        if (f == KU_FAST_SKIP) continue;
+        const uint32_t enc = ks_encode(ku_fmix64(((uint64_t)k_hi << 32) | k_lo));
+        if (f != KU_FAST_WALK && !(enc & 1u)) rollup_to_bitmap(p, f, enc);
+        else rollup_entry(p, hot, slot, enc);
+      }
+    }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < p.n_hot * KU_ROLLUP_BINS; i += blockDim.x)
@@ -184,24 +213,29 @@ __global__ __launch_bounds__(256) void ku_bitmap_hist_kernel(const uint32_t *__r
   __shared__ uint32_t bins[16];
   if (threadIdx.x < 16) bins[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t *src = bm + (size_t)blockIdx.y * KU_BM_WORDS;
+  const uint4 *src = reinterpret_cast<const uint4 *>(bm + (size_t)blockIdx.y * KU_BM_WORDS);
   uint32_t cnt[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) cnt[i] = 0;
-  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < KU_BM_WORDS; w += gridDim.x * blockDim.x) {
-    const uint32_t v = src[w];
-    if (!v) continue;
-    const uint32_t lo = w & 0xFFu;
-    if (lo) {
-      const uint32_t r = (uint32_t)__clz(lo) - 24u + 1u;  // 1 .. 8
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < KU_BM_WORDS / 4; q += gridDim.x * blockDim.x) {
+    const uint4 v4 = src[q];  // words 4 q .. 4 q + 3
+    const uint32_t vs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-      for (int i = 1; i <= 8; ++i) cnt[i] += r == (uint32_t)i ? (uint32_t)__popc(v) : 0u;
-    } else {
-      cnt[9] += (uint32_t)__popc(v & 0xFFFF0000u);
-      cnt[10] += (uint32_t)__popc(v & 0x0000FF00u);
-      cnt[11] += (uint32_t)__popc(v & 0x000000F0u);
-      cnt[12] += (uint32_t)__popc(v & 0x0000000Cu);
-      cnt[13] += (uint32_t)__popc(v & 0x00000002u);
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t v = vs[u];
+      if (!v) continue;
+      const uint32_t lo = (4u * q + u) & 0xFFu;
+      if (lo) {
+        const uint32_t r = (uint32_t)__clz(lo) - 24u + 1u;  // 1 .. 8
+#pragma unroll
+        for (int i = 1; i <= 8; ++i) cnt[i] += r == (uint32_t)i ? (uint32_t)__popc(v) : 0u;
+      } else {
+        cnt[9] += (uint32_t)__popc(v & 0xFFFF0000u);
+        cnt[10] += (uint32_t)__popc(v & 0x0000FF00u);
+        cnt[11] += (uint32_t)__popc(v & 0x000000F0u);
+        cnt[12] += (uint32_t)__popc(v & 0x0000000Cu);
+        cnt[13] += (uint32_t)__popc(v & 0x00000002u);
+      }
     }
   }
 #pragma unroll
@@ -262,7 +296,8 @@ int ku_launch_rollup_sparse(const unsigned long long *d_g_key, uint64_t g_cells,
 
 int ku_launch_rollup_table(const void *d_table, uint64_t n_lines, const KuRollupPlan &plan, int n_cu, hipStream_t stream) {
   if (!n_lines) return KU_OK;
-  const uint64_t want = (n_lines * KU_LINE_SLOTS + 255) / 256;
+  if (!plan.slot_fast) return KU_EINVAL;
+  const uint64_t want = (n_lines + 511) / 512;
   const unsigned blocks = (unsigned)(want < (uint64_t)n_cu * 8 ? want : (uint64_t)n_cu * 8);
   ku_rollup_table_kernel<<<blocks, 256, 0, stream>>>((const uint32_t *)d_table, n_lines, plan);
   return hipGetLastError() == hipSuccess ? KU_OK : KU_EHIP;

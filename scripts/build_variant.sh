@@ -11,8 +11,9 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include $*"
 /opt/rocm/bin/hipcc $F -c ku_short.hip -o /tmp/kuvar_$NAME/ku_short.o &
 /opt/rocm/bin/hipcc $F -c ku_kernels.hip -o /tmp/kuvar_$NAME/ku_kernels.o &
 /opt/rocm/bin/hipcc $F -c ku_route.hip -o /tmp/kuvar_$NAME/ku_route.o &
+/opt/rocm/bin/hipcc $F -c ku_report.hip -o /tmp/kuvar_$NAME/ku_report.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libku_$NAME.so /tmp/kuvar_$NAME/ku_kernels.o /tmp/kuvar_$NAME/ku_short.o /tmp/kuvar_$NAME/ku_route.o \
-  ku_sparse.o ku_report.o ku_dbsort.o ku_setlcas.o ku_api.o ku_api_sparse.o ku_api_classify.o ku_api_rle.o ku_api_ooc.o ku_api_report.o ku_mgpu.o ku_host.o -ldl -lpthread
+  ku_sparse.o /tmp/kuvar_$NAME/ku_report.o ku_dbsort.o ku_setlcas.o ku_api.o ku_api_sparse.o ku_api_classify.o ku_api_rle.o ku_api_ooc.o ku_api_report.o ku_mgpu.o ku_host.o -ldl -lpthread
 mkdir -p ../variants/$NAME && cp ../variants/libku_$NAME.so ../variants/$NAME/libkrakenuniq_amd.so
 echo built ../variants/libku_$NAME.so
