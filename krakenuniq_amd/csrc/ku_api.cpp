@@ -423,7 +423,6 @@ extern "C" void ku_ctx_destroy(ku_ctx *ctx) {
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   for (hipStream_t &ks : ctx->k_streams) if (ks) { (void)hipStreamDestroy(ks); ks = nullptr; }
   if (ctx->main_ev) (void)hipEventDestroy(ctx->main_ev);
-  if (ctx->tail_ready) (void)hipEventDestroy(ctx->tail_ready);
   if (ctx->fetch_stream) (void)hipStreamDestroy(ctx->fetch_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -458,30 +458,26 @@ static int rle_job_enqueue(ku_ctx *ctx, RleJob &j, const char *seqs, uint64_t n_
   }
   const double t_c0 = g_rle_times ? rle_now() : 0.0;
   if (sparse) {
-    // unit 0 continues the open unit: the inserts that unit had before this batch join its row here, behind the kernels -- the
-    // batch before this one writes them behind ITS kernels, on the other stream (tail_ready), and only this small step waits
-    if (j.cont_tail && j.n_units) {
-      if (ctx->tail_ready_set && s != ctx->stream) HIP_TRY(hipStreamWaitEvent(s, ctx->tail_ready, 0));
+    // The open unit's insert counts (sp.tail_row) travel from batch to batch through this small step behind the kernels: it
+    // reads what the batch before wrote behind ITS kernels on the other stream, and what it writes must not land before that
+    // batch has read -- so the step (not the kernels) waits for the whole of the batch before, in enqueue order.
+    if (ctx->prev_kernels_done && s != ctx->stream) HIP_TRY(hipStreamWaitEvent(s, ctx->prev_kernels_done, 0));
+    // unit 0 continues the open unit: the inserts that unit had before this batch join its row
+    if (j.cont_tail && j.n_units)
       KU_TRY(ku_launch_add_u32((uint32_t *)j.u_cnt.p, (const uint32_t *)sp.tail_row.p, ctx->tax.n_slots, s));
-    }
     KU_TRY(ku_launch_sparse_flag_units((const uint32_t *)j.u_cnt.p, (uint64_t)j.n_units * ctx->tax.n_slots, ctx->tax.n_slots, sp.dev.dense,
                                        (uint8_t *)j.u_flag.p, s));
     // the unit that stays open (tail form): its insert counts so far
-    if (j.open_after && !(j.cont_carry && j.n_units == 1)) {
+    if (j.open_after && !(j.cont_carry && j.n_units == 1))
       HIP_TRY(hipMemcpyAsync(sp.tail_row.p, (const uint32_t *)j.u_cnt.p + (size_t)(j.n_units - 1) * ctx->tax.n_slots, (size_t)ctx->tax.n_slots * 4,
                              hipMemcpyDeviceToDevice, s));
-      if (s != ctx->stream) {
-        if (!ctx->tail_ready) HIP_TRY(hipEventCreateWithFlags(&ctx->tail_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ctx->tail_ready, s));
-        ctx->tail_ready_set = true;
-      }
-    }
   }
   if (g_rle_times && clock_started) HIP_TRY(hipEventRecord(j.t_k1, s));
   // ---- the copies back run on a stream of their own, behind this batch's kernels -- not in front of the next batch's
   static const bool own_d2h_stream = !(getenv("KU_RLE_D2H_STREAM") && atoi(getenv("KU_RLE_D2H_STREAM")) == 0);
   hipStream_t ds = own_d2h_stream ? ctx->d2h_stream : s;
   HIP_TRY(hipEventRecord(j.kernels_done, s));
+  ctx->prev_kernels_done = j.kernels_done;  // (the jobs' events live as long as the context)
   if (own_d2h_stream) {
     HIP_TRY(hipStreamWaitEvent(ds, j.kernels_done, 0));
   }
@@ -631,7 +627,13 @@ static int rle_job_finish(ku_ctx *ctx, RleJob &j, uint64_t *n_runs, bool *classi
     }
     const double t_ex0 = g_rle_times ? rle_now() : 0.0;
     if (g_rle_times) g_rle_x[0] += t_ex0 - t_rf0;
-    if (!flagged.empty()) KU_TRY(sparse_fast_exact(ctx, j, flagged, flag_all, carry_stays_open, s));
+    if (!flagged.empty()) {
+      // as on one stream, where they were queued in front of it: the kernels of the batches in flight come before the exact pass
+      // (it closes work units -- sketches turn dense, entries join the run-wide set -- and those kernels read both)
+      for (const RleJob &q : ctx->rle)
+        if (q.busy && q.kernels_done) HIP_TRY(hipStreamWaitEvent(s, q.kernels_done, 0));
+      KU_TRY(sparse_fast_exact(ctx, j, flagged, flag_all, carry_stays_open, s));
+    }
     if (g_rle_times && !flagged.empty()) {
       g_rle_x[1] += rle_now() - t_ex0;
       g_rle_x[2] += 1;

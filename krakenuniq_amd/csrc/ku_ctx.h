@@ -184,11 +184,12 @@ struct ku_ctx {
   // Round 6: the kernels of consecutive batches in flight run on TWO streams in turn, so that the tail of one batch's launch --
   // its last waves, their counter flushes -- lies under the start of the next one's: launches of ~120 k reads then cost what the
   // bench's 10 M-read launch costs per read (scripts/launch_shape_probe.py: 30.3 -> 19.5 ms per 10 M reads; 19.8 in one launch).
-  // What orders the batches: main_ev (work queued on the context's own stream before the batch), tail_ready (the open work unit's
-  // insert counts travel from batch to batch), and the host, which waits for a batch's event before it settles it.
+  // What orders the batches: main_ev (work queued on the context's own stream before the batch), prev_kernels_done (the batch
+  // enqueued before: the open work unit's insert counts travel from batch to batch behind the kernels; the exact pass of a batch
+  // waits for the kernels of every batch in flight), and the host, which waits for a batch's event before it settles it.
   hipStream_t k_streams[2] = {nullptr, nullptr};
-  hipEvent_t main_ev = nullptr, tail_ready = nullptr;
-  bool tail_ready_set = false;
+  hipEvent_t main_ev = nullptr;
+  hipEvent_t prev_kernels_done = nullptr;  // (a job's event, not owned)
   std::vector<hipEvent_t> seg_events;
   uint32_t *d_scalar = nullptr;
   // ku_classify_batch_rle in two steps: up to two batches in flight (FIFO: rle_head is the oldest)
