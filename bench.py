@@ -759,6 +759,13 @@ def start_budget_watchdog(rank, ws, t_start, state):
     """rank 0 prints one JSON line with what there is when the budget runs out (state["result"], or a line that names the step that
     did not return); every rank leaves.  Cancelled by main() when the run is through."""
     def expire():
+        try:  # where every rank stands, for the log
+            import faulthandler
+            sys.stderr.write(f"[bench] rank {rank}: the budget of {BUDGET_S:.0f} s ran out while: {state.get('doing', '?')}\n")
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            sys.stderr.flush()
+        except Exception:
+            pass
         if rank == 0:
             r = state.get("result") or {"metric": "Mreads/s (150 bp)", "value": None, "unit": "Mreads/s", "n_gpus": ws,
                                         "higher_is_better": True, "data": "synthetic"}
