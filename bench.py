@@ -641,11 +641,19 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
                 tj = json.load(open(tpath))
                 key = f"nt{a.nt}_species{a.species}_shards{n_shards}_ws{ws}_reads{a.reads}_len{L}"
                 ent = tj.get("workloads", {}).get(key)
+                # the counters were collected with ONE rank doing every rank's scan and resolve and the owner work of shard 0
+                # (scripts/profile_r06.sh): a world that holds the whole layout finds its workload under ws1 -- a rank's scan
+                # and resolve are 1 / ws of those passes, its owner work the same
+                ent1 = tj.get("workloads", {}).get(f"nt{a.nt}_species{a.species}_shards{n_shards}_ws1_reads{a.reads}_len{L}") if ws == n_shards and ws > 1 else None
                 if ent and tj.get("kernel_rev") == rev:
                     by = ent["hbm_bytes_per_step"]
                     traffic = (by.get("scan", 0) + by.get("resolve", 0)) * share + by.get("owner", 0)
                     tnote = ent.get("source", "profiles/route_traffic.json")
-                elif ent:
+                elif ent1 and tj.get("kernel_rev") == rev:
+                    by = ent1["hbm_bytes_per_step"]
+                    traffic = (by.get("scan", 0) + by.get("resolve", 0)) / ws + by.get("owner", 0)
+                    tnote = ent1.get("source", "profiles/route_traffic.json") + f" -- collected with one rank doing all {ws} ranks' scan and resolve: those two taken at 1 / {ws}, the owner stage as measured"
+                elif ent or ent1:
                     tnote = f"profiles/route_traffic.json is of kernel source {tj.get('kernel_rev')}, this is {rev}: refused"
             except Exception:
                 pass
