@@ -1,5 +1,5 @@
 """-m gpu: a bounded slice of the extended differential runs (tests/fuzz_gpu_parity.py, fuzz_gpu_sparse.py, fuzz_gpu_mgpu.py,
-fuzz_cli.py -- the long runs are logged under profiles/r06_fuzz_*.log): random databases, read shapes, batch cuts, ranks and
+fuzz_gpu_step_device.py, fuzz_cli.py -- the long runs are logged under profiles/r06_fuzz_*.log): random databases, read shapes, batch cuts, ranks and
 flag sets against the oracle, and the executable against the compiled reference on the same files."""
 import os
 import shutil
@@ -27,6 +27,12 @@ def test_two_step_call_with_batches_in_flight_and_the_emulation_against_the_orac
 def test_groups_of_ranks_against_the_oracle(seed):
     import fuzz_gpu_mgpu
     fuzz_gpu_mgpu.one_case(seed)
+
+
+@pytest.mark.parametrize("seed", range(9400, 9440))
+def test_routed_device_step_against_one_context(seed):
+    import fuzz_gpu_step_device
+    fuzz_gpu_step_device.one_case(seed)
 
 
 def test_executable_against_the_compiled_reference_on_random_inputs_and_flags():
