@@ -1,5 +1,5 @@
 """-m gpu: a bounded slice of the extended differential runs (tests/fuzz_gpu_parity.py, fuzz_gpu_sparse.py, fuzz_gpu_mgpu.py,
-fuzz_gpu_step_device.py, fuzz_cli.py -- the long runs are logged under profiles/r06_fuzz_*.log): random databases, read shapes, batch cuts, ranks and
+fuzz_gpu_step_device.py, fuzz_cli.py, fuzz_build_tools.py -- the long runs are logged under profiles/r06_fuzz_*.log): random databases, read shapes, batch cuts, ranks and
 flag sets against the oracle, and the executable against the compiled reference on the same files."""
 import os
 import shutil
@@ -45,5 +45,17 @@ def test_executable_against_the_compiled_reference_on_random_inputs_and_flags():
         for seed in range(9300, 9316):
             compared += "reference died" not in fuzz_cli.one_case(seed, tmp)
         assert compared >= 8
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_build_tools_against_the_compiled_reference_on_random_inputs():
+    import fuzz_build_tools
+    if not os.path.exists(os.path.join(fuzz_build_tools.REF, "db_sort")):
+        pytest.skip("oracle/_ref/db_sort is not built here")
+    tmp = tempfile.mkdtemp(prefix="ku_fuzz_build_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for seed in range(9500, 9508):
+            fuzz_build_tools.one_case(seed, tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
