@@ -213,14 +213,20 @@ int Run::run(int argc_, char **argv_) {
     fprintf(stderr, "Reading UID mapping file %s\n", uid_map_file.c_str());  // src/classify.cpp:163
     KU_CHECK(ku_uid_map_open(uid_map_file.c_str(), &uid_map));
   }
-  // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference; one chunk = everything resident as usual
+  // -x SIZE (src/krakendb.cpp:463-522): the chunk plan of the reference.  The reference runs its chunk mode whenever -x is given
+  // (src/classify.cpp:196-198,251-252), also when the plan has ONE chunk -- and that mode differs from the plain one in what it
+  // counts: every k-mer goes into the run's global sketches (one work unit: :719), and quick mode calls the taxon of the read's
+  // last unambiguous k-mer (:686-737).  One chunk and no -q: everything resident, the plain pipeline with that accounting;
+  // one chunk with -q: the chunked pipeline over its single chunk (its own quick kernel).
+  bool one_chunk = false;
   if (chunk_bytes) {
     chunk_bounds.resize(info.n_bins + 2 < (1u << 20) ? info.n_bins + 2 : (1u << 20));
     uint32_t n_chunks = 0;
     KU_CHECK(ku_db_chunk_plan(db, chunk_bytes, chunk_bounds.data(), (uint32_t)chunk_bounds.size() - 1, &n_chunks));
     chunk_bounds.resize(n_chunks + 1);
     chunk_bounds.back() = info.n_bins;  // the bins behind the last chunk hold no pairs
-    if (n_chunks <= 1) chunk_bounds.clear();
+    one_chunk = n_chunks <= 1;
+    if (n_chunks == 0 || (one_chunk && !quick)) chunk_bounds.clear();
   }
   chunked = !chunk_bounds.empty();
   // KU_DEVICES with -x (more chunks than one): the first GPU runs the out-of-core pipeline, the others are HELPERS -- each
@@ -348,8 +354,8 @@ int Run::run(int argc_, char **argv_) {
     // (Rounds 3-4 sized the run-wide (slot, encoding) set from the input files here, up to 16 GB: every k-mer went into it.
     // Since round 5 the k-mers the database holds are marked in the probe table itself and the set only takes the misses of
     // the first work units: the default of 2^26 cells, which grows on demand, does.)
-    int st = mg ? ku_mgpu_enable_sparse(mg, work_unit_nt, g_log2)
-                : ku_ctx_enable_sparse(ctx, chunked ? 0 : work_unit_nt, g_log2);
+    int st = mg ? ku_mgpu_enable_sparse(mg, one_chunk ? 0 : work_unit_nt, g_log2)
+                : ku_ctx_enable_sparse(ctx, chunked || one_chunk ? 0 : work_unit_nt, g_log2);
     if (st == KU_EUNSUP) { fprintf(stderr, "classify: %s -- the report will carry dense estimates\n", ku_last_error()); sparse = false; }
     else KU_CHECK(st);
   }

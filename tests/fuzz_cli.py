@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Extended differential run on a GPU box (not collected by pytest; `python tests/fuzz_cli.py [cases] [first_seed]`): the drop-in
 executable krakenuniq_amd/bin/classify against the compiled reference oracle/_ref/classify ON THE SAME FILES AND FLAGS --
-random databases (nt, taxonomy), FASTA / FASTQ inputs (one or two files, wrapped lines, ambiguous bases, short and empty
-reads), random flags (-q -m, -c, -s, -u, -p, -x, -C, -U, -r): the Kraken file, the classified / unclassified read files byte
+random databases (nt, taxonomy), FASTA / FASTQ inputs (one or two files, plain or .gz with one or several members, wrapped
+lines, ambiguous bases, short and empty reads), random flags (-q -m, -c, -s, -u, -p, -x, -C, -U, -r): the Kraken file, the classified / unclassified read files byte
 for byte, the report row for row.  The reference runs with -t 1 (its output order is its input order only then)."""
 import os
 import shutil
@@ -77,6 +77,17 @@ def one_case(seed, tmp):
         else:
             seqs = [s if s else b"N" for s in seqs]
             synth.write_fasta(path, seqs, ids, width=int(rng.choice([0, 0, 60, 70])))
+        if rng.random() < 0.3:  # the same text as a .gz file (the reference reads it through gzstream, this executable through its inflating team)
+            import gzip
+            raw = open(path, "rb").read()
+            os.unlink(path)
+            path += ".gz"
+            if rng.random() < 0.5:
+                open(path, "wb").write(gzip.compress(raw, compresslevel=int(rng.integers(1, 10))))
+            else:  # several members
+                cut = sorted(rng.integers(0, len(raw) + 1, size=int(rng.integers(1, 4))).tolist())
+                parts = [raw[a:b] for a, b in zip([0] + cut, cut + [len(raw)])]
+                open(path, "wb").write(b"".join(gzip.compress(x) for x in parts))
         files.append(path)
     flags = []
     if rng.random() < 0.25:
@@ -89,11 +100,12 @@ def one_case(seed, tmp):
         flags += ["-u", str(int(rng.choice([1, 1500, 7000, 30000, 150000])))]
     if rng.random() < 0.3:
         flags += ["-p", str(int(rng.choice([0, 10, 12, 14, 16])))]
-    if rng.random() < 0.25:
+    bias = os.environ.get("KU_FUZZ_CLI_BIAS", "")  # "chunk": every case in the reference's chunk mode, with a report
+    if rng.random() < 0.25 or bias == "chunk":
         flags += ["-x", str(int(rng.integers(64, 400))) + "K"]
     if rng.random() < 0.3:
         flags += ["-M"]
-    want_c, want_u, want_r = rng.random() < 0.3, rng.random() < 0.3, rng.random() < 0.7
+    want_c, want_u, want_r = rng.random() < 0.3, rng.random() < 0.3, rng.random() < 0.7 or bias == "chunk"
     outs = {}
     for who, exe, threads in (("ref", REF, "1"), ("ours", OURS, "1" if os.environ.get("KU_FUZZ_CLI_OURS") else str(int(rng.integers(1, 9))))):
         d = dirs[who]

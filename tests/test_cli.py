@@ -272,6 +272,30 @@ def test_out_of_core_chunked_run(tmp_path, size):
 
 
 @pytest.mark.gpu
+def test_a_preload_size_that_holds_the_whole_database_is_still_the_chunk_mode(tmp_path):
+    """-x SIZE with a plan of ONE chunk: the reference runs its chunk mode all the same (src/classify.cpp:196-198,251-252) --
+    quick mode calls the taxon of the read's last unambiguous k-mer, -u is ignored (one work unit for the run); found by
+    tests/fuzz_cli.py.  The goldens are the reference's -x 70K outputs, which its -x 10M run reproduces byte for byte."""
+    d = tmp_path / "db"
+    d.mkdir()
+    for fn in ("database.kdb", "database.idx", "taxDB"):
+        (d / fn).write_bytes(open(f"{F1}/{fn}", "rb").read())
+    db = ["-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB"]
+    out, rep = tmp_path / "out.tsv", tmp_path / "rep.tsv"
+    r = run(db + ["-x", "10M", "-t", "3", "-q", "-m", "2", "-o", str(out), "-r", str(rep), f"{F1}/reads.fq"])
+    assert r.returncode == 0, r.stderr.decode()
+    assert out.read_bytes() == open(f"{F1}/out_chunk_quick.tsv", "rb").read()
+    assert out.read_bytes() != open(f"{F1}/out_quick.tsv", "rb").read()  # (the plain run's quick mode calls differently)
+    assert rows(rep.read_text()) == rows(open(f"{F1}/report_chunk_quick.tsv").read())
+    # without -q everything stays resident (no streaming), with the chunk mode's accounting: -u does not apply
+    r = run(db + ["-x", "10M", "-u", "1000", "-o", str(out), "-r", str(tmp_path / "rep2.tsv"), f"{F1}/reads.fq"])
+    assert r.returncode == 0 and b"Streaming the database" not in r.stderr
+    assert out.read_bytes() == open(f"{F1}/out_chunk.tsv", "rb").read()
+    assert rows((tmp_path / "rep2.tsv").read_text()) == rows(open(f"{F1}/report_chunk.tsv").read())
+    assert rows(open(f"{F1}/report_chunk.tsv").read()) != rows(open(f"{F1}/report_u1000.tsv").read())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("devices,size", [("0,0", "30K"), ("0,0,0", "30K"), ("0,0,0,0,0,0,0", "70K")])
 def test_out_of_core_run_on_several_gpus(tmp_path, devices, size):
     """KU_DEVICES with -x: the chunks are dealt out among the GPUs (chunk c on GPU c mod N; more GPUs than chunks: the rest
