@@ -2,7 +2,7 @@
 """Extended differential run on a GPU box (not collected by pytest; `python tests/fuzz_cli.py [cases] [first_seed]`): the drop-in
 executable krakenuniq_amd/bin/classify against the compiled reference oracle/_ref/classify ON THE SAME FILES AND FLAGS --
 random databases (nt, taxonomy), FASTA / FASTQ inputs (one or two files, plain or .gz with one or several members, wrapped
-lines, ambiguous bases, short and empty reads), random flags (-q -m, -c, -s, -u, -p, -x, -C, -U, -r): the Kraken file, the classified / unclassified read files byte
+lines, ambiguous bases, short and empty reads), random flags (-q -m, -c, -s, -u, -p, -x, -M, -C, -U, -r), sometimes a second database behind the first, sometimes as classifyExact: the Kraken file, the classified / unclassified read files byte
 for byte, the report row for row.  The reference runs with -t 1 (its output order is its input order only then)."""
 import os
 import shutil
@@ -47,7 +47,16 @@ def one_case(seed, tmp):
             for fn in ("database.kdb", "database.idx", "taxDB"):
                 os.symlink(os.path.join(dirs["ref"], fn), os.path.join(d, fn))
         dirs[who] = d
-    sp = list(db["genomes"])
+    # a second database searched behind the first (classify -d A -d B, src/classify.cpp:928-936): other genomes, same taxonomy
+    two_dbs = rng.random() < 0.2 and os.environ.get("KU_FUZZ_CLI_BIAS", "") != "chunk"
+    genome_pool = dict(db["genomes"])
+    if two_dbs:
+        nt_b = int(rng.choice([6, 9, 10, 11]))
+        db_b = gc.random_db(rng, n_genomes=n_gen, glen=int(rng.integers(2000, 5000)), k=k, nt=nt_b, tax=tax)
+        synth.write_db(os.path.join(tmp, "db_b"), db_b["kmers"], db_b["vals"], db_b["offsets"], k, nt_b)
+        genome_pool = {("a", t): g for t, g in db["genomes"].items()}
+        genome_pool.update({("b", t): g for t, g in db_b["genomes"].items()})
+    sp = list(genome_pool)
     weights = rng.pareto(0.7, size=len(sp)) + 0.01
     weights = weights / weights.sum()
     files = []
@@ -58,7 +67,7 @@ def one_case(seed, tmp):
             if rng.random() < 0.08:
                 s = bytes(rng.choice(np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8), size=int(rng.integers(0, 220))).tobytes())
             else:
-                g = db["genomes"][sp[int(rng.choice(len(sp), p=weights))]]
+                g = genome_pool[sp[int(rng.choice(len(sp), p=weights))]]
                 n = int(rng.integers(k - 2, min(600, len(g) - 1)))
                 a = int(rng.integers(0, len(g) - n))
                 c = g[a:a + n]
@@ -101,19 +110,24 @@ def one_case(seed, tmp):
     if rng.random() < 0.3:
         flags += ["-p", str(int(rng.choice([0, 10, 12, 14, 16])))]
     bias = os.environ.get("KU_FUZZ_CLI_BIAS", "")  # "chunk": every case in the reference's chunk mode, with a report
-    if rng.random() < 0.25 or bias == "chunk":
+    if (rng.random() < 0.25 and not two_dbs) or bias == "chunk":
         flags += ["-x", str(int(rng.integers(64, 400))) + "K"]
     if rng.random() < 0.3:
         flags += ["-M"]
     want_c, want_u, want_r = rng.random() < 0.3, rng.random() < 0.3, rng.random() < 0.7 or bias == "chunk"
     outs = {}
-    for who, exe, threads in (("ref", REF, "1"), ("ours", OURS, "1" if os.environ.get("KU_FUZZ_CLI_OURS") else str(int(rng.integers(1, 9))))):
+    exact = rng.random() < 0.15  # classifyExact: the same executable under its other name (exact distinct k-mer counts in the report)
+    sfx = "Exact" if exact else ""
+    for who, exe, threads in (("ref", REF + sfx, "1"), ("ours", OURS + sfx, "1" if os.environ.get("KU_FUZZ_CLI_OURS") else str(int(rng.integers(1, 9))))):
         d = dirs[who]
         o = {kk: os.path.join(tmp, f"{who}_{kk}") for kk in ("out", "rep", "cls", "ucls")}
         for p in o.values():
             if os.path.exists(p):
                 os.unlink(p)
-        cmd = [exe, "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx", "-a", f"{d}/taxDB", "-t", threads, "-o", o["out"]] + flags
+        cmd = [exe, "-d", f"{d}/database.kdb", "-i", f"{d}/database.idx"]
+        if two_dbs:
+            cmd += ["-d", os.path.join(tmp, "db_b", "database.kdb"), "-i", os.path.join(tmp, "db_b", "database.idx")]
+        cmd += ["-a", f"{d}/taxDB", "-t", threads, "-o", o["out"]] + flags
         if want_r:
             cmd += ["-r", o["rep"]]
         if want_c:
@@ -123,7 +137,7 @@ def one_case(seed, tmp):
         r = subprocess.run(cmd + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         outs[who] = (r.returncode, {kk: (open(p, "rb").read() if os.path.exists(p) else None) for kk, p in o.items()}, r.stderr.decode(errors="replace")[-400:])
     (rc_r, f_r, e_r), (rc_o, f_o, e_o) = outs["ref"], outs["ours"]
-    desc = f"nt {nt} genomes {n_gen} files {[os.path.basename(f) for f in files]} flags {' '.join(flags)}{' -r' if want_r else ''}{' -C' if want_c else ''}{' -U' if want_u else ''}"
+    desc = f"{'classifyExact ' if exact else ''}{'two databases ' if two_dbs else ''}nt {nt} genomes {n_gen} files {[os.path.basename(f) for f in files]} flags {' '.join(flags)}{' -r' if want_r else ''}{' -C' if want_c else ''}{' -U' if want_u else ''}"
     if rc_r < 0:
         return desc + f" (the reference died of signal {-rc_r}: nothing to compare; this executable exits {rc_o})"
     assert rc_r == rc_o, (desc, "exit codes", rc_r, rc_o, e_r, e_o)
