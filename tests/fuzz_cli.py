@@ -109,7 +109,7 @@ def one_case(seed, tmp):
         flags += ["-u", str(int(rng.choice([1, 1500, 7000, 30000, 150000])))]
     if rng.random() < 0.3:
         flags += ["-p", str(int(rng.choice([0, 10, 12, 14, 16])))]
-    bias = os.environ.get("KU_FUZZ_CLI_BIAS", "")  # "chunk": every case in the reference's chunk mode, with a report
+    bias = os.environ.get("KU_FUZZ_CLI_BIAS", "")  # "chunk": every case in the reference's chunk mode, with a report; "devices": this executable with KU_DEVICES=0,0,...
     if (rng.random() < 0.25 and not two_dbs) or bias == "chunk":
         flags += ["-x", str(int(rng.integers(64, 400))) + "K"]
     if rng.random() < 0.3:
@@ -134,7 +134,12 @@ def one_case(seed, tmp):
             cmd += ["-C", o["cls"]]
         if want_u:
             cmd += ["-U", o["ucls"]]
-        r = subprocess.run(cmd + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        env = dict(os.environ)
+        # a group of ranks on the one device (minimizer-range shards, or chunks dealt out with -x); classifyExact on a group takes
+        # neither quick mode nor a second database (the executable says so and exits 70)
+        if who == "ours" and bias == "devices" and not (exact and ("-q" in flags or two_dbs)):
+            env["KU_DEVICES"] = ",".join(["0"] * int(rng.integers(2, 6)))
+        r = subprocess.run(cmd + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
         outs[who] = (r.returncode, {kk: (open(p, "rb").read() if os.path.exists(p) else None) for kk, p in o.items()}, r.stderr.decode(errors="replace")[-400:])
     (rc_r, f_r, e_r), (rc_o, f_o, e_o) = outs["ref"], outs["ours"]
     desc = f"{'classifyExact ' if exact else ''}{'two databases ' if two_dbs else ''}nt {nt} genomes {n_gen} files {[os.path.basename(f) for f in files]} flags {' '.join(flags)}{' -r' if want_r else ''}{' -C' if want_c else ''}{' -U' if want_u else ''}"
