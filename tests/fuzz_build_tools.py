@@ -4,7 +4,8 @@ the build steps krakenuniq_amd/bin/db_sort and bin/set_lcas against the compiled
 oracle/_ref/set_lcas ON THE SAME FILES -- a shuffled Jellyfish-style k-mer list of random genomes -> sorted database + index
 (random minimizer length, with and without -z), then the LCAs from a random multi-FASTA library under a random taxonomy
 (sequences of known, unknown and unmapped ids, wrapped lines, lower case, ambiguous bases, k-mers missing from the database
-with -x): database.kdb / database.idx byte for byte."""
+with -x): database.kdb / database.idx byte for byte; then the UID form of the same (set_lcas -I: database and UID map byte for
+byte) and classify -I over it with both executables (Kraken file byte for byte, report row for row)."""
 import os
 import shutil
 import subprocess
@@ -104,7 +105,64 @@ def one_case(seed, tmp):
     assert res["ref"][0] == res["ours"][0], ("set_lcas exit codes", res["ref"][0], res["ours"][0], res["ref"][2], res["ours"][2])
     if res["ref"][0] == 0:
         assert res["ref"][1] == res["ours"][1], "set_lcas: database.kdb"
-    return f"nt {nt} genomes {n_gen} k-mers {len(kmers)}{' -z' if zero else ''} sequences {n_seq} (set_lcas exit {res['ref'][0]})"
+    # ---- UID databases (set_lcas -I, src/uid_mapping.cpp): the k-mers' values are ids of taxid SETS, numbered as they come up;
+    # then classify -I over the reference's UID database with both executables (resolve_uids3, src/classify.cpp:1067-...)
+    uid_note = ""
+    if rng.random() < 0.6:
+        zdb = os.path.join(tmp, "zero")
+        os.makedirs(zdb, exist_ok=True)
+        rc, err = run([os.path.join(REF, "db_sort"), "-z", "-t", "1", "-n", str(nt), "-d", jdb, "-o", f"{zdb}/database.kdb", "-i", f"{zdb}/database.idx"])
+        assert rc == 0, ("db_sort -z", err)
+        ures = {}
+        for who, d in (("ref", REF), ("ours", BIN)):
+            ukdb, umap = os.path.join(tmp, f"{who}_uid.kdb"), os.path.join(tmp, f"{who}_uid.map")
+            for pth in (ukdb, umap):
+                if os.path.exists(pth):
+                    os.unlink(pth)
+            zin = os.path.join(tmp, f"{who}_zero.kdb")  # (its own copy: the reference's set_lcas writes through its mapping of the input)
+            shutil.copy(f"{zdb}/database.kdb", zin)
+            rc, err = run([os.path.join(d, "set_lcas"), "-x", "-t", "1", "-d", zin, "-I", umap, "-o", ukdb, "-i", f"{zdb}/database.idx",
+                           "-b", taxdb, "-m", smap, "-F", lib])
+            ures[who] = (rc, open(ukdb, "rb").read() if os.path.exists(ukdb) else None, open(umap, "rb").read() if os.path.exists(umap) else None, err)
+        assert ures["ref"][0] == ures["ours"][0], ("set_lcas -I exit codes", ures["ref"][0], ures["ours"][0], ures["ref"][3], ures["ours"][3])
+        if ures["ref"][0] == 0:
+            assert ures["ref"][1] == ures["ours"][1], "set_lcas -I: database.kdb"
+            assert ures["ref"][2] == ures["ours"][2], "set_lcas -I: UID map"
+            # reads over the UID database
+            reads = os.path.join(tmp, "reads.fa")
+            with open(reads, "wb") as f:
+                tids = list(genomes)
+                for i in range(int(rng.integers(50, 600))):
+                    g = genomes[tids[int(rng.integers(0, len(tids)))]]
+                    n = int(rng.integers(K - 1, min(400, len(g) - 1)))
+                    a = int(rng.integers(0, len(g) - n))
+                    r = bytearray(synth.codes_to_ascii(g[a:a + n]))
+                    if rng.random() < 0.3:
+                        r[int(rng.integers(0, n))] = ord("ACGTN"[int(rng.integers(0, 5))])
+                    f.write(f">r{i}\n".encode() + bytes(r) + b"\n")
+            outs = {}
+            for who, exe in (("ref", os.path.join(REF, "classify")), ("ours", os.path.join(BIN, "classify"))):
+                udir = os.path.join(tmp, f"udb_{who}")
+                shutil.rmtree(udir, ignore_errors=True)
+                os.makedirs(udir)
+                shutil.copy(os.path.join(tmp, "ref_uid.kdb"), f"{udir}/database.kdb")
+                shutil.copy(f"{zdb}/database.idx", f"{udir}/database.idx")
+                o, rp = os.path.join(tmp, f"{who}_uid_out"), os.path.join(tmp, f"{who}_uid_rep")
+                for pth in (o, rp):
+                    if os.path.exists(pth):
+                        os.unlink(pth)
+                rc, err = run([exe, "-d", f"{udir}/database.kdb", "-i", f"{udir}/database.idx", "-a", taxdb, "-I", os.path.join(tmp, "ref_uid.map"),
+                               "-t", "1", "-o", o, "-r", rp, reads])
+                outs[who] = (rc, open(o, "rb").read() if os.path.exists(o) else None,
+                             sorted(open(rp).read().strip("\n").split("\n")) if os.path.exists(rp) else None, err)
+            assert outs["ref"][0] == outs["ours"][0], ("classify -I exit codes", outs["ref"][0], outs["ours"][0], outs["ref"][3], outs["ours"][3])
+            if outs["ref"][0] == 0:
+                assert outs["ref"][1] == outs["ours"][1], "classify -I: Kraken file"
+                assert outs["ref"][2] == outs["ours"][2], "classify -I: report"
+            uid_note = f", UID build + classify -I (exit {outs['ref'][0]})"
+        else:
+            uid_note = f", set_lcas -I exit {ures['ref'][0]} on both"
+    return f"nt {nt} genomes {n_gen} k-mers {len(kmers)}{' -z' if zero else ''} sequences {n_seq} (set_lcas exit {res['ref'][0]}){uid_note}"
 
 
 def main():
