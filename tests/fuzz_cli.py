@@ -34,7 +34,9 @@ def one_case(seed, tmp):
     nt = int(rng.choice([6, 9, 10, 11, 12]))  # (the index file holds 8 * 4^nt bytes: 134 MB at 12, 8.6 GB at 15)
     n_gen = int(rng.integers(2, 7))
     tax = synth.random_taxonomy(n_gen, rng, levels=tuple(int(x) for x in rng.integers(2, 7, size=int(rng.integers(2, 6)))))
-    db = gc.random_db(rng, n_genomes=n_gen, glen=int(rng.integers(2000, 5000)), k=k, nt=nt, tax=tax)
+    long_reads = os.environ.get("KU_FUZZ_CLI_BIAS", "") == "long"  # reads of several kbp (the windowed kernel, many runs per read)
+    db = gc.random_db(rng, n_genomes=min(n_gen, 4) if long_reads else n_gen, glen=int(rng.integers(12000, 30000)) if long_reads else int(rng.integers(2000, 5000)),
+                      k=k, nt=nt, tax=tax)
     dirs = {}
     for who in ("ref", "ours"):  # (each run writes its own database.kdb.counts; the files themselves are shared)
         d = os.path.join(tmp, f"db_{who}")
@@ -61,14 +63,14 @@ def one_case(seed, tmp):
     weights = weights / weights.sum()
     files = []
     for fi in range(int(rng.integers(1, 3))):
-        n_reads = int(rng.integers(1, 1500))
+        n_reads = int(rng.integers(1, 1500)) if not long_reads else int(rng.integers(1, 300))
         seqs, ids = [], []
         for i in range(n_reads):
             if rng.random() < 0.08:
                 s = bytes(rng.choice(np.frombuffer(b"ACGTNacgtnRY", dtype=np.uint8), size=int(rng.integers(0, 220))).tobytes())
             else:
                 g = genome_pool[sp[int(rng.choice(len(sp), p=weights))]]
-                n = int(rng.integers(k - 2, min(600, len(g) - 1)))
+                n = int(rng.integers(k - 2, min(600, len(g) - 1))) if not (long_reads and rng.random() < 0.5) else int(rng.integers(600, len(g) - 1))
                 a = int(rng.integers(0, len(g) - n))
                 c = g[a:a + n]
                 r = bytearray(synth.codes_to_ascii(c if rng.random() < 0.5 else synth.revcomp_codes(c)))
@@ -76,6 +78,9 @@ def one_case(seed, tmp):
                     r[int(rng.integers(0, n))] = ord("N")
                 if rng.random() < 0.2:
                     r[int(rng.integers(0, n))] = ord("ACGT"[int(rng.integers(0, 4))])
+                if long_reads:  # substitutions all along: the taxon changes every few k-mers
+                    for _ in range(int(rng.poisson(n * float(rng.choice([0.0, 0.01, 0.05]))))):
+                        r[int(rng.integers(0, n))] = ord("ACGTN"[int(rng.integers(0, 5))])
                 s = bytes(r)
             seqs.append(s)
             ids.append(f"f{fi}r{i}" + (" some description" if rng.random() < 0.2 else ""))
