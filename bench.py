@@ -634,29 +634,7 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
         bytes_algo = a.reads / n_shards * (L + 4.0) + st["lookups"] * 20 + 12 * st["sum_ceil_log2"]
         achieved = bytes_algo / (t_equiv * 1e-3) / 1e9 if t_equiv else 0.0
         rev = capi.kernel_rev()
-        traffic, tnote = None, "no counter profile of this kernel source in profiles/route_traffic.json"
-        tpath = os.path.join(ROOT, "profiles", "route_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"nt{a.nt}_species{a.species}_shards{n_shards}_ws{ws}_reads{a.reads}_len{L}"
-                ent = tj.get("workloads", {}).get(key)
-                # the counters were collected with ONE rank doing every rank's scan and resolve and the owner work of shard 0
-                # (scripts/profile_r06.sh): a world that holds the whole layout finds its workload under ws1 -- a rank's scan
-                # and resolve are 1 / ws of those passes, its owner work the same
-                ent1 = tj.get("workloads", {}).get(f"nt{a.nt}_species{a.species}_shards{n_shards}_ws1_reads{a.reads}_len{L}") if ws == n_shards and ws > 1 else None
-                if ent and tj.get("kernel_rev") == rev:
-                    by = ent["hbm_bytes_per_step"]
-                    traffic = (by.get("scan", 0) + by.get("resolve", 0)) * share + by.get("owner", 0)
-                    tnote = ent.get("source", "profiles/route_traffic.json")
-                elif ent1 and tj.get("kernel_rev") == rev:
-                    by = ent1["hbm_bytes_per_step"]
-                    traffic = (by.get("scan", 0) + by.get("resolve", 0)) / ws + by.get("owner", 0)
-                    tnote = ent1.get("source", "profiles/route_traffic.json") + f" -- collected with one rank doing all {ws} ranks' scan and resolve: those two taken at 1 / {ws}, the owner stage as measured"
-                elif ent or ent1:
-                    tnote = f"profiles/route_traffic.json is of kernel source {tj.get('kernel_rev')}, this is {rev}: refused"
-            except Exception:
-                pass
+        traffic, tnote = routed_traffic(os.path.join(ROOT, "profiles", "route_traffic.json"), rev, a.nt, a.species, n_shards, ws, a.reads, L, share)
         rf = {"bound": "hbm", "kernel": "this rank's stages of an owner-routed step: ku_lookup_kernel<3,...> (scan -> records) + "
                                         "ku_route_owner_kernel (probe, HLL, n_kmers) + ku_classify_short_kernel<..., ROUTE> (tickets -> calls), "
                                         "with the prefix sums between them",
@@ -730,6 +708,36 @@ def sharded_run(a, capi, synth_torch, dev, rank, local_rank, ws, uid, k, steps, 
 BUDGET_S = float(os.environ.get("KU_BENCH_BUDGET_S", "1500"))
 SYNTH_PAIRS_PER_S = 3.4e7   # shard synthesis on one MI355X (profiles/README.md: 3.1 G pairs in ~90 s)
 TABLE_PAIRS_PER_S = 3.8e9   # slot table + probe table behind it (0.61 G pairs in 0.16 s)
+
+
+def routed_traffic(path, rev, nt, species, n_shards, ws, reads, read_len, share):
+    """counter-measured HBM bytes of one rank's routed step (profiles/route_traffic.json, collected by scripts/profile_r06.sh with
+    ONE rank doing every rank's scan and resolve and the owner work of shard 0) -> (bytes or None, where they come from).
+    The workload as it ran (`..._ws{ws}_...`): scan and resolve at `share` of the profile's; a world that holds the whole layout
+    (ws == n_shards > 1) finds its workload under ws1: a rank's scan and resolve are 1 / ws of those passes, its owner work the
+    same.  A profile of another kernel source is refused."""
+    traffic, tnote = None, "no counter profile of this kernel source in profiles/route_traffic.json"
+    if not os.path.exists(path):
+        return traffic, tnote
+    try:
+        tj = json.load(open(path))
+        wl = tj.get("workloads", {})
+        ent = wl.get(f"nt{nt}_species{species}_shards{n_shards}_ws{ws}_reads{reads}_len{read_len}")
+        ent1 = wl.get(f"nt{nt}_species{species}_shards{n_shards}_ws1_reads{reads}_len{read_len}") if ws == n_shards and ws > 1 else None
+        if ent and tj.get("kernel_rev") == rev:
+            by = ent["hbm_bytes_per_step"]
+            traffic = (by.get("scan", 0) + by.get("resolve", 0)) * share + by.get("owner", 0)
+            tnote = ent.get("source", "profiles/route_traffic.json")
+        elif ent1 and tj.get("kernel_rev") == rev:
+            by = ent1["hbm_bytes_per_step"]
+            traffic = (by.get("scan", 0) + by.get("resolve", 0)) / ws + by.get("owner", 0)
+            tnote = (ent1.get("source", "profiles/route_traffic.json") +
+                     f" -- collected with one rank doing all {ws} ranks' scan and resolve: those two taken at 1 / {ws}, the owner stage as measured")
+        elif ent or ent1:
+            tnote = f"profiles/route_traffic.json is of kernel source {tj.get('kernel_rev')}, this is {rev}: refused"
+    except Exception:
+        pass
+    return traffic, tnote
 
 
 def planned_table_bytes(n_pairs, free_hbm):
